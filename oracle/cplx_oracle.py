@@ -1,0 +1,521 @@
+"""CPU oracle: a numpy restatement of the cplxmodule hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in ``cplxmodule_amd`` may import this file;
+only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` use it, and only as the checker / the timed CPU baseline.
+
+Every function restates one reference function (cited as file:line under
+``/root/reference``) in plain numpy.  Forward passes follow the reference's op
+order; backward passes are the hand-derived formulas of SURVEY.md Appendix A
+(the reference relies on autograd).  Both directions are pinned against
+outputs of the real reference in ``tests/golden/*.npz`` (generated here by
+``oracle/gen_golden.py``, which imports ``/root/reference``).
+
+Parity status: PINNED (tests/test_oracle_golden.py).
+
+Complex tensors are passed as two planar arrays ``(re, im)`` of equal shape,
+which is the reference's own ``Cplx`` layout (cplxmodule/cplx.py:10-52).
+All functions are dtype-generic: the arithmetic runs in the dtype of the
+inputs (float32 or float64).
+"""
+import numpy as np
+from scipy.special import expi as _scipy_expi
+
+EULER_GAMMA = float(np.euler_gamma)
+
+# constants of the softplus-sigmoid KL approximation,
+# cplxmodule/nn/relevance/real/vd.py:74-76
+K1, K2, K3 = 0.63576, 1.87320, 1.48695
+
+KINDS = ("real_vd", "real_ard", "cplx_vd", "cplx_ard")
+
+
+# --------------------------------------------------------------------------- #
+#  complex linear                                                             #
+# --------------------------------------------------------------------------- #
+def cplx_linear(xr, xi, wr, wi, br=None, bi=None, algo="4m"):
+    """y = x W^T + b for planar complex tensors.
+
+    4m: cplxmodule/cplx.py:634-648 (linear_naive);
+    3m: cplxmodule/cplx.py:669-694 (linear_3m, Gauss trick);
+    cat: cplxmodule/cplx.py:651-666 (one fat real GEMM).
+    """
+    if algo == "4m":
+        re = xr @ wr.T - xi @ wi.T
+        im = xr @ wi.T + xi @ wr.T
+    elif algo == "3m":
+        k1 = (xr + xi) @ wr.T
+        k2 = xr @ (wi - wr).T
+        k3 = xi @ (wr + wi).T
+        re, im = k1 - k3, k1 + k2
+    elif algo == "cat":
+        ww = np.concatenate(
+            [np.concatenate([wr, wi], 0), np.concatenate([-wi, wr], 0)], 1)
+        out = np.concatenate([xr, xi], -1) @ ww.T
+        re, im = np.split(out, 2, axis=-1)
+    else:
+        raise ValueError(algo)
+    if br is not None:
+        re, im = re + br, im + bi
+    return re, im
+
+
+def cplx_linear_bwd(gr, gi, xr, xi, wr, wi, has_bias=True):
+    """Gradients of ``cplx_linear``: dX = G conj(W),
+    dW = G^T conj(X), db = sum_b G.  Inputs may carry leading batch dims."""
+    O, I = wr.shape
+    g2r, g2i = gr.reshape(-1, O), gi.reshape(-1, O)
+    x2r, x2i = xr.reshape(-1, I), xi.reshape(-1, I)
+    dxr = (g2r @ wr + g2i @ wi).reshape(xr.shape)
+    dxi = (-g2r @ wi + g2i @ wr).reshape(xr.shape)
+    dwr = g2r.T @ x2r + g2i.T @ x2i
+    dwi = -g2r.T @ x2i + g2i.T @ x2r
+    out = dict(dxr=dxr, dxi=dxi, dwr=dwr, dwi=dwi)
+    if has_bias:
+        out["dbr"], out["dbi"] = g2r.sum(0), g2i.sum(0)
+    return out
+
+
+def cplx_matmul(ur, ui, vr, vi):
+    """Cplx.__matmul__, cplxmodule/cplx.py:167-174."""
+    return ur @ vr - ui @ vi, ui @ vr + ur @ vi
+
+
+# --------------------------------------------------------------------------- #
+#  noise                                                                      #
+# --------------------------------------------------------------------------- #
+def cplx_randn_from_tape(tape):
+    """cplx.randn, cplxmodule/cplx.py:544-550: ONE normal draw of shape
+    [2, *size] divided by sqrt(2); plane 0 -> real, plane 1 -> imag."""
+    z = tape / np.asarray(np.sqrt(2.0), dtype=tape.dtype)
+    return z[0], z[1]
+
+
+# --------------------------------------------------------------------------- #
+#  local reparameterization                                                   #
+# --------------------------------------------------------------------------- #
+def lrt_cplx_linear(xr, xi, wr, wi, br, bi, log_sigma2, eps_r, eps_i):
+    """CplxLinearGaussian.forward in training mode,
+    cplxmodule/nn/relevance/complex/base.py:43-56."""
+    mur, mui = cplx_linear(xr, xi, wr, wi, br, bi)
+    s2 = (xr * xr + xi * xi) @ np.exp(log_sigma2).T
+    sd = np.sqrt(np.maximum(s2, np.asarray(1e-8, s2.dtype)))
+    return mur + eps_r * sd, mui + eps_i * sd, dict(mur=mur, mui=mui, s2=s2)
+
+
+def lrt_cplx_linear_bwd(gr, gi, xr, xi, wr, wi, log_sigma2, eps_r, eps_i,
+                        has_bias=True):
+    """SURVEY.md A.2 (complex).  torch.clamp passes the gradient AT the
+    boundary (s2 == 1e-8) and blocks it below."""
+    dt = xr.dtype
+    S = np.exp(log_sigma2)
+    a = xr * xr + xi * xi
+    s2 = a @ S.T
+    lo = np.asarray(1e-8, dt)
+    sd = np.sqrt(np.maximum(s2, lo))
+    gsd = gr * eps_r + gi * eps_i
+    gs2 = np.where(s2 >= lo, gsd * np.asarray(0.5, dt) / sd, np.asarray(0, dt))
+    ga = gs2 @ S
+    out = cplx_linear_bwd(gr, gi, xr, xi, wr, wi, has_bias)
+    out["dxr"] = out["dxr"] + 2 * xr * ga
+    out["dxi"] = out["dxi"] + 2 * xi * ga
+    out["dlog_sigma2"] = (gs2.reshape(-1, S.shape[0]).T
+                          @ a.reshape(-1, S.shape[1])) * S
+    return out
+
+
+def lrt_real_linear(x, w, b, log_sigma2, eps):
+    """LinearGaussian.forward in training mode,
+    cplxmodule/nn/relevance/real/base.py:43-49."""
+    mu = x @ w.T
+    if b is not None:
+        mu = mu + b
+    s2 = (x * x) @ np.exp(log_sigma2).T
+    sd = np.sqrt(np.maximum(s2, np.asarray(1e-8, s2.dtype)))
+    return mu + eps * sd, dict(mu=mu, s2=s2)
+
+
+def lrt_real_linear_bwd(g, x, w, log_sigma2, eps, has_bias=True):
+    """SURVEY.md A.2 (real)."""
+    dt = x.dtype
+    S = np.exp(log_sigma2)
+    a = x * x
+    s2 = a @ S.T
+    lo = np.asarray(1e-8, dt)
+    sd = np.sqrt(np.maximum(s2, lo))
+    gs2 = np.where(s2 >= lo, g * eps * np.asarray(0.5, dt) / sd,
+                   np.asarray(0, dt))
+    ga = gs2 @ S
+    O, I = w.shape
+    g2, x2 = g.reshape(-1, O), x.reshape(-1, I)
+    out = dict(dx=(g2 @ w).reshape(x.shape) + 2 * x * ga, dw=g2.T @ x2,
+               dlog_sigma2=(gs2.reshape(-1, O).T @ a.reshape(-1, I)) * S)
+    if has_bias:
+        out["db"] = g2.sum(0)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+#  log-alpha, KL penalties, masks                                             #
+# --------------------------------------------------------------------------- #
+def cplx_abs(wr, wi):
+    """Cplx.__abs__, cplxmodule/cplx.py:183-192 (stack + 2-norm over dim 0).
+    torch's CPU kernel evaluates sqrt(fma(wi, wi, round(wr*wr))): verified
+    bit-for-bit on 2^20 float32 samples ("mask exactness")."""
+    if wr.dtype == np.float32:
+        sq = (wr * wr).astype(np.float64) + wi.astype(np.float64) ** 2
+        return np.sqrt(sq.astype(np.float32))
+    return np.sqrt(wr * wr + wi * wi)
+
+
+def log_alpha(log_sigma2, wr, wi=None):
+    """GaussianMixin.log_alpha: complex cplxmodule/nn/relevance/complex/base.py:27-31,
+    real cplxmodule/nn/relevance/real/base.py:23-26."""
+    theta = np.abs(wr) if wi is None else cplx_abs(wr, wi)
+    eps0 = np.asarray(1e-12, log_sigma2.dtype)
+    return log_sigma2 - 2 * np.log(theta + eps0)
+
+
+def softplus(x):
+    """torch.nn.functional.softplus, beta=1, threshold=20."""
+    with np.errstate(over="ignore"):
+        return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+
+
+def sigmoid(x):
+    return 1 / (1 + np.exp(-x))
+
+
+def softplus_grad(x):
+    """torch's softplus backward: exactly 1 above the linear threshold 20."""
+    return np.where(x > 20, np.asarray(1, x.dtype), sigmoid(x))
+
+
+def expi(x):
+    """torch_expi == scipy.special.expi evaluated in the input dtype's loop
+    (float32 loop computes in double, rounds once),
+    cplxmodule/nn/relevance/complex/vd.py:31-36."""
+    return _scipy_expi(x).astype(x.dtype)
+
+
+def penalty(kind, log_sigma2, wr, wi=None):
+    """Elementwise KL penalty, shape of the weight.
+    real_vd  cplxmodule/nn/relevance/real/vd.py:54-76
+    real_ard cplxmodule/nn/relevance/real/ard.py:10-39
+    cplx_vd  cplxmodule/nn/relevance/complex/vd.py:95-99
+    cplx_ard cplxmodule/nn/relevance/complex/ard.py:9-39
+    """
+    dt = log_sigma2.dtype
+    t = -log_alpha(log_sigma2, wr, wi)
+    if kind == "real_vd":
+        sg = sigmoid(np.asarray(K3, dt) * t - np.asarray(K2, dt))
+        return softplus(t) / 2 + np.asarray(K1, dt) * sg
+    if kind == "real_ard":
+        return np.asarray(0.5, dt) * softplus(t)
+    if kind == "cplx_vd":
+        with np.errstate(over="ignore"):
+            return np.asarray(EULER_GAMMA, dt) + t - expi(-np.exp(t))
+    if kind == "cplx_ard":
+        return softplus(t)
+    raise ValueError(kind)
+
+
+def penalty_dt(kind, t):
+    """f'(t) with t = -log_alpha."""
+    dt = t.dtype
+    if kind == "real_vd":
+        u = np.asarray(K3, dt) * t - np.asarray(K2, dt)
+        su = sigmoid(u)
+        return softplus_grad(t) / 2 + np.asarray(K1 * K3, dt) * su * (1 - su)
+    if kind == "real_ard":
+        return softplus_grad(t) / 2
+    if kind == "cplx_vd":
+        with np.errstate(over="ignore"):
+            return -np.expm1(-np.exp(t))
+    if kind == "cplx_ard":
+        return softplus_grad(t)
+    raise ValueError(kind)
+
+
+def penalty_bwd(kind, g, log_sigma2, wr, wi=None):
+    """Gradient of sum(g * penalty) wrt (log_sigma2, wr, wi), SURVEY.md A.3.
+    The gradient wrt the weight is 0 where |w| == 0 (torch subgradient)."""
+    dt = log_sigma2.dtype
+    t = -log_alpha(log_sigma2, wr, wi)
+    fp = g * penalty_dt(kind, t)
+    eps0 = np.asarray(1e-12, dt)
+    out = dict(dlog_sigma2=-fp)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if wi is None:
+            theta = np.abs(wr)
+            out["dwr"] = np.where(theta > 0,
+                                  fp * 2 * np.sign(wr) / (theta + eps0), 0
+                                  ).astype(dt)
+        else:
+            theta = cplx_abs(wr, wi)
+            den = theta * (theta + eps0)
+            out["dwr"] = np.where(theta > 0, fp * 2 * wr / den, 0).astype(dt)
+            out["dwi"] = np.where(theta > 0, fp * 2 * wi / den, 0).astype(dt)
+    return out
+
+
+def relevance_mask(threshold, log_sigma2, wr, wi=None):
+    """RelevanceMixin.relevance: real cplxmodule/nn/relevance/real/vd.py:16-19,
+    complex cplxmodule/nn/relevance/complex/vd.py:50-53.  Float 0/1 mask."""
+    la = log_alpha(log_sigma2, wr, wi)
+    return (la <= np.asarray(threshold, la.dtype)).astype(la.dtype)
+
+
+# --------------------------------------------------------------------------- #
+#  convolution                                                                #
+# --------------------------------------------------------------------------- #
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _im2col(x, kh, kw, stride, padding, dilation):
+    """x [B, C, H, W] -> cols [B, C, kh, kw, Ho, Wo] with zero padding."""
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    B, C, H, W = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    cols = np.empty((B, C, kh, kw, Ho, Wo), x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            cols[:, :, i, j] = xp[:, :, i * dh: i * dh + sh * (Ho - 1) + 1: sh,
+                                  j * dw: j * dw + sw * (Wo - 1) + 1: sw]
+    return cols
+
+
+def real_conv2d(x, w, stride=1, padding=0, dilation=1, groups=1):
+    """torch.nn.functional.conv2d (cross-correlation), zero padding."""
+    Co, Cg, kh, kw = w.shape
+    cols = _im2col(x, kh, kw, stride, padding, dilation)
+    B, C, _, _, Ho, Wo = cols.shape
+    cols = cols.reshape(B, groups, Cg * kh * kw, Ho * Wo)
+    wg = w.reshape(groups, Co // groups, Cg * kh * kw)
+    out = np.einsum("gok,bgkp->bgop", wg, cols)
+    return out.reshape(B, Co, Ho, Wo)
+
+
+def real_conv2d_bwd(g, x, w, stride=1, padding=0, dilation=1, groups=1):
+    """(dx, dw) of ``real_conv2d`` via col2im."""
+    (sh, sw), (ph, pw), (dh, dw_) = _pair(stride), _pair(padding), _pair(dilation)
+    Co, Cg, kh, kw = w.shape
+    B, C, H, W = x.shape
+    cols = _im2col(x, kh, kw, stride, padding, dilation)
+    Ho, Wo = cols.shape[-2:]
+    colsg = cols.reshape(B, groups, Cg * kh * kw, Ho * Wo)
+    gg = g.reshape(B, groups, Co // groups, Ho * Wo)
+    wg = w.reshape(groups, Co // groups, Cg * kh * kw)
+    dw = np.einsum("bgop,bgkp->gok", gg, colsg).reshape(w.shape)
+    dcols = np.einsum("gok,bgop->bgkp", wg, gg).reshape(B, C, kh, kw, Ho, Wo)
+    dxp = np.zeros((B, C, H + 2 * ph, W + 2 * pw), x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            dxp[:, :, i * dh: i * dh + sh * (Ho - 1) + 1: sh,
+                j * dw_: j * dw_ + sw * (Wo - 1) + 1: sw] += dcols[:, :, i, j]
+    return dxp[:, :, ph: ph + H, pw: pw + W], dw
+
+
+def circular_pad2d(x, padding):
+    """symmetric_circular_padding, cplxmodule/cplx.py:701-714: each spatial dim
+    gets ((pad+1)//2, pad//2); F.pad's tuple runs from the LAST dim backwards,
+    so the first entry of ``padding`` pads the last dim."""
+    pads = _pair(padding)
+    (wl, wr_), (hl, hr) = [((p + 1) // 2, p // 2) for p in pads]
+    return np.pad(x, ((0, 0), (0, 0), (hl, hr), (wl, wr_)), mode="wrap")
+
+
+def cplx_conv2d(xr, xi, wr, wi, br=None, bi=None, stride=1, padding=0,
+                dilation=1, groups=1, padding_mode="zeros"):
+    """cplx.conv2d -> convnd, cplxmodule/cplx.py:770-800, 822-838:
+    re = conv(xr, wr) - conv(xi, wi); im = conv(xr, wi) + conv(xi, wr)
+    (no conjugation), bias broadcast over the spatial dims."""
+    if padding_mode == "circular":
+        xr, xi = circular_pad2d(xr, padding), circular_pad2d(xi, padding)
+        padding = 0
+    elif padding_mode != "zeros":
+        raise ValueError("padding_mode must be 'zeros' or 'circular'.")
+    a = (stride, padding, dilation, groups)
+    re = real_conv2d(xr, wr, *a) - real_conv2d(xi, wi, *a)
+    im = real_conv2d(xr, wi, *a) + real_conv2d(xi, wr, *a)
+    if br is not None:
+        re, im = re + br.reshape(1, -1, 1, 1), im + bi.reshape(1, -1, 1, 1)
+    return re, im
+
+
+def cplx_conv2d_bwd(gr, gi, xr, xi, wr, wi, stride=1, padding=0, dilation=1,
+                    groups=1, has_bias=True):
+    """Zero-padding complex conv gradients: the A.1 algebra with conv."""
+    a = (stride, padding, dilation, groups)
+    # re = c(xr,wr) - c(xi,wi); im = c(xr,wi) + c(xi,wr)
+    dx_rr, dw_rr = real_conv2d_bwd(gr, xr, wr, *a)   # d re / (xr, wr)
+    dx_ii, dw_ii = real_conv2d_bwd(gr, xi, wi, *a)   # d(-re) / (xi, wi)
+    dx_ri, dw_ri = real_conv2d_bwd(gi, xr, wi, *a)   # d im / (xr, wi)
+    dx_ir, dw_ir = real_conv2d_bwd(gi, xi, wr, *a)   # d im / (xi, wr)
+    out = dict(dxr=dx_rr + dx_ri, dxi=-dx_ii + dx_ir,
+               dwr=dw_rr + dw_ir, dwi=-dw_ii + dw_ri)
+    if has_bias:
+        out["dbr"], out["dbi"] = gr.sum((0, 2, 3)), gi.sum((0, 2, 3))
+    return out
+
+
+def lrt_cplx_conv2d(xr, xi, wr, wi, br, bi, log_sigma2, eps_r, eps_i,
+                    stride=1, padding=0, dilation=1, groups=1):
+    """CplxConvNdGaussianMixin._forward_impl,
+    cplxmodule/nn/relevance/complex/base.py:120-135 (zeros padding only)."""
+    a = (stride, padding, dilation, groups)
+    mur, mui = cplx_conv2d(xr, xi, wr, wi, br, bi, *a)
+    s2 = real_conv2d(xr * xr + xi * xi, np.exp(log_sigma2), *a)
+    sd = np.sqrt(np.maximum(s2, np.asarray(1e-8, s2.dtype)))
+    return mur + eps_r * sd, mui + eps_i * sd, dict(mur=mur, mui=mui, s2=s2)
+
+
+def lrt_cplx_conv2d_bwd(gr, gi, xr, xi, wr, wi, log_sigma2, eps_r, eps_i,
+                        stride=1, padding=0, dilation=1, groups=1,
+                        has_bias=True):
+    dt = xr.dtype
+    a = (stride, padding, dilation, groups)
+    S = np.exp(log_sigma2)
+    ab = xr * xr + xi * xi
+    s2 = real_conv2d(ab, S, *a)
+    lo = np.asarray(1e-8, dt)
+    sd = np.sqrt(np.maximum(s2, lo))
+    gs2 = np.where(s2 >= lo, (gr * eps_r + gi * eps_i) * np.asarray(0.5, dt) / sd,
+                   np.asarray(0, dt))
+    ga, dS = real_conv2d_bwd(gs2, ab, S, *a)
+    out = cplx_conv2d_bwd(gr, gi, xr, xi, wr, wi, *a, has_bias=has_bias)
+    out["dxr"] = out["dxr"] + 2 * xr * ga
+    out["dxi"] = out["dxi"] + 2 * xi * ga
+    out["dlog_sigma2"] = dS * S
+    return out
+
+
+def lrt_real_conv2d(x, w, b, log_sigma2, eps, stride=1, padding=0, dilation=1,
+                    groups=1):
+    """ConvNdGaussianMixin._forward_impl,
+    cplxmodule/nn/relevance/real/base.py:116-163."""
+    a = (stride, padding, dilation, groups)
+    mu = real_conv2d(x, w, *a)
+    if b is not None:
+        mu = mu + b.reshape(1, -1, 1, 1)
+    s2 = real_conv2d(x * x, np.exp(log_sigma2), *a)
+    sd = np.sqrt(np.maximum(s2, np.asarray(1e-8, s2.dtype)))
+    return mu + eps * sd, dict(mu=mu, s2=s2)
+
+
+# --------------------------------------------------------------------------- #
+#  complex batch normalisation                                                #
+# --------------------------------------------------------------------------- #
+def _bn_axes(x):
+    return (0,) + tuple(range(2, x.ndim))
+
+
+def _bn_shape(x):
+    return (1, x.shape[1]) + (1,) * (x.ndim - 2)
+
+
+def _inv_sqrt_2x2(vuu, vuv, vvv):
+    """Closed-form inverse square root of [[vuu, vuv], [vuv, vvv]],
+    cplxmodule/nn/modules/batchnorm.py:108-113."""
+    s = np.sqrt(vuu * vvv - vuv * vuv)
+    t = s * np.sqrt(vuu + 2 * s + vvv)
+    return (vvv + s) / t, -vuv / t, -vuv / t, (vuu + s) / t
+
+
+def cplx_batch_norm(xr, xi, running_mean, running_var, weight=None, bias=None,
+                    training=True, momentum=0.1, eps=1e-5):
+    """cplx_batch_norm + whiten2x2, cplxmodule/nn/modules/batchnorm.py:62-123,
+    189-278.  ``running_mean`` [2,F] / ``running_var`` [2,2,F] are updated IN
+    PLACE when training (biased covariance, nugget on the diagonal only).
+    Returns (yr, yi)."""
+    ax, shp = _bn_axes(xr), _bn_shape(xr)
+    if training or running_mean is None:
+        mu, mv = xr.mean(ax), xi.mean(ax)
+        if running_mean is not None:
+            running_mean += momentum * (np.stack([mu, mv]) - running_mean)
+    else:
+        mu, mv = running_mean
+    cu, cv = xr - mu.reshape(shp), xi - mv.reshape(shp)
+    if training or running_var is None:
+        vuu = (cu * cu).mean(ax) + np.asarray(eps, xr.dtype)
+        vvv = (cv * cv).mean(ax) + np.asarray(eps, xr.dtype)
+        vuv = (cu * cv).mean(ax)
+        if running_var is not None:
+            cov = np.stack([vuu, vuv, vuv, vvv]).reshape(2, 2, -1)
+            running_var += momentum * (cov - running_var)
+    else:
+        vuu, vuv, _, vvv = running_var.reshape(4, -1)
+    p, q, r, w = _inv_sqrt_2x2(vuu, vuv, vvv)
+    zu = cu * p.reshape(shp) + cv * r.reshape(shp)
+    zv = cu * q.reshape(shp) + cv * w.reshape(shp)
+    if weight is not None:
+        W = weight.reshape(2, 2, *shp)
+        zu, zv = (zu * W[0, 0] + zv * W[0, 1] + bias[0].reshape(shp),
+                  zu * W[1, 0] + zv * W[1, 1] + bias[1].reshape(shp))
+    return zu, zv
+
+
+def cplx_batch_norm_bwd(gr, gi, xr, xi, running_mean, running_var, weight=None,
+                        training=True, eps=1e-5):
+    """Gradient of ``cplx_batch_norm`` wrt (xr, xi, weight, bias), derived by
+    hand through the closed-form 2x2 inverse square root (gradients DO flow
+    through s and t, cf. the comment at batchnorm.py:105-107).
+    ``running_*`` are the statistics used in eval mode (ignored if training)."""
+    ax, shp = _bn_axes(xr), _bn_shape(xr)
+    N = xr.size // xr.shape[1]
+    if training:
+        mu, mv = xr.mean(ax), xi.mean(ax)
+    else:
+        mu, mv = running_mean
+    cu, cv = xr - mu.reshape(shp), xi - mv.reshape(shp)
+    if training:
+        a = (cu * cu).mean(ax) + np.asarray(eps, xr.dtype)
+        d = (cv * cv).mean(ax) + np.asarray(eps, xr.dtype)
+        b = (cu * cv).mean(ax)
+    else:
+        a, b, _, d = running_var.reshape(4, -1)
+    p, q, r, w = _inv_sqrt_2x2(a, b, d)
+    out = {}
+    if weight is not None:
+        zu = cu * p.reshape(shp) + cv * r.reshape(shp)
+        zv = cu * q.reshape(shp) + cv * w.reshape(shp)
+        out["dweight"] = np.stack([(gr * zu).sum(ax), (gr * zv).sum(ax),
+                                   (gi * zu).sum(ax), (gi * zv).sum(ax)]
+                                  ).reshape(2, 2, -1)
+        out["dbias"] = np.stack([gr.sum(ax), gi.sum(ax)])
+        W = weight.reshape(2, 2, *shp)
+        gzu = gr * W[0, 0] + gi * W[1, 0]
+        gzv = gr * W[0, 1] + gi * W[1, 1]
+    else:
+        gzu, gzv = gr, gi
+    P, Q, R, Wd = (v.reshape(shp) for v in (p, q, r, w))
+    if not training:
+        out["dxr"], out["dxi"] = gzu * P + gzv * Q, gzu * R + gzv * Wd
+        return out
+    # sums that drive the gradient wrt the whitening matrix
+    gp, gr_ = (gzu * cu).sum(ax), (gzu * cv).sum(ax)
+    gq, gw = (gzv * cu).sum(ax), (gzv * cv).sum(ax)
+    gqr = gq + gr_
+    s = np.sqrt(a * d - b * b)
+    tau = a + d + 2 * s
+    rt = np.sqrt(tau)
+    t = s * rt
+    ds = dict(a=d / (2 * s), d=a / (2 * s), b=-b / s)
+    gcov = {}
+    for X in "adb":
+        dtau = (0.0 if X == "b" else 1.0) + 2 * ds[X]
+        dt_ = ds[X] * rt + s * dtau / (2 * rt)
+        dp = (((1.0 if X == "d" else 0.0) + ds[X]) * t - (d + s) * dt_) / (t * t)
+        dw = (((1.0 if X == "a" else 0.0) + ds[X]) * t - (a + s) * dt_) / (t * t)
+        dq = (-(1.0 if X == "b" else 0.0) * t + b * dt_) / (t * t)
+        gcov[X] = gp * dp + gw * dw + gqr * dq
+    gA, gD, gB = (gcov[k].reshape(shp) for k in "adb")
+    sgu, sgv = gzu.sum(ax).reshape(shp), gzv.sum(ax).reshape(shp)
+    out["dxr"] = (gzu * P + gzv * Q + (2 * gA / N) * cu + (gB / N) * cv
+                  - (P * sgu + Q * sgv) / N)
+    out["dxi"] = (gzu * R + gzv * Wd + (2 * gD / N) * cv + (gB / N) * cu
+                  - (R * sgu + Wd * sgv) / N)
+    return out

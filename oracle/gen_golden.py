@@ -1,0 +1,405 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference).
+
+Run in the build container only (the reference does not travel to the GPU
+box):  ``python oracle/gen_golden.py``.  Every fixture holds seeded inputs
+and the outputs / autograd gradients the reference produced for them, in
+float32 and float64.  Fixtures are data only.
+
+TEST INFRASTRUCTURE: never imported by the product package.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    # cplxmodule/__init__.py:2 imports a setup.py-generated __version__ module
+    sys.path.insert(0, REF)
+    m = types.ModuleType("cplxmodule.__version__")
+    m.__version__ = open(os.path.join(REF, "VERSION")).read().strip()
+    sys.modules["cplxmodule.__version__"] = m
+    import cplxmodule  # noqa: F401
+    return cplxmodule
+
+
+cm = import_reference()
+from cplxmodule import cplx  # noqa: E402
+from cplxmodule.nn import CplxLinear, CplxConv2d, CplxBatchNorm1d, CplxBatchNorm2d  # noqa: E402
+from cplxmodule.nn.modules.batchnorm import cplx_batch_norm  # noqa: E402
+from cplxmodule.nn import relevance as rel  # noqa: E402
+from cplxmodule.nn.relevance.complex import torch_expi  # noqa: E402
+
+DT = {"f32": torch.float32, "f64": torch.float64}
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def C(re, im):
+    return cplx.Cplx(re, im)
+
+
+def leaf(*shape, dtype, scale=1.0):
+    return (torch.randn(*shape, dtype=dtype) * scale).requires_grad_(True)
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: {len(d)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------- #
+def gen_linear():
+    d = {}
+    for tag, dt in DT.items():
+        for case, (lead, I, O) in {"a": ((5, 5), 200, 321), "b": ((64,), 128, 128),
+                                   "c": ((7,), 33, 19)}.items():
+            torch.manual_seed(11)
+            xr, xi = leaf(*lead, I, dtype=dt), leaf(*lead, I, dtype=dt)
+            wr, wi = leaf(O, I, dtype=dt, scale=0.1), leaf(O, I, dtype=dt, scale=0.1)
+            br, bi = leaf(O, dtype=dt), leaf(O, dtype=dt)
+            gr, gi = torch.randn(*lead, O, dtype=dt), torch.randn(*lead, O, dtype=dt)
+            k = f"{tag}_{case}_"
+            for nm, t in dict(xr=xr, xi=xi, wr=wr, wi=wi, br=br, bi=bi, gr=gr, gi=gi).items():
+                d[k + nm] = npy(t)
+            for algo in ("naive", "3m", "cat"):
+                y = getattr(cplx, "linear_" + algo)(C(xr, xi), C(wr, wi), C(br, bi))
+                d[k + f"y_{algo}_r"], d[k + f"y_{algo}_i"] = npy(y.real), npy(y.imag)
+            y = cplx.linear(C(xr, xi), C(wr, wi), C(br, bi))
+            grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(),
+                                        [xr, xi, wr, wi, br, bi])
+            for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi"], grads):
+                d[k + nm] = npy(g)
+            y = cplx.linear(C(xr, xi), C(wr, wi), None)
+            d[k + "y_nobias_r"], d[k + "y_nobias_i"] = npy(y.real), npy(y.imag)
+        # Cplx.__matmul__ (batched)
+        torch.manual_seed(12)
+        ur, ui = torch.randn(3, 9, 17, dtype=dt), torch.randn(3, 9, 17, dtype=dt)
+        vr, vi = torch.randn(3, 17, 6, dtype=dt), torch.randn(3, 17, 6, dtype=dt)
+        m = C(ur, ui) @ C(vr, vi)
+        for nm, t in dict(ur=ur, ui=ui, vr=vr, vi=vi, mr=m.real, mi=m.imag).items():
+            d[f"{tag}_mm_{nm}"] = npy(t)
+    save("linear", d)
+
+
+def _mixed_vd_params(O, I, dt, cplx_w=True):
+    wr = torch.empty(O, I, dtype=dt).uniform_(-0.09, 0.09)
+    wi = torch.empty(O, I, dtype=dt).uniform_(-0.09, 0.09)
+    ls2 = torch.empty(O, I, dtype=dt).uniform_(-12, 4)
+    # special values: exact zeros, tiny weights, huge/small variances
+    wr.view(-1)[:3] = 0.0
+    wi.view(-1)[:2] = 0.0
+    wr.view(-1)[5], wi.view(-1)[5] = 1e-20, 0.0
+    wr.view(-1)[6], wi.view(-1)[6] = 3e-7, -2e-7
+    ls2.view(-1)[7], ls2.view(-1)[8], ls2.view(-1)[9] = -30.0, 9.0, -10.0
+    return wr, wi, ls2
+
+
+def gen_lrt_linear():
+    d = {}
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        B, I, O = 64, 128, 128
+        # complex VD, training mode
+        torch.manual_seed(21)
+        layer = rel.CplxLinearVD(I, O, bias=True)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        x = cplx.randn(B, I)
+        xr, xi = x.real.clone().requires_grad_(True), x.imag.clone().requires_grad_(True)
+        gr, gi = torch.randn(B, O), torch.randn(B, O)
+        layer.train()
+        torch.manual_seed(77)
+        y = layer(C(xr, xi))
+        torch.manual_seed(77)
+        tape = torch.randn(2, B, O)
+        ps = [xr, xi, layer.weight.real, layer.weight.imag, layer.bias.real,
+              layer.bias.imag, layer.log_sigma2]
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), ps)
+        k = f"{tag}_cplx_"
+        for nm, t in dict(xr=xr, xi=xi, wr=ps[2], wi=ps[3], br=ps[4], bi=ps[5],
+                          ls2=ps[6], gr=gr, gi=gi, tape=tape, yr=y.real, yi=y.imag).items():
+            d[k + nm] = npy(t)
+        for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi", "dls2"], grads):
+            d[k + nm] = npy(g)
+        layer.eval()
+        y = layer(C(xr, xi))
+        d[k + "yr_eval"], d[k + "yi_eval"] = npy(y.real), npy(y.imag)
+        # clamp boundary: tiny activations so that s2 < 1e-8 for some rows
+        xs = C(xr.detach() * 1e-3, xi.detach() * 1e-3)
+        xs_r, xs_i = xs.real.clone().requires_grad_(True), xs.imag.clone().requires_grad_(True)
+        with torch.no_grad():
+            layer.log_sigma2.fill_(-9.0)
+            layer.log_sigma2[: O // 2] = -13.5
+        layer.train()
+        torch.manual_seed(78)
+        y = layer(C(xs_r, xs_i))
+        torch.manual_seed(78)
+        tape2 = torch.randn(2, B, O)
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(),
+                                    [xs_r, xs_i, layer.log_sigma2])
+        d[k + "clamp_ls2"] = npy(layer.log_sigma2)
+        for nm, t in dict(clamp_xr=xs_r, clamp_xi=xs_i, clamp_tape=tape2, clamp_yr=y.real,
+                          clamp_yi=y.imag, clamp_dxr=grads[0], clamp_dxi=grads[1],
+                          clamp_dls2=grads[2]).items():
+            d[k + nm] = npy(t)
+
+        # real VD, training mode
+        torch.manual_seed(22)
+        layer = rel.LinearVD(I, O, bias=True)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        x = torch.randn(B, I).requires_grad_(True)
+        g = torch.randn(B, O)
+        layer.train()
+        torch.manual_seed(79)
+        y = layer(x)
+        torch.manual_seed(79)
+        eps = torch.randn(B, O)
+        grads = torch.autograd.grad((y * g).sum(), [x, layer.weight, layer.bias, layer.log_sigma2])
+        k = f"{tag}_real_"
+        for nm, t in dict(x=x, w=layer.weight, b=layer.bias, ls2=layer.log_sigma2, g=g,
+                          eps=eps, y=y, dx=grads[0], dw=grads[1], db=grads[2],
+                          dls2=grads[3]).items():
+            d[k + nm] = npy(t)
+    torch.set_default_dtype(torch.float32)
+    save("lrt_linear", d)
+
+
+def gen_penalty():
+    d = {}
+    kinds = {"real_vd": rel.LinearVD, "real_ard": rel.LinearARD,
+             "cplx_vd": rel.CplxLinearVD, "cplx_ard": rel.CplxLinearARD}
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        O, I = 48, 40
+        torch.manual_seed(31)
+        wr, wi, ls2 = _mixed_vd_params(O, I, dt)
+        g = torch.rand(O, I)
+        k = f"{tag}_"
+        for nm, t in dict(wr=wr, wi=wi, ls2=ls2, g=g).items():
+            d[k + nm] = npy(t)
+        for kind, cls in kinds.items():
+            layer = cls(I, O, bias=False)
+            with torch.no_grad():
+                layer.log_sigma2.copy_(ls2)
+                if kind.startswith("cplx"):
+                    layer.weight.real.copy_(wr)
+                    layer.weight.imag.copy_(wi)
+                    wps = [layer.weight.real, layer.weight.imag]
+                else:
+                    layer.weight.copy_(wr)
+                    wps = [layer.weight]
+            pen = layer.penalty
+            d[k + kind + "_log_alpha"] = npy(layer.log_alpha)
+            d[k + kind + "_penalty"] = npy(pen)
+            d[k + kind + "_sum"] = npy(sum(rel.penalties(layer, reduction="sum")))
+            d[k + kind + "_mean"] = npy(sum(rel.penalties(layer, reduction="mean")))
+            grads = torch.autograd.grad((pen * g).sum(), [layer.log_sigma2] + wps)
+            d[k + kind + "_dls2"] = npy(grads[0])
+            d[k + kind + "_dwr"] = npy(grads[1])
+            if len(grads) > 2:
+                d[k + kind + "_dwi"] = npy(grads[2])
+            gs = torch.autograd.grad(layer.penalty.sum(), [layer.log_sigma2] + wps)
+            d[k + kind + "_sum_dls2"] = npy(gs[0])
+            d[k + kind + "_sum_dwr"] = npy(gs[1])
+            if len(gs) > 2:
+                d[k + kind + "_sum_dwi"] = npy(gs[2])
+            for th in (-0.5, 1.0, 3.0):
+                m = layer.relevance(threshold=th)
+                d[k + kind + f"_mask_{th}"] = npy(m)
+                la = layer.log_alpha.detach()
+                # near-threshold census: elements within 4 ulp of the threshold
+                ulp = torch.abs(la) * torch.finfo(dt).eps
+                d[k + kind + f"_near_{th}"] = np.array(int((torch.abs(la - th) < 4 * ulp).sum()))
+            masks = rel.compute_ard_masks(layer, hard=False, threshold=1.0)
+            assert list(masks) == ["mask"]
+        # expi primitive on a grid (both signs) + the reference's backward
+        x = torch.cat([-torch.logspace(-8, 3, 300), torch.logspace(-8, 1.5, 100),
+                       torch.randn(200)]).to(dt).requires_grad_(True)
+        y = torch_expi(x)
+        gx, = torch.autograd.grad(y.sum(), x)
+        d[k + "expi_x"], d[k + "expi_y"], d[k + "expi_dx"] = npy(x), npy(y), npy(gx)
+    torch.set_default_dtype(torch.float32)
+    save("penalty", d)
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_golden_cases import CONV_CASES  # noqa: E402
+
+
+def gen_conv():
+    d = {}
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        for name, (B, Ci, Co, H, W, ks, st, pd, dl, gp, mode) in CONV_CASES.items():
+            torch.manual_seed(41)
+            layer = CplxConv2d(Ci, Co, ks, stride=st, padding=pd, dilation=dl,
+                               groups=gp, bias=True, padding_mode=mode)
+            x = cplx.randn(B, Ci, H, W)
+            xr, xi = x.real.clone().requires_grad_(True), x.imag.clone().requires_grad_(True)
+            y = layer(C(xr, xi))
+            gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+            ps = [xr, xi, layer.weight.real, layer.weight.imag, layer.bias.real, layer.bias.imag]
+            grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), ps)
+            k = f"{tag}_{name}_"
+            for nm, t in dict(xr=xr, xi=xi, wr=ps[2], wi=ps[3], br=ps[4], bi=ps[5], gr=gr,
+                              gi=gi, yr=y.real, yi=y.imag).items():
+                d[k + nm] = npy(t)
+            for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi"], grads):
+                d[k + nm] = npy(g)
+        # LRT complex conv (training) and real conv VD
+        torch.manual_seed(42)
+        layer = rel.CplxConv2dVD(3, 4, 3, stride=1, padding=1)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        x = cplx.randn(2, 3, 8, 7)
+        xr, xi = x.real.clone().requires_grad_(True), x.imag.clone().requires_grad_(True)
+        layer.train()
+        torch.manual_seed(91)
+        y = layer(C(xr, xi))
+        torch.manual_seed(91)
+        tape = torch.randn(2, *y.real.shape)
+        gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+        ps = [xr, xi, layer.weight.real, layer.weight.imag, layer.bias.real,
+              layer.bias.imag, layer.log_sigma2]
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), ps)
+        k = f"{tag}_lrtc_"
+        for nm, t in dict(xr=xr, xi=xi, wr=ps[2], wi=ps[3], br=ps[4], bi=ps[5], ls2=ps[6],
+                          gr=gr, gi=gi, tape=tape, yr=y.real, yi=y.imag).items():
+            d[k + nm] = npy(t)
+        for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi", "dls2"], grads):
+            d[k + nm] = npy(g)
+        d[k + "penalty_sum"] = npy(sum(rel.penalties(layer)))
+
+        torch.manual_seed(43)
+        layer = rel.Conv2dVD(3, 4, 3, stride=2, padding=1)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        x = torch.randn(2, 3, 9, 8).requires_grad_(True)
+        layer.train()
+        torch.manual_seed(92)
+        y = layer(x)
+        torch.manual_seed(92)
+        eps = torch.randn(*y.shape)
+        g = torch.randn_like(y)
+        grads = torch.autograd.grad((y * g).sum(), [x, layer.weight, layer.bias, layer.log_sigma2])
+        k = f"{tag}_lrtr_"
+        for nm, t in dict(x=x, w=layer.weight, b=layer.bias, ls2=layer.log_sigma2, g=g,
+                          eps=eps, y=y, dx=grads[0], dw=grads[1], db=grads[2],
+                          dls2=grads[3]).items():
+            d[k + nm] = npy(t)
+    torch.set_default_dtype(torch.float32)
+    save("conv", d)
+
+
+def gen_batchnorm():
+    d = {}
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        for name, shape, cls in (("2d", (6, 5, 7, 4), CplxBatchNorm2d),
+                                 ("1d", (16, 9), CplxBatchNorm1d),
+                                 ("1d3", (4, 3, 10), CplxBatchNorm1d)):
+            torch.manual_seed(51)
+            F_ = shape[1]
+            bn = cls(F_, eps=1e-5, momentum=0.1, affine=True)
+            with torch.no_grad():
+                bn.weight.add_(0.3 * torch.randn(2, 2, F_))
+                bn.bias.add_(0.3 * torch.randn(2, F_))
+            k = f"{tag}_{name}_"
+            d[k + "weight"], d[k + "bias"] = npy(bn.weight), npy(bn.bias)
+            bn.train()
+            for step in range(3):
+                base = torch.randn(*shape)
+                xr = (1.5 * base + 0.4 * torch.randn(*shape) + 0.7).requires_grad_(True)
+                xi = (0.8 * base - 0.5 * torch.randn(*shape) - 0.2).requires_grad_(True)
+                y = bn(C(xr, xi))
+                gr, gi = torch.randn_like(xr), torch.randn_like(xi)
+                grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(),
+                                            [xr, xi, bn.weight, bn.bias])
+                s = k + f"s{step}_"
+                for nm, t in dict(xr=xr, xi=xi, yr=y.real, yi=y.imag, gr=gr, gi=gi,
+                                  dxr=grads[0], dxi=grads[1], dweight=grads[2], dbias=grads[3],
+                                  running_mean=bn.running_mean, running_var=bn.running_var,
+                                  nbt=bn.num_batches_tracked).items():
+                    d[s + nm] = npy(t)
+            bn.eval()
+            y = bn(C(xr, xi))
+            grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(),
+                                        [xr, xi, bn.weight, bn.bias])
+            for nm, t in dict(yr=y.real, yi=y.imag, dxr=grads[0], dxi=grads[1],
+                              dweight=grads[2], dbias=grads[3]).items():
+                d[k + "eval_" + nm] = npy(t)
+        # functional form: no affine, no running stats; cumulative momentum
+        torch.manual_seed(52)
+        xr = torch.randn(8, 3, 5).requires_grad_(True)
+        xi = (0.5 * xr.detach() + torch.randn(8, 3, 5)).requires_grad_(True)
+        y = cplx_batch_norm(C(xr, xi), None, None, None, None, True, 0.1, 1e-3)
+        gr, gi = torch.randn_like(xr), torch.randn_like(xi)
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), [xr, xi])
+        for nm, t in dict(xr=xr, xi=xi, yr=y.real, yi=y.imag, gr=gr, gi=gi, dxr=grads[0],
+                          dxi=grads[1]).items():
+            d[f"{tag}_func_{nm}"] = npy(t)
+        bn = CplxBatchNorm1d(3, momentum=None, affine=False)
+        bn.train()
+        for step in range(2):
+            y = bn(C(xr.detach() + step, xi.detach() * (1 + step)))
+        d[f"{tag}_cma_running_mean"] = npy(bn.running_mean)
+        d[f"{tag}_cma_running_var"] = npy(bn.running_var)
+        d[f"{tag}_cma_yr"], d[f"{tag}_cma_yi"] = npy(y.real), npy(y.imag)
+    torch.set_default_dtype(torch.float32)
+    save("batchnorm", d)
+
+
+def gen_api():
+    """Host-side contract: state-dict keys/shapes, init bounds, walker names."""
+    d = {}
+    torch.manual_seed(61)
+    layers = {
+        "CplxLinear": CplxLinear(100, 400),
+        "CplxLinearVD": rel.CplxLinearVD(12, 7),
+        "CplxLinearARD": rel.CplxLinearARD(12, 7, bias=False),
+        "LinearVD": rel.LinearVD(12, 7),
+        "LinearARD": rel.LinearARD(12, 7),
+        "CplxConv2d": CplxConv2d(6, 4, (3, 2), groups=2),
+        "CplxConv2dVD": rel.CplxConv2dVD(6, 4, 3),
+        "Conv2dARD": rel.Conv2dARD(6, 4, 3),
+        "CplxBatchNorm2d": CplxBatchNorm2d(5),
+    }
+    for name, layer in layers.items():
+        sd = layer.state_dict()
+        d[name + "__keys"] = np.array(list(sd.keys()))
+        d[name + "__shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        d[name + "__params"] = np.array([n for n, _ in layer.named_parameters()])
+    lin = layers["CplxLinear"]
+    d["CplxLinear__wmax"] = np.array(float(max(lin.weight.real.abs().max(), lin.weight.imag.abs().max())))
+    d["CplxLinear__bmax"] = np.array(float(max(lin.bias.real.abs().max(), lin.bias.imag.abs().max())))
+    cv = layers["CplxConv2d"]
+    d["CplxConv2d__wmax"] = np.array(float(max(cv.weight.real.abs().max(), cv.weight.imag.abs().max())))
+    d["CplxConv2d__bmax"] = np.array(float(max(cv.bias.real.abs().max(), cv.bias.imag.abs().max())))
+    d["CplxLinearVD__ls2"] = npy(layers["CplxLinearVD"].log_sigma2)
+    # walker names on a nested model
+    model = torch.nn.Sequential(rel.CplxLinearVD(4, 5), torch.nn.Sequential(rel.CplxLinearARD(5, 3)))
+    d["walk__penalty_names"] = np.array([n for n, _ in rel.named_penalties(model)])
+    d["walk__mask_names"] = np.array(list(rel.compute_ard_masks(model, threshold=1.0)))
+    d["walk__mask_names_prefix"] = np.array(list(rel.compute_ard_masks(model, prefix="net", threshold=1.0)))
+    save("api", d)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)  # reproducible summation order
+    gen_linear()
+    gen_lrt_linear()
+    gen_penalty()
+    gen_conv()
+    gen_batchnorm()
+    gen_api()

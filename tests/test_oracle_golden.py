@@ -1,0 +1,217 @@
+"""The numpy oracle (oracle/cplx_oracle.py) against outputs of the REAL
+reference stored in tests/golden/ (made by oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import TOL
+from oracle import cplx_oracle as orc
+from oracle.gen_golden_cases import CONV_CASES
+
+TAGS = ("f32", "f64")
+
+
+def close(a, b, tag, scale=1.0):
+    t = TOL[tag]
+    np.testing.assert_allclose(a, b, rtol=t["rtol"] * scale, atol=t["atol"] * scale)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("case", "abc")
+def test_linear(golden, tag, case):
+    g = golden("linear")
+    k = f"{tag}_{case}_"
+    a = [g[k + n] for n in ("xr", "xi", "wr", "wi", "br", "bi")]
+    for algo, ref in (("4m", "naive"), ("3m", "3m"), ("cat", "cat")):
+        yr, yi = orc.cplx_linear(*a, algo=algo)
+        close(yr, g[k + f"y_{ref}_r"], tag, 10)
+        close(yi, g[k + f"y_{ref}_i"], tag, 10)
+    yr, yi = orc.cplx_linear(*a[:4])
+    close(yr, g[k + "y_nobias_r"], tag, 10)
+    bw = orc.cplx_linear_bwd(g[k + "gr"], g[k + "gi"], *a[:4])
+    for n in ("dxr", "dxi", "dwr", "dwi", "dbr", "dbi"):
+        close(bw[n], g[k + n], tag, 30)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_matmul(golden, tag):
+    g = golden("linear")
+    k = f"{tag}_mm_"
+    mr, mi = orc.cplx_matmul(g[k + "ur"], g[k + "ui"], g[k + "vr"], g[k + "vi"])
+    close(mr, g[k + "mr"], tag, 10)
+    close(mi, g[k + "mi"], tag, 10)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_lrt_cplx_linear(golden, tag):
+    g = golden("lrt_linear")
+    k = f"{tag}_cplx_"
+    er, ei = orc.cplx_randn_from_tape(g[k + "tape"])
+    a = [g[k + n] for n in ("xr", "xi", "wr", "wi", "br", "bi", "ls2")]
+    yr, yi, _ = orc.lrt_cplx_linear(*a, er, ei)
+    close(yr, g[k + "yr"], tag, 10)
+    close(yi, g[k + "yi"], tag, 10)
+    mur, mui = orc.cplx_linear(*a[:6])
+    close(mur, g[k + "yr_eval"], tag, 10)
+    bw = orc.lrt_cplx_linear_bwd(g[k + "gr"], g[k + "gi"], *a[:4], a[6], er, ei)
+    for n, m in (("dxr", "dxr"), ("dxi", "dxi"), ("dwr", "dwr"), ("dwi", "dwi"),
+                 ("dbr", "dbr"), ("dbi", "dbi"), ("dlog_sigma2", "dls2")):
+        close(bw[n], g[k + m], tag, 100)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_lrt_clamp_boundary(golden, tag):
+    g = golden("lrt_linear")
+    k = f"{tag}_cplx_"
+    er, ei = orc.cplx_randn_from_tape(g[k + "clamp_tape"])
+    a = [g[k + n] for n in ("clamp_xr", "clamp_xi", "wr", "wi", "br", "bi", "clamp_ls2")]
+    yr, yi, aux = orc.lrt_cplx_linear(*a, er, ei)
+    assert (aux["s2"] < 1e-8).any() and (aux["s2"] > 1e-8).any()
+    close(yr, g[k + "clamp_yr"], tag, 10)
+    bw = orc.lrt_cplx_linear_bwd(g[k + "gr"], g[k + "gi"], *a[:4], a[6], er, ei)
+    close(bw["dlog_sigma2"], g[k + "clamp_dls2"], tag, 100)
+    close(bw["dxr"], g[k + "clamp_dxr"], tag, 100)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_lrt_real_linear(golden, tag):
+    g = golden("lrt_linear")
+    k = f"{tag}_real_"
+    y, _ = orc.lrt_real_linear(g[k + "x"], g[k + "w"], g[k + "b"], g[k + "ls2"], g[k + "eps"])
+    close(y, g[k + "y"], tag, 10)
+    bw = orc.lrt_real_linear_bwd(g[k + "g"], g[k + "x"], g[k + "w"], g[k + "ls2"], g[k + "eps"])
+    for n, m in (("dx", "dx"), ("dw", "dw"), ("db", "db"), ("dlog_sigma2", "dls2")):
+        close(bw[n], g[k + m], tag, 100)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("kind", orc.KINDS)
+def test_penalty(golden, tag, kind):
+    g = golden("penalty")
+    k = f"{tag}_"
+    wr, ls2 = g[k + "wr"], g[k + "ls2"]
+    wi = g[k + "wi"] if kind.startswith("cplx") else None
+    la = orc.log_alpha(ls2, wr, wi)
+    fin = np.isfinite(g[k + kind + "_log_alpha"])
+    np.testing.assert_array_equal(np.isfinite(la), fin)
+    close(la[fin], g[k + kind + "_log_alpha"][fin], tag)
+    pen = orc.penalty(kind, ls2, wr, wi)
+    ref = g[k + kind + "_penalty"]
+    fin = np.isfinite(ref)
+    close(pen[fin], ref[fin], tag, 4)
+    close(pen[fin].sum(), ref[fin].sum(), tag, 4)
+    bw = orc.penalty_bwd(kind, g[k + "g"], ls2, wr, wi)
+    # The reference forms f'(t) by autograd as a sum of O(1) terms (e.g.
+    # 1 - exp(-e^t)), so its f' carries an ABSOLUTE error of a few ulp(1); the
+    # weight gradient multiplies that by amp = 2|w| / (theta (theta + 1e-12)),
+    # which is huge for tiny weights.  The oracle evaluates f' without the
+    # cancellation, hence the amplification-aware tolerance.
+    eps = np.finfo(ls2.dtype).eps
+    theta = np.abs(wr) if wi is None else orc.cplx_abs(wr, wi)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        amp = np.where(theta > 0, 2 / (theta + 1e-12), 0)
+    rt = 2e-5 if tag == "f32" else 1e-10
+    for n, m, a in (("dlog_sigma2", "dls2", 1.0), ("dwr", "dwr", amp), ("dwi", "dwi", amp)):
+        if n in bw:
+            r = g[k + kind + "_" + m]
+            ok = np.isfinite(r)
+            err = np.abs(bw[n] - r)
+            bound = rt * np.abs(r) + 8 * eps * np.maximum(a, 1.0)
+            assert (err[ok] <= bound[ok] if np.ndim(bound) else err[ok] <= bound).all(), (n, err[ok].max())
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("kind", orc.KINDS)
+@pytest.mark.parametrize("th", (-0.5, 1.0, 3.0))
+def test_masks_bit_exact(golden, tag, kind, th):
+    g = golden("penalty")
+    k = f"{tag}_"
+    wi = g[k + "wi"] if kind.startswith("cplx") else None
+    m = orc.relevance_mask(th, g[k + "ls2"], g[k + "wr"], wi)
+    assert int(g[k + kind + f"_near_{th}"]) == 0
+    np.testing.assert_array_equal(m, g[k + kind + f"_mask_{th}"])
+    assert 0 < m.sum() < m.size
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_expi(golden, tag):
+    g = golden("penalty")
+    x = g[f"{tag}_expi_x"]
+    close(orc.expi(x), g[f"{tag}_expi_y"], tag)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("case", list(CONV_CASES))
+def test_conv2d(golden, tag, case):
+    g = golden("conv")
+    B, Ci, Co, H, W, ks, st, pd, dl, gp, mode = CONV_CASES[case]
+    k = f"{tag}_{case}_"
+    a = [g[k + n] for n in ("xr", "xi", "wr", "wi", "br", "bi")]
+    yr, yi = orc.cplx_conv2d(*a, stride=st, padding=pd, dilation=dl, groups=gp, padding_mode=mode)
+    close(yr, g[k + "yr"], tag, 10)
+    close(yi, g[k + "yi"], tag, 10)
+    if mode == "zeros":
+        bw = orc.cplx_conv2d_bwd(g[k + "gr"], g[k + "gi"], *a[:4], stride=st, padding=pd,
+                                 dilation=dl, groups=gp)
+        for n in ("dxr", "dxi", "dwr", "dwi", "dbr", "dbi"):
+            close(bw[n], g[k + n], tag, 50)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_lrt_conv(golden, tag):
+    g = golden("conv")
+    k = f"{tag}_lrtc_"
+    er, ei = orc.cplx_randn_from_tape(g[k + "tape"])
+    a = [g[k + n] for n in ("xr", "xi", "wr", "wi", "br", "bi", "ls2")]
+    yr, yi, _ = orc.lrt_cplx_conv2d(*a, er, ei, stride=1, padding=1)
+    close(yr, g[k + "yr"], tag, 10)
+    close(yi, g[k + "yi"], tag, 10)
+    bw = orc.lrt_cplx_conv2d_bwd(g[k + "gr"], g[k + "gi"], *a[:4], a[6], er, ei, stride=1, padding=1)
+    for n, m in (("dxr", "dxr"), ("dxi", "dxi"), ("dwr", "dwr"), ("dwi", "dwi"),
+                 ("dbr", "dbr"), ("dlog_sigma2", "dls2")):
+        close(bw[n], g[k + m], tag, 100)
+    close(orc.penalty("cplx_vd", a[6], a[2], a[3]).sum(), g[k + "penalty_sum"], tag, 10)
+    k = f"{tag}_lrtr_"
+    y, _ = orc.lrt_real_conv2d(g[k + "x"], g[k + "w"], g[k + "b"], g[k + "ls2"], g[k + "eps"],
+                               stride=2, padding=1)
+    close(y, g[k + "y"], tag, 10)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("name", ("2d", "1d", "1d3"))
+def test_batchnorm(golden, tag, name):
+    g = golden("batchnorm")
+    k = f"{tag}_{name}_"
+    W, b = g[k + "weight"], g[k + "bias"]
+    F_ = W.shape[-1]
+    rm = np.zeros((2, F_), W.dtype)
+    rv = np.stack([np.ones(F_), np.zeros(F_), np.zeros(F_), np.ones(F_)]).reshape(2, 2, F_).astype(W.dtype)
+    sc = 200 if tag == "f32" else 1e4
+    for step in range(3):
+        s = k + f"s{step}_"
+        yr, yi = orc.cplx_batch_norm(g[s + "xr"], g[s + "xi"], rm, rv, W, b, True, 0.1, 1e-5)
+        close(yr, g[s + "yr"], tag, sc)
+        close(yi, g[s + "yi"], tag, sc)
+        close(rm, g[s + "running_mean"], tag, 10)
+        close(rv, g[s + "running_var"], tag, 10)
+        bw = orc.cplx_batch_norm_bwd(g[s + "gr"], g[s + "gi"], g[s + "xr"], g[s + "xi"], None, None,
+                                     W, True, 1e-5)
+        for n in ("dxr", "dxi", "dweight", "dbias"):
+            close(bw[n], g[s + n], tag, sc)
+    yr, yi = orc.cplx_batch_norm(g[s + "xr"], g[s + "xi"], rm, rv, W, b, False, 0.1, 1e-5)
+    close(yr, g[k + "eval_yr"], tag, sc)
+    bw = orc.cplx_batch_norm_bwd(g[s + "gr"], g[s + "gi"], g[s + "xr"], g[s + "xi"], rm, rv, W,
+                                 False, 1e-5)
+    for n in ("dxr", "dxi", "dweight", "dbias"):
+        close(bw[n], g[k + "eval_" + n], tag, sc)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_batchnorm_functional(golden, tag):
+    g = golden("batchnorm")
+    k = f"{tag}_func_"
+    yr, yi = orc.cplx_batch_norm(g[k + "xr"], g[k + "xi"], None, None, None, None, True, 0.1, 1e-3)
+    close(yr, g[k + "yr"], tag, 100)
+    bw = orc.cplx_batch_norm_bwd(g[k + "gr"], g[k + "gi"], g[k + "xr"], g[k + "xi"], None, None,
+                                 None, True, 1e-3)
+    close(bw["dxr"], g[k + "dxr"], tag, 100)
+    close(bw["dxi"], g[k + "dxi"], tag, 100)
