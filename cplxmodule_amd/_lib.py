@@ -1,0 +1,124 @@
+"""ctypes binding of libcplxamd.so (the C ABI declared in include/cplxamd.h).
+
+The library is the product: there is NO fallback.  If it is missing, was built for another
+ABI version, or a kernel is asked to run on a non-HIP tensor, this module raises.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcplxamd.so")
+ABI_VERSION = 1
+
+F32, BF16 = 0, 1
+KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3}
+
+_P, _I, _L, _U, _F = c_void_p, c_int, c_int64, c_uint64, c_float
+
+# name -> argtypes; restype is int unless listed in _RESTYPES
+SIGNATURES = {
+    "cplxamd_abi_version": [],
+    "cplxamd_vd_kl_ws_bytes": [],
+    "cplxamd_vd_kl_fwd": [_P, _P, _P, _I, _P, _P, _P, _L, _P],
+    "cplxamd_vd_kl_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P],
+    "cplxamd_vd_kl_fwd_bwd": [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _L, _P],
+    "cplxamd_vd_log_alpha": [_P, _P, _P, _P, _L, _P],
+    "cplxamd_vd_mask": [_P, _P, _P, _F, _P, _P, _P, _L, _P],
+    "cplxamd_expi_fwd": [_P, _P, _L, _P],
+    "cplxamd_expi_bwd": [_P, _P, _P, _L, _P],
+    "cplxamd_lrt_reparam_fwd": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _P],
+    "cplxamd_lrt_reparam_bwd": [_P, _P, _P, _P, _P, _U, _U, _P, _L, _I, _I, _P],
+    "cplxamd_philox_normal": [_P, _P, _U, _U, _L, _P],
+    "cplxamd_cgemm": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,
+                      _I, _I, _I, _P],
+    "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "cplxamd_abs2": [_P, _P, _P, _L, _I, _I, _P],
+    "cplxamd_modulus": [_P, _P, _P, _L, _P],
+    "cplxamd_exp": [_P, _P, _L, _I, _P],
+    "cplxamd_cast": [_P, _P, _L, _I, _I, _P],
+    "cplxamd_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
+    "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P],
+    "cplxamd_lrt_dx_accum": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+}
+_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64}
+
+_lib = None
+
+
+class CplxAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises CplxAmdError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CplxAmdError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or cplxmodule_amd/csrc/build.sh).  cplxmodule_amd has no CPU or "
+            "pure-torch fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise CplxAmdError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CplxAmdError(f"{LIB_PATH} does not export `{name}` (stale build?)") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    if lib.cplxamd_abi_version() != ABI_VERSION:
+        raise CplxAmdError("libcplxamd.so ABI version mismatch: rebuild the library")
+    _lib = lib
+    return lib
+
+
+_ERRORS = {-1: "invalid argument", -2: "misaligned pointer / leading dimension",
+           -3: "unsupported shape", -4: "workspace too small"}
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero return codes become exceptions."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        what = _ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise CplxAmdError(f"{name} failed: {what}")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise CplxAmdError(f"unsupported dtype {t.dtype}: the kernels take float32 and bfloat16")
+
+
+def require_device(*tensors):
+    """Every kernel argument must live on one HIP device; anything else is an error."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise CplxAmdError(
+                "cplxmodule_amd runs on MI355X only: got a tensor on "
+                f"'{t.device}'.  Move the module and its inputs to 'cuda' (there is no CPU path).")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise CplxAmdError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev

@@ -1,0 +1,368 @@
+"""Planar complex tensors and the functional complex algebra of the hot path.
+
+`Cplx` keeps the reference's contract (cplxmodule/cplx.py:10-376): a light container over two
+real tensors of identical shape which are never copied on construction.  The GEMM-shaped
+functions (`linear`, `conv2d`, `@`) and `abs` run on the HIP kernels of libcplxamd.so; cheap
+pointwise arithmetic and views stay as torch plumbing on the two planes.
+"""
+import math
+from copy import deepcopy
+
+import torch
+
+from . import ops
+from ._lib import CplxAmdError
+
+
+class Cplx:
+    """Complex tensor in split (real, imag) layout."""
+
+    __slots__ = ("_re", "_im")
+
+    def __new__(cls, real, imag=None):
+        if isinstance(real, cls):
+            return real
+        if isinstance(real, complex):
+            real, imag = torch.tensor(real.real), torch.tensor(real.imag)
+        elif isinstance(real, float):
+            if imag is None:
+                imag = 0.0
+            elif not isinstance(imag, float):
+                raise TypeError("Imaginary part must be float.")
+            real, imag = torch.tensor(real), torch.tensor(imag)
+        elif not isinstance(real, torch.Tensor):
+            raise TypeError("Real part must be torch.Tensor.")
+        if imag is None:
+            imag = torch.zeros_like(real)
+        elif not isinstance(imag, torch.Tensor):
+            raise TypeError("Imaginary part must be torch.Tensor.")
+        if real.shape != imag.shape:
+            raise ValueError("Real and imaginary parts have mistmatching shape.")
+        obj = super().__new__(cls)
+        obj._re, obj._im = real, imag
+        return obj
+
+    # -- parts and basic protocol ---------------------------------------------------------
+    real = property(lambda self: self._re)
+    imag = property(lambda self: self._im)
+    shape = property(lambda self: self._re.shape)
+    dtype = property(lambda self: self._re.dtype)
+    device = property(lambda self: self._re.device)
+
+    def _map(self, fn, *a, **k):
+        return type(self)(fn(self._re, *a, **k), fn(self._im, *a, **k))
+
+    def apply(self, f, *a, **k):
+        """Apply `f` to the real and the imaginary planes independently."""
+        return self._map(f, *a, **k)
+
+    def __copy__(self):
+        return type(self)(self._re, self._im)
+
+    def __deepcopy__(self, memo):
+        return type(self)(deepcopy(self._re, memo), deepcopy(self._im, memo))
+
+    def __getitem__(self, key):
+        return type(self)(self._re[key], self._im[key])
+
+    def __setitem__(self, key, value):
+        if isinstance(value, (Cplx, complex)):
+            self._re[key], self._im[key] = value.real, value.imag
+        else:
+            self._re[key], self._im[key] = value, value
+
+    def __iter__(self):
+        return map(type(self), self._re, self._im)
+
+    def __reversed__(self):
+        return type(self)(reversed(self._re), reversed(self._im))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __repr__(self):
+        return f"{type(self).__name__}(\n  real={self._re},\n  imag={self._im}\n)"
+
+    def clone(self):
+        return self._map(torch.clone)
+
+    def detach(self):
+        return self._map(torch.Tensor.detach)
+
+    def requires_grad_(self, requires_grad=True):
+        return type(self)(self._re.requires_grad_(requires_grad),
+                          self._im.requires_grad_(requires_grad))
+
+    @property
+    def grad(self):
+        re, im = self._re.grad, self._im.grad
+        return None if re is None or im is None else type(self)(re, im)
+
+    def is_complex(self):
+        return True
+
+    def dim(self):
+        return self._re.dim()
+
+    def size(self, *dim):
+        return self._re.size(*dim)
+
+    def item(self):
+        return float(self._re) + 1j * float(self._im)
+
+    # -- placement ------------------------------------------------------------------------
+    def to(self, *a, **k):
+        return self._map(torch.Tensor.to, *a, **k)
+
+    def cuda(self, device=None, non_blocking=False):
+        return self._map(torch.Tensor.cuda, device=device, non_blocking=non_blocking)
+
+    def cpu(self):
+        return self._map(torch.Tensor.cpu)
+
+    @classmethod
+    def from_numpy(cls, array):
+        return cls(torch.from_numpy(array.real.copy()), torch.from_numpy(array.imag.copy()))
+
+    def numpy(self):
+        return self._re.numpy() + 1j * self._im.numpy()
+
+    # -- constructors ---------------------------------------------------------------------
+    @classmethod
+    def _filled(cls, maker, sizes, dtype, device, requires_grad, imag_maker=None):
+        re = maker(*sizes, dtype=dtype, device=device, requires_grad=requires_grad)
+        im = (imag_maker or maker)(*sizes, dtype=dtype, device=device, requires_grad=requires_grad)
+        return cls(re, im)
+
+    @classmethod
+    def empty(cls, *sizes, dtype=None, device=None, requires_grad=False):
+        return cls._filled(torch.empty, sizes, dtype, device, requires_grad)
+
+    @classmethod
+    def zeros(cls, *sizes, dtype=None, device=None, requires_grad=False):
+        return cls._filled(torch.zeros, sizes, dtype, device, requires_grad)
+
+    @classmethod
+    def ones(cls, *sizes, dtype=None, device=None, requires_grad=False):
+        return cls._filled(torch.ones, sizes, dtype, device, requires_grad, torch.zeros)
+
+    # -- shape manipulation ---------------------------------------------------------------
+    def t(self):
+        return self._map(torch.Tensor.t)
+
+    def h(self):
+        return self.conj.t()
+
+    def flatten(self, start_dim=0, end_dim=-1):
+        return self._map(torch.flatten, start_dim, end_dim)
+
+    def view(self, *shape):
+        shape = shape[0] if shape and isinstance(shape[0], tuple) else shape
+        return self._map(torch.Tensor.view, *shape)
+
+    def view_as(self, other):
+        return self.view(*other.shape)
+
+    def reshape(self, *shape):
+        shape = shape[0] if shape and isinstance(shape[0], tuple) else shape
+        return self._map(torch.Tensor.reshape, *shape)
+
+    def squeeze(self, dim=None):
+        return self._map(torch.squeeze) if dim is None else self._map(torch.squeeze, dim)
+
+    def unsqueeze(self, dim):
+        return self._map(torch.unsqueeze, dim)
+
+    def permute(self, *dims):
+        return self._map(torch.Tensor.permute, *dims)
+
+    def transpose(self, dim0, dim1):
+        return self._map(torch.transpose, dim0, dim1)
+
+    # -- arithmetic -----------------------------------------------------------------------
+    @property
+    def conj(self):
+        return type(self)(self._re, -self._im)
+
+    def conjugate(self):
+        return self.conj
+
+    def __pos__(self):
+        return self
+
+    def __neg__(self):
+        return type(self)(-self._re, -self._im)
+
+    def __add__(self, other):
+        if isinstance(other, (Cplx, complex)):
+            return type(self)(self._re + other.real, self._im + other.imag)
+        return type(self)(self._re + other, self._im)
+
+    __radd__ = __iadd__ = __add__
+
+    def __sub__(self, other):
+        if isinstance(other, (Cplx, complex)):
+            return type(self)(self._re - other.real, self._im - other.imag)
+        return type(self)(self._re - other, self._im)
+
+    __isub__ = __sub__
+
+    def __rsub__(self, other):
+        return -self + other
+
+    def __mul__(self, other):
+        if isinstance(other, (Cplx, complex)):
+            return type(self)(self._re * other.real - self._im * other.imag,
+                              self._im * other.real + self._re * other.imag)
+        return type(self)(self._re * other, self._im * other)
+
+    __rmul__ = __imul__ = __mul__
+
+    def __truediv__(self, other):
+        if isinstance(other, (Cplx, complex)):
+            other = Cplx(other) if isinstance(other, complex) else other
+            den = other.real * other.real + other.imag * other.imag
+            return self * (other.conj / den)
+        return type(self)(self._re / other, self._im / other)
+
+    __itruediv__ = __truediv__
+
+    def __rtruediv__(self, other):
+        den = self._re * self._re + self._im * self._im
+        return (self.conj / den) * other
+
+    def __matmul__(self, other):
+        """Complex matrix product on the complex GEMM kernel (reference: 4 torch.matmul,
+        cplxmodule/cplx.py:167-174)."""
+        if not isinstance(other, Cplx):
+            other = Cplx(other)
+        return matmul(self, other)
+
+    __imatmul__ = __matmul__
+
+    def __rmatmul__(self, other):
+        return matmul(Cplx(other), self)
+
+    def __abs__(self):
+        """Modulus via one fused kernel (reference: stack + norm, cplxmodule/cplx.py:183-192)."""
+        if self._re.dtype == torch.float32 and not (self._re.requires_grad or self._im.requires_grad):
+            return ops.modulus(self._re, self._im)
+        return torch.sqrt(self._re * self._re + self._im * self._im)
+
+    @property
+    def angle(self):
+        return torch.atan2(self._im, self._re)
+
+
+# ------------------------------------------------------------------------------------------ #
+#  functional API                                                                            #
+# ------------------------------------------------------------------------------------------ #
+def randn(*size, dtype=None, device=None, requires_grad=False):
+    """Standard complex Gaussian noise: ONE normal draw of shape [2, *size] / sqrt(2), plane 0 ->
+    real, plane 1 -> imag (same layout as cplxmodule/cplx.py:544-550, so that a recorded noise
+    tape can be shared with the reference)."""
+    z = torch.randn(2, *size, dtype=dtype, device=device) / math.sqrt(2)
+    out = Cplx(z[0], z[1])
+    return out.requires_grad_(True) if requires_grad else out
+
+
+def randn_like(input, dtype=None, device=None, requires_grad=False):
+    return randn(*input.size(), dtype=input.dtype if dtype is None else dtype,
+                 device=input.device if device is None else device, requires_grad=requires_grad)
+
+
+def linear(input, weight, bias=None):
+    """y = x W^T + b on the complex GEMM kernel (replaces linear_naive, cplxmodule/cplx.py:634-648)."""
+    br, bi = (None, None) if bias is None else (bias.real, bias.imag)
+    yr, yi = ops.CplxLinearFn.apply(input.real, input.imag, weight.real, weight.imag, br, bi)
+    return Cplx(yr, yi)
+
+
+# interchangeable algorithm names of the reference (cplx.py:634-698); one kernel serves them all
+linear_naive = linear_cat = linear_3m = linear
+
+
+def matmul(u, v):
+    """u[..., M, K] @ v[..., K, N]; batch dims of `v` (if any) must equal those of `u`."""
+    ur, ui, vr, vi = u.real, u.imag, v.real, v.imag
+    if vr.dim() == 2:
+        lead, K = ur.shape[:-1], ur.shape[-1]
+        # (x W^T) with W = v^T: feed v through the strided B operand, no copy
+        a_r, a_i = ur.reshape(-1, K).contiguous(), ui.reshape(-1, K).contiguous()
+        N = vr.shape[1]
+        yr, yi = _MatmulFn.apply(a_r, a_i, vr.contiguous(), vi.contiguous())
+        return Cplx(yr.view(*lead, N), yi.view(*lead, N))
+    if ur.shape[:-2] != vr.shape[:-2]:
+        raise CplxAmdError("batched complex matmul needs identical batch dimensions")
+    batch = ur.shape[:-2]
+    M, K, N = ur.shape[-2], ur.shape[-1], vr.shape[-1]
+    outs = [_MatmulFn.apply(a.contiguous(), b.contiguous(), c.contiguous(), d.contiguous())
+            for a, b, c, d in zip(ur.reshape(-1, M, K), ui.reshape(-1, M, K),
+                                  vr.reshape(-1, K, N), vi.reshape(-1, K, N))]
+    yr = torch.stack([o[0] for o in outs]).view(*batch, M, N)
+    yi = torch.stack([o[1] for o in outs]).view(*batch, M, N)
+    return Cplx(yr, yi)
+
+
+class _MatmulFn(torch.autograd.Function):
+    """[M,K] @ [K,N] (no conjugation) on the generic complex GEMM."""
+
+    @staticmethod
+    def forward(ctx, ar, ai, vr, vi):
+        M, K = ar.shape
+        N = vr.shape[1]
+        ctx.save_for_backward(ar, ai, vr, vi)
+        if ar.dtype != vr.dtype:
+            raise CplxAmdError("matmul operands must share a dtype")
+        return ops.cgemm(ar, ai, (K, 1), vr, vi, (1, N), M, N, K, out_dtype=ar.dtype)
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        ar, ai, vr, vi = ctx.saved_tensors
+        M, K = ar.shape
+        N = vr.shape[1]
+        gr, gi = gr.contiguous(), gi.contiguous()
+        # dA = G conj(V)^T : dA[m,k] = sum_n G[m,n] conj(V[k,n])
+        dar, dai = ops.cgemm(gr, gi, (N, 1), vr, vi, (N, 1), M, K, N, conj_b=True, out_dtype=ar.dtype)
+        # dV = conj(A)^T G : dV[k,n] = sum_m conj(A[m,k]) G[m,n]; computed as conj(sum A conj(G))
+        tr, ti = ops.cgemm(ar, ai, (1, K), gr, gi, (1, N), K, N, M, conj_b=True, out_dtype=ar.dtype)
+        return dar, dai, tr, -ti
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+           padding_mode="zeros"):
+    """Complex 2-d cross-correlation y = x * W + b (no conjugation), cplxmodule/cplx.py:770-838."""
+    from . import conv  # late import: conv pulls in its own kernels
+    return conv.cplx_conv2d(input, weight, bias, stride, padding, dilation, groups, padding_mode)
+
+
+def from_interleaved_real(input, copy=True, dim=-1):
+    """[..., 2D] interleaved (re, im) -> Cplx [..., D]  (cplxmodule/cplx.py:451-455)."""
+    shape = list(input.shape)
+    dim = dim % input.dim()
+    shape[dim:dim + 1] = [shape[dim] // 2, 2]
+    pair = input.reshape(shape)
+    re, im = pair.select(dim + 1, 0), pair.select(dim + 1, 1)
+    return Cplx(re.clone(), im.clone()) if copy else Cplx(re, im)
+
+
+from_real = from_interleaved_real
+
+
+def to_interleaved_real(input, flatten=True, dim=-1):
+    """Cplx [..., D] -> real [..., 2D] interleaved (cplxmodule/cplx.py:466-470)."""
+    dim = dim % input.dim() + 1
+    out = torch.stack([input.real, input.imag], dim=dim)
+    return out.flatten(dim - 1, dim) if flatten else out
+
+
+to_real = to_interleaved_real
+
+
+def from_concatenated_real(input, copy=True, dim=-1):
+    re, im = torch.chunk(input, 2, dim=dim)
+    return Cplx(re.clone(), im.clone()) if copy else Cplx(re, im)
+
+
+def to_concatenated_real(input, flatten=None, dim=-1):
+    return torch.cat([input.real, input.imag], dim=dim)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libcplxamd.so (gfx950 only) in-tree: cplxmodule_amd/libcplxamd.so
+set -e
+cd "$(dirname "$0")"
+OUT=../libcplxamd.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
+mkdir -p build
+pids=()
+for f in *.hip; do
+  o=build/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm.h -nt "$o" ] || [ ../../include/cplxamd.h -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+echo "built $(realpath $OUT)"

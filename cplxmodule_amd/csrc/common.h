@@ -1,0 +1,97 @@
+// Shared device helpers for the cplxamd kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cplxamd.h"
+
+#define CPLXAMD_CHECK_LAUNCH()                          \
+  do {                                                  \
+    hipError_t e__ = hipGetLastError();                 \
+    if (e__ != hipSuccess) return (int)e__;             \
+  } while (0)
+
+namespace cplxamd {
+
+constexpr int kWave = 64;
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct io;
+template <> struct io<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct io<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 4-wide vector access (16 B for float, 8 B for bf16)
+struct f4 { float v[4]; };
+__device__ __forceinline__ f4 ld4(const float* p) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  return f4{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ void st4(float* p, const f4& a) {
+  *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+__device__ __forceinline__ f4 ld4(const bf16_t* p) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  return f4{{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+             __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)}};
+}
+__device__ __forceinline__ void st4(bf16_t* p, const f4& a) {
+  uint2 t;
+  t.x = (uint32_t)f32_to_bf16(a.v[0]) | ((uint32_t)f32_to_bf16(a.v[1]) << 16);
+  t.y = (uint32_t)f32_to_bf16(a.v[2]) | ((uint32_t)f32_to_bf16(a.v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ---------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a block of NT threads; result valid in thread 0.  `smem` holds NT/64 T's.
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T* smem) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  T r = T(0);
+  if (threadIdx.x < NT / 64) r = smem[threadIdx.x];
+  if (wid == 0) r = wave_sum(r);
+  __syncthreads();
+  return r;
+}
+
+// grid for HBM-bound streaming kernels: cap at 256 CUs x 8 blocks, grid-stride the rest
+inline int stream_grid(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+}  // namespace cplxamd

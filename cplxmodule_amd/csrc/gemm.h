@@ -1,0 +1,25 @@
+// Internal interface between the GEMM translation units.
+#pragma once
+#include "common.h"
+
+namespace cplxamd {
+
+struct GemmArgs {
+  const void* a_r; const void* a_i; int64_t a_rs, a_cs;   // A[m*a_rs + k*a_cs]
+  const void* b_r; const void* b_i; int64_t b_rs, b_cs;   // B[n*b_rs + k*b_cs]
+  const float* bias_r; const float* bias_i; const float* emul;
+  void* c_r; void* c_i; int64_t ldc;
+  int M, N, K;
+  int conj_b, accumulate;
+};
+
+// any strides / shapes, exact-f32 MFMA (gemm_generic.hip)
+template <bool CPLX>
+int launch_gemm_generic(const GemmArgs& g, int in_dtype, int out_dtype, hipStream_t st);
+
+// bf16 MFMA fast path (gemm_bf16.hip); returns CPLXAMD_ESHAPE when the arguments do not
+// qualify so that the caller can fall back to the generic kernel.
+template <bool CPLX>
+int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st);
+
+}  // namespace cplxamd

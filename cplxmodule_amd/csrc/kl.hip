@@ -1,0 +1,460 @@
+// K6/K7: log-alpha -> KL penalty (+ wavefront-shuffle reduction, + gradients) and masks.
+//
+// One pass over (wr, wi, log_sigma2): 12 B/element read for the complex kinds (8 B real),
+// + 12 B/element written when gradients are produced.  HBM-bound; the arithmetic (one fp64
+// log only in the mask/log-alpha kernels, fp32 otherwise) stays well under the VALU budget.
+//
+// Reference arithmetic restated here (file:line under /root/reference/cplxmodule):
+//   log_alpha  nn/relevance/complex/base.py:27-31, nn/relevance/real/base.py:23-26
+//   abs(Cplx)  cplx.py:183-192
+//   penalties  nn/relevance/real/vd.py:54-76, real/ard.py:10-39, complex/vd.py:95-99,
+//              complex/ard.py:9-39;  Ei backward complex/vd.py:39-41
+//   masks      nn/relevance/real/vd.py:16-19, complex/vd.py:50-53
+#include "common.h"
+
+namespace cplxamd {
+
+constexpr int kKlThreads = 256;
+constexpr int kKlMaxBlocks = 2048;
+
+constexpr float kEulerGamma = 0.57721566490153286f;
+constexpr float kK1 = 0.63576f, kK2 = 1.87320f, kK3 = 1.48695f;
+
+// |w| exactly as torch's CPU 2-norm kernel rounds it: sqrt(fma(wi, wi, rn(wr*wr)))
+// (bit-for-bit on 2^20 samples, DESIGN.md "mask exactness").
+template <bool CPLX>
+__device__ __forceinline__ float weight_abs(float wr, float wi) {
+  if (CPLX) return __fsqrt_rn(__fmaf_rn(wi, wi, __fmul_rn(wr, wr)));
+  return fabsf(wr);
+}
+
+// EXACT: the log is evaluated in fp64 and rounded once, i.e. correctly rounded, which is
+// what the reference's libm delivers on > 99.99 % of inputs -> masks come out bit-identical.
+template <bool CPLX, bool EXACT>
+__device__ __forceinline__ float log_alpha_of(float ls2, float wr, float wi, float& theta) {
+  theta = weight_abs<CPLX>(wr, wi);
+  const float u = __fadd_rn(theta, 1e-12f);
+  const float l = EXACT ? (float)log((double)u) : logf(u);
+  return __fsub_rn(ls2, __fmul_rn(2.0f, l));
+}
+
+__device__ __forceinline__ float softplus_f(float t) {
+  return t > 20.0f ? t : log1pf(expf(t));
+}
+__device__ __forceinline__ float sigmoid_f(float t) { return 1.0f / (1.0f + expf(-t)); }
+__device__ __forceinline__ float softplus_grad_f(float t) {
+  return t > 20.0f ? 1.0f : sigmoid_f(t);
+}
+
+// f(t) = gamma + t - Ei(-e^t) = gamma + ln x + E1(x), x = e^t.
+//  x <= 1: the power series of E1 cancels gamma + ln x analytically:
+//          f = -sum_{k>=1} (-x)^k / (k k!)                       (11 terms, rel err 2e-10)
+//  x  > 1: E1(x) = e^-x / x * P4(x)/Q4(x), Abramowitz & Stegun 5.1.56 (|err| < 2e-8)
+__device__ __forceinline__ float cplx_vd_value(float t) {
+  const float x = expf(t);
+  if (x <= 1.0f) {
+    float s = 2.2774860e-9f;           // +1/(11*11!)
+    s = fmaf(s, x, -2.7557319e-8f);    // -1/(10*10!)
+    s = fmaf(s, x, 3.0619244e-7f);     // +1/(9*9!)
+    s = fmaf(s, x, -3.1001984e-6f);    // -1/(8*8!)
+    s = fmaf(s, x, 2.8344671e-5f);     // +1/(7*7!)
+    s = fmaf(s, x, -2.3148148e-4f);    // -1/(6*6!)
+    s = fmaf(s, x, 1.6666667e-3f);     // +1/(5*5!)
+    s = fmaf(s, x, -1.0416667e-2f);    // -1/(4*4!)
+    s = fmaf(s, x, 5.5555556e-2f);     // +1/(3*3!)
+    s = fmaf(s, x, -0.25f);            // -1/(2*2!)
+    s = fmaf(s, x, 1.0f);              // +1/(1*1!)
+    return s * x;
+  }
+  float e1 = 0.0f;
+  if (x < 104.0f) {
+    const float num = fmaf(fmaf(fmaf(fmaf(1.0f, x, 8.5733287401f), x, 18.0590169730f), x,
+                                8.6347608925f), x, 0.2677737343f);
+    const float den = fmaf(fmaf(fmaf(fmaf(1.0f, x, 9.5733223454f), x, 25.6329561486f), x,
+                                21.0996530827f), x, 3.9584969228f);
+    e1 = expf(-x) / x * (num / den);
+  }
+  return kEulerGamma + t + e1;
+}
+
+template <int KIND>
+__device__ __forceinline__ float kl_value(float t) {
+  if (KIND == CPLXAMD_KL_REAL_VD)
+    return fmaf(0.5f, softplus_f(t), kK1 * sigmoid_f(fmaf(kK3, t, -kK2)));
+  if (KIND == CPLXAMD_KL_REAL_ARD) return 0.5f * softplus_f(t);
+  if (KIND == CPLXAMD_KL_CPLX_VD) return cplx_vd_value(t);
+  return softplus_f(t);
+}
+
+// f'(t)
+template <int KIND>
+__device__ __forceinline__ float kl_slope(float t) {
+  if (KIND == CPLXAMD_KL_REAL_VD) {
+    const float su = sigmoid_f(fmaf(kK3, t, -kK2));
+    return fmaf(0.5f, softplus_grad_f(t), kK1 * kK3 * su * (1.0f - su));
+  }
+  if (KIND == CPLXAMD_KL_REAL_ARD) return 0.5f * softplus_grad_f(t);
+  if (KIND == CPLXAMD_KL_CPLX_VD) return -expm1f(-expf(t));  // 1 - exp(-e^t)
+  return softplus_grad_f(t);
+}
+
+template <bool CPLX>
+__device__ __forceinline__ void weight_grad(float fp, float wr, float wi, float theta,
+                                            float& gwr, float& gwi) {
+  // d(-log_alpha)/dw = 2 w / (theta (theta + 1e-12)); 0 at theta == 0 (torch subgradient)
+  if (theta > 0.0f) {
+    if (CPLX) {
+      const float c = 2.0f * fp / (theta * (theta + 1e-12f));
+      gwr = c * wr;
+      gwi = c * wi;
+    } else {
+      gwr = copysignf(2.0f * fp / (theta + 1e-12f), wr);
+      gwi = 0.0f;
+    }
+  } else {
+    gwr = 0.0f;
+    gwi = 0.0f;
+  }
+}
+
+struct KlArgs {
+  const float* wr;
+  const float* wi;
+  const float* ls2;
+  const float* g_elem;    // upstream per-element gradient (nullable)
+  const float* g_scalar;  // upstream scalar gradient on device (nullable)
+  float gscale;           // host scalar multiplier (used when both above are null)
+  float* out_elem;
+  double* partial;        // per-block partial sums (nullable)
+  float* g_ls2;
+  float* g_wr;
+  float* g_wi;
+  int64_t n;
+};
+
+template <int KIND, bool VALUE, bool GRAD>
+__global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
+  constexpr bool CPLX = (KIND == CPLXAMD_KL_CPLX_VD || KIND == CPLXAMD_KL_CPLX_ARD);
+  __shared__ double red[kKlThreads / 64];
+  const int64_t n4 = a.n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kKlThreads;
+  float gs = a.gscale;
+  if (GRAD && a.g_scalar) gs *= *a.g_scalar;
+  double acc = 0.0;
+
+  for (int64_t i = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i < n4; i += stride) {
+    const f4 wr = ld4(a.wr + 4 * i);
+    const f4 ls = ld4(a.ls2 + 4 * i);
+    f4 wi = {{0.f, 0.f, 0.f, 0.f}};
+    if (CPLX) wi = ld4(a.wi + 4 * i);
+    f4 ge = {{1.f, 1.f, 1.f, 1.f}};
+    if (GRAD && a.g_elem) ge = ld4(a.g_elem + 4 * i);
+    f4 val, d_ls, d_wr, d_wi;
+    float part = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float theta;
+      const float t = -log_alpha_of<CPLX, false>(ls.v[j], wr.v[j], wi.v[j], theta);
+      if (VALUE) {
+        val.v[j] = kl_value<KIND>(t);
+        part += val.v[j];
+      }
+      if (GRAD) {
+        const float fp = kl_slope<KIND>(t) * ge.v[j] * gs;
+        d_ls.v[j] = -fp;
+        weight_grad<CPLX>(fp, wr.v[j], wi.v[j], theta, d_wr.v[j], d_wi.v[j]);
+      }
+    }
+    if (VALUE) {
+      acc += (double)part;
+      if (a.out_elem) st4(a.out_elem + 4 * i, val);
+    }
+    if (GRAD) {
+      if (a.g_ls2) st4(a.g_ls2 + 4 * i, d_ls);
+      if (a.g_wr) st4(a.g_wr + 4 * i, d_wr);
+      if (CPLX && a.g_wi) st4(a.g_wi + 4 * i, d_wi);
+    }
+  }
+  // scalar tail (n % 4 elements), handled by block 0
+  if (blockIdx.x == 0) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    if (i < a.n) {
+      const float wr = a.wr[i], ls = a.ls2[i];
+      const float wi = CPLX ? a.wi[i] : 0.0f;
+      float theta;
+      const float t = -log_alpha_of<CPLX, false>(ls, wr, wi, theta);
+      if (VALUE) {
+        const float v = kl_value<KIND>(t);
+        acc += (double)v;
+        if (a.out_elem) a.out_elem[i] = v;
+      }
+      if (GRAD) {
+        const float ge = a.g_elem ? a.g_elem[i] : 1.0f;
+        const float fp = kl_slope<KIND>(t) * ge * gs;
+        float gwr, gwi;
+        weight_grad<CPLX>(fp, wr, wi, theta, gwr, gwi);
+        if (a.g_ls2) a.g_ls2[i] = -fp;
+        if (a.g_wr) a.g_wr[i] = gwr;
+        if (CPLX && a.g_wi) a.g_wi[i] = gwi;
+      }
+    }
+  }
+  if (VALUE && a.partial) {
+    const double s = block_sum<double, kKlThreads>(acc, red);
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+  }
+}
+
+// one block: out = sum(partial[0..m))
+__global__ __launch_bounds__(kKlThreads) void kl_final_kernel(const double* partial, int m,
+                                                              float* out) {
+  __shared__ double red[kKlThreads / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < m; i += kKlThreads) acc += partial[i];
+  const double s = block_sum<double, kKlThreads>(acc, red);
+  if (threadIdx.x == 0) *out = (float)s;
+}
+
+template <bool VALUE, bool GRAD>
+static int launch_kl(int kind, const KlArgs& a, int grid, hipStream_t st) {
+  switch (kind) {
+    case CPLXAMD_KL_REAL_VD:
+      kl_kernel<CPLXAMD_KL_REAL_VD, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
+      break;
+    case CPLXAMD_KL_REAL_ARD:
+      kl_kernel<CPLXAMD_KL_REAL_ARD, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
+      break;
+    case CPLXAMD_KL_CPLX_VD:
+      kl_kernel<CPLXAMD_KL_CPLX_VD, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
+      break;
+    case CPLXAMD_KL_CPLX_ARD:
+      kl_kernel<CPLXAMD_KL_CPLX_ARD, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
+      break;
+    default:
+      return CPLXAMD_EINVAL;
+  }
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+static bool kl_args_ok(const float* wr, const float* wi, const float* ls2, int kind, int64_t n) {
+  if (!wr || !ls2 || n < 0 || kind < 0 || kind > 3) return false;
+  const bool cplx = kind >= CPLXAMD_KL_CPLX_VD;
+  return cplx ? wi != nullptr : true;
+}
+
+// ---- log-alpha / mask ---------------------------------------------------------------------
+template <bool CPLX, bool MASK>
+__global__ __launch_bounds__(kKlThreads) void log_alpha_kernel(const float* wr, const float* wi,
+                                                               const float* ls2, float thr,
+                                                               float* out, double* partial,
+                                                               int64_t n) {
+  __shared__ double red[kKlThreads / 64];
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kKlThreads;
+  double cnt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i < n4; i += stride) {
+    const f4 a = ld4(wr + 4 * i), l = ld4(ls2 + 4 * i);
+    f4 b = {{0.f, 0.f, 0.f, 0.f}};
+    if (CPLX) b = ld4(wi + 4 * i);
+    f4 o;
+    float c = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float theta;
+      const float la = log_alpha_of<CPLX, true>(l.v[j], a.v[j], b.v[j], theta);
+      o.v[j] = MASK ? (la <= thr ? 1.0f : 0.0f) : la;
+      c += MASK ? o.v[j] : 0.0f;
+    }
+    st4(out + 4 * i, o);
+    cnt += (double)c;
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    if (i < n) {
+      float theta;
+      const float la = log_alpha_of<CPLX, true>(ls2[i], wr[i], CPLX ? wi[i] : 0.0f, theta);
+      const float o = MASK ? (la <= thr ? 1.0f : 0.0f) : la;
+      out[i] = o;
+      if (MASK) cnt += (double)o;
+    }
+  }
+  if (MASK && partial) {
+    const double s = block_sum<double, kKlThreads>(cnt, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(kKlThreads) void count_final_kernel(const double* partial, int m,
+                                                                 int64_t* out) {
+  __shared__ double red[kKlThreads / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < m; i += kKlThreads) acc += partial[i];
+  const double s = block_sum<double, kKlThreads>(acc, red);
+  if (threadIdx.x == 0) *out = (int64_t)(s + 0.5);
+}
+
+// ---- Ei(x) for the torch_expi seam (both signs) ----------------------------------------------
+// x < 0: Ei(x) = -E1(-x).  x > 0: power series gamma + ln x + sum x^k/(k k!) for x <= 40 (in
+// fp64: the series terms alternate in magnitude but not in sign, no cancellation), asymptotic
+// e^x/x * sum k!/x^k beyond.  Matches scipy (double compute, one rounding) to ~1e-7 relative.
+__device__ __forceinline__ float expi_f(float xf) {
+  const double x = (double)xf;
+  if (xf == 0.0f) return -INFINITY;
+  if (xf < 0.0f) {
+    const double y = -x;
+    if (y <= 1.0) {
+      double s = 0.0, term = 1.0;
+      for (int k = 1; k <= 20; ++k) {
+        term *= -y / k;
+        s += term / k;
+      }
+      return (float)(0.57721566490153286 + log(y) + s);
+    }
+    if (y > 745.0) return -0.0f;
+    // continued fraction for E1 (modified Lentz), converges fast for y > 1
+    double b = y + 1.0, c = 1e300, d = 1.0 / b, h = d;
+    for (int i = 1; i <= 60; ++i) {
+      const double an = -(double)i * i;
+      b += 2.0;
+      d = 1.0 / (an * d + b);
+      c = b + an / c;
+      const double del = c * d;
+      h *= del;
+      if (fabs(del - 1.0) < 1e-15) break;
+    }
+    return (float)(-h * exp(-y));
+  }
+  if (x <= 40.0) {
+    double s = 0.0, term = 1.0;
+    for (int k = 1; k <= 200; ++k) {
+      term *= x / k;
+      const double add = term / k;
+      s += add;
+      if (add < s * 1e-17) break;
+    }
+    return (float)(0.57721566490153286 + log(x) + s);
+  }
+  double s = 1.0, term = 1.0;
+  for (int k = 1; k <= 40; ++k) {
+    const double nt = term * k / x;
+    if (nt > term) break;
+    term = nt;
+    s += term;
+  }
+  return (float)(exp(x) / x * s);
+}
+
+__global__ __launch_bounds__(kKlThreads) void expi_fwd_kernel(const float* x, float* y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kKlThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i < n; i += stride)
+    y[i] = expi_f(x[i]);
+}
+__global__ __launch_bounds__(kKlThreads) void expi_bwd_kernel(const float* g, const float* x,
+                                                              float* gx, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kKlThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i < n; i += stride)
+    gx[i] = g[i] * expf(x[i]) / x[i];  // nn/relevance/complex/vd.py:39-41
+}
+
+}  // namespace cplxamd
+
+using namespace cplxamd;
+
+extern "C" {
+
+int cplxamd_abi_version(void) { return CPLXAMD_ABI_VERSION; }
+
+int64_t cplxamd_vd_kl_ws_bytes(void) { return (int64_t)kKlMaxBlocks * sizeof(double); }
+
+int cplxamd_vd_kl_fwd(const float* wr, const float* wi, const float* log_sigma2, int kind,
+                      float* out_elem, float* out_sum, void* ws, int64_t n, void* stream) {
+  if (!kl_args_ok(wr, wi, log_sigma2, kind, n) || (out_sum && !ws)) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(n >> 2, kKlThreads);
+  KlArgs a{wr, wi, log_sigma2, nullptr, nullptr, 1.0f, out_elem,
+           out_sum ? (double*)ws : nullptr, nullptr, nullptr, nullptr, n};
+  int rc = launch_kl<true, false>(kind, a, grid, st);
+  if (rc) return rc;
+  if (out_sum) {
+    kl_final_kernel<<<1, kKlThreads, 0, st>>>((const double*)ws, grid, out_sum);
+    CPLXAMD_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int cplxamd_vd_kl_bwd(const float* wr, const float* wi, const float* log_sigma2, int kind,
+                      const float* g_elem, const float* g_scalar, float* g_log_sigma2,
+                      float* g_wr, float* g_wi, int64_t n, void* stream) {
+  if (!kl_args_ok(wr, wi, log_sigma2, kind, n)) return CPLXAMD_EINVAL;
+  const int grid = stream_grid(n >> 2, kKlThreads);
+  KlArgs a{wr, wi, log_sigma2, g_elem, g_scalar, 1.0f, nullptr, nullptr,
+           g_log_sigma2, g_wr, g_wi, n};
+  return launch_kl<false, true>(kind, a, grid, (hipStream_t)stream);
+}
+
+int cplxamd_vd_kl_fwd_bwd(const float* wr, const float* wi, const float* log_sigma2, int kind,
+                          float gscale, float* out_sum, float* g_log_sigma2, float* g_wr,
+                          float* g_wi, void* ws, int64_t n, void* stream) {
+  if (!kl_args_ok(wr, wi, log_sigma2, kind, n) || !out_sum || !ws) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(n >> 2, kKlThreads);
+  KlArgs a{wr, wi, log_sigma2, nullptr, nullptr, gscale, nullptr, (double*)ws,
+           g_log_sigma2, g_wr, g_wi, n};
+  int rc = launch_kl<true, true>(kind, a, grid, st);
+  if (rc) return rc;
+  kl_final_kernel<<<1, kKlThreads, 0, st>>>((const double*)ws, grid, out_sum);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+int cplxamd_vd_log_alpha(const float* wr, const float* wi, const float* log_sigma2, float* out,
+                         int64_t n, void* stream) {
+  if (!wr || !log_sigma2 || !out || n < 0) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(n >> 2, kKlThreads);
+  if (wi)
+    log_alpha_kernel<true, false><<<grid, kKlThreads, 0, st>>>(wr, wi, log_sigma2, 0.f, out,
+                                                               nullptr, n);
+  else
+    log_alpha_kernel<false, false><<<grid, kKlThreads, 0, st>>>(wr, wi, log_sigma2, 0.f, out,
+                                                                nullptr, n);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+int cplxamd_vd_mask(const float* wr, const float* wi, const float* log_sigma2, float threshold,
+                    float* mask, int64_t* count, void* ws, int64_t n, void* stream) {
+  if (!wr || !log_sigma2 || !mask || n < 0 || (count && !ws)) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(n >> 2, kKlThreads);
+  double* partial = count ? (double*)ws : nullptr;
+  if (wi)
+    log_alpha_kernel<true, true><<<grid, kKlThreads, 0, st>>>(wr, wi, log_sigma2, threshold,
+                                                              mask, partial, n);
+  else
+    log_alpha_kernel<false, true><<<grid, kKlThreads, 0, st>>>(wr, wi, log_sigma2, threshold,
+                                                               mask, partial, n);
+  CPLXAMD_CHECK_LAUNCH();
+  if (count) {
+    count_final_kernel<<<1, kKlThreads, 0, st>>>(partial, grid, count);
+    CPLXAMD_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int cplxamd_expi_fwd(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n < 0) return CPLXAMD_EINVAL;
+  expi_fwd_kernel<<<stream_grid(n, kKlThreads), kKlThreads, 0, (hipStream_t)stream>>>(x, y, n);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+int cplxamd_expi_bwd(const float* g, const float* x, float* gx, int64_t n, void* stream) {
+  if (!g || !x || !gx || n < 0) return CPLXAMD_EINVAL;
+  expi_bwd_kernel<<<stream_grid(n, kKlThreads), kKlThreads, 0, (hipStream_t)stream>>>(g, x, gx, n);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// K5: local-reparameterization noise injection  y = mu + eps * sqrt(max(s2, 1e-8))  and its
+// backward, with the noise either supplied (parity mode) or generated in-kernel from a
+// counter-based Philox4x32-10 stream (so the backward regenerates it instead of storing it).
+//
+// Reference arithmetic (file:line under /root/reference/cplxmodule):
+//   nn/relevance/complex/base.py:56, nn/relevance/real/base.py:49, cplx.py:544-562 (randn).
+//
+// HBM traffic (fp32, complex, Philox): read mu_r, mu_i, s2, write y_r, y_i = 20 B/output;
+// backward: read g_r, g_i, s2, write g_s2 = 16 B/output.
+//
+// Noise stream ("DESIGN.md: noise stream"): group g = 4 normals from one Philox call with
+// counter (g_lo, g_hi, offset_lo, offset_hi) and key (seed_lo, seed_hi); u_k = ((x_k >> 8) + 0.5)
+// * 2^-24; (z0, z1) = BoxMuller(u0, u1), (z2, z3) = BoxMuller(u2, u3) with
+// BoxMuller(a, b) = sqrt(-2 ln a) * (cos 2 pi b, sin 2 pi b).
+//   real layers   : elements 4g .. 4g+3            = z0, z1, z2, z3
+//   complex layers: element 2g   (eps_r, eps_i)    = (z0, z1) / sqrt 2
+//                   element 2g+1 (eps_r, eps_i)    = (z2, z3) / sqrt 2
+#include "common.h"
+
+namespace cplxamd {
+
+constexpr int kRpThreads = 256;
+
+struct u32x4 { uint32_t v[4]; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+  uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+    const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return u32x4{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ float u01(uint32_t x) {
+  return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f;  // 2^-24
+}
+
+// scale = 1 for real noise, 1/sqrt(2) for complex
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float scale, float& z0,
+                                           float& z1) {
+  const float r = scale * __fsqrt_rn(-2.0f * __logf(u01(a)));
+  const float ang = u01(b);                  // in revolutions: v_sin/v_cos take x / 2 pi
+  z0 = r * __builtin_amdgcn_cosf(ang);
+  z1 = r * __builtin_amdgcn_sinf(ang);
+}
+
+__device__ __forceinline__ f4 philox_normals(uint64_t group, uint64_t seed, uint64_t offset,
+                                             float scale) {
+  const u32x4 x = philox4x32_10(group, offset, seed);
+  f4 z;
+  box_muller(x.v[0], x.v[1], scale, z.v[0], z.v[1]);
+  box_muller(x.v[2], x.v[3], scale, z.v[2], z.v[3]);
+  return z;
+}
+
+constexpr float kRsqrt2 = 0.70710678118654752f;
+
+// noise for the 4 consecutive elements 4*i4 .. 4*i4+3
+template <bool CPLX>
+__device__ __forceinline__ void noise_vec(int64_t i4, uint64_t seed, uint64_t offset, f4& er,
+                                          f4& ei) {
+  if (CPLX) {
+    const f4 a = philox_normals(2 * (uint64_t)i4, seed, offset, kRsqrt2);
+    const f4 b = philox_normals(2 * (uint64_t)i4 + 1, seed, offset, kRsqrt2);
+    er = f4{{a.v[0], a.v[2], b.v[0], b.v[2]}};
+    ei = f4{{a.v[1], a.v[3], b.v[1], b.v[3]}};
+  } else {
+    er = philox_normals((uint64_t)i4, seed, offset, 1.0f);
+  }
+}
+
+template <bool CPLX>
+__device__ __forceinline__ void noise_one(int64_t e, uint64_t seed, uint64_t offset, float& er,
+                                          float& ei) {
+  if (CPLX) {
+    const f4 a = philox_normals((uint64_t)e >> 1, seed, offset, kRsqrt2);
+    er = (e & 1) ? a.v[2] : a.v[0];
+    ei = (e & 1) ? a.v[3] : a.v[1];
+  } else {
+    const f4 a = philox_normals((uint64_t)e >> 2, seed, offset, 1.0f);
+    er = a.v[e & 3];
+    ei = 0.0f;
+  }
+}
+
+__device__ __forceinline__ float lrt_std(float s2) { return __fsqrt_rn(fmaxf(s2, 1e-8f)); }
+
+template <typename T, bool CPLX, bool PHILOX>
+__global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
+    const T* mu_r, const T* mu_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
+    uint64_t offset, T* y_r, T* y_i, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kRpThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n4; i += stride) {
+    const f4 s = ld4(s2 + 4 * i);
+    const f4 mr = ld4(mu_r + 4 * i);
+    f4 mi, er, ei, yr, yi;
+    if (CPLX) mi = ld4(mu_i + 4 * i);
+    if (PHILOX) {
+      noise_vec<CPLX>(i, seed, offset, er, ei);
+    } else {
+      er = ld4(eps_r + 4 * i);
+      if (CPLX) ei = ld4(eps_i + 4 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sd = lrt_std(s.v[j]);
+      yr.v[j] = __fadd_rn(mr.v[j], __fmul_rn(er.v[j], sd));
+      if (CPLX) yi.v[j] = __fadd_rn(mi.v[j], __fmul_rn(ei.v[j], sd));
+    }
+    st4(y_r + 4 * i, yr);
+    if (CPLX) st4(y_i + 4 * i, yi);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      float er, ei = 0.0f;
+      if (PHILOX) {
+        noise_one<CPLX>(e, seed, offset, er, ei);
+      } else {
+        er = io<T>::ld(eps_r + e);
+        if (CPLX) ei = io<T>::ld(eps_i + e);
+      }
+      const float sd = lrt_std(s2[e]);
+      io<T>::st(y_r + e, __fadd_rn(io<T>::ld(mu_r + e), __fmul_rn(er, sd)));
+      if (CPLX) io<T>::st(y_i + e, __fadd_rn(io<T>::ld(mu_i + e), __fmul_rn(ei, sd)));
+    }
+  }
+}
+
+__device__ __forceinline__ float lrt_gs2(float gs, float s2) {
+  // torch.clamp passes the gradient AT the boundary
+  return s2 >= 1e-8f ? (gs * 0.5f) / lrt_std(s2) : 0.0f;
+}
+
+template <typename T, typename TG, bool CPLX, bool PHILOX>
+__global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
+    const T* g_r, const T* g_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
+    uint64_t offset, TG* g_s2, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kRpThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n4; i += stride) {
+    const f4 s = ld4(s2 + 4 * i);
+    const f4 gr = ld4(g_r + 4 * i);
+    f4 gi, er, ei, o;
+    if (CPLX) gi = ld4(g_i + 4 * i);
+    if (PHILOX) {
+      noise_vec<CPLX>(i, seed, offset, er, ei);
+    } else {
+      er = ld4(eps_r + 4 * i);
+      if (CPLX) ei = ld4(eps_i + 4 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gs = __fmul_rn(gr.v[j], er.v[j]);
+      if (CPLX) gs = __fadd_rn(gs, __fmul_rn(gi.v[j], ei.v[j]));
+      o.v[j] = lrt_gs2(gs, s.v[j]);
+    }
+    st4(g_s2 + 4 * i, o);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      float er, ei = 0.0f;
+      if (PHILOX) {
+        noise_one<CPLX>(e, seed, offset, er, ei);
+      } else {
+        er = io<T>::ld(eps_r + e);
+        if (CPLX) ei = io<T>::ld(eps_i + e);
+      }
+      float gs = __fmul_rn(io<T>::ld(g_r + e), er);
+      if (CPLX) gs = __fadd_rn(gs, __fmul_rn(io<T>::ld(g_i + e), ei));
+      io<TG>::st(g_s2 + e, lrt_gs2(gs, s2[e]));
+    }
+  }
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(kRpThreads) void philox_normal_kernel(float* er, float* ei,
+                                                                   uint64_t seed, uint64_t offset,
+                                                                   int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kRpThreads;
+  for (int64_t e = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; e < n; e += stride) {
+    float a, b;
+    noise_one<CPLX>(e, seed, offset, a, b);
+    er[e] = a;
+    if (CPLX) ei[e] = b;
+  }
+}
+
+template <typename T>
+static int launch_fwd(const void* mu_r, const void* mu_i, const float* s2, const void* eps_r,
+                      const void* eps_i, uint64_t seed, uint64_t offset, void* y_r, void* y_i,
+                      int64_t n, hipStream_t st) {
+  const int grid = stream_grid(n >> 2, kRpThreads);
+  const bool cplx = mu_i != nullptr, philox = eps_r == nullptr;
+#define RP_FWD(C, P)                                                                       \
+  reparam_fwd_kernel<T, C, P><<<grid, kRpThreads, 0, st>>>(                                \
+      (const T*)mu_r, (const T*)mu_i, s2, (const T*)eps_r, (const T*)eps_i, seed, offset,  \
+      (T*)y_r, (T*)y_i, n)
+  if (cplx && philox) RP_FWD(true, true);
+  else if (cplx) RP_FWD(true, false);
+  else if (philox) RP_FWD(false, true);
+  else RP_FWD(false, false);
+#undef RP_FWD
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, typename TG>
+static int launch_bwd(const void* g_r, const void* g_i, const float* s2, const void* eps_r,
+                      const void* eps_i, uint64_t seed, uint64_t offset, void* g_s2, int64_t n,
+                      hipStream_t st) {
+  const int grid = stream_grid(n >> 2, kRpThreads);
+  const bool cplx = g_i != nullptr, philox = eps_r == nullptr;
+#define RP_BWD(C, P)                                                                      \
+  reparam_bwd_kernel<T, TG, C, P><<<grid, kRpThreads, 0, st>>>(                           \
+      (const T*)g_r, (const T*)g_i, s2, (const T*)eps_r, (const T*)eps_i, seed, offset,   \
+      (TG*)g_s2, n)
+  if (cplx && philox) RP_BWD(true, true);
+  else if (cplx) RP_BWD(true, false);
+  else if (philox) RP_BWD(false, true);
+  else RP_BWD(false, false);
+#undef RP_BWD
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace cplxamd
+
+using namespace cplxamd;
+
+extern "C" {
+
+int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
+                            const void* eps_r, const void* eps_i, uint64_t seed,
+                            uint64_t offset, void* y_r, void* y_i, int64_t n, int dtype,
+                            void* stream) {
+  if (!mu_r || !s2 || !y_r || n < 0) return CPLXAMD_EINVAL;
+  if ((mu_i == nullptr) != (y_i == nullptr)) return CPLXAMD_EINVAL;
+  if (eps_r && mu_i && !eps_i) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CPLXAMD_F32)
+    return launch_fwd<float>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, y_r, y_i, n, st);
+  if (dtype == CPLXAMD_BF16)
+    return launch_fwd<bf16_t>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, y_r, y_i, n, st);
+  return CPLXAMD_EINVAL;
+}
+
+int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
+                            const void* eps_r, const void* eps_i, uint64_t seed,
+                            uint64_t offset, void* g_s2, int64_t n, int dtype, int gs2_dtype,
+                            void* stream) {
+  if (!g_r || !s2 || !g_s2 || n < 0) return CPLXAMD_EINVAL;
+  if (eps_r && g_i && !eps_i) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CPLXAMD_F32 && gs2_dtype == CPLXAMD_F32)
+    return launch_bwd<float, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, g_s2, n, st);
+  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_F32)
+    return launch_bwd<bf16_t, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, g_s2, n, st);
+  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_BF16)
+    return launch_bwd<bf16_t, bf16_t>(g_r, g_i, s2, eps_r, eps_i, seed, offset, g_s2, n, st);
+  return CPLXAMD_EINVAL;
+}
+
+int cplxamd_philox_normal(float* eps_r, float* eps_i, uint64_t seed, uint64_t offset,
+                          int64_t n, void* stream) {
+  if (!eps_r || n < 0) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(n, kRpThreads);
+  if (eps_i)
+    philox_normal_kernel<true><<<grid, kRpThreads, 0, st>>>(eps_r, eps_i, seed, offset, n);
+  else
+    philox_normal_kernel<false><<<grid, kRpThreads, 0, st>>>(eps_r, eps_i, seed, offset, n);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""Complex batch normalisation (Trabelsi et al.) on the 2-pass moment / apply kernels.
+
+Layer contract of cplxmodule/nn/modules/batchnorm.py:281-407: affine weight [2,2,F] (init I2),
+bias [2,F], running_mean [2,F], running_var [2,2,F] (init I2), num_batches_tracked; momentum=None
+selects the cumulative average; statistics are those of the local batch (no cross-rank sync).
+"""
+import torch
+
+from .base import CplxToCplx
+from ... import cplx
+
+
+def cplx_batch_norm(input, running_mean, running_var, weight=None, bias=None, training=True,
+                    momentum=0.1, eps=1e-5):
+    """Functional form (batchnorm.py:189-278).  Running statistics are updated in place."""
+    assert (running_mean is None) == (running_var is None)
+    assert (weight is None) == (bias is None)
+    from ... import bn
+    yr, yi = bn.CplxBatchNormFn.apply(input.real, input.imag, weight, bias, running_mean,
+                                      running_var, bool(training), float(momentum), float(eps))
+    return cplx.Cplx(yr, yi)
+
+
+class _CplxBatchNorm(CplxToCplx):
+    _dims = ()
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True,
+                 track_running_stats=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        if affine:
+            self.weight = torch.nn.Parameter(torch.empty(2, 2, num_features))
+            self.bias = torch.nn.Parameter(torch.empty(2, num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        if track_running_stats:
+            self.register_buffer("running_mean", torch.empty(2, num_features))
+            self.register_buffer("running_var", torch.empty(2, 2, num_features))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        else:
+            self.register_parameter("running_mean", None)
+            self.register_parameter("running_var", None)
+            self.register_parameter("num_batches_tracked", None)
+        self.reset_running_stats()
+        self.reset_parameters()
+
+    def reset_running_stats(self):
+        if self.track_running_stats:
+            self.num_batches_tracked.zero_()
+            self.running_mean.zero_()
+            self.running_var.copy_(torch.eye(2).unsqueeze(-1))
+
+    def reset_parameters(self):
+        if self.affine:
+            with torch.no_grad():
+                self.weight.copy_(torch.eye(2).unsqueeze(-1))
+                self.bias.zero_()
+
+    def _check_input_dim(self, input):
+        if input.dim() not in self._dims:
+            want = " or ".join(f"{d}D" for d in self._dims)
+            raise ValueError(f"expected {want} input (got {input.dim()}D input)")
+
+    def forward(self, input):
+        self._check_input_dim(input)
+        factor = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked += 1
+            if self.momentum is None:
+                factor = 1.0 / float(self.num_batches_tracked)
+        return cplx_batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias,
+                               self.training or not self.track_running_stats, factor, self.eps)
+
+    def extra_repr(self):
+        return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, "
+                f"affine={self.affine}, track_running_stats={self.track_running_stats}")
+
+
+class CplxBatchNorm1d(_CplxBatchNorm):
+    _dims = (2, 3)
+
+
+class CplxBatchNorm2d(_CplxBatchNorm):
+    _dims = (4,)
+
+
+class CplxBatchNorm3d(_CplxBatchNorm):
+    _dims = (5,)

@@ -1,0 +1,57 @@
+"""CplxConv2d: complex 2-d cross-correlation layer (cplxmodule/nn/modules/conv.py:11-92, 147-196)."""
+import math
+
+from torch.nn.modules.utils import _pair
+
+from .base import CplxToCplx, CplxParameter
+from .. import init
+from ... import cplx
+
+
+class CplxConv2d(CplxToCplx):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        super().__init__()
+        if in_channels % groups != 0:
+            raise ValueError("in_channels must be divisible by groups")
+        if out_channels % groups != 0:
+            raise ValueError("out_channels must be divisible by groups")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.transposed, self.output_padding = False, _pair(0)
+        self.groups, self.padding_mode = groups, padding_mode
+        self.weight = CplxParameter(
+            cplx.Cplx.empty(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = CplxParameter(cplx.Cplx.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        weight = self.weight
+        init.cplx_kaiming_uniform_(weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init.get_fans(weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.cplx_uniform_independent_(self.bias, -bound, bound)
+
+    def forward(self, input):
+        return cplx.conv2d(input, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.groups, self.padding_mode)
+
+    def extra_repr(self):
+        s = (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
+             f"stride={self.stride}")
+        if any(self.padding):
+            s += f", padding={self.padding}"
+        if any(d != 1 for d in self.dilation):
+            s += f", dilation={self.dilation}"
+        if self.groups != 1:
+            s += f", groups={self.groups}"
+        if self.bias is None:
+            s += ", bias=False"
+        if self.padding_mode != "zeros":
+            s += f", padding_mode='{self.padding_mode}'"
+        return s

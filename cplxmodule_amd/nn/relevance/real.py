@@ -1,0 +1,96 @@
+"""Real-valued variational dropout / ARD layers (cplxmodule/nn/relevance/real/{base,vd,ard}.py)
+on the real GEMM + fused LRT / KL kernels."""
+import torch
+
+from .base import BaseARD
+from .noise import noise
+from ..utils.sparsity import SparsityStats
+from ... import ops
+
+
+class _RealGaussianMixin:
+    _kl_kind = "real_vd"
+    __sparsity_ignore__ = ("log_sigma2",)
+
+    def _init_variational(self):
+        self.log_sigma2 = torch.nn.Parameter(torch.empty(*self.weight.shape))
+        self.reset_variational_parameters()
+
+    def reset_variational_parameters(self):
+        self.log_sigma2.data.fill_(-10.0)
+
+    @property
+    def log_alpha(self):
+        if torch.is_grad_enabled() and (self.log_sigma2.requires_grad or self.weight.requires_grad):
+            return self.log_sigma2 - 2 * torch.log(abs(self.weight) + 1e-12)
+        return ops.log_alpha(self.weight, None, self.log_sigma2).view_as(self.log_sigma2)
+
+    @property
+    def penalty(self):
+        return ops.PenaltyFn.apply(self._kl_kind, self.log_sigma2, self.weight, None)
+
+    def _penalty_reduced(self, reduction):
+        total = ops.PenaltySumFn.apply(self._kl_kind, self.log_sigma2, self.weight, None)
+        return total / self.log_sigma2.numel() if reduction == "mean" else total
+
+    def relevance(self, *, threshold, **kwargs):
+        with torch.no_grad():
+            return ops.relevance_mask(self.weight, None, self.log_sigma2, threshold)
+
+    def sparsity(self, *, threshold, **kwargs):
+        with torch.no_grad():
+            _, kept = ops.relevance_mask(self.weight, None, self.log_sigma2, threshold, count=True)
+        return [(id(self.weight), self.weight.numel() - float(kept.item()))]
+
+    def _draw_noise(self, shape, like):
+        if noise.mode == "torch":
+            return torch.randn(*shape, dtype=like.dtype, device=like.device), 0, 0
+        seed, offset = noise.next()
+        return None, seed, offset
+
+
+class LinearGaussian(_RealGaussianMixin, torch.nn.Linear):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__(in_features, out_features, bias=bias)
+        self._init_variational()
+
+    def forward(self, input, eps=None):
+        if not self.training:
+            return ops.RealLinearFn.apply(input, self.weight, self.bias)
+        seed = offset = 0
+        if eps is None:
+            eps, seed, offset = self._draw_noise((*input.shape[:-1], self.out_features), input)
+        return ops.RealLinearLRTFn.apply(input, self.weight, self.bias, self.log_sigma2, eps,
+                                         seed, offset)
+
+
+class LinearVD(_RealGaussianMixin, SparsityStats, LinearGaussian, BaseARD):
+    """Linear layer with variational dropout (softplus-sigmoid KL approximation)."""
+    _kl_kind = "real_vd"
+
+
+class LinearARD(LinearVD):
+    """Linear layer with automatic relevance determination."""
+    _kl_kind = "real_ard"
+
+
+class Conv2dGaussian(_RealGaussianMixin, torch.nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                         dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode)
+        if self.padding_mode != "zeros":
+            raise ValueError(f"Only `zeros` padding mode is supported. Got `{self.padding_mode}`.")
+        self._init_variational()
+
+    def forward(self, input, eps=None):
+        from ... import conv
+        return conv.real_conv2d_layer(self, input, eps)
+
+
+class Conv2dVD(_RealGaussianMixin, SparsityStats, Conv2dGaussian, BaseARD):
+    _kl_kind = "real_vd"
+
+
+class Conv2dARD(Conv2dVD):
+    _kl_kind = "real_ard"

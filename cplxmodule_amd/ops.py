@@ -1,0 +1,485 @@
+"""Kernel wrappers (tensor in, tensor out) and the autograd Functions built on them.
+
+Everything here launches libcplxamd.so kernels on the current HIP stream; torch is used only
+to allocate outputs and to hook the kernels into autograd.  Shapes follow the reference:
+complex tensors are (real, imag) pairs of equal-shaped planes (cplxmodule/cplx.py:10-52).
+"""
+import torch
+
+from . import _lib
+from ._lib import call, dtype_code, ptr, require_device, stream_ptr
+
+_ws_cache = {}
+
+
+def _ws(device):
+    key = (device.type, device.index)
+    if key not in _ws_cache:
+        nbytes = int(_lib.load().cplxamd_vd_kl_ws_bytes())
+        _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _ws_cache[key]
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise _lib.CplxAmdError(f"expected a float32 tensor, got {t.dtype}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------ #
+#  raw kernels                                                                               #
+# ------------------------------------------------------------------------------------------ #
+def cast(t, dtype):
+    """dtype conversion kernel (float32 <-> bfloat16); returns `t` itself if nothing to do."""
+    if t.dtype == dtype:
+        return t
+    require_device(t)
+    t = t.contiguous()
+    out = torch.empty_like(t, dtype=dtype)
+    call("cplxamd_cast", ptr(t), ptr(out), t.numel(), dtype_code(t), dtype_code(out), stream_ptr())
+    return out
+
+
+def transpose2d(t):
+    """[R, C] -> contiguous [C, R] through the LDS-tiled transpose kernel."""
+    require_device(t)
+    t = t.contiguous()
+    R, C = t.shape
+    out = torch.empty(C, R, dtype=t.dtype, device=t.device)
+    call("cplxamd_transpose", ptr(t), C, ptr(out), R, R, C, dtype_code(t), stream_ptr())
+    return out
+
+
+def colsum(t):
+    """sum over dim 0 of a [R, C] matrix -> float32 [C]."""
+    require_device(t)
+    t = t.contiguous()
+    R, C = t.shape
+    out = torch.empty(C, dtype=torch.float32, device=t.device)
+    call("cplxamd_colsum", ptr(t), C, ptr(out), R, C, dtype_code(t), stream_ptr())
+    return out
+
+
+def abs2(xr, xi=None, out_dtype=None):
+    """xr^2 + xi^2 (or xr^2), cplxmodule/nn/relevance/complex/base.py:51."""
+    require_device(xr, xi)
+    xr, xi = _c(xr), _c(xi)
+    out = torch.empty_like(xr, dtype=out_dtype or xr.dtype)
+    call("cplxamd_abs2", ptr(xr), ptr(xi), ptr(out), xr.numel(), dtype_code(xr),
+         dtype_code(out), stream_ptr())
+    return out
+
+
+def modulus(xr, xi):
+    """abs(Cplx), cplxmodule/cplx.py:183-192, float32 only."""
+    require_device(xr, xi)
+    xr, xi = _f32(_c(xr)), _f32(_c(xi))
+    out = torch.empty_like(xr)
+    call("cplxamd_modulus", ptr(xr), ptr(xi), ptr(out), xr.numel(), stream_ptr())
+    return out
+
+
+def exp(x, out_dtype=torch.float32):
+    require_device(x)
+    x = _f32(_c(x))
+    out = torch.empty_like(x, dtype=out_dtype)
+    call("cplxamd_exp", ptr(x), ptr(out), x.numel(), dtype_code(out), stream_ptr())
+    return out
+
+
+def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False,
+          out_dtype=torch.float32, out=None, accumulate=False):
+    """C[m,n] = sum_k A[m,k] op(B[n,k]) (+ bias[n]) on planar complex operands.
+    `a_strides` / `b_strides` are (row, col) element strides into the given planes."""
+    require_device(ar, ai, br, bi)
+    if out is None:
+        cr = torch.empty(M, N, dtype=out_dtype, device=ar.device)
+        ci = torch.empty(M, N, dtype=out_dtype, device=ar.device)
+    else:
+        cr, ci = out
+    b_r, b_i = (None, None) if bias is None else bias
+    call("cplxamd_cgemm", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
+         b_strides[0], b_strides[1], ptr(b_r), ptr(b_i), ptr(cr), ptr(ci), N, M, N, K,
+         int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), 0, stream_ptr())
+    return cr, ci
+
+
+def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=torch.float32):
+    require_device(a, b, bias, emul)
+    c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    call("cplxamd_rgemm", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
+         ptr(bias), ptr(emul), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c), 0, stream_ptr())
+    return c
+
+
+def philox_normal(n, seed, offset, device, complex_=False):
+    """The in-kernel Philox noise stream, materialised (tests / debugging)."""
+    er = torch.empty(n, dtype=torch.float32, device=device)
+    ei = torch.empty(n, dtype=torch.float32, device=device) if complex_ else None
+    require_device(er)
+    call("cplxamd_philox_normal", ptr(er), ptr(ei), seed, offset, n, stream_ptr())
+    return (er, ei) if complex_ else er
+
+
+def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
+    """y = mu + eps * sqrt(max(s2, 1e-8)); eps=(eps_r, eps_i) / eps_r tensor or None (Philox)."""
+    require_device(mu_r, mu_i, s2)
+    mu_r, mu_i, s2 = _c(mu_r), _c(mu_i), _f32(_c(s2))
+    e_r = e_i = None
+    if eps is not None:
+        e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
+        e_r, e_i = _c(cast(e_r, mu_r.dtype)), (None if e_i is None else _c(cast(e_i, mu_r.dtype)))
+    y_r = mu_r if inplace else torch.empty_like(mu_r)
+    y_i = None if mu_i is None else (mu_i if inplace else torch.empty_like(mu_i))
+    call("cplxamd_lrt_reparam_fwd", ptr(mu_r), ptr(mu_i), ptr(s2), ptr(e_r), ptr(e_i), seed,
+         offset, ptr(y_r), ptr(y_i), mu_r.numel(), dtype_code(mu_r), stream_ptr())
+    return y_r, y_i
+
+
+def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float32):
+    require_device(g_r, g_i, s2)
+    g_r, g_i, s2 = _c(g_r), _c(g_i), _f32(_c(s2))
+    e_r = e_i = None
+    if eps is not None:
+        e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
+        e_r, e_i = _c(cast(e_r, g_r.dtype)), (None if e_i is None else _c(cast(e_i, g_r.dtype)))
+    g_s2 = torch.empty_like(s2, dtype=out_dtype)
+    call("cplxamd_lrt_reparam_bwd", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), seed, offset,
+         ptr(g_s2), g_r.numel(), dtype_code(g_r), dtype_code(g_s2), stream_ptr())
+    return g_s2
+
+
+def lrt_dx_accum(dxr, dxi, xr, xi, ga):
+    require_device(dxr, dxi, xr, xi, ga)
+    call("cplxamd_lrt_dx_accum", ptr(dxr), ptr(dxi), ptr(xr), ptr(xi), ptr(ga), dxr.numel(),
+         dtype_code(dxr), dtype_code(ga), stream_ptr())
+
+
+def kl_fwd(kind, wr, wi, ls2, elementwise=False, total=True):
+    require_device(wr, wi, ls2)
+    wr, wi, ls2 = _f32(_c(wr)), _f32(_c(wi)), _f32(_c(ls2))
+    elem = torch.empty_like(wr) if elementwise else None
+    tot = torch.empty((), dtype=torch.float32, device=wr.device) if total else None
+    call("cplxamd_vd_kl_fwd", ptr(wr), ptr(wi), ptr(ls2), _lib.KL_KINDS[kind], ptr(elem), ptr(tot),
+         ptr(_ws(wr.device)), wr.numel(), stream_ptr())
+    return elem, tot
+
+
+def kl_bwd(kind, wr, wi, ls2, g_elem=None, g_scalar=None, need=(True, True, True)):
+    require_device(wr, wi, ls2, g_elem, g_scalar)
+    wr, wi, ls2 = _f32(_c(wr)), _f32(_c(wi)), _f32(_c(ls2))
+    g_elem = _f32(_c(g_elem))
+    if g_scalar is not None:
+        g_scalar = _f32(g_scalar.reshape(()).contiguous())
+    g_ls2 = torch.empty_like(ls2) if need[0] else None
+    g_wr = torch.empty_like(wr) if need[1] else None
+    g_wi = torch.empty_like(wi) if (wi is not None and need[2]) else None
+    call("cplxamd_vd_kl_bwd", ptr(wr), ptr(wi), ptr(ls2), _lib.KL_KINDS[kind], ptr(g_elem),
+         ptr(g_scalar), ptr(g_ls2), ptr(g_wr), ptr(g_wi), wr.numel(), stream_ptr())
+    return g_ls2, g_wr, g_wi
+
+
+def kl_fwd_bwd(kind, wr, wi, ls2, gscale=1.0):
+    """One pass: (sum(penalty), gscale * d sum / d(log_sigma2, wr, wi))."""
+    require_device(wr, wi, ls2)
+    wr, wi, ls2 = _f32(_c(wr)), _f32(_c(wi)), _f32(_c(ls2))
+    tot = torch.empty((), dtype=torch.float32, device=wr.device)
+    g_ls2, g_wr = torch.empty_like(ls2), torch.empty_like(wr)
+    g_wi = None if wi is None else torch.empty_like(wi)
+    call("cplxamd_vd_kl_fwd_bwd", ptr(wr), ptr(wi), ptr(ls2), _lib.KL_KINDS[kind], float(gscale),
+         ptr(tot), ptr(g_ls2), ptr(g_wr), ptr(g_wi), ptr(_ws(wr.device)), wr.numel(), stream_ptr())
+    return tot, g_ls2, g_wr, g_wi
+
+
+def log_alpha(wr, wi, ls2):
+    require_device(wr, wi, ls2)
+    wr, wi, ls2 = _f32(_c(wr)), _f32(_c(wi)), _f32(_c(ls2))
+    out = torch.empty_like(ls2)
+    call("cplxamd_vd_log_alpha", ptr(wr), ptr(wi), ptr(ls2), ptr(out), wr.numel(), stream_ptr())
+    return out
+
+
+def relevance_mask(wr, wi, ls2, threshold, count=False):
+    """float 0/1 mask of (log_alpha <= threshold) and, optionally, the on-device count of ones."""
+    require_device(wr, wi, ls2)
+    wr, wi, ls2 = _f32(_c(wr)), _f32(_c(wi)), _f32(_c(ls2))
+    mask = torch.empty_like(ls2)
+    cnt = torch.empty((), dtype=torch.int64, device=wr.device) if count else None
+    call("cplxamd_vd_mask", ptr(wr), ptr(wi), ptr(ls2), float(threshold), ptr(mask), ptr(cnt),
+         ptr(_ws(wr.device)), wr.numel(), stream_ptr())
+    return (mask, cnt) if count else mask
+
+
+# ------------------------------------------------------------------------------------------ #
+#  linear algebra with layout handling                                                       #
+# ------------------------------------------------------------------------------------------ #
+def _is_bf16(t):
+    return t.dtype == torch.bfloat16
+
+
+def _cplx_linear_fwd(x2r, x2i, wr, wi, bias):
+    """[B,I] x [O,I]^T -> [B,O]; weights are cast to the activation dtype (bf16 MFMA path)."""
+    B, I = x2r.shape
+    O = wr.shape[0]
+    wcr, wci = cast(wr, x2r.dtype), cast(wi, x2r.dtype)
+    return cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
+
+
+def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype):
+    """dX = G conj(W):  dX[b,i] = sum_o G[b,o] conj(W[o,i])."""
+    B, O = g2r.shape
+    I = wr.shape[1]
+    if _is_bf16(g2r):
+        wtr, wti = transpose2d(cast(wr, torch.bfloat16)), transpose2d(cast(wi, torch.bfloat16))
+        return cgemm(g2r, g2i, (O, 1), wtr, wti, (O, 1), B, I, O, conj_b=True, out_dtype=out_dtype)
+    return cgemm(g2r, g2i, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=out_dtype)
+
+
+def _cplx_linear_dw(g2r, g2i, x2r, x2i):
+    """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]."""
+    B, O = g2r.shape
+    I = x2r.shape[1]
+    if _is_bf16(g2r) and B % 32 == 0 and B >= 32:
+        gtr, gti = transpose2d(g2r), transpose2d(g2i)
+        xtr, xti = transpose2d(x2r), transpose2d(x2i)
+        return cgemm(gtr, gti, (B, 1), xtr, xti, (B, 1), O, I, B, conj_b=True)
+    return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True)
+
+
+def _real_linear_dx(g2, w, out_dtype):
+    B, O = g2.shape
+    I = w.shape[1]
+    if _is_bf16(g2):
+        return rgemm(g2, (O, 1), transpose2d(cast(w, torch.bfloat16)), (O, 1), B, I, O,
+                     out_dtype=out_dtype)
+    return rgemm(g2, (O, 1), w, (1, I), B, I, O, out_dtype=out_dtype)
+
+
+def _real_linear_dw(g2, x2, emul=None):
+    B, O = g2.shape
+    I = x2.shape[1]
+    if _is_bf16(g2) and _is_bf16(x2) and B % 32 == 0 and B >= 32:
+        return rgemm(transpose2d(g2), (B, 1), transpose2d(x2), (B, 1), O, I, B, emul=emul)
+    if g2.dtype != x2.dtype:
+        g2, x2 = cast(g2, torch.float32), cast(x2, torch.float32)
+    return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul)
+
+
+class CplxLinearFn(torch.autograd.Function):
+    """cplx.linear (cplxmodule/cplx.py:634-648) + its backward."""
+
+    @staticmethod
+    def forward(ctx, xr, xi, wr, wi, br, bi):
+        require_device(xr, xi, wr, wi, br, bi)
+        I, O = wr.shape[1], wr.shape[0]
+        x2r, x2i = xr.reshape(-1, I).contiguous(), xi.reshape(-1, I).contiguous()
+        bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
+        yr, yi = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
+        ctx.save_for_backward(x2r, x2i, wr, wi)
+        ctx.has_bias = br is not None
+        ctx.lead = xr.shape[:-1]
+        return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O)
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        x2r, x2i, wr, wi = ctx.saved_tensors
+        O, I = wr.shape
+        g2r, g2i = gr.reshape(-1, O).contiguous(), gi.reshape(-1, O).contiguous()
+        need = ctx.needs_input_grad
+        dxr = dxi = dwr = dwi = dbr = dbi = None
+        if need[0] or need[1]:
+            dxr, dxi = _cplx_linear_dx(g2r, g2i, _c(wr), _c(wi), x2r.dtype)
+            dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
+        if need[2] or need[3]:
+            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
+        if ctx.has_bias and (need[4] or need[5]):
+            dbr, dbi = colsum(g2r), colsum(g2i)
+        return dxr, dxi, dwr, dwi, dbr, dbi
+
+
+class CplxLinearLRTFn(torch.autograd.Function):
+    """CplxLinearGaussian.forward in training mode (nn/relevance/complex/base.py:43-56):
+    mu GEMM + variance GEMM + noise injection, backward per SURVEY A.2."""
+
+    @staticmethod
+    def forward(ctx, xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i, seed, offset):
+        require_device(xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i)
+        O, I = wr.shape
+        x2r, x2i = xr.reshape(-1, I).contiguous(), xi.reshape(-1, I).contiguous()
+        B = x2r.shape[0]
+        bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
+        mur, mui = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
+        a = abs2(x2r, x2i)                                   # [B,I], activation dtype
+        S = exp(_c(ls2), out_dtype=x2r.dtype)                # [O,I]
+        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)            # float32 [B,O]
+        eps = None
+        if eps_r is not None:
+            eps = (eps_r.reshape(B, O), eps_i.reshape(B, O))
+        yr, yi = reparam_fwd(mur, mui, s2, eps, seed, offset, inplace=True)
+        ctx.save_for_backward(x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i)
+        ctx.has_bias = br is not None
+        ctx.lead, ctx.seed, ctx.offset = xr.shape[:-1], seed, offset
+        return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O)
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i = ctx.saved_tensors
+        O, I = wr.shape
+        B = x2r.shape[0]
+        g2r, g2i = gr.reshape(B, O).contiguous(), gi.reshape(B, O).contiguous()
+        need = ctx.needs_input_grad
+        eps = None if eps_r is None else (eps_r.reshape(B, O), eps_i.reshape(B, O))
+        dt = x2r.dtype
+        gs2 = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt)
+        dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
+        if need[0] or need[1]:
+            dxr, dxi = _cplx_linear_dx(g2r, g2i, _c(wr), _c(wi), dt)
+            S = exp(_c(ls2), out_dtype=dt)
+            ga = _real_linear_dx(gs2, S, dt)                 # gs2 . S -> [B,I]
+            lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
+            dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
+        if need[2] or need[3]:
+            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
+        if ctx.has_bias and (need[4] or need[5]):
+            dbr, dbi = colsum(g2r), colsum(g2i)
+        if need[6]:
+            dls2 = _real_linear_dw(gs2, a, emul=exp(_c(ls2)))  # (gs2^T a) * exp(ls2)
+        return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None
+
+
+class RealLinearFn(torch.autograd.Function):
+    """F.linear on the real GEMM kernel (the mean of LinearGaussian, real/base.py:44)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, w, b)
+        O, I = w.shape
+        x2 = x.reshape(-1, I).contiguous()
+        y = rgemm(x2, (I, 1), cast(_c(w), x2.dtype), (I, 1), x2.shape[0], O, I, bias=_c(b),
+                  out_dtype=x2.dtype)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias, ctx.lead = b is not None, x.shape[:-1]
+        return y.view(*ctx.lead, O)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        O, I = w.shape
+        g2 = g.reshape(-1, O).contiguous()
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        if need[0]:
+            dx = _real_linear_dx(g2, _c(w), x2.dtype).view(*ctx.lead, I)
+        if need[1]:
+            dw = _real_linear_dw(g2, x2)
+        if ctx.has_bias and need[2]:
+            db = colsum(g2)
+        return dx, dw, db
+
+
+class RealLinearLRTFn(torch.autograd.Function):
+    """LinearGaussian.forward in training mode (nn/relevance/real/base.py:43-49)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, ls2, eps, seed, offset):
+        require_device(x, w, b, ls2, eps)
+        O, I = w.shape
+        x2 = x.reshape(-1, I).contiguous()
+        B = x2.shape[0]
+        mu = rgemm(x2, (I, 1), cast(_c(w), x2.dtype), (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
+        a = abs2(x2)
+        S = exp(_c(ls2), out_dtype=x2.dtype)
+        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)
+        e = None if eps is None else eps.reshape(B, O)
+        y, _ = reparam_fwd(mu, None, s2, e, seed, offset, inplace=True)
+        ctx.save_for_backward(x2, w, ls2, s2, a, eps)
+        ctx.has_bias, ctx.lead, ctx.seed, ctx.offset = b is not None, x.shape[:-1], seed, offset
+        return y.view(*ctx.lead, O)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, ls2, s2, a, eps = ctx.saved_tensors
+        O, I = w.shape
+        B = x2.shape[0]
+        g2 = g.reshape(B, O).contiguous()
+        need = ctx.needs_input_grad
+        dt = x2.dtype
+        e = None if eps is None else eps.reshape(B, O)
+        gs2 = reparam_bwd(g2, None, s2, e, ctx.seed, ctx.offset, out_dtype=dt)
+        dx = dw = db = dls2 = None
+        if need[0]:
+            dx = _real_linear_dx(g2, _c(w), dt)
+            ga = _real_linear_dx(gs2, exp(_c(ls2), out_dtype=dt), dt)
+            lrt_dx_accum(dx, None, x2, None, ga)
+            dx = dx.view(*ctx.lead, I)
+        if need[1]:
+            dw = _real_linear_dw(g2, x2)
+        if ctx.has_bias and need[2]:
+            db = colsum(g2)
+        if need[3]:
+            dls2 = _real_linear_dw(gs2, a, emul=exp(_c(ls2)))
+        return dx, dw, db, dls2, None, None, None
+
+
+class PenaltyFn(torch.autograd.Function):
+    """Elementwise KL penalty tensor (the `.penalty` property of the VD / ARD layers)."""
+
+    @staticmethod
+    def forward(ctx, kind, ls2, wr, wi):
+        elem, _ = kl_fwd(kind, wr, wi, ls2, elementwise=True, total=False)
+        ctx.kind = kind
+        ctx.save_for_backward(ls2, wr, wi)
+        return elem.view_as(ls2)
+
+    @staticmethod
+    def backward(ctx, g):
+        ls2, wr, wi = ctx.saved_tensors
+        need = ctx.needs_input_grad[1:]
+        g_ls2, g_wr, g_wi = kl_bwd(ctx.kind, wr, wi, ls2, g_elem=g.contiguous(), need=need)
+        v = lambda t: None if t is None else t.view_as(ls2)  # noqa: E731
+        return None, v(g_ls2), v(g_wr), v(g_wi)
+
+
+class PenaltySumFn(torch.autograd.Function):
+    """sum(penalty) as ONE fused elementwise + wavefront-shuffle reduction kernel; the backward
+    re-reads the parameters and scales by the upstream scalar read on-device (no host sync)."""
+
+    @staticmethod
+    def forward(ctx, kind, ls2, wr, wi):
+        _, tot = kl_fwd(kind, wr, wi, ls2, elementwise=False, total=True)
+        ctx.kind = kind
+        ctx.save_for_backward(ls2, wr, wi)
+        return tot
+
+    @staticmethod
+    def backward(ctx, g):
+        ls2, wr, wi = ctx.saved_tensors
+        need = ctx.needs_input_grad[1:]
+        g_ls2, g_wr, g_wi = kl_bwd(ctx.kind, wr, wi, ls2, g_scalar=g, need=need)
+        v = lambda t: None if t is None else t.view_as(ls2)  # noqa: E731
+        return None, v(g_ls2), v(g_wr), v(g_wi)
+
+
+class ExpiFn(torch.autograd.Function):
+    """torch_expi (cplxmodule/nn/relevance/complex/vd.py:15-44) without the host round trip."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_device(x)
+        xc = _f32(x.contiguous())
+        y = torch.empty_like(xc)
+        call("cplxamd_expi_fwd", ptr(xc), ptr(y), xc.numel(), stream_ptr())
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _f32(g.contiguous())
+        gx = torch.empty_like(x)
+        call("cplxamd_expi_bwd", ptr(g), ptr(x), ptr(gx), x.numel(), stream_ptr())
+        return gx

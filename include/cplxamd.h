@@ -1,0 +1,172 @@
+/* cplxamd.h -- C ABI of libcplxamd.so: the MI355X (gfx950) kernels behind the
+ * cplxmodule hot path (complex linear / conv / batch-norm forward+backward and the
+ * variational-dropout local-reparameterization + KL path).
+ *
+ * Conventions
+ *  - plain device pointers, sizes and element strides; no torch / C++ types.
+ *  - complex tensors are two planar arrays (re, im): the reference's `Cplx` layout,
+ *    /root/reference/cplxmodule/cplx.py:10-52.
+ *  - every entry point is asynchronous on `stream` (a hipStream_t passed as void*),
+ *    never allocates, never synchronises, and returns 0 on success, a hipError_t
+ *    (> 0) for a failed launch, or a negative CPLXAMD_E* code for a bad argument.
+ *  - scratch memory is supplied by the caller; sizes come from the *_ws_bytes() helpers.
+ *
+ * Each entry point cites the reference function (file:line under /root/reference) whose
+ * arithmetic it replaces.
+ */
+#ifndef CPLXAMD_H
+#define CPLXAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPLXAMD_ABI_VERSION 1
+
+/* element types of activations / outputs */
+enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
+
+/* KL penalty kinds */
+enum {
+  CPLXAMD_KL_REAL_VD = 0,  /* cplxmodule/nn/relevance/real/vd.py:54-76     */
+  CPLXAMD_KL_REAL_ARD = 1, /* cplxmodule/nn/relevance/real/ard.py:10-39    */
+  CPLXAMD_KL_CPLX_VD = 2,  /* cplxmodule/nn/relevance/complex/vd.py:95-99  */
+  CPLXAMD_KL_CPLX_ARD = 3  /* cplxmodule/nn/relevance/complex/ard.py:9-39  */
+};
+
+/* error codes (negative; positive values are hipError_t) */
+enum {
+  CPLXAMD_OK = 0,
+  CPLXAMD_EINVAL = -1,   /* bad enum / null pointer / negative size */
+  CPLXAMD_EALIGN = -2,   /* pointer or leading dimension not aligned as required */
+  CPLXAMD_ESHAPE = -3,   /* shape not supported by this entry point */
+  CPLXAMD_EWS = -4       /* workspace too small */
+};
+
+int cplxamd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * K6/K7  log-alpha, KL penalty (+ reduction, + gradients), relevance masks.
+ * Replaces: GaussianMixin.log_alpha      nn/relevance/{complex/base.py:27-31, real/base.py:23-26}
+ *           Cplx.__abs__                  cplx.py:183-192  (stack + norm)
+ *           *.penalty                     (the four files listed at the KL kinds above)
+ *           ExpiFunction fwd/bwd          nn/relevance/complex/vd.py:15-44 (scipy host round trip)
+ *           named_penalties' .sum()       nn/relevance/base.py:135-139
+ *           RelevanceMixin.relevance      nn/relevance/real/vd.py:16-19, complex/vd.py:50-53
+ * `wi` is NULL for the real kinds.  All tensors float32, contiguous, n elements.
+ * ---------------------------------------------------------------------------------- */
+
+/* bytes of scratch the KL reductions need (independent of n) */
+int64_t cplxamd_vd_kl_ws_bytes(void);
+
+/* out_elem[n] (nullable) = penalty; out_sum[1] (nullable) = sum(penalty) (fp64 accumulate). */
+int cplxamd_vd_kl_fwd(const float* wr, const float* wi, const float* log_sigma2, int kind,
+                      float* out_elem, float* out_sum, void* ws, int64_t n, void* stream);
+
+/* Gradient of  sum_j g_j * penalty_j  wrt (log_sigma2, wr, wi).  The upstream gradient is
+ * either a tensor g_elem[n] or, when g_elem is NULL, the scalar *g_scalar read on the device
+ * (no host sync).  Gradient outputs are nullable; they are overwritten, not accumulated. */
+int cplxamd_vd_kl_bwd(const float* wr, const float* wi, const float* log_sigma2, int kind,
+                      const float* g_elem, const float* g_scalar, float* g_log_sigma2,
+                      float* g_wr, float* g_wi, int64_t n, void* stream);
+
+/* One pass: out_sum = sum(penalty) AND the gradients of gscale * sum(penalty). */
+int cplxamd_vd_kl_fwd_bwd(const float* wr, const float* wi, const float* log_sigma2, int kind,
+                          float gscale, float* out_sum, float* g_log_sigma2, float* g_wr,
+                          float* g_wi, void* ws, int64_t n, void* stream);
+
+/* out[n] = log_sigma2 - 2 log(|w| + 1e-12), evaluated so that it reproduces the reference's
+ * float32 CPU result bit-for-bit wherever the libm log is correctly rounded. */
+int cplxamd_vd_log_alpha(const float* wr, const float* wi, const float* log_sigma2, float* out,
+                         int64_t n, void* stream);
+
+/* mask[n] = (log_alpha <= threshold) ? 1.f : 0.f;  count[1] (nullable, int64) = #ones. */
+int cplxamd_vd_mask(const float* wr, const float* wi, const float* log_sigma2, float threshold,
+                    float* mask, int64_t* count, void* ws, int64_t n, void* stream);
+
+/* torch_expi seam (nn/relevance/complex/vd.py:44): y = Ei(x), gx = g * exp(x) / x. */
+int cplxamd_expi_fwd(const float* x, float* y, int64_t n, void* stream);
+int cplxamd_expi_bwd(const float* g, const float* x, float* gx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5  local-reparameterization noise injection.
+ * Replaces: CplxLinearGaussian.forward line 56   nn/relevance/complex/base.py:56
+ *           LinearGaussian.forward line 49       nn/relevance/real/base.py:49
+ *           cplx.randn / randn_like              cplx.py:544-562
+ *   y = mu + eps * sqrt(max(s2, 1e-8))
+ * mu_i / y_i / eps_i NULL  => real layer (eps ~ N(0,1)); else eps_r, eps_i ~ N(0,1/2).
+ * eps_r NULL => noise from the counter-based Philox4x32-10 stream (seed, offset) defined in
+ * DESIGN.md ("noise stream"); the backward regenerates it from the same (seed, offset).
+ * s2 is float32; mu / y / eps / g have element type `dtype`.
+ * ---------------------------------------------------------------------------------- */
+int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
+                            const void* eps_r, const void* eps_i, uint64_t seed,
+                            uint64_t offset, void* y_r, void* y_i, int64_t n, int dtype,
+                            void* stream);
+
+/* g_s2 = (g_r*eps_r + g_i*eps_i) * 0.5 / sqrt(max(s2,1e-8)) * [s2 >= 1e-8]
+ * g_s2 has element type gs2_dtype (float32, or bf16 when it feeds the bf16 GEMMs). */
+int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
+                            const void* eps_r, const void* eps_i, uint64_t seed,
+                            uint64_t offset, void* g_s2, int64_t n, int dtype, int gs2_dtype,
+                            void* stream);
+
+/* Writes the Philox noise itself (float32), for tests: real (eps_i NULL) or complex. */
+int cplxamd_philox_normal(float* eps_r, float* eps_i, uint64_t seed, uint64_t offset,
+                          int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1/K4  complex and real GEMM,  C[m,n] = sum_k A[m,k] * op(B[n,k]) (+ bias[n]).
+ * Replaces: cplx.linear_naive / linear_3m / linear_cat   cplx.py:634-694
+ *           Cplx.__matmul__                               cplx.py:167-174
+ *           the LRT variance GEMM                         nn/relevance/complex/base.py:50-54,
+ *                                                         nn/relevance/real/base.py:48
+ * and their autograd backward (dX = G conj(W), dW = G^T conj(X)).
+ * A is addressed as A[m*a_rs + k*a_cs], B as B[n*b_rs + k*b_cs] (element strides), so one
+ * entry point covers NT / NN / TN.  conj_b: use conj(B).  in_dtype: element type of A and B;
+ * out_dtype: element type of C (row-major, leading dimension ldc).  bias is float32 [N].
+ * accumulate != 0: C += result (C must then be float32).
+ * The MFMA fast path (bf16 inputs, a_cs == b_cs == 1, K % 32 == 0, 16-byte aligned rows) is
+ * chosen automatically; everything else runs the generic float32-MFMA kernel.
+ * algo: 0 = 4M (four real products), 1 = 3M (Gauss; bf16 fast path only).
+ * ---------------------------------------------------------------------------------- */
+int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
+                  const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
+                  const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
+                  int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
+                  int algo, void* stream);
+
+/* real GEMM; emul (nullable, float32 [M,N] with leading dimension ldc): C = (A B^T) * emul. */
+int cplxamd_rgemm(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
+                  int64_t b_cs, const float* bias, const float* emul, void* c, int64_t ldc,
+                  int M, int N, int K, int in_dtype, int out_dtype, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * elementwise / layout helpers used by the layers (all HBM-bound streaming kernels)
+ * ---------------------------------------------------------------------------------- */
+/* out = xr^2 + xi^2 (xi NULL: xr^2)            nn/relevance/complex/base.py:51 */
+int cplxamd_abs2(const void* xr, const void* xi, void* out, int64_t n, int in_dtype,
+                 int out_dtype, void* stream);
+/* out = |x| = sqrt(xr^2 + xi^2), float32, rounded exactly like torch's CPU 2-norm
+ * (Cplx.__abs__, cplx.py:183-192) */
+int cplxamd_modulus(const float* xr, const float* xi, float* out, int64_t n, void* stream);
+/* out = exp(x), x float32                      nn/relevance/complex/base.py:52 */
+int cplxamd_exp(const float* x, void* out, int64_t n, int out_dtype, void* stream);
+/* dtype conversion */
+int cplxamd_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
+/* out[c, r] = in[r, c]  (rows x cols row-major in, ld = leading dims) */
+int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
+                      int cols, int dtype, void* stream);
+/* out[n] = sum_m in[m, n]   (bias gradient; float32 out) */
+int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, int dtype,
+                   void* stream);
+/* dxr += 2 xr ga ; dxi += 2 xi ga   (LRT backward; xi/dxi NULL for real) */
+int cplxamd_lrt_dx_accum(void* dxr, void* dxi, const void* xr, const void* xi, const void* ga,
+                         int64_t n, int dtype, int ga_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPLXAMD_H */
