@@ -64,7 +64,7 @@ class LinearGaussian(_RealGaussianMixin, torch.nn.Linear):
                                          seed, offset)
 
 
-class LinearVD(_RealGaussianMixin, SparsityStats, LinearGaussian, BaseARD):
+class LinearVD(SparsityStats, LinearGaussian, BaseARD):
     """Linear layer with variational dropout (softplus-sigmoid KL approximation)."""
     _kl_kind = "real_vd"
 
@@ -88,7 +88,7 @@ class Conv2dGaussian(_RealGaussianMixin, torch.nn.Conv2d):
         return conv.real_conv2d_layer(self, input, eps)
 
 
-class Conv2dVD(_RealGaussianMixin, SparsityStats, Conv2dGaussian, BaseARD):
+class Conv2dVD(SparsityStats, Conv2dGaussian, BaseARD):
     _kl_kind = "real_vd"
 
 
