@@ -42,8 +42,11 @@ SIGNATURES = {
     "cplxamd_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P],
     "cplxamd_lrt_dx_accum": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "cplxamd_bn_ws_bytes": [_I],
+    "cplxamd_bn_fwd": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P],
+    "cplxamd_bn_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _L, _P],
 }
-_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64}
+_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64}
 
 _lib = None
 

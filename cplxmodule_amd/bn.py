@@ -1,0 +1,63 @@
+"""Complex batch-norm autograd Function over the 2-pass moment / apply kernels (csrc/bn.hip)."""
+import torch
+
+from . import _lib
+from ._lib import call, dtype_code, ptr, require_device, stream_ptr
+
+_ws_cache = {}
+
+
+def _ws(device, F):
+    need = int(_lib.load().cplxamd_bn_ws_bytes(F))
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return buf
+
+
+def _geom(x):
+    B, F = x.shape[0], x.shape[1]
+    S = 1
+    for d in x.shape[2:]:
+        S *= d
+    return B, F, S
+
+
+class CplxBatchNormFn(torch.autograd.Function):
+    """cplx_batch_norm (cplxmodule/nn/modules/batchnorm.py:189-278) incl. whiten2x2 (:62-123)."""
+
+    @staticmethod
+    def forward(ctx, xr, xi, weight, bias, running_mean, running_var, training, momentum, eps):
+        require_device(xr, xi, weight, bias, running_mean, running_var)
+        if not training and running_mean is None:
+            raise ValueError("evaluation mode requires running statistics")
+        xr, xi = xr.contiguous(), xi.contiguous()
+        B, F, S = _geom(xr)
+        yr, yi = torch.empty_like(xr), torch.empty_like(xi)
+        saved = torch.empty(8, F, dtype=torch.float32, device=xr.device)
+        ws = _ws(xr.device, F)
+        w = None if weight is None else weight.detach().contiguous()
+        b = None if bias is None else bias.detach().contiguous()
+        call("cplxamd_bn_fwd", ptr(xr), ptr(xi), ptr(yr), ptr(yi), B, F, S, ptr(w), ptr(b),
+             ptr(running_mean), ptr(running_var), ptr(saved), int(training), dtype_code(xr),
+             momentum, eps, ptr(ws), ws.numel(), stream_ptr())
+        ctx.save_for_backward(xr, xi, w, saved)
+        ctx.training, ctx.affine = training, weight is not None
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        xr, xi, w, saved = ctx.saved_tensors
+        gr, gi = gr.contiguous(), gi.contiguous()
+        B, F, S = _geom(xr)
+        dxr, dxi = torch.empty_like(xr), torch.empty_like(xi)
+        dw = db = None
+        if ctx.affine:
+            dw = torch.empty(2, 2, F, dtype=torch.float32, device=xr.device)
+            db = torch.empty(2, F, dtype=torch.float32, device=xr.device)
+        ws = _ws(xr.device, F)
+        call("cplxamd_bn_bwd", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S,
+             ptr(w), ptr(saved), ptr(dw), ptr(db), int(ctx.training), dtype_code(xr), ptr(ws),
+             ws.numel(), stream_ptr())
+        return dxr, dxi, dw, db, None, None, None, None, None

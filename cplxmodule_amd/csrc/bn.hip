@@ -1,0 +1,436 @@
+// K3: complex batch normalisation (Trabelsi et al.), forward and backward, as
+//   pass 1  per-feature moment reduction (wave shuffles + fp64 accumulation)  -> partials
+//   tiny    per-feature finalize: 2x2 inverse square root, affine folded in, running stats
+//   pass 2  elementwise apply
+// instead of the reference's ~25 full-tensor passes (cplxmodule/nn/modules/batchnorm.py:62-123
+// whiten2x2, :254-278 affine).  Layout: planar (re, im), each [B, F, S] contiguous (S = product
+// of the spatial dims, 1 for [B, F] inputs).  HBM traffic fwd: 2 reads + 1 write of both planes.
+//
+// Backward is derived by hand through the closed-form inverse square root (gradients flow
+// through s and t, batchnorm.py:105-113); formulas in oracle/cplx_oracle.py:cplx_batch_norm_bwd.
+#include "common.h"
+
+namespace cplxamd {
+
+constexpr int kBnT = 256;
+constexpr int kBnMaxChunks = 512;
+constexpr int kSaved = 8;    // per-feature saved stats: mu, mv, p, q, w, vuu, vuv, vvv
+constexpr int kFwdCoef = 8;  // mu, mv, a00, a01, a10, a11, b0, b1
+constexpr int kBwdCoef = 12; // mu, mv, e00, e01, e10, e11, cuu, cuv, cvv, ku, kv, pad
+
+struct BnGeom {
+  int64_t B, S;
+  int F;
+  int seg;        // segments per plane
+  int64_t seglen; // elements per segment (multiple of 4)
+  int chunks;     // gridDim.y of the reduction kernels
+};
+
+static BnGeom bn_geom(int64_t B, int F, int64_t S) {
+  BnGeom g{B, S, F, 1, S, 1};
+  if (S > 1) {
+    // aim at ~4096 blocks of >= 4096 elements
+    int64_t want = 4096 / (F > 0 ? F : 1);
+    if (want < 1) want = 1;
+    int64_t seg = 1;
+    while (B * seg < want && S / (seg * 2) >= 4096) seg *= 2;
+    g.seg = (int)seg;
+    g.seglen = ((S + seg - 1) / seg + 3) / 4 * 4;
+    int64_t units = B * seg;
+    g.chunks = (int)(units < want ? units : want);
+  } else {
+    int64_t want = 2048 / ((F + 63) / 64);
+    if (want < 1) want = 1;
+    int64_t rows4 = (B + 3) / 4;
+    g.chunks = (int)(rows4 < want ? rows4 : want);
+  }
+  if (g.chunks > kBnMaxChunks) g.chunks = kBnMaxChunks;
+  if (g.chunks < 1) g.chunks = 1;
+  return g;
+}
+
+template <int NS> struct Acc { double v[NS]; };
+
+template <int NS, bool BWD>
+__device__ __forceinline__ void accum(Acc<NS>& a, float x0, float x1, float g0, float g1,
+                                      float mu, float mv) {
+  if (!BWD) {
+    const double u = x0, v = x1;
+    a.v[0] += u; a.v[1] += v; a.v[2] += u * u; a.v[3] += v * v; a.v[4] += u * v;
+  } else {
+    const float cu = x0 - mu, cv = x1 - mv;
+    a.v[0] += (double)g0; a.v[1] += (double)g1;
+    a.v[2] += (double)(g0 * cu); a.v[3] += (double)(g0 * cv);
+    a.v[4] += (double)(g1 * cu); a.v[5] += (double)(g1 * cv);
+  }
+}
+
+// S > 1: one block per (feature, chunk); partial[(chunk*F + f)*NS + j]
+template <typename T, int NS, bool BWD>
+__global__ __launch_bounds__(kBnT) void bn_reduce_planes(const T* xr, const T* xi, const T* gr,
+                                                         const T* gi, const float* saved,
+                                                         BnGeom g, double* partial) {
+  __shared__ double red[kBnT / 64];
+  const int f = blockIdx.x;
+  float mu = 0.f, mv = 0.f;
+  if (BWD) { mu = saved[f]; mv = saved[g.F + f]; }
+  Acc<NS> a;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) a.v[j] = 0.0;
+  const int64_t units = g.B * g.seg;
+  const bool vec = (g.S & 3) == 0;
+  for (int64_t unit = blockIdx.y; unit < units; unit += gridDim.y) {
+    const int64_t b = unit / g.seg;
+    const int sg = (int)(unit - b * g.seg);
+    const int64_t s0 = (int64_t)sg * g.seglen;
+    int64_t s1 = s0 + g.seglen;
+    if (s1 > g.S) s1 = g.S;
+    const int64_t base = (b * g.F + f) * g.S;
+    if (vec) {
+      for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 4 * kBnT) {
+        const f4 u = ld4(xr + base + s), v = ld4(xi + base + s);
+        f4 p = u, q = v;
+        if (BWD) { p = ld4(gr + base + s); q = ld4(gi + base + s); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accum<NS, BWD>(a, u.v[j], v.v[j], p.v[j], q.v[j], mu, mv);
+      }
+    } else {
+      for (int64_t s = s0 + threadIdx.x; s < s1; s += kBnT) {
+        const float u = io<T>::ld(xr + base + s), v = io<T>::ld(xi + base + s);
+        float p = 0.f, q = 0.f;
+        if (BWD) { p = io<T>::ld(gr + base + s); q = io<T>::ld(gi + base + s); }
+        accum<NS, BWD>(a, u, v, p, q, mu, mv);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const double s = block_sum<double, kBnT>(a.v[j], red);
+    if (threadIdx.x == 0) partial[((int64_t)blockIdx.y * g.F + f) * NS + j] = s;
+  }
+}
+
+// S == 1 ([B, F] input): threads run along F (coalesced), 4 row lanes per block
+template <typename T, int NS, bool BWD>
+__global__ __launch_bounds__(kBnT) void bn_reduce_cols(const T* xr, const T* xi, const T* gr,
+                                                       const T* gi, const float* saved, BnGeom g,
+                                                       double* partial) {
+  __shared__ double red[4][64];
+  const int fx = threadIdx.x & 63, by = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fx;
+  Acc<NS> a;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) a.v[j] = 0.0;
+  if (f < g.F) {
+    float mu = 0.f, mv = 0.f;
+    if (BWD) { mu = saved[f]; mv = saved[g.F + f]; }
+    for (int64_t b = (int64_t)blockIdx.y * 4 + by; b < g.B; b += 4 * (int64_t)gridDim.y) {
+      const int64_t o = b * g.F + f;
+      const float u = io<T>::ld(xr + o), v = io<T>::ld(xi + o);
+      float p = 0.f, q = 0.f;
+      if (BWD) { p = io<T>::ld(gr + o); q = io<T>::ld(gi + o); }
+      accum<NS, BWD>(a, u, v, p, q, mu, mv);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    red[by][fx] = a.v[j];
+    __syncthreads();
+    if (by == 0 && f < g.F)
+      partial[((int64_t)blockIdx.y * g.F + f) * NS + j] = red[0][fx] + red[1][fx] + red[2][fx] + red[3][fx];
+    __syncthreads();
+  }
+}
+
+struct Whiten { double p, q, w; };
+
+__device__ __forceinline__ Whiten inv_sqrt_2x2(double a, double b, double d) {
+  const double s = sqrt(a * d - b * b);
+  const double t = s * sqrt(a + d + 2.0 * s);
+  return Whiten{(d + s) / t, -b / t, (a + s) / t};
+}
+
+// forward finalize: one thread per feature
+__global__ void bn_fwd_finalize(const double* partial, int chunks, int F, double count,
+                                const float* weight, const float* bias, float* running_mean,
+                                float* running_var, int training, float momentum, float eps,
+                                float* saved, float* coef) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double mu, mv, vuu, vuv, vvv;
+  if (training) {
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int c = 0; c < chunks; ++c)
+      for (int j = 0; j < 5; ++j) s[j] += partial[((int64_t)c * F + f) * 5 + j];
+    mu = s[0] / count; mv = s[1] / count;
+    vuu = s[2] / count - mu * mu + (double)eps;
+    vvv = s[3] / count - mv * mv + (double)eps;
+    vuv = s[4] / count - mu * mv;
+    if (running_mean) {
+      // batchnorm.py:73,99  x += momentum * (new - x), in float32 like the reference
+      const float fm[2] = {(float)mu, (float)mv};
+      const float fc[4] = {(float)vuu, (float)vuv, (float)vuv, (float)vvv};
+      for (int j = 0; j < 2; ++j) running_mean[j * F + f] += momentum * (fm[j] - running_mean[j * F + f]);
+      for (int j = 0; j < 4; ++j) running_var[j * F + f] += momentum * (fc[j] - running_var[j * F + f]);
+    }
+  } else {
+    mu = running_mean[f]; mv = running_mean[F + f];
+    vuu = running_var[f]; vuv = running_var[F + f]; vvv = running_var[3 * F + f];
+  }
+  const Whiten r = inv_sqrt_2x2(vuu, vuv, vvv);
+  saved[0 * F + f] = (float)mu; saved[1 * F + f] = (float)mv;
+  saved[2 * F + f] = (float)r.p; saved[3 * F + f] = (float)r.q; saved[4 * F + f] = (float)r.w;
+  saved[5 * F + f] = (float)vuu; saved[6 * F + f] = (float)vuv; saved[7 * F + f] = (float)vvv;
+  double w00 = 1, w01 = 0, w10 = 0, w11 = 1, b0 = 0, b1 = 0;
+  if (weight) {
+    w00 = weight[f]; w01 = weight[F + f]; w10 = weight[2 * F + f]; w11 = weight[3 * F + f];
+    b0 = bias[f]; b1 = bias[F + f];
+  }
+  // zu = p cu + q cv ; zv = q cu + w cv ; out = W z + b
+  float* c = coef + (int64_t)f * kFwdCoef;
+  c[0] = (float)mu; c[1] = (float)mv;
+  c[2] = (float)(w00 * r.p + w01 * r.q); c[3] = (float)(w00 * r.q + w01 * r.w);
+  c[4] = (float)(w10 * r.p + w11 * r.q); c[5] = (float)(w10 * r.q + w11 * r.w);
+  c[6] = (float)b0; c[7] = (float)b1;
+}
+
+__global__ void bn_bwd_finalize(const double* partial, int chunks, int F, double count,
+                                const float* weight, const float* saved, int training,
+                                float* dweight, float* dbias, float* coef) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < chunks; ++c)
+    for (int j = 0; j < 6; ++j) s[j] += partial[((int64_t)c * F + f) * 6 + j];
+  const double Sgu = s[0], Sgv = s[1], Suu = s[2], Suv = s[3], Svu = s[4], Svv = s[5];
+  const double p = saved[2 * F + f], q = saved[3 * F + f], w = saved[4 * F + f];
+  double w00 = 1, w01 = 0, w10 = 0, w11 = 1;
+  if (weight) {
+    w00 = weight[f]; w01 = weight[F + f]; w10 = weight[2 * F + f]; w11 = weight[3 * F + f];
+  }
+  if (dweight) {
+    dweight[0 * F + f] = (float)(p * Suu + q * Suv);   // sum gou zu
+    dweight[1 * F + f] = (float)(q * Suu + w * Suv);   // sum gou zv
+    dweight[2 * F + f] = (float)(p * Svu + q * Svv);   // sum gov zu
+    dweight[3 * F + f] = (float)(q * Svu + w * Svv);   // sum gov zv
+  }
+  if (dbias) { dbias[f] = (float)Sgu; dbias[F + f] = (float)Sgv; }
+  float* c = coef + (int64_t)f * kBwdCoef;
+  c[0] = saved[f]; c[1] = saved[F + f];
+  // gzu = w00 gou + w10 gov ; gzv = w01 gou + w11 gov ; gu = p gzu + q gzv + ... ; gv = q gzu + w gzv + ...
+  c[2] = (float)(p * w00 + q * w01); c[3] = (float)(p * w10 + q * w11);
+  c[4] = (float)(q * w00 + w * w01); c[5] = (float)(q * w10 + w * w11);
+  double cuu = 0, cuv = 0, cvv = 0, ku = 0, kv = 0;
+  if (training) {
+    const double a = saved[5 * F + f], b = saved[6 * F + f], d = saved[7 * F + f];
+    const double sgzu = w00 * Sgu + w10 * Sgv, sgzv = w01 * Sgu + w11 * Sgv;
+    const double gp = w00 * Suu + w10 * Svu, gr_ = w00 * Suv + w10 * Svv;
+    const double gq = w01 * Suu + w11 * Svu, gw = w01 * Suv + w11 * Svv;
+    const double gqr = gq + gr_;
+    const double sd = sqrt(a * d - b * b), tau = a + d + 2.0 * sd, rt = sqrt(tau), t = sd * rt;
+    const double dsv[3] = {d / (2.0 * sd), a / (2.0 * sd), -b / sd};   // d s / d(a, d, b)
+    double gcov[3];
+    for (int X = 0; X < 3; ++X) {
+      const double dtau = (X == 2 ? 0.0 : 1.0) + 2.0 * dsv[X];
+      const double dt = dsv[X] * rt + sd * dtau / (2.0 * rt);
+      const double dp = (((X == 1 ? 1.0 : 0.0) + dsv[X]) * t - (d + sd) * dt) / (t * t);
+      const double dw = (((X == 0 ? 1.0 : 0.0) + dsv[X]) * t - (a + sd) * dt) / (t * t);
+      const double dq = (-(X == 2 ? 1.0 : 0.0) * t + b * dt) / (t * t);
+      gcov[X] = gp * dp + gw * dw + gqr * dq;
+    }
+    cuu = 2.0 * gcov[0] / count; cvv = 2.0 * gcov[1] / count; cuv = gcov[2] / count;
+    ku = (p * sgzu + q * sgzv) / count; kv = (q * sgzu + w * sgzv) / count;
+  }
+  c[6] = (float)cuu; c[7] = (float)cuv; c[8] = (float)cvv; c[9] = (float)ku; c[10] = (float)kv;
+  c[11] = 0.f;
+}
+
+// apply, S > 1: grid (ceil(S/(4*256)) , B*F)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(kBnT) void bn_apply_planes(const T* xr, const T* xi, const T* gr,
+                                                        const T* gi, T* yr, T* yi,
+                                                        const float* coef, int F, int64_t S) {
+  const int f = blockIdx.y % F;
+  const float* c = coef + (int64_t)f * (BWD ? kBwdCoef : kFwdCoef);
+  const float mu = c[0], mv = c[1], a00 = c[2], a01 = c[3], a10 = c[4], a11 = c[5];
+  const float k6 = c[6], k7 = c[7];
+  float cvv = 0.f, ku = 0.f, kv = 0.f;
+  if (BWD) { cvv = c[8]; ku = c[9]; kv = c[10]; }
+  const int64_t base = (int64_t)blockIdx.y * S;
+  if ((S & 3) == 0) {
+    const int64_t s = ((int64_t)blockIdx.x * kBnT + threadIdx.x) * 4;
+    if (s >= S) return;
+    const f4 u = ld4(xr + base + s), v = ld4(xi + base + s);
+    f4 ou, ov;
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float cu = u.v[j] - mu, cv = v.v[j] - mv;
+        ou.v[j] = fmaf(a00, cu, fmaf(a01, cv, k6));
+        ov.v[j] = fmaf(a10, cu, fmaf(a11, cv, k7));
+      }
+    } else {
+      const f4 p = ld4(gr + base + s), q = ld4(gi + base + s);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float cu = u.v[j] - mu, cv = v.v[j] - mv;
+        ou.v[j] = a00 * p.v[j] + a01 * q.v[j] + k6 * cu + k7 * cv - ku;
+        ov.v[j] = a10 * p.v[j] + a11 * q.v[j] + cvv * cv + k7 * cu - kv;
+      }
+    }
+    st4(yr + base + s, ou);
+    st4(yi + base + s, ov);
+  } else {
+    for (int j = 0; j < 4; ++j) {
+      const int64_t s = ((int64_t)blockIdx.x * 4 + j) * kBnT + threadIdx.x;
+      if (s >= S) return;
+      const float cu = io<T>::ld(xr + base + s) - mu, cv = io<T>::ld(xi + base + s) - mv;
+      float ou, ov;
+      if (!BWD) {
+        ou = fmaf(a00, cu, fmaf(a01, cv, k6));
+        ov = fmaf(a10, cu, fmaf(a11, cv, k7));
+      } else {
+        const float p = io<T>::ld(gr + base + s), q = io<T>::ld(gi + base + s);
+        ou = a00 * p + a01 * q + k6 * cu + k7 * cv - ku;
+        ov = a10 * p + a11 * q + cvv * cv + k7 * cu - kv;
+      }
+      io<T>::st(yr + base + s, ou);
+      io<T>::st(yi + base + s, ov);
+    }
+  }
+}
+
+// apply, S == 1
+template <typename T, bool BWD>
+__global__ __launch_bounds__(kBnT) void bn_apply_cols(const T* xr, const T* xi, const T* gr,
+                                                      const T* gi, T* yr, T* yi, const float* coef,
+                                                      int F, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kBnT;
+  for (int64_t e = (int64_t)blockIdx.x * kBnT + threadIdx.x; e < n; e += stride) {
+    const int f = (int)(e % F);
+    const float* c = coef + (int64_t)f * (BWD ? kBwdCoef : kFwdCoef);
+    const float cu = io<T>::ld(xr + e) - c[0], cv = io<T>::ld(xi + e) - c[1];
+    float ou, ov;
+    if (!BWD) {
+      ou = fmaf(c[2], cu, fmaf(c[3], cv, c[6]));
+      ov = fmaf(c[4], cu, fmaf(c[5], cv, c[7]));
+    } else {
+      const float p = io<T>::ld(gr + e), q = io<T>::ld(gi + e);
+      ou = c[2] * p + c[3] * q + c[6] * cu + c[7] * cv - c[9];
+      ov = c[4] * p + c[5] * q + c[8] * cv + c[7] * cu - c[10];
+    }
+    io<T>::st(yr + e, ou);
+    io<T>::st(yi + e, ov);
+  }
+}
+
+static int64_t bn_ws_bytes(int F) {
+  return (int64_t)kBnMaxChunks * F * 6 * sizeof(double) + (int64_t)F * kBwdCoef * sizeof(float);
+}
+
+template <typename T, bool BWD>
+static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi, void* yr,
+                  void* yi, int64_t B, int F, int64_t S, const float* weight, const float* bias,
+                  float* running_mean, float* running_var, float* saved, float* dweight,
+                  float* dbias, int training, float momentum, float eps, void* ws,
+                  hipStream_t st) {
+  const BnGeom g = bn_geom(B, F, S);
+  double* partial = (double*)ws;
+  float* coef = (float*)((char*)ws + (int64_t)kBnMaxChunks * F * 6 * sizeof(double));
+  constexpr int NS = BWD ? 6 : 5;
+  const bool need_reduce = BWD ? true : (training != 0);
+  if (need_reduce) {
+    if (S > 1) {
+      dim3 grid(F, g.chunks);
+      bn_reduce_planes<T, NS, BWD><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr,
+                                                          (const T*)gi, saved, g, partial);
+    } else {
+      dim3 grid((F + 63) / 64, g.chunks);
+      bn_reduce_cols<T, NS, BWD><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr,
+                                                        (const T*)gi, saved, g, partial);
+    }
+    CPLXAMD_CHECK_LAUNCH();
+  }
+  const double count = (double)B * (double)S;
+  const int fb = (F + 127) / 128;
+  if (!BWD)
+    bn_fwd_finalize<<<fb, 128, 0, st>>>(partial, g.chunks, F, count, weight, bias, running_mean,
+                                        running_var, training, momentum, eps, saved, coef);
+  else
+    bn_bwd_finalize<<<fb, 128, 0, st>>>(partial, g.chunks, F, count, weight, saved, training,
+                                        dweight, dbias, coef);
+  CPLXAMD_CHECK_LAUNCH();
+  if (S > 1) {
+    const int64_t planes = B * F;
+    if (planes > 0x7fffffff / 1) return CPLXAMD_ESHAPE;
+    // gridDim.y is limited to 65535: fold planes over several launches
+    const unsigned gx = (unsigned)((S + 4 * kBnT - 1) / (4 * kBnT));
+    for (int64_t p0 = 0; p0 < planes; p0 += 65535 - (65535 % F)) {
+      int64_t np = planes - p0;
+      const int64_t cap = 65535 - (65535 % F);
+      if (np > cap) np = cap;
+      dim3 grid(gx, (unsigned)np);
+      const int64_t off = p0 * S;
+      bn_apply_planes<T, BWD><<<grid, kBnT, 0, st>>>(
+          (const T*)xr + off, (const T*)xi + off, gr ? (const T*)gr + off : nullptr,
+          gi ? (const T*)gi + off : nullptr, (T*)yr + off, (T*)yi + off, coef, F, S);
+      CPLXAMD_CHECK_LAUNCH();
+    }
+  } else {
+    const int64_t n = B * F;
+    bn_apply_cols<T, BWD><<<stream_grid(n, kBnT), kBnT, 0, st>>>(
+        (const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr, (T*)yi, coef, F, n);
+    CPLXAMD_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+}  // namespace cplxamd
+
+using namespace cplxamd;
+
+extern "C" {
+
+int64_t cplxamd_bn_ws_bytes(int F) { return bn_ws_bytes(F); }
+
+int cplxamd_bn_fwd(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F,
+                   int64_t S, const float* weight, const float* bias, float* running_mean,
+                   float* running_var, float* saved, int training, int dtype, float momentum,
+                   float eps, void* ws, int64_t ws_bytes, void* stream) {
+  if (!xr || !xi || !yr || !yi || !saved || !ws || B <= 0 || F <= 0 || S <= 0) return CPLXAMD_EINVAL;
+  if ((weight == nullptr) != (bias == nullptr)) return CPLXAMD_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CPLXAMD_EINVAL;
+  if (!training && !running_mean) return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CPLXAMD_F32)
+    return bn_run<float, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias,
+                                running_mean, running_var, saved, nullptr, nullptr, training,
+                                momentum, eps, ws, st);
+  if (dtype == CPLXAMD_BF16)
+    return bn_run<bf16_t, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias,
+                                 running_mean, running_var, saved, nullptr, nullptr, training,
+                                 momentum, eps, ws, st);
+  return CPLXAMD_EINVAL;
+}
+
+int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr,
+                   void* dxi, int64_t B, int F, int64_t S, const float* weight,
+                   const float* saved, float* dweight, float* dbias, int training, int dtype,
+                   void* ws, int64_t ws_bytes, void* stream) {
+  if (!gr || !gi || !xr || !xi || !dxr || !dxi || !saved || !ws || B <= 0 || F <= 0 || S <= 0)
+    return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CPLXAMD_F32)
+    return bn_run<float, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr,
+                               nullptr, const_cast<float*>(saved), dweight, dbias, training, 0.f,
+                               0.f, ws, st);
+  if (dtype == CPLXAMD_BF16)
+    return bn_run<bf16_t, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr,
+                                nullptr, const_cast<float*>(saved), dweight, dbias, training, 0.f,
+                                0.f, ws, st);
+  return CPLXAMD_EINVAL;
+}
+
+}  // extern "C"

@@ -93,7 +93,7 @@ class CplxLinearGaussian(_CplxGaussianMixin, CplxLinear):
         return cplx.Cplx(yr, yi)
 
 
-class CplxLinearVD(SparsityStats, CplxLinearGaussian, BaseARD):
+class CplxLinearVD(CplxLinearGaussian, SparsityStats, BaseARD):
     """Complex linear layer with variational dropout (exact KL via Ei)."""
     _kl_kind = "cplx_vd"
 
@@ -119,7 +119,7 @@ class CplxConv2dGaussian(_CplxGaussianMixin, CplxConv2d):
         return conv.cplx_conv2d_lrt(self, input, eps)
 
 
-class CplxConv2dVD(SparsityStats, CplxConv2dGaussian, BaseARD):
+class CplxConv2dVD(CplxConv2dGaussian, SparsityStats, BaseARD):
     _kl_kind = "cplx_vd"
 
 

@@ -64,7 +64,7 @@ class LinearGaussian(_RealGaussianMixin, torch.nn.Linear):
                                          seed, offset)
 
 
-class LinearVD(SparsityStats, LinearGaussian, BaseARD):
+class LinearVD(LinearGaussian, SparsityStats, BaseARD):
     """Linear layer with variational dropout (softplus-sigmoid KL approximation)."""
     _kl_kind = "real_vd"
 
@@ -88,7 +88,7 @@ class Conv2dGaussian(_RealGaussianMixin, torch.nn.Conv2d):
         return conv.real_conv2d_layer(self, input, eps)
 
 
-class Conv2dVD(SparsityStats, Conv2dGaussian, BaseARD):
+class Conv2dVD(Conv2dGaussian, SparsityStats, BaseARD):
     _kl_kind = "real_vd"
 
 

@@ -166,6 +166,26 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
 int cplxamd_lrt_dx_accum(void* dxr, void* dxi, const void* xr, const void* xi, const void* ga,
                          int64_t n, int dtype, int ga_dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K3  complex batch normalisation (2x2 whitening + 2x2 affine), forward and backward.
+ * Replaces: whiten2x2        nn/modules/batchnorm.py:62-123
+ *           cplx_batch_norm  nn/modules/batchnorm.py:189-278 (and its autograd backward)
+ * Tensors: planar x / y / g [B, F, S] contiguous (S = product of spatial dims, 1 for [B,F]);
+ * weight [2,2,F], bias [2,F], running_mean [2,F], running_var [2,2,F] float32 (nullable pairs);
+ * saved [8,F] float32 = per-feature (mean_u, mean_v, p, q, w, Vuu, Vuv, Vvv) handed from the
+ * forward to the backward.  training != 0: batch statistics (biased covariance, eps on the
+ * diagonal) and in-place running-stat update x += momentum (new - x); else running stats.
+ * ---------------------------------------------------------------------------------- */
+int64_t cplxamd_bn_ws_bytes(int F);
+int cplxamd_bn_fwd(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F,
+                   int64_t S, const float* weight, const float* bias, float* running_mean,
+                   float* running_var, float* saved, int training, int dtype, float momentum,
+                   float eps, void* ws, int64_t ws_bytes, void* stream);
+int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr,
+                   void* dxi, int64_t B, int F, int64_t S, const float* weight,
+                   const float* saved, float* dweight, float* dbias, int training, int dtype,
+                   void* ws, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

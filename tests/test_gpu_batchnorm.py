@@ -1,0 +1,112 @@
+"""Complex batch-norm kernels vs the reference's outputs / autograd gradients / running stats."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cplx_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(ref, r=2e-5):
+    return dict(rtol=r, atol=r * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name,cls", [("2d", "CplxBatchNorm2d"), ("1d", "CplxBatchNorm1d"),
+                                      ("1d3", "CplxBatchNorm1d")])
+def test_batchnorm_layer_golden(golden, name, cls):
+    from gpu_util import T, N
+    from cplxmodule_amd import Cplx, nn
+    g = golden("batchnorm")
+    k = f"f32_{name}_"
+    F_ = g[k + "weight"].shape[-1]
+    bn = getattr(nn, cls)(F_).to("cuda")
+    with torch.no_grad():
+        bn.weight.copy_(T(g[k + "weight"]))
+        bn.bias.copy_(T(g[k + "bias"]))
+    bn.train()
+    for step in range(3):
+        s = k + f"s{step}_"
+        xr, xi = T(g[s + "xr"]).requires_grad_(True), T(g[s + "xi"]).requires_grad_(True)
+        y = bn(Cplx(xr, xi))
+        np.testing.assert_allclose(N(y.real), g[s + "yr"], **_tol(g[s + "yr"]))
+        np.testing.assert_allclose(N(y.imag), g[s + "yi"], **_tol(g[s + "yi"]))
+        np.testing.assert_allclose(N(bn.running_mean), g[s + "running_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(N(bn.running_var), g[s + "running_var"], rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == int(g[s + "nbt"])
+        bn.zero_grad()
+        ((y.real * T(g[s + "gr"])).sum() + (y.imag * T(g[s + "gi"])).sum()).backward()
+        for n, t in dict(dxr=xr.grad, dxi=xi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
+            np.testing.assert_allclose(N(t), g[s + n], **_tol(g[s + n], 1e-4), err_msg=f"{n} step {step}")
+    bn.eval()
+    bn.zero_grad()
+    xr, xi = xr.detach().requires_grad_(True), xi.detach().requires_grad_(True)
+    y = bn(Cplx(xr, xi))
+    np.testing.assert_allclose(N(y.real), g[k + "eval_yr"], **_tol(g[k + "eval_yr"]))
+    ((y.real * T(g[s + "gr"])).sum() + (y.imag * T(g[s + "gi"])).sum()).backward()
+    for n, t in dict(dxr=xr.grad, dxi=xi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
+        np.testing.assert_allclose(N(t), g[k + "eval_" + n], **_tol(g[k + "eval_" + n], 1e-4), err_msg=n)
+
+
+def test_batchnorm_functional_and_cma(golden):
+    from gpu_util import T, N
+    from cplxmodule_amd import Cplx, nn
+    from cplxmodule_amd.nn.modules.batchnorm import cplx_batch_norm
+    g = golden("batchnorm")
+    k = "f32_func_"
+    xr, xi = T(g[k + "xr"]).requires_grad_(True), T(g[k + "xi"]).requires_grad_(True)
+    y = cplx_batch_norm(Cplx(xr, xi), None, None, None, None, True, 0.1, 1e-3)
+    np.testing.assert_allclose(N(y.real), g[k + "yr"], **_tol(g[k + "yr"]))
+    ((y.real * T(g[k + "gr"])).sum() + (y.imag * T(g[k + "gi"])).sum()).backward()
+    np.testing.assert_allclose(N(xr.grad), g[k + "dxr"], **_tol(g[k + "dxr"], 1e-4))
+    np.testing.assert_allclose(N(xi.grad), g[k + "dxi"], **_tol(g[k + "dxi"], 1e-4))
+    bn = nn.CplxBatchNorm1d(3, momentum=None, affine=False).to("cuda")
+    bn.train()
+    for step in range(2):
+        y = bn(Cplx(xr.detach() + step, xi.detach() * (1 + step)))
+    np.testing.assert_allclose(N(bn.running_mean), g["f32_cma_running_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(N(bn.running_var), g["f32_cma_running_var"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(N(y.real), g["f32_cma_yr"], **_tol(g["f32_cma_yr"]))
+    with pytest.raises(ValueError):
+        nn.CplxBatchNorm2d(3).to("cuda")(Cplx(xr, xi))
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 33, 20), (3, 5, 7, 9), (512, 24), (2, 64, 128, 128)])
+def test_batchnorm_vs_oracle_shapes(shape):
+    """Shapes that exercise the vector / scalar paths, plane segmentation and the [B,F] kernel;
+    output moments must come out as (0, I): whitening property, size independent."""
+    from gpu_util import T, N
+    from cplxmodule_amd import Cplx, nn
+    rs = np.random.RandomState(sum(shape))
+    base = rs.randn(*shape)
+    xr = (1.5 * base + 0.4 * rs.randn(*shape) + 0.7).astype(np.float32)
+    xi = (0.8 * base - 0.5 * rs.randn(*shape) - 0.2).astype(np.float32)
+    F_ = shape[1]
+    W = (np.eye(2)[:, :, None] + 0.2 * rs.randn(2, 2, F_)).astype(np.float32)
+    b = (0.3 * rs.randn(2, F_)).astype(np.float32)
+    gr, gi = rs.randn(*shape).astype(np.float32), rs.randn(*shape).astype(np.float32)
+    cls = {2: nn.CplxBatchNorm1d, 4: nn.CplxBatchNorm2d}[len(shape)]
+    bn = cls(F_).to("cuda")
+    with torch.no_grad():
+        bn.weight.copy_(T(W)); bn.bias.copy_(T(b))
+    txr, txi = T(xr).requires_grad_(True), T(xi).requires_grad_(True)
+    y = bn(Cplx(txr, txi))
+    f = np.float64
+    rm, rv = np.zeros((2, F_)), np.stack([np.ones(F_), np.zeros(F_), np.zeros(F_), np.ones(F_)]).reshape(2, 2, F_)
+    yr, yi = orc.cplx_batch_norm(xr.astype(f), xi.astype(f), rm, rv, W.astype(f), b.astype(f), True, 0.1, 1e-5)
+    np.testing.assert_allclose(N(y.real), yr, **_tol(yr))
+    np.testing.assert_allclose(N(y.imag), yi, **_tol(yi))
+    np.testing.assert_allclose(N(bn.running_var), rv, rtol=1e-5, atol=1e-6)
+    ((y.real * T(gr)).sum() + (y.imag * T(gi)).sum()).backward()
+    bw = orc.cplx_batch_norm_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), None, None, W.astype(f), True, 1e-5)
+    for n, t in dict(dxr=txr.grad, dxi=txi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
+        np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], 1e-4), err_msg=n)
+    # whitening property without affine
+    bn2 = cls(F_, affine=False).to("cuda")
+    z = bn2(Cplx(T(xr), T(xi)))
+    ax = (0,) + tuple(range(2, len(shape)))
+    zr, zi = N(z.real).astype(f), N(z.imag).astype(f)
+    assert np.abs(zr.mean(ax)).max() < 1e-4 and np.abs(zi.mean(ax)).max() < 1e-4
+    np.testing.assert_allclose((zr * zr).mean(ax), 1, atol=2e-3)
+    np.testing.assert_allclose((zi * zi).mean(ax), 1, atol=2e-3)
+    assert np.abs((zr * zi).mean(ax)).max() < 2e-3
