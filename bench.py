@@ -1,0 +1,209 @@
+"""bench.py -- Cplx-samples/sec, forward + backward (+ KL) of CplxLinearVD(4096, 4096) with bf16
+activations, batch 8192 per GPU (BASELINE.json configs[1] "+ VD"), data parallel over N GPUs.
+
+One step = zero_grad + LRT forward (complex GEMM + variance GEMM + Philox noise injection)
++ fused KL + loss (sum |y|^2 + 1e-3 KL, upstream gradient 2y) + full backward (dX, dW, db,
+dlog_sigma2, dKL) [+ flat-bucket gradient all-reduce and scalar KL all-reduce for N > 1].
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+the bf16 complex MFMA GEMM, timed live with HIP events on the launch stream) and `cpu_baseline`
+(the numpy oracle on a bounded sample, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+IN_F = OUT_F = 4096
+BATCH = 8192
+KLW = 1e-3
+BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event pairs around selected kernel launches, on the stream they are launched on."""
+
+    def __init__(self):
+        self.spans = {}
+        self.enabled = False
+
+    def wrap(self, mod, name, key_fn):
+        inner = getattr(mod, name)
+
+        def timed(*a, **k):
+            if not self.enabled:
+                return inner(*a, **k)
+            key = key_fn(*a, **k)
+            if key is None:
+                return inner(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = inner(*a, **k)
+            e.record()
+            self.spans.setdefault(key, []).append((s, e))
+            return out
+
+        setattr(mod, name, timed)
+
+    def mean_ms(self, key):
+        ev = self.spans.get(key, [])
+        return sum(s.elapsed_time(e) for s, e in ev) / len(ev) if ev else None
+
+
+def cpu_baseline(sample_rows):
+    """The numpy oracle (a port of the reference's op sequence) on the host cores: forward +
+    backward + exact KL of CplxLinearVD(4096, 4096) on `sample_rows` rows, float32."""
+    import numpy as np
+    from oracle import cplx_oracle as orc
+    rs = np.random.RandomState(0)
+    f = np.float32
+    I, O, B = IN_F, OUT_F, sample_rows
+    xr, xi = rs.randn(B, I).astype(f), rs.randn(B, I).astype(f)
+    bound = (1.0 / (2 * I)) ** 0.5
+    wr, wi = rs.uniform(-bound, bound, (O, I)).astype(f), rs.uniform(-bound, bound, (O, I)).astype(f)
+    br, bi = np.zeros(O, f), np.zeros(O, f)
+    ls2 = np.full((O, I), -10, f)
+    er, ei = (rs.randn(B, O) / np.sqrt(2)).astype(f), (rs.randn(B, O) / np.sqrt(2)).astype(f)
+    t0 = time.perf_counter()
+    yr, yi, _ = orc.lrt_cplx_linear(xr, xi, wr, wi, br, bi, ls2, er, ei)
+    kl = orc.penalty("cplx_vd", ls2, wr, wi).sum()
+    orc.lrt_cplx_linear_bwd(2 * yr, 2 * yi, xr, xi, wr, wi, ls2, er, ei)
+    orc.penalty_bwd("cplx_vd", np.full_like(ls2, KLW), ls2, wr, wi)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(kl)
+    return {"value": round(B / dt, 2), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{B} of {BATCH} rows through the numpy oracle (fwd+bwd), plus the full "
+                      f"{O}x{I} exact KL fwd+bwd (scipy expi); {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cplxmodule_amd import Cplx, dp, ops
+    from cplxmodule_amd.nn import relevance as rel
+    from cplxmodule_amd.nn.relevance import noise
+
+    timer = KernelTimer()
+    timer.wrap(ops, "cgemm", lambda ar, *a, **k: "cgemm" if ar.dtype == torch.bfloat16 else None)
+    timer.wrap(ops, "kl_fwd", lambda *a, **k: "kl_fwd")
+    timer.wrap(ops, "kl_bwd", lambda *a, **k: "kl_bwd")
+    timer.wrap(ops, "reparam_fwd", lambda *a, **k: "reparam_fwd")
+    timer.wrap(ops, "reparam_bwd", lambda *a, **k: "reparam_bwd")
+
+    torch.manual_seed(0)                       # identical init on every rank (then broadcast)
+    layer = rel.CplxLinearVD(IN_F, OUT_F).to(dev)
+    with torch.no_grad():                      # mixed relevance so both Ei branches are exercised
+        layer.log_sigma2.uniform_(-12, 4)
+    model = dp.DataParallel(layer)
+    noise.manual_seed(1234 + rank)
+    torch.manual_seed(1 + rank)                # per-rank synthetic shard
+    B = args.batch
+    x = Cplx(torch.randn(B, IN_F, device=dev).bfloat16().requires_grad_(True),
+             torch.randn(B, IN_F, device=dev).bfloat16().requires_grad_(True))
+    klw = torch.tensor(KLW, device=dev)
+    layer.train()
+
+    def step():
+        model.zero_grad()
+        x.real.grad = x.imag.grad = None
+        y = model(x)
+        kl = sum(rel.penalties(layer, reduction="sum"))
+        gy_r, gy_i = y.real.detach() * 2, y.imag.detach() * 2      # d(sum |y|^2)/dy
+        torch.autograd.backward((y.real, y.imag, kl), (gy_r, gy_i, klw))
+        model.sync_gradients()
+        return dp.all_reduce_scalar_mean(kl) if world > 1 else kl
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kl = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        gemm_ms = timer.mean_ms("cgemm")
+        flops = 8.0 * B * IN_F * OUT_F          # algorithmic flop of ONE 4M complex GEMM launch
+        achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
+        nw = IN_F * OUT_F
+        kl_f, kl_b = timer.mean_ms("kl_fwd"), timer.mean_ms("kl_bwd")
+        rp_f, rp_b = timer.mean_ms("reparam_fwd"), timer.mean_ms("reparam_bwd")
+        nout = B * OUT_F
+        line = {
+            "metric": "Cplx-samples/sec fwd+bwd (CplxLinear-4096 + VD)",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "CplxLinearVD 4096->4096, bf16 activations / fp32 master weights, "
+                                   f"batch {B} per GPU, LRT fwd + KL + full bwd (BASELINE configs[1] + VD)",
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "kl_weight": KLW, "noise": "in-kernel Philox4x32-10"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM, 3 launches/step)",
+                         "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,
+                         "traffic": None, "flop_per_launch": flops,
+                         "avg_launch_ms": round(gemm_ms, 4) if gemm_ms else None},
+            "hbm_kernels_GBps": {
+                "kl_fwd(12B/elt)": round(12 * nw / (kl_f * 1e-3) / 1e9, 1) if kl_f else None,
+                "kl_bwd(24B/elt)": round(24 * nw / (kl_b * 1e-3) / 1e9, 1) if kl_b else None,
+                "reparam_fwd(12B/out bf16)": round(12 * nout / (rp_f * 1e-3) / 1e9, 1) if rp_f else None,
+                "reparam_bwd(10B/out bf16)": round(10 * nout / (rp_b * 1e-3) / 1e9, 1) if rp_b else None,
+                "peak": HBM_PEAK_GBS},
+            "kl": round(float(kl), 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(512)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,11 +42,19 @@ SIGNATURES = {
     "cplxamd_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P],
     "cplxamd_lrt_dx_accum": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "cplxamd_conv2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "cplxamd_conv2d_dgrad": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "cplxamd_conv2d_wgrad_splits": [_P],
+    "cplxamd_conv2d_wgrad_ws_bytes": [_P, _I],
+    "cplxamd_conv2d_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
+    "cplxamd_conv2d_out_shape": [_P, _P, _P],
+    "cplxamd_chansum": [_P, _P, _L, _I, _L, _I, _P, _P],
     "cplxamd_bn_ws_bytes": [_I],
     "cplxamd_bn_fwd": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P],
     "cplxamd_bn_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _L, _P],
 }
-_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64}
+_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
+             "cplxamd_conv2d_wgrad_ws_bytes": c_int64}
 
 _lib = None
 

@@ -1,0 +1,272 @@
+"""Complex / real 2-d convolution on the implicit-GEMM kernels (csrc/conv.hip), with autograd,
+and the conv flavours of the local-reparameterization layers.
+
+Reference: cplx.conv2d -> convnd (cplxmodule/cplx.py:770-838), CplxConvNdGaussianMixin
+(nn/relevance/complex/base.py:120-135), ConvNdGaussianMixin (nn/relevance/real/base.py:116-163).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import call, dtype_code, ptr, require_device, stream_ptr
+from .cplx import Cplx
+
+_ws_cache = {}
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _geom(x_shape, w_shape, stride, padding, dilation, groups):
+    B, Ci, H, W = x_shape
+    Co, _, KH, KW = w_shape
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    arr = (ctypes.c_int * 14)(B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups)
+    Ho = (H + 2 * ph - dh * (KH - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (KW - 1) - 1) // sw + 1
+    if Ho <= 0 or Wo <= 0:
+        raise ValueError("convolution output would be empty")
+    return arr, (B, Co, Ho, Wo)
+
+
+def _scratch(device, nbytes):
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _ws_cache[key] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+    return buf
+
+
+def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape):
+    yr = torch.empty(out_shape, dtype=xr.dtype, device=xr.device)
+    yi = None if xi is None else torch.empty_like(yr)
+    call("cplxamd_conv2d_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
+         ptr(yi), geom, dtype_code(xr), stream_ptr())
+    return yr, yi
+
+
+def conv_dgrad(gr, gi, wr, wi, geom, x_shape):
+    dxr = torch.empty(x_shape, dtype=gr.dtype, device=gr.device)
+    dxi = None if gi is None else torch.empty_like(dxr)
+    call("cplxamd_conv2d_dgrad", ptr(gr), ptr(gi), ptr(wr), ptr(wi), ptr(dxr), ptr(dxi), geom,
+         dtype_code(gr), stream_ptr())
+    return dxr, dxi
+
+
+def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
+    lib = _lib.load()
+    cplx = gi is not None
+    nbytes = int(lib.cplxamd_conv2d_wgrad_ws_bytes(geom, int(cplx)))
+    ws = _scratch(gr.device, nbytes)
+    dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)
+    dwi = torch.empty_like(dwr) if cplx else None
+    call("cplxamd_conv2d_wgrad", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul), ptr(dwr), ptr(dwi),
+         geom, dtype_code(gr), ptr(ws), ws.numel(), stream_ptr())
+    return dwr, dwi
+
+
+def chansum(g):
+    """sum over (batch, spatial) per channel of an NCHW tensor -> float32 [C]."""
+    B, C = g.shape[0], g.shape[1]
+    S = g.numel() // (B * C)
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    ws = _scratch(g.device, 64 * C * 8)
+    call("cplxamd_chansum", ptr(g), ptr(out), B, C, S, dtype_code(g), ptr(ws), stream_ptr())
+    return out
+
+
+class CplxConv2dFn(torch.autograd.Function):
+    """Zero-padded complex conv (A.1 algebra with cross-correlation)."""
+
+    @staticmethod
+    def forward(ctx, xr, xi, wr, wi, br, bi, stride, padding, dilation, groups):
+        require_device(xr, xi, wr, wi, br, bi)
+        xr, xi = xr.contiguous(), xi.contiguous()
+        wcr, wci = ops.cast(wr.contiguous(), xr.dtype), ops.cast(wi.contiguous(), xr.dtype)
+        geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
+        b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
+        yr, yi = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape)
+        ctx.save_for_backward(xr, xi, wcr, wci)
+        ctx.geom, ctx.has_bias, ctx.wshape = geom, br is not None, wr.shape
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        xr, xi, wcr, wci = ctx.saved_tensors
+        gr, gi = gr.contiguous(), gi.contiguous()
+        need = ctx.needs_input_grad
+        dxr = dxi = dwr = dwi = dbr = dbi = None
+        if need[0] or need[1]:
+            dxr, dxi = conv_dgrad(gr, gi, wcr, wci, ctx.geom, xr.shape)
+        if need[2] or need[3]:
+            dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape)
+        if ctx.has_bias and (need[4] or need[5]):
+            dbr, dbi = chansum(gr), chansum(gi)
+        return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
+
+
+class RealConv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation, groups):
+        require_device(x, w, b)
+        x = x.contiguous()
+        wc = ops.cast(w.contiguous(), x.dtype)
+        geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
+        y, _ = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom, oshape)
+        ctx.save_for_backward(x, wc)
+        ctx.geom, ctx.has_bias, ctx.wshape = geom, b is not None, w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wc = ctx.saved_tensors
+        g = g.contiguous()
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        if need[0]:
+            dx, _ = conv_dgrad(g, None, wc, None, ctx.geom, x.shape)
+        if need[1]:
+            dw, _ = conv_wgrad(g, None, x, None, ctx.geom, ctx.wshape)
+        if ctx.has_bias and need[2]:
+            db = chansum(g)
+        return dx, dw, db, None, None, None, None
+
+
+def _circular_pad(t, padding):
+    """symmetric_circular_padding (cplxmodule/cplx.py:701-714): ((p+1)//2, p//2) per spatial
+    dim; F.pad's tuple starts at the LAST dim, the reference feeds `padding` in that order."""
+    pads = []
+    for p in _pair(padding):
+        pads.extend(((p + 1) // 2, p // 2))
+    return F.pad(t, tuple(pads), mode="circular")
+
+
+def cplx_conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                padding_mode="zeros"):
+    xr, xi = input.real, input.imag
+    if padding_mode == "circular":
+        xr, xi, padding = _circular_pad(xr, padding), _circular_pad(xi, padding), 0
+    elif padding_mode != "zeros":
+        raise ValueError("padding_mode must be 'zeros' or 'circular'.")
+    br, bi = (None, None) if bias is None else (bias.real, bias.imag)
+    yr, yi = CplxConv2dFn.apply(xr, xi, weight.real, weight.imag, br, bi, stride, padding,
+                                dilation, groups)
+    return Cplx(yr, yi)
+
+
+class CplxConv2dLRTFn(torch.autograd.Function):
+    """mu conv + variance conv + noise injection; backward per SURVEY A.2 with conv."""
+
+    @staticmethod
+    def forward(ctx, xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i, seed, offset, stride, padding,
+                dilation, groups):
+        require_device(xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i)
+        xr, xi = xr.contiguous(), xi.contiguous()
+        dt = xr.dtype
+        wcr, wci = ops.cast(wr.contiguous(), dt), ops.cast(wi.contiguous(), dt)
+        geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
+        b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
+        mur, mui = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape)
+        a = ops.abs2(xr, xi)
+        S = ops.exp(ls2.contiguous(), out_dtype=dt)
+        s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
+        s2 = ops.cast(s2, torch.float32)
+        eps = None if eps_r is None else (eps_r, eps_i)
+        yr, yi = ops.reparam_fwd(mur, mui, s2, eps, seed, offset, inplace=True)
+        ctx.save_for_backward(xr, xi, wcr, wci, ls2, s2, a, S, eps_r, eps_i)
+        ctx.geom, ctx.has_bias, ctx.wshape = geom, br is not None, wr.shape
+        ctx.seed, ctx.offset = seed, offset
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        xr, xi, wcr, wci, ls2, s2, a, S, eps_r, eps_i = ctx.saved_tensors
+        gr, gi = gr.contiguous(), gi.contiguous()
+        need = ctx.needs_input_grad
+        eps = None if eps_r is None else (eps_r, eps_i)
+        gs2 = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype)
+        dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
+        if need[0] or need[1]:
+            dxr, dxi = conv_dgrad(gr, gi, wcr, wci, ctx.geom, xr.shape)
+            ga, _ = conv_dgrad(gs2, None, S, None, ctx.geom, xr.shape)
+            ops.lrt_dx_accum(dxr, dxi, xr, xi, ga)
+        if need[2] or need[3]:
+            dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape)
+        if ctx.has_bias and (need[4] or need[5]):
+            dbr, dbi = chansum(gr), chansum(gi)
+        if need[6]:
+            dls2, _ = conv_wgrad(gs2, None, a, None, ctx.geom, ctx.wshape,
+                                 emul=ops.exp(ls2.contiguous()))
+        return (dxr, dxi, dwr, dwi, dbr, dbi, dls2) + (None,) * 8
+
+
+def cplx_conv2d_lrt(layer, input, eps=None):
+    """Training-mode forward of CplxConv2dVD / ARD."""
+    w, b = layer.weight, layer.bias
+    br, bi = (None, None) if b is None else (b.real, b.imag)
+    if eps is not None:
+        er, ei, seed, offset = eps.real.contiguous(), eps.imag.contiguous(), 0, 0
+    else:
+        _, oshape = _geom(input.shape, w.shape, layer.stride, layer.padding, layer.dilation,
+                          layer.groups)
+        er, ei, seed, offset = layer._draw_noise(oshape, input)
+    yr, yi = CplxConv2dLRTFn.apply(input.real, input.imag, w.real, w.imag, br, bi,
+                                   layer.log_sigma2, er, ei, seed, offset, layer.stride,
+                                   layer.padding, layer.dilation, layer.groups)
+    return Cplx(yr, yi)
+
+
+class RealConv2dLRTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, ls2, eps, seed, offset, stride, padding, dilation, groups):
+        require_device(x, w, b, ls2, eps)
+        x = x.contiguous()
+        dt = x.dtype
+        wc = ops.cast(w.contiguous(), dt)
+        geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
+        mu, _ = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom, oshape)
+        a = ops.abs2(x)
+        S = ops.exp(ls2.contiguous(), out_dtype=dt)
+        s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
+        s2 = ops.cast(s2, torch.float32)
+        y, _ = ops.reparam_fwd(mu, None, s2, eps, seed, offset, inplace=True)
+        ctx.save_for_backward(x, wc, ls2, s2, a, S, eps)
+        ctx.geom, ctx.has_bias, ctx.wshape = geom, b is not None, w.shape
+        ctx.seed, ctx.offset = seed, offset
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wc, ls2, s2, a, S, eps = ctx.saved_tensors
+        g = g.contiguous()
+        need = ctx.needs_input_grad
+        gs2 = ops.reparam_bwd(g, None, s2, eps, ctx.seed, ctx.offset, out_dtype=x.dtype)
+        dx = dw = db = dls2 = None
+        if need[0]:
+            dx, _ = conv_dgrad(g, None, wc, None, ctx.geom, x.shape)
+            ga, _ = conv_dgrad(gs2, None, S, None, ctx.geom, x.shape)
+            ops.lrt_dx_accum(dx, None, x, None, ga)
+        if need[1]:
+            dw, _ = conv_wgrad(g, None, x, None, ctx.geom, ctx.wshape)
+        if ctx.has_bias and need[2]:
+            db = chansum(g)
+        if need[3]:
+            dls2, _ = conv_wgrad(gs2, None, a, None, ctx.geom, ctx.wshape,
+                                 emul=ops.exp(ls2.contiguous()))
+        return (dx, dw, db, dls2) + (None,) * 7
+
+
+def real_conv2d_layer(layer, input, eps=None):
+    """Forward of Conv2dVD / ARD (eval: mean only; train: LRT)."""
+    args = (layer.stride, layer.padding, layer.dilation, layer.groups)
+    if not layer.training:
+        return RealConv2dFn.apply(input, layer.weight, layer.bias, *args)
+    seed = offset = 0
+    if eps is None:
+        _, oshape = _geom(input.shape, layer.weight.shape, *args)
+        eps, seed, offset = layer._draw_noise(oshape, input)
+    return RealConv2dLRTFn.apply(input, layer.weight, layer.bias, layer.log_sigma2, eps, seed,
+                                 offset, *args)

@@ -12,6 +12,11 @@
 //   masks      nn/relevance/real/vd.py:16-19, complex/vd.py:50-53
 #include "common.h"
 
+// The reference issues separate torch ops (one rounding each); keep the compiler from
+// fusing a*b+c into fma so that parity-mode results are bit-identical.  Explicit fmaf()
+// calls below are deliberate.
+#pragma clang fp contract(off)
+
 namespace cplxamd {
 
 constexpr int kKlThreads = 256;

@@ -17,6 +17,11 @@
 //                   element 2g+1 (eps_r, eps_i)    = (z2, z3) / sqrt 2
 #include "common.h"
 
+// The reference issues separate torch ops (one rounding each); keep the compiler from
+// fusing a*b+c into fma so that parity-mode results are bit-identical.  Explicit fmaf()
+// calls below are deliberate.
+#pragma clang fp contract(off)
+
 namespace cplxamd {
 
 constexpr int kRpThreads = 256;

@@ -1,6 +1,11 @@
 // HBM-bound elementwise / layout helpers of the layers (include/cplxamd.h, last section).
 #include "common.h"
 
+// The reference issues separate torch ops (one rounding each); keep the compiler from
+// fusing a*b+c into fma so that parity-mode results are bit-identical.  Explicit fmaf()
+// calls below are deliberate.
+#pragma clang fp contract(off)
+
 namespace cplxamd {
 
 constexpr int kUT = 256;

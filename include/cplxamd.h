@@ -167,6 +167,33 @@ int cplxamd_lrt_dx_accum(void* dxr, void* dxi, const void* xr, const void* xi, c
                          int64_t n, int dtype, int ga_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K2  complex / real 2-d convolution (cross-correlation, NCHW, zero padding) as implicit GEMM.
+ * Replaces: cplx.convnd / convnd_quick / convnd_naive / conv2d   cplx.py:717-838
+ *           the LRT variance conv   nn/relevance/complex/base.py:125-133, real/base.py:152-162
+ * and their autograd backward.  Planes of element type `dtype`; xi / wi / yi NULL => real conv.
+ * geom = int[14] {B, Ci, Co, H, W, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups};
+ * weight [Co, Ci/groups, KH, KW]; bias float32 [Co] (nullable pair).
+ *   fwd   : y = x (*) w (+ bias)            (no conjugation, cplx.py:719-726)
+ *   dgrad : dx = g (*)^T conj(w)
+ *   wgrad : dw = sum g conj(x)  (float32 out; emul nullable: dw_r *= emul, the LRT exp(ls2) factor)
+ *           split-K partial slabs live in `ws` (>= cplxamd_conv2d_wgrad_ws_bytes).
+ * ---------------------------------------------------------------------------------- */
+int cplxamd_conv2d_out_shape(const int* geom, int* ho, int* wo);
+int cplxamd_conv2d_fwd(const void* xr, const void* xi, const void* wr, const void* wi,
+                       const float* bias_r, const float* bias_i, void* yr, void* yi,
+                       const int* geom, int dtype, void* stream);
+int cplxamd_conv2d_dgrad(const void* gr, const void* gi, const void* wr, const void* wi,
+                         void* dxr, void* dxi, const int* geom, int dtype, void* stream);
+int cplxamd_conv2d_wgrad_splits(const int* geom);
+int64_t cplxamd_conv2d_wgrad_ws_bytes(const int* geom, int cplx);
+int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const void* xi,
+                         const float* emul, float* dwr, float* dwi, const int* geom, int dtype,
+                         void* ws, int64_t ws_bytes, void* stream);
+/* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
+int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K3  complex batch normalisation (2x2 whitening + 2x2 affine), forward and backward.
  * Replaces: whiten2x2        nn/modules/batchnorm.py:62-123
  *           cplx_batch_norm  nn/modules/batchnorm.py:189-278 (and its autograd backward)

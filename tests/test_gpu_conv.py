@@ -1,0 +1,119 @@
+"""Implicit-GEMM complex / real conv kernels vs the reference's outputs and autograd grads."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cplx_oracle as orc
+from oracle.gen_golden_cases import CONV_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(ref, r=2e-5):
+    return dict(rtol=r, atol=r * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("case", list(CONV_CASES))
+def test_cplx_conv2d_layer_golden(golden, case):
+    from gpu_util import T, N
+    from cplxmodule_amd import Cplx, nn
+    g = golden("conv")
+    B, Ci, Co, H, W, ks, st, pd, dl, gp, mode = CONV_CASES[case]
+    k = f"f32_{case}_"
+    layer = nn.CplxConv2d(Ci, Co, ks, stride=st, padding=pd, dilation=dl, groups=gp,
+                          padding_mode=mode).to("cuda")
+    layer.load_state_dict({"weight.real": T(g[k + "wr"]), "weight.imag": T(g[k + "wi"]),
+                           "bias.real": T(g[k + "br"]), "bias.imag": T(g[k + "bi"])})
+    xr, xi = T(g[k + "xr"]).requires_grad_(True), T(g[k + "xi"]).requires_grad_(True)
+    y = layer(Cplx(xr, xi))
+    assert tuple(y.shape) == g[k + "yr"].shape
+    np.testing.assert_allclose(N(y.real), g[k + "yr"], **_tol(g[k + "yr"]))
+    np.testing.assert_allclose(N(y.imag), g[k + "yi"], **_tol(g[k + "yi"]))
+    ((y.real * T(g[k + "gr"])).sum() + (y.imag * T(g[k + "gi"])).sum()).backward()
+    got = dict(dxr=xr.grad, dxi=xi.grad, dwr=layer.weight.real.grad, dwi=layer.weight.imag.grad,
+               dbr=layer.bias.real.grad, dbi=layer.bias.imag.grad)
+    for n, t in got.items():
+        np.testing.assert_allclose(N(t), g[k + n], **_tol(g[k + n], 5e-5), err_msg=n)
+
+
+def test_conv_errors():
+    from cplxmodule_amd import Cplx, nn, cplx
+    with pytest.raises(ValueError):
+        nn.CplxConv2d(3, 4, 3, groups=2)
+    with pytest.raises(ValueError):
+        cplx.conv2d(Cplx(torch.zeros(1, 1, 4, 4, device="cuda")), Cplx(torch.zeros(1, 1, 3, 3, device="cuda")),
+                    padding_mode="reflect")
+    from cplxmodule_amd.nn import relevance as rel
+    with pytest.raises(ValueError):
+        rel.CplxConv2dVD(2, 2, 3, padding_mode="circular")
+
+
+def test_lrt_cplx_conv_golden(golden):
+    from gpu_util import T, N
+    from cplxmodule_amd import Cplx
+    from cplxmodule_amd.nn import relevance as rel
+    g = golden("conv")
+    k = "f32_lrtc_"
+    layer = rel.CplxConv2dVD(3, 4, 3, stride=1, padding=1).to("cuda")
+    layer.load_state_dict({"weight.real": T(g[k + "wr"]), "weight.imag": T(g[k + "wi"]),
+                           "bias.real": T(g[k + "br"]), "bias.imag": T(g[k + "bi"]),
+                           "log_sigma2": T(g[k + "ls2"])})
+    xr, xi = T(g[k + "xr"]).requires_grad_(True), T(g[k + "xi"]).requires_grad_(True)
+    tape = T(g[k + "tape"]) / np.float32(np.sqrt(2.0))
+    layer.train()
+    y = layer(Cplx(xr, xi), eps=Cplx(tape[0], tape[1]))
+    np.testing.assert_allclose(N(y.real), g[k + "yr"], **_tol(g[k + "yr"]))
+    np.testing.assert_allclose(N(y.imag), g[k + "yi"], **_tol(g[k + "yi"]))
+    ((y.real * T(g[k + "gr"])).sum() + (y.imag * T(g[k + "gi"])).sum()).backward()
+    got = dict(dxr=xr.grad, dxi=xi.grad, dwr=layer.weight.real.grad, dwi=layer.weight.imag.grad,
+               dbr=layer.bias.real.grad, dbi=layer.bias.imag.grad, dls2=layer.log_sigma2.grad)
+    for n, t in got.items():
+        np.testing.assert_allclose(N(t), g[k + n], **_tol(g[k + n], 5e-5), err_msg=n)
+    tot = sum(rel.penalties(layer))
+    np.testing.assert_allclose(float(tot), float(g[k + "penalty_sum"]), rtol=1e-5)
+    layer.eval()
+    y0 = layer(Cplx(xr, xi))
+    mur, mui = orc.cplx_conv2d(g[k + "xr"], g[k + "xi"], g[k + "wr"], g[k + "wi"], g[k + "br"], g[k + "bi"],
+                               stride=1, padding=1)
+    np.testing.assert_allclose(N(y0.real), mur, **_tol(mur))
+
+
+def test_lrt_real_conv_golden(golden):
+    from gpu_util import T, N
+    from cplxmodule_amd.nn import relevance as rel
+    g = golden("conv")
+    k = "f32_lrtr_"
+    layer = rel.Conv2dVD(3, 4, 3, stride=2, padding=1).to("cuda")
+    layer.load_state_dict({"weight": T(g[k + "w"]), "bias": T(g[k + "b"]), "log_sigma2": T(g[k + "ls2"])})
+    x = T(g[k + "x"]).requires_grad_(True)
+    layer.train()
+    y = layer(x, eps=T(g[k + "eps"]))
+    np.testing.assert_allclose(N(y), g[k + "y"], **_tol(g[k + "y"]))
+    (y * T(g[k + "g"])).sum().backward()
+    for n, t in dict(dx=x.grad, dw=layer.weight.grad, db=layer.bias.grad, dls2=layer.log_sigma2.grad).items():
+        np.testing.assert_allclose(N(t), g[k + n], **_tol(g[k + n], 5e-5), err_msg=n)
+
+
+def test_conv_bf16_and_larger_vs_oracle():
+    """A larger case (several tiles along every GEMM dim, split-K wgrad) in bf16: the oracle gets
+    the bf16-rounded operands; linearity in x checks the full-size property cheaply."""
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import Cplx, cplx
+    rs = np.random.RandomState(3)
+    B, Ci, Co, H, W = 3, 16, 72, 20, 19
+    xr, xi = bf16_round(rs.randn(B, Ci, H, W)), bf16_round(rs.randn(B, Ci, H, W))
+    wr, wi = bf16_round(rs.randn(Co, Ci, 3, 3) * 0.1), bf16_round(rs.randn(Co, Ci, 3, 3) * 0.1)
+    q = lambda a: T(a, torch.bfloat16)  # noqa: E731
+    txr, txi = q(xr).requires_grad_(True), q(xi).requires_grad_(True)
+    twr, twi = T(wr).requires_grad_(True), T(wi).requires_grad_(True)
+    y = cplx.conv2d(Cplx(txr, txi), Cplx(twr, twi), None, stride=1, padding=1)
+    f = np.float64
+    yr, yi = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), padding=1)
+    np.testing.assert_allclose(N(y.real), yr, rtol=1e-2, atol=1e-2 * np.abs(yr).max())
+    np.testing.assert_allclose(N(y.imag), yi, rtol=1e-2, atol=1e-2 * np.abs(yi).max())
+    gr, gi = bf16_round(rs.randn(*yr.shape)), bf16_round(rs.randn(*yr.shape))
+    ((y.real * q(gr)).sum() + (y.imag * q(gi)).sum()).backward()
+    bw = orc.cplx_conv2d_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), wr.astype(f),
+                             wi.astype(f), padding=1, has_bias=False)
+    for n, t in dict(dxr=txr.grad, dxi=txi.grad, dwr=twr.grad, dwi=twi.grad).items():
+        np.testing.assert_allclose(N(t), bw[n], rtol=2e-2, atol=2e-2 * np.abs(bw[n]).max(), err_msg=n)

@@ -88,8 +88,12 @@ def test_masks_bit_exact(golden, ops, kind, th):
     la = ops.log_alpha(T(wr), twi, T(ls2))
     rla = g[f"f32_{kind}_log_alpha"]
     fin = np.isfinite(rla)
-    ulp = np.abs(N(la)[fin].view(np.int32).astype(np.int64) - rla[fin].view(np.int32).astype(np.int64))
-    assert ulp.max() <= 2 and (ulp > 0).mean() < 1e-2
+    # log_alpha = ls2 - 2 log(.) cancels: the honest yardstick is an ulp of the OPERANDS.  The
+    # device log is correctly rounded, the reference's libm is within 1 ulp of that.
+    scale = np.maximum(np.abs(ls2), np.abs(ls2 - rla))[fin]
+    err = np.abs(N(la)[fin].astype(np.float64) - rla[fin])
+    assert (err <= 2 * np.finfo(np.float32).eps * scale).all()
+    assert (err > 0).mean() < 1e-2          # and almost always bit-identical
 
 
 def test_masks_large_random_vs_oracle(ops):
