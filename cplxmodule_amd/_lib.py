@@ -40,7 +40,8 @@ SIGNATURES = {
     "cplxamd_exp": [_P, _P, _L, _I, _P],
     "cplxamd_cast": [_P, _P, _L, _I, _I, _P],
     "cplxamd_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
-    "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P],
+    "cplxamd_colsum_ws_bytes": [_I],
+    "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P, _P],
     "cplxamd_lrt_dx_accum": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "cplxamd_conv2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "cplxamd_conv2d_dgrad": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
@@ -54,7 +55,7 @@ SIGNATURES = {
     "cplxamd_bn_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _L, _P],
 }
 _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
-             "cplxamd_conv2d_wgrad_ws_bytes": c_int64}
+             "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64}
 
 _lib = None
 

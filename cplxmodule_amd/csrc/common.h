@@ -60,6 +60,21 @@ __device__ __forceinline__ void st4(bf16_t* p, const f4& a) {
   *reinterpret_cast<uint2*>(p) = t;
 }
 
+// ---- correctly rounded float32 primitives ---------------------------------------------------
+// HIP's __fsqrt_rn is the NATIVE (1 ulp) square root and __fmul_rn / __fadd_rn are plain
+// operators (clang __clang_hip_math.h); sqrtf() IS correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt.  Files that need one rounding per operation also
+// carry `#pragma clang fp contract(off)`.
+__device__ __forceinline__ float rn_sqrt(float x) { return sqrtf(x); }
+
+// log evaluated in fp64 and rounded once (= correctly rounded float32 log).  The empty asm
+// hides the float origin of `d`, otherwise LLVM shrinks (float)log((double)x) to logf(x).
+__device__ __forceinline__ float exact_logf(float x) {
+  double d = (double)x;
+  asm volatile("" : "+v"(d));
+  return (float)log(d);
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ---------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -29,7 +29,7 @@ constexpr float kK1 = 0.63576f, kK2 = 1.87320f, kK3 = 1.48695f;
 // (bit-for-bit on 2^20 samples, DESIGN.md "mask exactness").
 template <bool CPLX>
 __device__ __forceinline__ float weight_abs(float wr, float wi) {
-  if (CPLX) return __fsqrt_rn(__fmaf_rn(wi, wi, __fmul_rn(wr, wr)));
+  if (CPLX) return rn_sqrt(fmaf(wi, wi, wr * wr));
   return fabsf(wr);
 }
 
@@ -38,9 +38,9 @@ __device__ __forceinline__ float weight_abs(float wr, float wi) {
 template <bool CPLX, bool EXACT>
 __device__ __forceinline__ float log_alpha_of(float ls2, float wr, float wi, float& theta) {
   theta = weight_abs<CPLX>(wr, wi);
-  const float u = __fadd_rn(theta, 1e-12f);
-  const float l = EXACT ? (float)log((double)u) : logf(u);
-  return __fsub_rn(ls2, __fmul_rn(2.0f, l));
+  const float u = theta + 1e-12f;
+  const float l = EXACT ? exact_logf(u) : logf(u);
+  return ls2 - 2.0f * l;
 }
 
 __device__ __forceinline__ float softplus_f(float t) {

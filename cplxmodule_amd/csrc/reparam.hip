@@ -53,7 +53,7 @@ __device__ __forceinline__ float u01(uint32_t x) {
 // scale = 1 for real noise, 1/sqrt(2) for complex
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float scale, float& z0,
                                            float& z1) {
-  const float r = scale * __fsqrt_rn(-2.0f * __logf(u01(a)));
+  const float r = scale * __builtin_amdgcn_sqrtf(-2.0f * __logf(u01(a)));
   const float ang = u01(b);                  // in revolutions: v_sin/v_cos take x / 2 pi
   z0 = r * __builtin_amdgcn_cosf(ang);
   z1 = r * __builtin_amdgcn_sinf(ang);
@@ -98,7 +98,7 @@ __device__ __forceinline__ void noise_one(int64_t e, uint64_t seed, uint64_t off
   }
 }
 
-__device__ __forceinline__ float lrt_std(float s2) { return __fsqrt_rn(fmaxf(s2, 1e-8f)); }
+__device__ __forceinline__ float lrt_std(float s2) { return rn_sqrt(fmaxf(s2, 1e-8f)); }
 
 template <typename T, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float sd = lrt_std(s.v[j]);
-      yr.v[j] = __fadd_rn(mr.v[j], __fmul_rn(er.v[j], sd));
-      if (CPLX) yi.v[j] = __fadd_rn(mi.v[j], __fmul_rn(ei.v[j], sd));
+      yr.v[j] = mr.v[j] + er.v[j] * sd;
+      if (CPLX) yi.v[j] = mi.v[j] + ei.v[j] * sd;
     }
     st4(y_r + 4 * i, yr);
     if (CPLX) st4(y_i + 4 * i, yi);
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
         if (CPLX) ei = io<T>::ld(eps_i + e);
       }
       const float sd = lrt_std(s2[e]);
-      io<T>::st(y_r + e, __fadd_rn(io<T>::ld(mu_r + e), __fmul_rn(er, sd)));
-      if (CPLX) io<T>::st(y_i + e, __fadd_rn(io<T>::ld(mu_i + e), __fmul_rn(ei, sd)));
+      io<T>::st(y_r + e, io<T>::ld(mu_r + e) + er * sd);
+      if (CPLX) io<T>::st(y_i + e, io<T>::ld(mu_i + e) + ei * sd);
     }
   }
 }
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float gs = __fmul_rn(gr.v[j], er.v[j]);
-      if (CPLX) gs = __fadd_rn(gs, __fmul_rn(gi.v[j], ei.v[j]));
+      float gs = gr.v[j] * er.v[j];
+      if (CPLX) gs = gs + gi.v[j] * ei.v[j];
       o.v[j] = lrt_gs2(gs, s.v[j]);
     }
     st4(g_s2 + 4 * i, o);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
         er = io<T>::ld(eps_r + e);
         if (CPLX) ei = io<T>::ld(eps_i + e);
       }
-      float gs = __fmul_rn(io<T>::ld(g_r + e), er);
-      if (CPLX) gs = __fadd_rn(gs, __fmul_rn(io<T>::ld(g_i + e), ei));
+      float gs = io<T>::ld(g_r + e) * er;
+      if (CPLX) gs = gs + io<T>::ld(g_i + e) * ei;
       io<TG>::st(g_s2 + e, lrt_gs2(gs, s2[e]));
     }
   }

@@ -20,10 +20,10 @@ __global__ __launch_bounds__(kUT) void ew_kernel(const TI* a, const TI* b, TO* o
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (OP == 0) o.v[j] = x.v[j];
-      if (OP == 1) o.v[j] = __fadd_rn(__fmul_rn(x.v[j], x.v[j]), __fmul_rn(y.v[j], y.v[j]));
+      if (OP == 1) o.v[j] = x.v[j] * x.v[j] + y.v[j] * y.v[j];
       if (OP == 2) o.v[j] = x.v[j] * x.v[j];
       if (OP == 3) o.v[j] = expf(x.v[j]);
-      if (OP == 4) o.v[j] = __fsqrt_rn(__fmaf_rn(y.v[j], y.v[j], __fmul_rn(x.v[j], x.v[j])));
+      if (OP == 4) o.v[j] = rn_sqrt(fmaf(y.v[j], y.v[j], x.v[j] * x.v[j]));
     }
     st4(out + 4 * i, o);
   }
@@ -34,13 +34,13 @@ __global__ __launch_bounds__(kUT) void ew_kernel(const TI* a, const TI* b, TO* o
       float o = x;
       if (OP == 1) {
         const float y = io<TI>::ld(b + e);
-        o = __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
+        o = x * x + y * y;
       }
       if (OP == 2) o = x * x;
       if (OP == 3) o = expf(x);
       if (OP == 4) {
         const float y = io<TI>::ld(b + e);
-        o = __fsqrt_rn(__fmaf_rn(y, y, __fmul_rn(x, x)));
+        o = rn_sqrt(fmaf(y, y, x * x));
       }
       io<TO>::st(out + e, o);
     }
@@ -82,7 +82,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int64_t ld_
   }
 }
 
-// out[c] = sum_r in[r, c]: each block owns 64 columns x a row slab; fp32 atomics-free two-level
+// out[c] = sum_r in[r, c].  Stage 1: block = 64 column-quads x 4 row lanes over one row chunk,
+// 8-16 B loads per lane, partial[chunk][c]; stage 2 sums the chunks.  (cols % 4 != 0: scalar path.)
+constexpr int kColChunks = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* in, int64_t ld, float* partial,
+                                                             int rows, int cols) {
+  __shared__ float red[4][64][4];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + tx) * 4;
+  const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per;
+  int r1 = r0 + rows_per;
+  if (r1 > rows) r1 = rows;
+  f4 acc = {{0.f, 0.f, 0.f, 0.f}};
+  if (c < cols)
+    for (int r = r0 + ty; r < r1; r += 4) {
+      const f4 v = ld4(in + (int64_t)r * ld + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j];
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[ty][tx][j] = acc.v[j];
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = red[0][tx][j] + red[1][tx][j] + red[2][tx][j] + red[3][tx][j];
+    st4(partial + (int64_t)blockIdx.y * cols + c, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int chunks, int cols,
+                                                           float* out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int j = 0; j < chunks; ++j) acc += partial[(int64_t)j * cols + c];
+  out[c] = acc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* in, int64_t ld, float* out, int rows,
                                                      int cols) {
@@ -173,11 +213,31 @@ int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, 
   return 0;
 }
 
+int64_t cplxamd_colsum_ws_bytes(int cols) { return (int64_t)kColChunks * cols * sizeof(float); }
+
 int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, int dtype,
-                   void* stream) {
+                   void* ws, void* stream) {
   if (!in || !out || rows < 0 || cols < 0) return CPLXAMD_EINVAL;
   if (cols == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  const bool vec = ws && (cols % 4 == 0) && (ld % 4 == 0) && rows >= 64 &&
+                   ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  if (vec) {
+    int chunks = rows / 32;
+    if (chunks > kColChunks) chunks = kColChunks;
+    if (chunks < 1) chunks = 1;
+    dim3 grid((cols / 4 + 63) / 64, chunks);
+    if (dtype == CPLXAMD_F32)
+      colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)in, ld, (float*)ws, rows, cols);
+    else if (dtype == CPLXAMD_BF16)
+      colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)in, ld, (float*)ws, rows, cols);
+    else
+      return CPLXAMD_EINVAL;
+    CPLXAMD_CHECK_LAUNCH();
+    colsum_final_kernel<<<(cols + 255) / 256, 256, 0, st>>>((const float*)ws, chunks, cols, out);
+    CPLXAMD_CHECK_LAUNCH();
+    return 0;
+  }
   const int grid = (cols + 63) / 64;
   if (dtype == CPLXAMD_F32)
     colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)in, ld, out, rows, cols);

@@ -30,17 +30,11 @@ class CplxParameter(torch.nn.ParameterDict):
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
                               unexpected_keys, error_msgs):
         have = [part for part in ("real", "imag") if prefix + part in state_dict]
-        whole = prefix[:-1]  # the parameter's own name, without the trailing dot
-        if not have and whole in state_dict:
-            # real -> complex promotion: the key names a plain tensor
-            value = state_dict[whole]
-            state_dict = {prefix + "real": value, prefix + "imag": torch.zeros_like(value)}
-            have = ["real", "imag"]
         missing, unexpected = [], []
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing,
                                       unexpected, error_msgs)
         if not have:
-            missing = [whole]  # the parameter as a whole is absent, not just one part
+            missing = [prefix[:-1]]  # the parameter as a whole is absent, not just one part
         elif len(have) == 1:
             error_msgs.append("Complex parameter requires both `.real` and `.imag` parts. "
                               f"Missing `{missing[0] if missing else prefix}`.")
@@ -53,7 +47,19 @@ class CplxParameter(torch.nn.ParameterDict):
 
 
 class CplxParameterAccessor:
-    """Attribute lookup that turns a stored CplxParameter into a `Cplx` pair on access."""
+    """Attribute lookup that turns a stored CplxParameter into a `Cplx` pair on access, plus
+    real -> complex promotion when a state dict holds a plain tensor under the parameter's name
+    (done here, in the owning module: torch hands child modules a pre-filtered state dict)."""
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for name, child in self._modules.items():
+            key = prefix + name
+            if isinstance(child, CplxParameter) and key in state_dict \
+                    and key + ".real" not in state_dict and key + ".imag" not in state_dict:
+                value = state_dict.pop(key)
+                state_dict[key + ".real"] = value
+                state_dict[key + ".imag"] = torch.zeros_like(value)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def __getattr__(self, name):
         value = super().__getattr__(name)

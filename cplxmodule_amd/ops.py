@@ -60,7 +60,8 @@ def colsum(t):
     t = t.contiguous()
     R, C = t.shape
     out = torch.empty(C, dtype=torch.float32, device=t.device)
-    call("cplxamd_colsum", ptr(t), C, ptr(out), R, C, dtype_code(t), stream_ptr())
+    ws = torch.empty(int(_lib.load().cplxamd_colsum_ws_bytes(C)), dtype=torch.uint8, device=t.device)
+    call("cplxamd_colsum", ptr(t), C, ptr(out), R, C, dtype_code(t), ptr(ws), stream_ptr())
     return out
 
 

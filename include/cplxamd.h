@@ -159,9 +159,11 @@ int cplxamd_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dty
 /* out[c, r] = in[r, c]  (rows x cols row-major in, ld = leading dims) */
 int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
                       int cols, int dtype, void* stream);
-/* out[n] = sum_m in[m, n]   (bias gradient; float32 out) */
+/* out[n] = sum_m in[m, n]   (bias gradient; float32 out); ws (nullable -> slow path) holds
+ * cplxamd_colsum_ws_bytes(cols) bytes of partial sums */
+int64_t cplxamd_colsum_ws_bytes(int cols);
 int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, int dtype,
-                   void* stream);
+                   void* ws, void* stream);
 /* dxr += 2 xr ga ; dxi += 2 xi ga   (LRT backward; xi/dxi NULL for real) */
 int cplxamd_lrt_dx_accum(void* dxr, void* dxi, const void* xr, const void* xi, const void* ga,
                          int64_t n, int dtype, int ga_dtype, void* stream);
