@@ -11,6 +11,7 @@ struct GemmArgs {
   void* c_r; void* c_i; int64_t ldc;
   int M, N, K;
   int conj_b, accumulate;
+  int order = 1, group_m = 4, setprio = 0;   // bf16 kernel tuning knobs (gemm_bf16.hip)
 };
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)

@@ -8,14 +8,22 @@
 // issues 4 separate GEMMs + 2 elementwise passes, cplx.py:641-646).  The sign flip for the
 // Ai Bi product (and for conj(B), used by dgrad / wgrad) is an XOR on the packed bf16 fragment.
 //
-// Structure (cdna_hip_programming.md sec. 5, "minimum 2-phase"): 128x128 (complex) output tile,
-// BK = 32, 256 threads = 4 waves as 2x2, each wave 64x64 outputs = 2x2 MFMA tiles x {re, im}
-// (128 accumulator registers).  Operand tiles go global -> LDS directly with
-// global_load_lds_dwordx4 (no VGPR round trip), double buffered, one barrier per K tile.
-// LDS image of a [128 rows][32 k] bf16 plane: 64 B rows, the four 16-B chunks of a row
-// XOR-swizzled with (row >> 2) & 3 so that each ds_read_b128 lane group touches 16 distinct
-// 16-B bank slots (conflict-free); because the LDS-DMA writes lane-linearly, the swizzle is
-// applied to the per-lane global SOURCE address and again on the read (rule 21 of the guide).
+// Structure: (64*WM) x (64*WN) output tile per workgroup of WM*WN waves, each wave owning a 64x64
+// sub-tile = 2x2 MFMA tiles x {re, im} (128 accumulator registers); BK = 32.  Operand tiles go
+// global -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip) into a ring of
+// STAGES buffers:
+//   STAGES = 2: issue tile t+1, compute tile t, __syncthreads (carries vmcnt(0))      ["2-phase"]
+//   STAGES = 3: tiles t+1 and t+2 stay in flight across the (raw) barrier; the wait for tile t
+//               is a COUNTED s_waitcnt vmcnt(loads per tile) (cdna_hip_programming.md T3/T4).
+// LDS image of a [rows][32 k] bf16 plane: 64-B rows, the four 16-B chunks of a row XOR-swizzled
+// with (row >> 2) & 3 so that each ds_read_b128 lane group touches 16 distinct 16-B bank slots;
+// the LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane global SOURCE
+// address and again on the read (rule 21 of the guide).
+// Tile order: XCD-aware (block b runs on XCD b % 8 -> each XCD gets a contiguous range of the
+// grouped tile order, GROUP_M row-panels x all column-panels per group) so that the 32-64 tiles
+// resident on one XCD share A / B panels in that XCD's private L2.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace cplxamd {
@@ -23,15 +31,8 @@ namespace cplxamd {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PLANE_BYTES = BM * BK * 2;  // 8 KiB per operand plane per stage
-
-template <bool CPLX>
-struct Smem {
-  static constexpr int NPLANES = CPLX ? 4 : 2;            // Ar, (Ai), Br, (Bi)
-  static constexpr int STAGE_BYTES = NPLANES * PLANE_BYTES;
-  static constexpr int TOTAL = 2 * STAGE_BYTES;           // 64 KiB complex, 32 KiB real
-};
+constexpr int BK = 32;
+constexpr int GROUP_M = 4;
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -39,21 +40,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Stage one [128 x 32] bf16 plane tile: 512 16-B chunks, 2 per thread.
-// LDS chunk p = j*256 + tid holds global chunk (row = p >> 2, kc = (p & 3) ^ ((row >> 2) & 3)).
+// Stage one [ROWS x 32] bf16 plane tile: ROWS*4 16-B chunks spread over NT threads.
+// LDS chunk p holds global chunk (row = p >> 2, kc = (p & 3) ^ ((row >> 2) & 3)).
+template <int ROWS, int NT>
 __device__ __forceinline__ void stage_plane(const bf16_t* base, int64_t ld, int row0, int rows,
                                             int k0, char* lds_plane) {
   const int tid = threadIdx.x;
   const int wave_chunk = (tid >> 6) * 64;
+  constexpr int PER = ROWS * 4 / NT;
+  static_assert(PER >= 1 && ROWS * 4 % NT == 0, "tile / thread-count mismatch");
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int p = j * 256 + tid;
+  for (int j = 0; j < PER; ++j) {
+    const int p = j * NT + tid;
     const int row = p >> 2;
     const int kc = (p & 3) ^ ((row >> 2) & 3);
     int grow = row0 + row;
     grow = grow < rows ? grow : rows - 1;  // clamp: out-of-range rows are never stored
     const bf16_t* src = base + (int64_t)grow * ld + k0 + kc * 8;
-    glds16(src, lds_plane + (j * 256 + wave_chunk) * 16);
+    glds16(src, lds_plane + (j * NT + wave_chunk) * 16);
   }
 }
 
@@ -68,18 +72,49 @@ __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
-template <typename TOUT, bool CPLX, bool CONJ>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  using S = Smem<CPLX>;
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-  // tile coordinates: consecutive blocks walk N first (they share the A row panel)
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+template <bool CPLX, int WM, int WN, int STAGES>
+struct Cfg {
+  static constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
+  static constexpr int SMEM = STAGES * STAGE_BYTES;
+  // LDS-DMA instructions each thread issues per K tile
+  static constexpr int LOADS = (CPLX ? 2 : 1) * (BM * 4 / NT + BN * 4 / NT);
+};
+
+template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using C = Cfg<CPLX, WM, WN, STAGES>;
+  constexpr int BM = C::BM, BN = C::BN, NT = C::NT;
+
+  // ---- XCD-aware grouped tile order ------------------------------------------------------
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  int lin = blockIdx.x;
+  int bm, bn;
+  if (g.order == 0) {            // natural: consecutive blocks walk N
+    bm = lin / tiles_n; bn = lin - bm * tiles_n;
+  } else {
+    if (g.order == 1) {          // each XCD gets a contiguous range of the grouped order
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = lin & 7, idx = lin >> 3;
+      lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective
+    }
+    const int GM = g.group_m;
+    const int per_group = GM * tiles_n;
+    const int grp = lin / per_group, in_grp = lin - grp * per_group;
+    const int first_m = grp * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    bm = first_m + in_grp % gm; bn = in_grp / gm;
+  }
   const int m0 = bm * BM, n0 = bn * BN;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+  const int wm = (wid / WN) * 64, wn = (wid % WN) * 64;
   const int l31 = lane & 31, lk = lane >> 5;
 
   const bf16_t* Ar = (const bf16_t*)g.a_r; const bf16_t* Ai = (const bf16_t*)g.a_i;
@@ -95,34 +130,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 
   auto stage = [&](int buf, int k0) {
-    char* s = smem + buf * S::STAGE_BYTES;
-    stage_plane(Ar, g.a_rs, m0, g.M, k0, s);
-    stage_plane(Br, g.b_rs, n0, g.N, k0, s + PLANE_BYTES);
+    char* s = smem + buf * C::STAGE_BYTES;
+    stage_plane<BM, NT>(Ar, g.a_rs, m0, g.M, k0, s);
+    stage_plane<BN, NT>(Br, g.b_rs, n0, g.N, k0, s + C::A_BYTES);
     if (CPLX) {
-      stage_plane(Ai, g.a_rs, m0, g.M, k0, s + 2 * PLANE_BYTES);
-      stage_plane(Bi, g.b_rs, n0, g.N, k0, s + 3 * PLANE_BYTES);
+      stage_plane<BM, NT>(Ai, g.a_rs, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES);
+      stage_plane<BN, NT>(Bi, g.b_rs, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES);
     }
   };
 
-  const int nt = g.K / BK;
-  stage(0, 0);
-  __syncthreads();  // the workgroup barrier carries vmcnt(0) for the in-flight LDS-DMA
-
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * BK);
-    const char* s = smem + cur * S::STAGE_BYTES;
+  auto compute = [&](int buf) {
+    const char* sA = smem + buf * C::STAGE_BYTES;
+    const char* sB = sA + C::A_BYTES;
+    const char* sAi = sB + C::B_BYTES;
+    const char* sBi = sAi + C::A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kc = ks * 2 + lk;
       bf16x8 ar[2], br[2], ai[2], bi[2], nai[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ar[i] = lds_frag(s, wm + i * 32 + l31, kc);
-        br[i] = lds_frag(s + PLANE_BYTES, wn + i * 32 + l31, kc);
+        ar[i] = lds_frag(sA, wm + i * 32 + l31, kc);
+        br[i] = lds_frag(sB, wn + i * 32 + l31, kc);
         if (CPLX) {
-          ai[i] = lds_frag(s + 2 * PLANE_BYTES, wm + i * 32 + l31, kc);
-          bi[i] = lds_frag(s + 3 * PLANE_BYTES, wn + i * 32 + l31, kc);
+          ai[i] = lds_frag(sAi, wm + i * 32 + l31, kc);
+          bi[i] = lds_frag(sBi, wn + i * 32 + l31, kc);
         }
       }
       if (CPLX) {
@@ -130,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) nai[i] = neg_frag(CONJ ? ar[i] : ai[i]);
       }
+      if (g.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -146,8 +179,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
             }
           }
         }
+      if (g.setprio) __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();
+  };
+
+  const int nt = g.K / BK;
+  if (STAGES == 2) {
+    stage(0, 0);
+    __syncthreads();  // the workgroup barrier carries vmcnt(0) for the in-flight LDS-DMA
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BK);
+      compute(t & 1);
+      __syncthreads();
+    }
+  } else {
+    // 3-deep ring: tiles t+1, t+2 in flight while tile t is consumed; one raw barrier per tile.
+    stage(0, 0);
+    if (nt > 1) stage(1, BK);
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();           // tile t landed for every wave; buffer (t-1)%3 free
+      int nxt = cur + 2; nxt = nxt >= 3 ? nxt - 3 : nxt;
+      if (t + 2 < nt) stage(nxt, (t + 2) * BK);
+      compute(cur);
+      cur = cur + 1 == 3 ? 0 : cur + 1;
+    }
   }
 
   // epilogue.  32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -182,6 +239,54 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// read-only tuning choice (set once from the environment; DESIGN.md "GEMM variants")
+static int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CPLXAMD_GEMM_VARIANT");
+    v = e ? atoi(e) : 3;
+  }
+  return v;
+}
+
+template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES>
+static int launch_cfg(const GemmArgs& g, hipStream_t st) {
+  using C = Cfg<CPLX, WM, WN, STAGES>;
+  const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
+  if (tiles > 0x7fffffff) return CPLXAMD_ESHAPE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES><<<dim3((unsigned)tiles), C::NT, C::SMEM, st>>>(g);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <typename TOUT, bool CPLX, bool CONJ>
+static int launch_variant(const GemmArgs& g0, hipStream_t st) {
+  static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 4),
+                   sp = env_int("CPLXAMD_GEMM_SETPRIO", 0);
+  GemmArgs g = g0;
+  g.order = order; g.group_m = gm > 0 ? gm : 1; g.setprio = sp;
+  switch (gemm_variant()) {
+    case 1: return launch_cfg<TOUT, CPLX, CONJ, 2, 2, 3>(g, st);   // 128x128, 3-stage
+    case 2: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 2>(g, st);   // 256x128, 2-stage
+    case 3: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3>(g, st);   // 256x128, 3-stage
+    case 4: return launch_cfg<TOUT, CPLX, CONJ, 2, 4, 3>(g, st);   // 128x256, 3-stage
+    case 0: return launch_cfg<TOUT, CPLX, CONJ, 2, 2, 2>(g, st);   // 128x128, 2-stage
+    default: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3>(g, st);  // 256x128, 3-stage (default)
+  }
+}
+
 template <bool CPLX>
 int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   if (g.a_cs != 1 || g.b_cs != 1 || g.K < BK || (g.K % BK) != 0) return CPLXAMD_ESHAPE;
@@ -189,31 +294,12 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   if (!aligned16(g.a_r) || !aligned16(g.b_r)) return CPLXAMD_ESHAPE;
   if (CPLX && (!aligned16(g.a_i) || !aligned16(g.b_i))) return CPLXAMD_ESHAPE;
   if (g.M <= 0 || g.N <= 0) return 0;
-  const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  if (tiles > 0x7fffffff) return CPLXAMD_ESHAPE;
-  const int smem = Smem<CPLX>::TOTAL;
-  dim3 grid((unsigned)tiles);
-#define LAUNCH(TOUT, CONJ)                                                                   \
-  do {                                                                                       \
-    static bool attr_set = false;                                                            \
-    if (!attr_set) {                                                                         \
-      hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ>,                   \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, smem);                 \
-      attr_set = true;                                                                       \
-    }                                                                                        \
-    gemm_bf16_kernel<TOUT, CPLX, CONJ><<<grid, 256, smem, st>>>(g);                          \
-  } while (0)
   const bool conj = CPLX && g.conj_b;
-  if (out_dtype == CPLXAMD_BF16) {
-    if (conj) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false);
-  } else if (out_dtype == CPLXAMD_F32) {
-    if (conj) LAUNCH(float, true); else LAUNCH(float, false);
-  } else {
-    return CPLXAMD_EINVAL;
-  }
-#undef LAUNCH
-  CPLXAMD_CHECK_LAUNCH();
-  return 0;
+  if (out_dtype == CPLXAMD_BF16)
+    return conj ? launch_variant<bf16_t, CPLX, true>(g, st) : launch_variant<bf16_t, CPLX, false>(g, st);
+  if (out_dtype == CPLXAMD_F32)
+    return conj ? launch_variant<float, CPLX, true>(g, st) : launch_variant<float, CPLX, false>(g, st);
+  return CPLXAMD_EINVAL;
 }
 
 template int launch_gemm_bf16<true>(const GemmArgs&, int, hipStream_t);
