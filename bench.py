@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for "
+                    "functional tests of the N > 1 path on a single GPU (with --share-device)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (tests)")
     return ap.parse_args()
 
 
@@ -105,11 +108,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from cplxmodule_amd import Cplx, dp, ops
     from cplxmodule_amd.nn import relevance as rel

@@ -167,15 +167,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], br[j], acc_r[i][j], 0, 0, 0);
+          // operands swapped (B fragment first): the accumulator holds the TRANSPOSED 32x32
+          // tile, i.e. lane <-> output row, registers <-> 4-column groups -> 8/16-byte stores
+          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[j], ar[i], acc_r[i][j], 0, 0, 0);
           if (CPLX) {
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[i], br[j], acc_i[i][j], 0, 0, 0);
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[j], ai[i], acc_i[i][j], 0, 0, 0);
             if (CONJ) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[i], bi[j], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nai[i], bi[j], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], ai[i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], nai[i], acc_i[i][j], 0, 0, 0);
             } else {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nai[i], bi[j], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], bi[j], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], nai[i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], ar[i], acc_i[i][j], 0, 0, 0);
             }
           }
         }
@@ -207,30 +209,73 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     }
   }
 
-  // epilogue.  32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // epilogue.  Transposed 32x32 C/D layout: output row = lane & 31, output columns
+  // 8 q + 4 (lane >> 5) + {0..3} for register group q = r >> 2: one 8-B (bf16) / 16-B (fp32)
+  // store per group instead of four scalar ones.
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
   TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
+  const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.c_r) & 15) == 0 &&
+                      (!CPLX || (reinterpret_cast<uintptr_t>(g.c_i) & 15) == 0) &&
+                      (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn + j * 32 + l31;
-    if (col >= g.N) continue;
-    const float b_r = g.bias_r ? g.bias_r[col] : 0.0f;
-    const float b_i = (CPLX && g.bias_i) ? g.bias_i[col] : 0.0f;
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wm + i * 32 + l31;
+    if (row >= g.M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn + j * 32 + 8 * q + 4 * lk;
+        if (col >= g.N) continue;
         const int64_t o = (int64_t)row * g.ldc + col;
-        float vr = acc_r[i][j][r] + b_r;
-        if (g.emul) vr *= g.emul[o];
-        if (g.accumulate) vr += io<TOUT>::ld(cr + o);
-        io<TOUT>::st(cr + o, vr);
-        if (CPLX) {
-          float vi = acc_i[i][j][r] + b_i;
-          if (g.accumulate) vi += io<TOUT>::ld(ci + o);
-          io<TOUT>::st(ci + o, vi);
+        f4 vr, vi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vr.v[e] = acc_r[i][j][4 * q + e];
+          vi.v[e] = CPLX ? acc_i[i][j][4 * q + e] : 0.f;
+        }
+        if (vec_ok && col + 3 < g.N) {
+          if (g.bias_r) {
+            const f4 b = ld4(g.bias_r + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vr.v[e] += b.v[e];
+            if (CPLX) {
+              const f4 c = ld4(g.bias_i + col);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vi.v[e] += c.v[e];
+            }
+          }
+          if (g.emul) {
+            const f4 m = ld4(g.emul + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vr.v[e] *= m.v[e];
+          }
+          if (g.accumulate) {
+            const f4 p = ld4(cr + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vr.v[e] += p.v[e];
+            if (CPLX) {
+              const f4 p2 = ld4(ci + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vi.v[e] += p2.v[e];
+            }
+          }
+          st4(cr + o, vr);
+          if (CPLX) st4(ci + o, vi);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (col + e >= g.N) break;
+            float xr = vr.v[e] + (g.bias_r ? g.bias_r[col + e] : 0.f);
+            if (g.emul) xr *= g.emul[o + e];
+            if (g.accumulate) xr += io<TOUT>::ld(cr + o + e);
+            io<TOUT>::st(cr + o + e, xr);
+            if (CPLX) {
+              float xi = vi.v[e] + (g.bias_i ? g.bias_i[col + e] : 0.f);
+              if (g.accumulate) xi += io<TOUT>::ld(ci + o + e);
+              io<TOUT>::st(ci + o + e, xi);
+            }
+          }
         }
       }
     }
@@ -277,6 +322,11 @@ static int launch_variant(const GemmArgs& g0, hipStream_t st) {
                    sp = env_int("CPLXAMD_GEMM_SETPRIO", 0);
   GemmArgs g = g0;
   g.order = order; g.group_m = gm > 0 ? gm : 1; g.setprio = sp;
+  if (!CPLX) {
+    static const int rv = env_int("CPLXAMD_RGEMM_VARIANT", 0);
+    if (rv == 1) return launch_cfg<TOUT, CPLX, CONJ, 4, 4, 3>(g, st);   // real: 256x256, 16 waves
+    if (rv == 2) return launch_cfg<TOUT, CPLX, CONJ, 4, 4, 2>(g, st);
+  }
   switch (gemm_variant()) {
     case 1: return launch_cfg<TOUT, CPLX, CONJ, 2, 2, 3>(g, st);   // 128x128, 3-stage
     case 2: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 2>(g, st);   // 256x128, 2-stage

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int64_t ld_
 
 // out[c] = sum_r in[r, c].  Stage 1: block = 64 column-quads x 4 row lanes over one row chunk,
 // 8-16 B loads per lane, partial[chunk][c]; stage 2 sums the chunks.  (cols % 4 != 0: scalar path.)
-constexpr int kColChunks = 128;
+constexpr int kColChunks = 32;
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* in, int64_t ld, float* partial,
@@ -223,7 +223,7 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
   const bool vec = ws && (cols % 4 == 0) && (ld % 4 == 0) && rows >= 64 &&
                    ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
   if (vec) {
-    int chunks = rows / 32;
+    int chunks = rows / 64;
     if (chunks > kColChunks) chunks = kColChunks;
     if (chunks < 1) chunks = 1;
     dim3 grid((cols / 4 + 63) / 64, chunks);

@@ -49,6 +49,10 @@ class GradBucket:
     def adopt(self):
         """Make every .grad a view into the flat bucket: backward then writes (accumulates)
         straight into it and no gather / scatter copy is needed around the collective."""
+        if not (is_initialized() and dist.get_world_size() > 1):
+            for p in self.params:          # single process: nothing to exchange, let autograd
+                p.grad = None              # adopt the kernels' output buffers (no extra pass)
+            return
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
