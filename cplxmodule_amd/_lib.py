@@ -49,13 +49,19 @@ SIGNATURES = {
     "cplxamd_conv2d_wgrad_ws_bytes": [_P, _I],
     "cplxamd_conv2d_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
     "cplxamd_conv2d_out_shape": [_P, _P, _P],
+    "cplxamd_conv2d_ktab_size": [_P, _I],
+    "cplxamd_conv2d_ktab_fill": [_P, _I, _P],
+    "cplxamd_conv2d_bf16_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "cplxamd_conv2d_bf16_dgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "cplxamd_conv2d_bf16_wgrad_ws_bytes": [_P, _I],
+    "cplxamd_conv2d_bf16_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "cplxamd_chansum": [_P, _P, _L, _I, _L, _I, _P, _P],
     "cplxamd_bn_ws_bytes": [_I],
     "cplxamd_bn_fwd": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P],
     "cplxamd_bn_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _L, _P],
 }
 _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
-             "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64}
+             "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64}
 
 _lib = None
 
@@ -93,6 +99,18 @@ def load():
 
 _ERRORS = {-1: "invalid argument", -2: "misaligned pointer / leading dimension",
            -3: "unsupported shape", -4: "workspace too small"}
+
+
+def try_call(name, *args):
+    """Like `call`, but returns False when the entry point declines the shape
+    (CPLXAMD_ESHAPE = "use the generic kernel"); every other failure raises."""
+    rc = getattr(load(), name)(*args)
+    if rc == -3:
+        return False
+    if rc != 0:
+        what = _ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise CplxAmdError(f"{name} failed: {what}")
+    return True
 
 
 def call(name, *args):

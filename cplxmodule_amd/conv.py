@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, ops
-from ._lib import call, dtype_code, ptr, require_device, stream_ptr
+from ._lib import call, try_call, dtype_code, ptr, require_device, stream_ptr
 from .cplx import Cplx
 
 _ws_cache = {}
@@ -40,9 +40,35 @@ def _scratch(device, nbytes):
     return buf
 
 
+_ktab_cache = {}
+
+
+def _ktab(geom, mode, device):
+    """Device copy of the (offset, dh, dw) table of the bf16 fast path (cached per geometry)."""
+    key = (tuple(geom), mode, device.index)
+    tab = _ktab_cache.get(key)
+    if tab is None:
+        lib = _lib.load()
+        n = int(lib.cplxamd_conv2d_ktab_size(geom, mode))
+        host = (ctypes.c_int * n)()
+        call("cplxamd_conv2d_ktab_fill", geom, mode, host)
+        tab = _ktab_cache[key] = torch.tensor(list(host), dtype=torch.int32, device=device)
+    return tab
+
+
+def _repack_dgrad(w, groups):
+    """[Co, Ci/g, KH, KW] -> [g][Ci/g][Co/g * KH * KW] (K-contiguous rows for the dgrad GEMM)."""
+    Co, Cg, KH, KW = w.shape
+    return w.view(groups, Co // groups, Cg, KH, KW).permute(0, 2, 1, 3, 4).contiguous()
+
+
 def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape):
     yr = torch.empty(out_shape, dtype=xr.dtype, device=xr.device)
     yi = None if xi is None else torch.empty_like(yr)
+    if xr.dtype == torch.bfloat16 and try_call(
+            "cplxamd_conv2d_bf16_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
+            ptr(yi), geom, ptr(_ktab(geom, 0, xr.device)), stream_ptr()):
+        return yr, yi
     call("cplxamd_conv2d_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
          ptr(yi), geom, dtype_code(xr), stream_ptr())
     return yr, yi
@@ -51,6 +77,12 @@ def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape):
 def conv_dgrad(gr, gi, wr, wi, geom, x_shape):
     dxr = torch.empty(x_shape, dtype=gr.dtype, device=gr.device)
     dxi = None if gi is None else torch.empty_like(dxr)
+    if gr.dtype == torch.bfloat16 and geom[7] == 1 and geom[8] == 1:
+        wtr = _repack_dgrad(wr, geom[13])
+        wti = None if wi is None else _repack_dgrad(wi, geom[13])
+        if try_call("cplxamd_conv2d_bf16_dgrad", ptr(gr), ptr(gi), ptr(wtr), ptr(wti), ptr(dxr),
+                    ptr(dxi), geom, ptr(_ktab(geom, 1, gr.device)), stream_ptr()):
+            return dxr, dxi
     call("cplxamd_conv2d_dgrad", ptr(gr), ptr(gi), ptr(wr), ptr(wi), ptr(dxr), ptr(dxi), geom,
          dtype_code(gr), stream_ptr())
     return dxr, dxi
@@ -59,6 +91,15 @@ def conv_dgrad(gr, gi, wr, wi, geom, x_shape):
 def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
     lib = _lib.load()
     cplx = gi is not None
+    if gr.dtype == torch.bfloat16:
+        nbytes = int(lib.cplxamd_conv2d_bf16_wgrad_ws_bytes(geom, int(cplx)))
+        ws = _scratch(gr.device, nbytes)
+        dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)
+        dwi = torch.empty_like(dwr) if cplx else None
+        if try_call("cplxamd_conv2d_bf16_wgrad", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul),
+                    ptr(dwr), ptr(dwi), geom, ptr(_ktab(geom, 0, gr.device)), ptr(ws), ws.numel(),
+                    stream_ptr()):
+            return dwr, dwi
     nbytes = int(lib.cplxamd_conv2d_wgrad_ws_bytes(geom, int(cplx)))
     ws = _scratch(gr.device, nbytes)
     dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)

@@ -191,6 +191,24 @@ int64_t cplxamd_conv2d_wgrad_ws_bytes(const int* geom, int cplx);
 int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const void* xi,
                          const float* emul, float* dwr, float* dwi, const int* geom, int dtype,
                          void* ws, int64_t ws_bytes, void* stream);
+/* bf16 fast path of the same three operations (bf16 MFMA, register-gathered operand tiles).
+ * ktab: device copy of the int[3*T] table written by cplxamd_conv2d_ktab_fill (a host-side
+ * helper; mode 0 = fwd / wgrad table over (ci, kh, kw), 1 = dgrad table over (co, kh, kw)).
+ * They return CPLXAMD_ESHAPE when the shape does not qualify (K % 32 != 0, strided dgrad):
+ * the caller then uses the generic entry points above.  dgrad takes the weight repacked to
+ * [groups][Ci/g][Co/g * KH * KW]. */
+int cplxamd_conv2d_ktab_size(const int* geom, int mode);
+int cplxamd_conv2d_ktab_fill(const int* geom, int mode, int* host_out);
+int cplxamd_conv2d_bf16_fwd(const void* xr, const void* xi, const void* wr, const void* wi,
+                            const float* bias_r, const float* bias_i, void* yr, void* yi,
+                            const int* geom, const int* ktab, void* stream);
+int cplxamd_conv2d_bf16_dgrad(const void* gr, const void* gi, const void* wtr, const void* wti,
+                              void* dxr, void* dxi, const int* geom, const int* ktab,
+                              void* stream);
+int64_t cplxamd_conv2d_bf16_wgrad_ws_bytes(const int* geom, int cplx);
+int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, const void* xi,
+                              const float* emul, float* dwr, float* dwi, const int* geom,
+                              const int* ktab, void* ws, int64_t ws_bytes, void* stream);
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);

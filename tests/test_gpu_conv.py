@@ -117,3 +117,42 @@ def test_conv_bf16_and_larger_vs_oracle():
                              wi.astype(f), padding=1, has_bias=False)
     for n, t in dict(dxr=txr.grad, dxi=txi.grad, dwr=twr.grad, dwi=twi.grad).items():
         np.testing.assert_allclose(N(t), bw[n], rtol=2e-2, atol=2e-2 * np.abs(bw[n]).max(), err_msg=n)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, Ci=32, Co=64, H=18, W=21, k=3, stride=1, padding=1, dilation=1, groups=1),
+    dict(B=3, Ci=32, Co=40, H=17, W=16, k=3, stride=1, padding=0, dilation=1, groups=1),
+    dict(B=2, Ci=64, Co=64, H=12, W=13, k=3, stride=1, padding=2, dilation=2, groups=2),
+    dict(B=2, Ci=32, Co=32, H=15, W=14, k=(3, 1), stride=2, padding=(1, 0), dilation=1, groups=1),
+    dict(B=1, Ci=64, Co=96, H=9, W=9, k=1, stride=1, padding=0, dilation=1, groups=1),
+])
+def test_conv_bf16_fast_path_vs_oracle(cfg):
+    """Shapes that take the bf16-MFMA conv kernels (K % 32 == 0): forward, dgrad (incl. the
+    generic fallback for stride 2), split-K wgrad, bias; oracle on the bf16-rounded operands."""
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import Cplx, cplx
+    rs = np.random.RandomState(cfg["Ci"] + cfg["Co"])
+    B, Ci, Co, H, W, g = cfg["B"], cfg["Ci"], cfg["Co"], cfg["H"], cfg["W"], cfg["groups"]
+    kh, kw = (cfg["k"], cfg["k"]) if isinstance(cfg["k"], int) else cfg["k"]
+    xr, xi = bf16_round(rs.randn(B, Ci, H, W)), bf16_round(rs.randn(B, Ci, H, W) + 0.2)
+    wr, wi = bf16_round(rs.randn(Co, Ci // g, kh, kw) * 0.1), bf16_round(rs.randn(Co, Ci // g, kh, kw) * 0.1)
+    br, bi = rs.randn(Co).astype(np.float32), rs.randn(Co).astype(np.float32)
+    q = lambda a: T(a, torch.bfloat16)  # noqa: E731
+    txr, txi = q(xr).requires_grad_(True), q(xi).requires_grad_(True)
+    twr, twi = T(wr).requires_grad_(True), T(wi).requires_grad_(True)
+    tbr, tbi = T(br).requires_grad_(True), T(bi).requires_grad_(True)
+    kw_ = dict(stride=cfg["stride"], padding=cfg["padding"], dilation=cfg["dilation"], groups=g)
+    y = cplx.conv2d(Cplx(txr, txi), Cplx(twr, twi), Cplx(tbr, tbi), **kw_)
+    f = np.float64
+    yr, yi = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), br.astype(f),
+                             bi.astype(f), **kw_)
+    assert tuple(y.shape) == yr.shape
+    np.testing.assert_allclose(N(y.real), yr, rtol=1e-2, atol=1e-2 * np.abs(yr).max())
+    np.testing.assert_allclose(N(y.imag), yi, rtol=1e-2, atol=1e-2 * np.abs(yi).max())
+    gr, gi = bf16_round(rs.randn(*yr.shape)), bf16_round(rs.randn(*yr.shape))
+    ((y.real * q(gr)).sum() + (y.imag * q(gi)).sum()).backward()
+    bw = orc.cplx_conv2d_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), wr.astype(f),
+                             wi.astype(f), **kw_)
+    got = dict(dxr=txr.grad, dxi=txi.grad, dwr=twr.grad, dwi=twi.grad, dbr=tbr.grad, dbi=tbi.grad)
+    for n, t in got.items():
+        np.testing.assert_allclose(N(t), bw[n], rtol=2e-2, atol=2e-2 * np.abs(bw[n]).max(), err_msg=n)
