@@ -29,7 +29,7 @@ struct ConvFP {
   int B, Ci, Co, H, W, KH, KW, Ho, Wo, sh, sw, ph, pw, dh, dw, G, Cg, Cog;
 };
 
-enum { FMODE_FWD = 0, FMODE_DGRAD = 1, FMODE_WGRAD = 2 };
+enum { FMODE_FWD = 0, FMODE_DGRAD = 1, FMODE_WGRAD = 2, FMODE_WGRAD_ROWS = 3 };
 
 struct ConvFArgs {
   const bf16_t* ar; const bf16_t* ai;   // A operand: FWD weight [Co][K]; DGRAD repacked weight
@@ -96,6 +96,23 @@ __device__ __forceinline__ void stage_rowfast(char* lds_r, char* lds_i, const bf
   }
 }
 
+// 8 consecutive bf16 from a 2-byte-aligned address (one global_load_dwordx4 on gfx950), the
+// first `valid` of them kept, the rest zero.
+struct __attribute__((packed, aligned(2))) U16x8 { uint16_t v[8]; };
+__device__ __forceinline__ uint4 load8_masked(const bf16_t* p, int valid) {
+  uint4 r = make_uint4(0, 0, 0, 0);
+  if (valid >= 8) {
+    const U16x8 u = *reinterpret_cast<const U16x8*>(p);
+    __builtin_memcpy(&r, &u, 16);
+  } else if (valid > 0) {
+    uint16_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = j < valid ? p[j] : (uint16_t)0;
+    r = make_uint4(pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7]));
+  }
+  return r;
+}
+
 __device__ __forceinline__ bf16x8 frag(const char* plane, int row, int kc) {
   return *reinterpret_cast<const bf16x8*>(plane + row * FROW + kc * 16);
 }
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvFArgs a) {
   // ---- per-thread row decode, hoisted out of the K loop ----
   // FWD / DGRAD: this thread's B row (pixel) for the row-fast gather
   bool b_ok = false; int64_t b_base = 0; int bh0 = 0, bw0 = 0;
-  if (MODE != FMODE_WGRAD) {
+  if (MODE == FMODE_FWD || MODE == FMODE_DGRAD) {
     const int64_t n = n0 + (t & 63);
     b_ok = n < a.N;
     if (b_ok) {
@@ -143,9 +160,43 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvFArgs a) {
   }
   const int Hl = (MODE == FMODE_DGRAD) ? p.Ho : p.H, Wl = (MODE == FMODE_DGRAD) ? p.Wo : p.W;
 
+  // WGRAD_ROWS (stride 1, no padding): a K tile is 32 consecutive output pixels of ONE output
+  // row (b, oh); both operand rows are then contiguous in memory and move as 16-B loads.
+  // K counts such tiles; this thread owns LDS chunk (row r, 8-pixel group q) of both operands.
+  int wr_off = 0;
+  const int wr_r = t >> 2, wr_q = t & 3;
+  const int chunks_w = (p.Wo + FBK - 1) / FBK;
+  if (MODE == FMODE_WGRAD_ROWS) {
+    const int64_t n = n0 + wr_r;
+    wr_off = n < a.N ? a.ktab[n] : -1;   // ci*H*W + kh*dh*W + kw*dw, hoisted for the whole loop
+  }
+
   f32x16 acc_r = {0}, acc_i = {0};
-  for (int64_t k0 = kbeg; k0 < kend; k0 += FBK) {
-    if (MODE == FMODE_FWD) {
+  for (int64_t k0 = kbeg; k0 < kend; k0 += (MODE == FMODE_WGRAD_ROWS ? 1 : FBK)) {
+    if (MODE == FMODE_WGRAD_ROWS) {
+      const int64_t bo = k0 / chunks_w;                 // (b, oh) index
+      const int c = (int)(k0 - bo * chunks_w);
+      const int64_t b = bo / p.Ho; const int oh = (int)(bo - b * p.Ho);
+      const int ow = c * FBK + wr_q * 8;
+      const int valid = p.Wo - ow;
+      uint4 gr4 = make_uint4(0, 0, 0, 0), gi4 = gr4, xr4 = gr4, xi4 = gr4;
+      if (m0 + wr_r < a.M) {
+        const int64_t off = ((b * p.Co + (int64_t)g * p.Cog + m0 + wr_r) * p.Ho + oh) * p.Wo + ow;
+        gr4 = load8_masked(a.ar + off, valid);
+        if (CPLX) gi4 = load8_masked(a.ai + off, valid);
+      }
+      if (wr_off >= 0) {
+        const int64_t off = (b * p.Ci + (int64_t)g * p.Cg) * HW + wr_off + (int64_t)oh * p.W + ow;
+        xr4 = load8_masked(a.br + off, valid);
+        if (CPLX) xi4 = load8_masked(a.bi + off, valid);
+      }
+      *reinterpret_cast<uint4*>(sAr + wr_r * FROW + wr_q * 16) = gr4;
+      *reinterpret_cast<uint4*>(sBr + wr_r * FROW + wr_q * 16) = xr4;
+      if (CPLX) {
+        *reinterpret_cast<uint4*>(sAi + wr_r * FROW + wr_q * 16) = gi4;
+        *reinterpret_cast<uint4*>(sBi + wr_r * FROW + wr_q * 16) = xi4;
+      }
+    } else if (MODE == FMODE_FWD) {
       const int64_t Kw = (int64_t)p.Cg * khw;
       stage_kvec<CPLX>(sAr, sAi, a.ar + (int64_t)g * p.Cog * Kw, a.ai + (int64_t)g * p.Cog * Kw, m0,
                        a.M, Kw, k0);
@@ -213,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvFArgs a) {
           acc_r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, bi, acc_r, 0, 0, 0);
           acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, bi, acc_i, 0, 0, 0);
           acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(negf(ai), br, acc_i, 0, 0, 0);
-        } else {
+        } else {   // both WGRAD flavours: A conj(B)
           acc_r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, bi, acc_r, 0, 0, 0);
           acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(negf(ar), bi, acc_i, 0, 0, 0);
           acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, br, acc_i, 0, 0, 0);
@@ -247,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvFArgs a) {
       vr += a.bias_r[g * p.Cog + m];
       if (CPLX) vi += a.bias_i[g * p.Cog + m];
     }
-    if (MODE == FMODE_WGRAD) {
+    if (MODE == FMODE_WGRAD || MODE == FMODE_WGRAD_ROWS) {
       reinterpret_cast<float*>(a.yr)[o] = vr;
       if (CPLX) reinterpret_cast<float*>(a.yi)[o] = vi;
     } else {
@@ -406,10 +457,17 @@ int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, co
   a.ktab = ktab; a.ktab_n = p.Cg * p.KH * p.KW;
   a.yr = ws; a.yi = (float*)ws + (int64_t)a.splits * wsz;
   a.M = p.Cog; a.N = (int64_t)p.Cg * p.KH * p.KW; a.K = (int64_t)p.B * p.Ho * p.Wo;
-  a.kchunk = ((a.K + a.splits - 1) / a.splits + FBK - 1) / FBK * FBK;
   hipStream_t st = (hipStream_t)stream;
   const bool check = p.ph > 0 || p.pw > 0;
-  rc = conv_bf16_launch<FMODE_WGRAD>(a, cplx, check, st);
+  if (p.sh == 1 && p.sw == 1 && !check && p.Wo >= 16) {
+    // contiguous-row formulation: K = number of (b, oh, 32-pixel chunk) tiles
+    a.K = (int64_t)p.B * p.Ho * ((p.Wo + FBK - 1) / FBK);
+    a.kchunk = (a.K + a.splits - 1) / a.splits;
+    rc = conv_bf16_launch<FMODE_WGRAD_ROWS>(a, cplx, false, st);
+  } else {
+    a.kchunk = ((a.K + a.splits - 1) / a.splits + FBK - 1) / FBK * FBK;
+    rc = conv_bf16_launch<FMODE_WGRAD>(a, cplx, check, st);
+  }
   if (rc) return rc;
   const int grid = stream_grid(wsz, 256);
   slab_sum2_kernel<<<grid, 256, 0, st>>>((const float*)a.yr, a.splits, wsz, emul, dwr);
