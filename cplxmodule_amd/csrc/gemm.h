@@ -12,6 +12,9 @@ struct GemmArgs {
   int M, N, K;
   int conj_b, accumulate;
   int order = 1, group_m = 4, setprio = 0;   // bf16 kernel tuning knobs (gemm_bf16.hip)
+  // split-K (bf16 kernel, fp32 output): block (split, tile) covers K range [split*kchunk, ...)
+  // and writes slab `split` of the workspace; a second kernel reduces the slabs.
+  int splits = 1; int kchunk = 0; void* ws = nullptr; int64_t ws_bytes = 0;
 };
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)
@@ -22,5 +25,8 @@ int launch_gemm_generic(const GemmArgs& g, int in_dtype, int out_dtype, hipStrea
 // qualify so that the caller can fall back to the generic kernel.
 template <bool CPLX>
 int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st);
+
+// workspace the bf16 path wants for split-K at this shape (0: no split-K)
+int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx);
 
 }  // namespace cplxamd

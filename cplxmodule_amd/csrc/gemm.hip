@@ -5,11 +5,17 @@ using namespace cplxamd;
 
 extern "C" {
 
+/* scratch the bf16 path wants for split-K at this shape (0 = none) */
+int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype) {
+  if (in_dtype != CPLXAMD_BF16 || out_dtype != CPLXAMD_F32) return 0;
+  return gemm_bf16_ws_bytes(M, N, K, cplx != 0);
+}
+
 int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
                   const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
                   const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
                   int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
-                  int algo, void* stream) {
+                  int algo, void* ws, int64_t ws_bytes, void* stream) {
   if (!a_r || !a_i || !b_r || !b_i || !c_r || !c_i) return CPLXAMD_EINVAL;
   if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
   if ((bias_r == nullptr) != (bias_i == nullptr)) return CPLXAMD_EINVAL;
@@ -17,6 +23,7 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
   if (algo != 0) return CPLXAMD_ESHAPE;  // 3M: not built yet
   GemmArgs g{a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, bias_r, bias_i, nullptr,
              c_r, c_i, ldc, M, N, K, conj_b ? 1 : 0, accumulate ? 1 : 0};
+  g.ws = ws; g.ws_bytes = ws_bytes;
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == CPLXAMD_BF16) {
     const int rc = launch_gemm_bf16<true>(g, out_dtype, st);
@@ -28,12 +35,13 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
 int cplxamd_rgemm(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
                   int64_t b_cs, const float* bias, const float* emul, void* c, int64_t ldc,
                   int M, int N, int K, int in_dtype, int out_dtype, int accumulate,
-                  void* stream) {
+                  void* ws, int64_t ws_bytes, void* stream) {
   if (!a || !b || !c) return CPLXAMD_EINVAL;
   if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
   if (accumulate && out_dtype != CPLXAMD_F32) return CPLXAMD_EINVAL;
   GemmArgs g{a, nullptr, a_rs, a_cs, b, nullptr, b_rs, b_cs, bias, nullptr, emul,
              c, nullptr, ldc, M, N, K, 0, accumulate ? 1 : 0};
+  g.ws = ws; g.ws_bytes = ws_bytes;
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == CPLXAMD_BF16) {
     const int rc = launch_gemm_bf16<false>(g, out_dtype, st);

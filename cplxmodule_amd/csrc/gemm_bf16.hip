@@ -95,7 +95,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   // ---- XCD-aware grouped tile order ------------------------------------------------------
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
-  int lin = blockIdx.x;
+  int lin = blockIdx.x, split = 0;
+  if (g.splits > 1) { split = lin / ntiles; lin -= split * ntiles; }
   int bm, bn;
   if (g.order == 0) {            // natural: consecutive blocks walk N
     bm = lin / tiles_n; bn = lin - bm * tiles_n;
@@ -129,7 +130,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
       acc_i[i][j] = f32x16{0};
     }
 
+  const int kbase = split * g.kchunk;
   auto stage = [&](int buf, int k0) {
+    k0 += kbase;
     char* s = smem + buf * C::STAGE_BYTES;
     stage_plane<BM, NT>(Ar, g.a_rs, m0, g.M, k0, s);
     stage_plane<BN, NT>(Br, g.b_rs, n0, g.N, k0, s + C::A_BYTES);
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     }
   };
 
-  const int nt = g.K / BK;
+  const int klen = g.splits > 1 ? ((g.K - kbase) < g.kchunk ? (g.K - kbase) : g.kchunk) : g.K;
+  const int nt = klen / BK;
   if (STAGES == 2) {
     stage(0, 0);
     __syncthreads();  // the workgroup barrier carries vmcnt(0) for the in-flight LDS-DMA
@@ -214,6 +218,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   // store per group instead of four scalar ones.
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
   TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
+  if (g.splits > 1) {  // fp32 partial slabs [split][plane][M][ldc]; bias / emul applied by the reducer
+    const int64_t slab = (int64_t)g.M * g.ldc;
+    cr = reinterpret_cast<TOUT*>(g.ws) + (int64_t)split * (CPLX ? 2 : 1) * slab;
+    ci = cr + slab;
+  }
   const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.c_r) & 15) == 0 &&
                       (!CPLX || (reinterpret_cast<uintptr_t>(g.c_i) & 15) == 0) &&
                       (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
@@ -306,7 +315,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES><<<dim3((unsigned)tiles), C::NT, C::SMEM, st>>>(g);
+  gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -337,6 +346,82 @@ static int launch_variant(const GemmArgs& g0, hipStream_t st) {
   }
 }
 
+// split-K plan for the default 256x128 tile: use it when the tile count leaves CUs idle
+static int plan_splits(int M, int N, int K) {
+  const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
+  if (tiles >= 192 || K < 64 * BK) return 1;
+  int s = (int)(256 / tiles);
+  const int maxs = K / (32 * BK);          // >= 32 K tiles per split
+  if (s > maxs) s = maxs;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : s;
+}
+
+int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx) {
+  const int s = plan_splits(M, N, K);
+  return s > 1 ? (int64_t)s * (cplx ? 2 : 1) * M * N * (int64_t)sizeof(float) : 0;
+}
+
+// out = sum_s slab[s] (+ bias[n]) (* emul) (+ out)   for one plane
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* slabs, int splits,
+                                                               int64_t slab_stride, int M, int N,
+                                                               int64_t ldc, const float* bias,
+                                                               const float* emul, int accumulate,
+                                                               float* out) {
+  const int64_t n4 = ((int64_t)M * ldc) >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f4 acc = ld4(slabs + 4 * i);
+    for (int s = 1; s < splits; ++s) {
+      const f4 v = ld4(slabs + (int64_t)s * slab_stride + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc.v[e] += v.v[e];
+    }
+    const int col = (int)((4 * i) % ldc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (bias && col + e < N) acc.v[e] += bias[col + e];
+    }
+    if (emul) {
+      const f4 m = ld4(emul + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc.v[e] *= m.v[e];
+    }
+    if (accumulate) {
+      const f4 o = ld4(out + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc.v[e] += o.v[e];
+    }
+    st4(out + 4 * i, acc);
+  }
+}
+
+template <bool CPLX>
+static int launch_gemm_bf16_splitk(const GemmArgs& g0, int splits, hipStream_t st) {
+  GemmArgs g = g0;
+  g.splits = splits;
+  g.kchunk = ((g.K / BK + splits - 1) / splits) * BK;
+  const bool conj = CPLX && g.conj_b;
+  // slabs use ldc = N (dense); the kernel writes float partials, no bias / emul / accumulate
+  GemmArgs k = g;
+  k.ldc = g.N; k.bias_r = k.bias_i = nullptr; k.emul = nullptr; k.accumulate = 0;
+  const int rc = conj ? launch_variant<float, CPLX, true>(k, st) : launch_variant<float, CPLX, false>(k, st);
+  if (rc) return rc;
+  const int64_t slab = (int64_t)g.M * g.N, stride = (CPLX ? 2 : 1) * slab;
+  const int grid = stream_grid(slab >> 2, 256);
+  if (g.ldc != g.N) return CPLXAMD_ESHAPE;
+  gemm_slab_reduce_kernel<<<grid, 256, 0, st>>>((const float*)g.ws, splits, stride, g.M, g.N, g.ldc,
+                                                g.bias_r, g.emul, g.accumulate, (float*)g.c_r);
+  CPLXAMD_CHECK_LAUNCH();
+  if (CPLX) {
+    gemm_slab_reduce_kernel<<<grid, 256, 0, st>>>((const float*)g.ws + slab, splits, stride, g.M, g.N,
+                                                  g.ldc, g.bias_i, nullptr, g.accumulate,
+                                                  (float*)g.c_i);
+    CPLXAMD_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 template <bool CPLX>
 int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   if (g.a_cs != 1 || g.b_cs != 1 || g.K < BK || (g.K % BK) != 0) return CPLXAMD_ESHAPE;
@@ -344,6 +429,11 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   if (!aligned16(g.a_r) || !aligned16(g.b_r)) return CPLXAMD_ESHAPE;
   if (CPLX && (!aligned16(g.a_i) || !aligned16(g.b_i))) return CPLXAMD_ESHAPE;
   if (g.M <= 0 || g.N <= 0) return 0;
+  if (out_dtype == CPLXAMD_F32 && g.ws && g.ldc == g.N && (g.N & 3) == 0 && gemm_variant() == 3) {
+    const int splits = plan_splits(g.M, g.N, g.K);
+    if (splits > 1 && g.ws_bytes >= gemm_bf16_ws_bytes(g.M, g.N, g.K, CPLX))
+      return launch_gemm_bf16_splitk<CPLX>(g, splits, st);
+  }
   const bool conj = CPLX && g.conj_b;
   if (out_dtype == CPLXAMD_BF16)
     return conj ? launch_variant<bf16_t, CPLX, true>(g, st) : launch_variant<bf16_t, CPLX, false>(g, st);

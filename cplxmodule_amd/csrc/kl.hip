@@ -27,9 +27,11 @@ constexpr float kK1 = 0.63576f, kK2 = 1.87320f, kK3 = 1.48695f;
 
 // |w| exactly as torch's CPU 2-norm kernel rounds it: sqrt(fma(wi, wi, rn(wr*wr)))
 // (bit-for-bit on 2^20 samples, DESIGN.md "mask exactness").
-template <bool CPLX>
+template <bool CPLX, bool EXACT = true>
 __device__ __forceinline__ float weight_abs(float wr, float wi) {
-  if (CPLX) return rn_sqrt(fmaf(wi, wi, wr * wr));
+  // EXACT (masks / log_alpha): correctly rounded sqrt.  KL values and slopes only need ~1e-6
+  // relative accuracy: the native v_sqrt_f32 (1 ulp) saves the Newton fix-up.
+  if (CPLX) return EXACT ? rn_sqrt(fmaf(wi, wi, wr * wr)) : __builtin_amdgcn_sqrtf(fmaf(wi, wi, wr * wr));
   return fabsf(wr);
 }
 
@@ -37,14 +39,21 @@ __device__ __forceinline__ float weight_abs(float wr, float wi) {
 // what the reference's libm delivers on > 99.99 % of inputs -> masks come out bit-identical.
 template <bool CPLX, bool EXACT>
 __device__ __forceinline__ float log_alpha_of(float ls2, float wr, float wi, float& theta) {
-  theta = weight_abs<CPLX>(wr, wi);
+  theta = weight_abs<CPLX, EXACT>(wr, wi);
   const float u = theta + 1e-12f;
   const float l = EXACT ? exact_logf(u) : logf(u);
   return ls2 - 2.0f * l;
 }
 
+// log1p(e) = log(u) * e / (u - 1), u = fl(1 + e): the rounding error of u cancels in the
+// ratio (Kahan / HP-15C trick), ~1 ulp, one log + one reciprocal instead of ocml's log1pf.
+__device__ __forceinline__ float log1p_pos(float e) {
+  const float u = 1.0f + e;
+  const float d = u - 1.0f;
+  return d == 0.0f ? e : logf(u) * e * __builtin_amdgcn_rcpf(d);
+}
 __device__ __forceinline__ float softplus_f(float t) {
-  return t > 20.0f ? t : log1pf(expf(t));
+  return t > 20.0f ? t : log1p_pos(expf(t));
 }
 __device__ __forceinline__ float sigmoid_f(float t) { return 1.0f / (1.0f + expf(-t)); }
 __device__ __forceinline__ float softplus_grad_f(float t) {
@@ -77,7 +86,7 @@ __device__ __forceinline__ float cplx_vd_value(float t) {
                                 8.6347608925f), x, 0.2677737343f);
     const float den = fmaf(fmaf(fmaf(fmaf(1.0f, x, 9.5733223454f), x, 25.6329561486f), x,
                                 21.0996530827f), x, 3.9584969228f);
-    e1 = expf(-x) / x * (num / den);
+    e1 = expf(-x) * num * __builtin_amdgcn_rcpf(x * den);   // one reciprocal (1 ulp) for both divisions
   }
   return kEulerGamma + t + e1;
 }

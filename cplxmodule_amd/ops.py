@@ -92,6 +92,23 @@ def exp(x, out_dtype=torch.float32):
     return out
 
 
+_gemm_ws_cache = {}
+
+
+def _gemm_ws(M, N, K, cplx, a, c):
+    """Split-K scratch (only asked for by few-tile / long-K bf16 -> fp32 GEMMs, e.g. wgrad)."""
+    if a.dtype != torch.bfloat16 or c.dtype != torch.float32:
+        return None
+    need = int(_lib.load().cplxamd_gemm_ws_bytes(M, N, K, int(cplx), 1, 0))
+    if need == 0:
+        return None
+    key = (a.device.type, a.device.index)
+    buf = _gemm_ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _gemm_ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=a.device)
+    return buf
+
+
 def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False,
           out_dtype=torch.float32, out=None, accumulate=False):
     """C[m,n] = sum_k A[m,k] op(B[n,k]) (+ bias[n]) on planar complex operands.
@@ -103,17 +120,21 @@ def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False
     else:
         cr, ci = out
     b_r, b_i = (None, None) if bias is None else bias
+    ws = _gemm_ws(M, N, K, True, ar, cr)
     call("cplxamd_cgemm", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
          b_strides[0], b_strides[1], ptr(b_r), ptr(b_i), ptr(cr), ptr(ci), N, M, N, K,
-         int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), 0, stream_ptr())
+         int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), 0, ptr(ws),
+         0 if ws is None else ws.numel(), stream_ptr())
     return cr, ci
 
 
 def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=torch.float32):
     require_device(a, b, bias, emul)
     c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    ws = _gemm_ws(M, N, K, False, a, c)
     call("cplxamd_rgemm", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
-         ptr(bias), ptr(emul), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c), 0, stream_ptr())
+         ptr(bias), ptr(emul), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c), 0, ptr(ws),
+         0 if ws is None else ws.numel(), stream_ptr())
     return c
 
 

@@ -136,12 +136,18 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
                   const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
                   const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
                   int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
-                  int algo, void* stream);
+                  int algo, void* ws, int64_t ws_bytes, void* stream);
+
+/* Optional scratch for split-K (bf16 inputs, float32 output, few output tiles, long K -- e.g. the
+ * weight gradient at batch 2^20): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be
+ * NULL (no split-K). */
+int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype);
 
 /* real GEMM; emul (nullable, float32 [M,N] with leading dimension ldc): C = (A B^T) * emul. */
 int cplxamd_rgemm(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
                   int64_t b_cs, const float* bias, const float* emul, void* c, int64_t ldc,
-                  int M, int N, int K, int in_dtype, int out_dtype, int accumulate, void* stream);
+                  int M, int N, int K, int in_dtype, int out_dtype, int accumulate, void* ws,
+                  int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * elementwise / layout helpers used by the layers (all HBM-bound streaming kernels)

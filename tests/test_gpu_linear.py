@@ -52,7 +52,8 @@ def test_matmul_golden(golden, pkg):
 
 
 @pytest.mark.parametrize("M,N_,K", [(128, 128, 32), (256, 384, 64), (200, 136, 96), (1, 5, 32),
-                                    (130, 130, 160), (64, 64, 40), (33, 17, 7)])
+                                    (130, 130, 160), (64, 64, 40), (33, 17, 7),
+                                    (128, 128, 4096), (260, 132, 2048)])  # last two: split-K
 @pytest.mark.parametrize("conj", (False, True))
 def test_cgemm_bf16_vs_oracle(pkg, M, N_, K, conj):
     """bf16 MFMA path (and its generic fallback for K % 32 != 0): inputs rounded to bf16, the
@@ -80,7 +81,7 @@ def test_cgemm_bf16_vs_oracle(pkg, M, N_, K, conj):
     np.testing.assert_allclose(N(ci16), ref2.imag, rtol=8e-3, atol=8e-3 * scale)
 
 
-@pytest.mark.parametrize("M,N_,K", [(128, 128, 64), (70, 190, 96), (64, 64, 24)])
+@pytest.mark.parametrize("M,N_,K", [(128, 128, 64), (70, 190, 96), (64, 64, 24), (128, 256, 4096)])
 def test_rgemm_bf16_and_f32(pkg, M, N_, K):
     from gpu_util import T, N, bf16_round
     from cplxmodule_amd import ops
