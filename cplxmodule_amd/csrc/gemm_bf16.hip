@@ -142,49 +142,53 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     }
   };
 
+  // fragments of BOTH K sub-steps are requested up front (16 ds_read_b128), so the second
+  // half's LDS latency hides behind the first half's 16 MFMAs
   auto compute = [&](int buf) {
     const char* sA = smem + buf * C::STAGE_BYTES;
     const char* sB = sA + C::A_BYTES;
     const char* sAi = sB + C::B_BYTES;
     const char* sBi = sAi + C::A_BYTES;
+    bf16x8 ar[2][2], br[2][2], ai[2][2], bi[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kc = ks * 2 + lk;
-      bf16x8 ar[2], br[2], ai[2], bi[2], nai[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ar[i] = lds_frag(sA, wm + i * 32 + l31, kc);
-        br[i] = lds_frag(sB, wn + i * 32 + l31, kc);
+        ar[ks][i] = lds_frag(sA, wm + i * 32 + l31, kc);
+        br[ks][i] = lds_frag(sB, wn + i * 32 + l31, kc);
         if (CPLX) {
-          ai[i] = lds_frag(sAi, wm + i * 32 + l31, kc);
-          bi[i] = lds_frag(sBi, wn + i * 32 + l31, kc);
+          ai[ks][i] = lds_frag(sAi, wm + i * 32 + l31, kc);
+          bi[ks][i] = lds_frag(sBi, wn + i * 32 + l31, kc);
         }
       }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 nai[2];
       if (CPLX) {
         // no conj: re -= Ai Bi, im += Ar Bi ; conj(B): re += Ai Bi, im -= Ar Bi
 #pragma unroll
-        for (int i = 0; i < 2; ++i) nai[i] = neg_frag(CONJ ? ar[i] : ai[i]);
+        for (int i = 0; i < 2; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
       }
-      if (g.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           // operands swapped (B fragment first): the accumulator holds the TRANSPOSED 32x32
           // tile, i.e. lane <-> output row, registers <-> 4-column groups -> 8/16-byte stores
-          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[j], ar[i], acc_r[i][j], 0, 0, 0);
+          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
           if (CPLX) {
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[j], ai[i], acc_i[i][j], 0, 0, 0);
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
             if (CONJ) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], ai[i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], nai[i], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
             } else {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], nai[i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[j], ar[i], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
             }
           }
         }
-      if (g.setprio) __builtin_amdgcn_s_setprio(0);
     }
   };
 
