@@ -72,6 +72,27 @@ class GradBucket:
         return work
 
 
+class OverlapHook:
+    """Installed as `ops.dp_hook` by DataParallel: averages a layer's data-term parameter
+    gradients across ranks asynchronously (RCCL stream) while the layer's backward continues
+    with the input-gradient GEMMs.  Parameters handled here are skipped by the bucket."""
+
+    def __init__(self):
+        self.done = set()
+
+    def reduce(self, flat, param_ptrs):
+        self.done.update(param_ptrs)
+        if dist.get_backend() == "nccl":
+            return (dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), None)
+        return (dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat)
+
+    def finish(self, handle):
+        work, flat = handle
+        work.wait()
+        if flat is not None:
+            flat.div_(dist.get_world_size())
+
+
 def all_reduce_scalar_mean(value):
     """Mean over ranks of a 0-d tensor (the KL term / the loss, for logging and for the sharded
     KL option); returns a new tensor, leaves autograd alone."""
@@ -88,21 +109,44 @@ class DataParallel(torch.nn.Module):
     function of the replicated weights only, so its gradient is identical on every rank and the
     mean leaves it unchanged."""
 
-    def __init__(self, module):
+    def __init__(self, module, overlap=True):
         super().__init__()
         self.module = module
         self.bucket = GradBucket(module)
+        self.hook = None
         if is_initialized() and dist.get_world_size() > 1:
             for p in module.parameters():              # replicate rank 0's parameters
                 dist.broadcast(p.data, src=0)
             for b in module.buffers():
                 dist.broadcast(b.data, src=0)
+            if overlap:
+                from . import ops
+                self.hook = ops.dp_hook = OverlapHook()
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
     def zero_grad(self, set_to_none=False):
+        if self.hook is not None:
+            self.hook.done.clear()
+            for p in self.bucket.params:               # gradients arrive already averaged (hook)
+                p.grad = None                          # or are averaged below
+            return
         self.bucket.adopt()
 
     def sync_gradients(self):
-        return self.bucket.all_reduce_mean()
+        """Average whatever the overlap hook did not already average.  (The KL term is a function
+        of the replicated weights: its gradient is identical on every rank and needs no exchange.)"""
+        if self.hook is None:
+            return self.bucket.all_reduce_mean()
+        rest = [p for p in self.bucket.params if p.grad is not None and p.data_ptr() not in self.hook.done]
+        if rest:
+            flat = torch.cat([p.grad.reshape(-1) for p in rest])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(dist.get_world_size())
+            off = 0
+            for p in rest:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+        return None

@@ -128,9 +128,10 @@ def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False
     return cr, ci
 
 
-def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=torch.float32):
+def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=torch.float32,
+          out=None):
     require_device(a, b, bias, emul)
-    c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    c = torch.empty(M, N, dtype=out_dtype, device=a.device) if out is None else out
     ws = _gemm_ws(M, N, K, False, a, c)
     call("cplxamd_rgemm", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
          ptr(bias), ptr(emul), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c), 0, ptr(ws),
@@ -261,15 +262,15 @@ def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype):
     return cgemm(g2r, g2i, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=out_dtype)
 
 
-def _cplx_linear_dw(g2r, g2i, x2r, x2i):
+def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None):
     """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]."""
     B, O = g2r.shape
     I = x2r.shape[1]
     if _is_bf16(g2r) and B % 32 == 0 and B >= 32:
         gtr, gti = transpose2d(g2r), transpose2d(g2i)
         xtr, xti = transpose2d(x2r), transpose2d(x2i)
-        return cgemm(gtr, gti, (B, 1), xtr, xti, (B, 1), O, I, B, conj_b=True)
-    return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True)
+        return cgemm(gtr, gti, (B, 1), xtr, xti, (B, 1), O, I, B, conj_b=True, out=out)
+    return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True, out=out)
 
 
 def _real_linear_dx(g2, w, out_dtype):
@@ -281,14 +282,21 @@ def _real_linear_dx(g2, w, out_dtype):
     return rgemm(g2, (O, 1), w, (1, I), B, I, O, out_dtype=out_dtype)
 
 
-def _real_linear_dw(g2, x2, emul=None):
+def _real_linear_dw(g2, x2, emul=None, out=None):
     B, O = g2.shape
     I = x2.shape[1]
     if _is_bf16(g2) and _is_bf16(x2) and B % 32 == 0 and B >= 32:
-        return rgemm(transpose2d(g2), (B, 1), transpose2d(x2), (B, 1), O, I, B, emul=emul)
+        return rgemm(transpose2d(g2), (B, 1), transpose2d(x2), (B, 1), O, I, B, emul=emul, out=out)
     if g2.dtype != x2.dtype:
         g2, x2 = cast(g2, torch.float32), cast(x2, torch.float32)
-    return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul)
+    return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul, out=out)
+
+
+# Data-parallel hook (cplxmodule_amd.dp): when set, the linear layers' backward hands the
+# parameter gradients of the DATA term to `reduce(flat)` as soon as they exist -- one flat
+# float32 buffer [dls2 | dwr | dwi | dbr | dbi] -- so the RCCL all-reduce overlaps the dX GEMMs
+# that follow; `finish(handle)` is called right before the gradients are returned to autograd.
+dp_hook = None
 
 
 class CplxLinearFn(torch.autograd.Function):
@@ -343,6 +351,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
             eps = (eps_r.reshape(B, O), eps_i.reshape(B, O))
         yr, yi = reparam_fwd(mur, mui, s2, eps, seed, offset, inplace=True)
         ctx.save_for_backward(x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i)
+        ctx.bias_ptrs = () if br is None else (br.data_ptr(), bi.data_ptr())
         ctx.has_bias = br is not None
         ctx.lead, ctx.seed, ctx.offset = xr.shape[:-1], seed, offset
         return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O)
@@ -358,18 +367,35 @@ class CplxLinearLRTFn(torch.autograd.Function):
         dt = x2r.dtype
         gs2 = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt)
         dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
+        # parameter gradients first: with a data-parallel hook their all-reduce overlaps dX
+        handle = None
+        want_w, want_b = need[2] or need[3], ctx.has_bias and (need[4] or need[5])
+        if dp_hook is not None and want_w and need[6]:
+            n_w = O * I
+            flat = torch.empty(3 * n_w + (2 * O if want_b else 0), dtype=torch.float32, device=x2r.device)
+            dls2, dwr, dwi = (flat[k * n_w:(k + 1) * n_w].view(O, I) for k in range(3))
+            _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi))
+            _real_linear_dw(gs2, a, emul=exp(_c(ls2)), out=dls2)
+            if want_b:
+                dbr, dbi = flat[3 * n_w:3 * n_w + O], flat[3 * n_w + O:]
+                dbr.copy_(colsum(g2r)); dbi.copy_(colsum(g2i))
+            handle = dp_hook.reduce(flat, (wr.data_ptr(), wi.data_ptr(), ls2.data_ptr()) +
+                                    (ctx.bias_ptrs if want_b else ()))
+        else:
+            if want_w:
+                dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
+            if want_b:
+                dbr, dbi = colsum(g2r), colsum(g2i)
+            if need[6]:
+                dls2 = _real_linear_dw(gs2, a, emul=exp(_c(ls2)))  # (gs2^T a) * exp(ls2)
         if need[0] or need[1]:
             dxr, dxi = _cplx_linear_dx(g2r, g2i, _c(wr), _c(wi), dt)
             S = exp(_c(ls2), out_dtype=dt)
             ga = _real_linear_dx(gs2, S, dt)                 # gs2 . S -> [B,I]
             lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
-        if need[2] or need[3]:
-            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
-        if ctx.has_bias and (need[4] or need[5]):
-            dbr, dbi = colsum(g2r), colsum(g2i)
-        if need[6]:
-            dls2 = _real_linear_dw(gs2, a, emul=exp(_c(ls2)))  # (gs2^T a) * exp(ls2)
+        if handle is not None:
+            dp_hook.finish(handle)
         return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None
 
 

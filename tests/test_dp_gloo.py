@@ -23,7 +23,7 @@ def _worker(rank, world, port, out):
     from cplxmodule_amd.nn import relevance as rel
     torch.manual_seed(100 + rank)              # different init per rank: broadcast must fix it
     model = torch.nn.Sequential(rel.CplxLinearVD(6, 5), rel.LinearARD(5, 3))
-    wrapped = dp.DataParallel(model)
+    wrapped = dp.DataParallel(model, overlap=False)
     names = wrapped.bucket.names
     first = model[0].weight.real.detach().clone()
     wrapped.zero_grad()
@@ -34,9 +34,26 @@ def _worker(rank, world, port, out):
     grads = [float(p.grad.mean()) for p in model.parameters()]
     lo, hi = dp.shard_rows(11)
     kl = dp.all_reduce_scalar_mean(torch.tensor(float(rank)))
+    alias = (model[0].weight.real.grad.data_ptr() ==
+             wrapped.bucket.views[names.index("0.weight.real")].data_ptr())
+    # overlap path: the hook averages a layer's flat gradient buffer asynchronously, the wrapper
+    # then averages only what the hook has not handled
+    over = dp.DataParallel(model, overlap=True)
+    over.zero_grad()
+    assert all(p.grad is None for p in model.parameters())
+    flat = torch.full((7,), float(rank + 1))
+    h = over.hook.reduce(flat, (model[0].log_sigma2.data_ptr(),))
+    over.hook.finish(h)
+    assert torch.allclose(flat, torch.full((7,), 1.5))
+    model[0].log_sigma2.grad = torch.full_like(model[0].log_sigma2, 9.0 + rank)   # "already averaged"
+    model[1].weight.grad = torch.full_like(model[1].weight, float(rank))          # left to the wrapper
+    over.sync_gradients()
+    assert float(model[0].log_sigma2.grad.mean()) == 9.0 + rank                    # untouched
+    assert abs(float(model[1].weight.grad.mean()) - 0.5) < 1e-6                    # averaged
+    from cplxmodule_amd import ops
+    ops.dp_hook = None
     out.put((rank, names, grads, first.numpy(), (lo, hi), float(kl),
-             wrapped.bucket.flat.numel(), model[0].weight.real.grad.data_ptr() ==
-             wrapped.bucket.views[names.index("0.weight.real")].data_ptr()))
+             wrapped.bucket.flat.numel(), alias))
     dist.destroy_process_group()
 
 
