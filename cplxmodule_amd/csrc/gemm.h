@@ -15,6 +15,7 @@ struct GemmArgs {
   // split-K (bf16 kernel, fp32 output): block (split, tile) covers K range [split*kchunk, ...)
   // and writes slab `split` of the workspace; a second kernel reduces the slabs.
   int splits = 1; int kchunk = 0; void* ws = nullptr; int64_t ws_bytes = 0;
+  int dbg = 0;   // ablation bits (CPLXAMD_GEMM_DBG): 1 no LDS-DMA after the prologue, 2 no MFMA
 };
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)

@@ -61,6 +61,21 @@ __device__ __forceinline__ void stage_plane(const bf16_t* base, int64_t ld, int 
   }
 }
 
+// One LDS-DMA instruction (piece j of a plane tile), so that the K loop can spread the pieces of
+// tile t+2 between the MFMAs of tile t instead of issuing them in one burst.
+template <int NT>
+__device__ __forceinline__ void stage_piece(const bf16_t* base, int64_t ld, int row0, int rows,
+                                            int k0, char* lds_plane, int j) {
+  const int tid = threadIdx.x;
+  const int wave_chunk = (tid >> 6) * 64;
+  const int p = j * NT + tid;
+  const int row = p >> 2;
+  const int kc = (p & 3) ^ ((row >> 2) & 3);
+  int grow = row0 + row;
+  grow = grow < rows ? grow : rows - 1;
+  glds16(base + (int64_t)grow * ld + k0 + kc * 8, lds_plane + (j * NT + wave_chunk) * 16);
+}
+
 __device__ __forceinline__ bf16x8 lds_frag(const char* lds_plane, int row, int kc) {
   const int off = row * 64 + ((kc ^ ((row >> 2) & 3)) << 4);
   return *reinterpret_cast<const bf16x8*>(lds_plane + off);
@@ -86,7 +101,7 @@ struct Cfg {
   static constexpr int LOADS = (CPLX ? 2 : 1) * (BM * 4 / NT + BN * 4 / NT);
 };
 
-template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES>
+template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES, int SCHED = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<CPLX, WM, WN, STAGES>;
@@ -192,6 +207,71 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     }
   };
 
+  // piece q (0 .. LOADS-1) of the tile at k0 into ring slot buf
+  auto stage_q = [&](int buf, int k0, int q) {
+    k0 += kbase;
+    char* s = smem + buf * C::STAGE_BYTES;
+    constexpr int PA = BM * 4 / NT, PB = BN * 4 / NT;      // pieces per A / B plane
+    if (q < PA) stage_piece<NT>(Ar, g.a_rs, m0, g.M, k0, s, q);
+    else if (q < PA + PB) stage_piece<NT>(Br, g.b_rs, n0, g.N, k0, s + C::A_BYTES, q - PA);
+    else if (q < 2 * PA + PB) stage_piece<NT>(Ai, g.a_rs, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES, q - PA - PB);
+    else stage_piece<NT>(Bi, g.b_rs, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES, q - 2 * PA - PB);
+  };
+
+  // compute(cur) with the LDS-DMA pieces of the tile at knext spread between the MFMAs
+  auto compute_interleaved = [&](int buf, int nbuf, int knext, bool do_stage) {
+    const char* sA = smem + buf * C::STAGE_BYTES;
+    const char* sB = sA + C::A_BYTES;
+    const char* sAi = sB + C::B_BYTES;
+    const char* sBi = sAi + C::A_BYTES;
+    bf16x8 ar[2][2], br[2][2], ai[2][2], bi[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 2 + lk;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ar[ks][i] = lds_frag(sA, wm + i * 32 + l31, kc);
+        br[ks][i] = lds_frag(sB, wn + i * 32 + l31, kc);
+        if (CPLX) {
+          ai[ks][i] = lds_frag(sAi, wm + i * 32 + l31, kc);
+          bi[ks][i] = lds_frag(sBi, wn + i * 32 + l31, kc);
+        }
+      }
+    }
+    int q = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 nai[2];
+      if (CPLX) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+          if (CPLX) {
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+            if (CONJ) {
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+            } else {
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+            }
+          }
+          // one LDS-DMA piece after each (i, j) group of MFMAs until the tile is fully requested
+          if (q < C::LOADS) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_stage) stage_q(nbuf, knext, q);
+            __builtin_amdgcn_sched_barrier(0);
+            ++q;
+          }
+        }
+    }
+  };
+
   const int klen = g.splits > 1 ? ((g.K - kbase) < g.kchunk ? (g.K - kbase) : g.kchunk) : g.K;
   const int nt = klen / BK;
   if (STAGES == 2) {
@@ -208,11 +288,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     if (nt > 1) stage(1, BK);
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
+      if (g.dbg & 1) wait_vmcnt<0>(); else if (t + 1 < nt) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();           // tile t landed for every wave; buffer (t-1)%3 free
       int nxt = cur + 2; nxt = nxt >= 3 ? nxt - 3 : nxt;
-      if (t + 2 < nt) stage(nxt, (t + 2) * BK);
-      compute(cur);
+      if (SCHED == 0) {            // burst issue of the next tile's LDS-DMA, then compute
+        if (t + 2 < nt && !(g.dbg & 1)) stage(nxt, (t + 2) * BK);
+        if (!(g.dbg & 2)) compute(cur);
+      } else {                     // LDS-DMA pieces spread between the MFMA groups
+        compute_interleaved(cur, nxt, (t + 2) * BK, t + 2 < nt && !(g.dbg & 1));
+      }
       cur = cur + 1 == 3 ? 0 : cur + 1;
     }
   }
@@ -302,24 +386,24 @@ static int gemm_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CPLXAMD_GEMM_VARIANT");
-    v = e ? atoi(e) : 3;
+    v = e ? atoi(e) : 7;
   }
   return v;
 }
 
-template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES>
+template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES, int SCHED = 0>
 static int launch_cfg(const GemmArgs& g, hipStream_t st) {
   using C = Cfg<CPLX, WM, WN, STAGES>;
   const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   if (tiles > 0x7fffffff) return CPLXAMD_ESHAPE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES, SCHED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
+  gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES, SCHED><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -335,6 +419,8 @@ static int launch_variant(const GemmArgs& g0, hipStream_t st) {
                    sp = env_int("CPLXAMD_GEMM_SETPRIO", 0);
   GemmArgs g = g0;
   g.order = order; g.group_m = gm > 0 ? gm : 1; g.setprio = sp;
+  static const int dbg = env_int("CPLXAMD_GEMM_DBG", 0);
+  g.dbg = dbg;
   if (!CPLX) {
     static const int rv = env_int("CPLXAMD_RGEMM_VARIANT", 0);
     if (rv == 1) return launch_cfg<TOUT, CPLX, CONJ, 4, 4, 3>(g, st);   // real: 256x256, 16 waves
@@ -345,8 +431,9 @@ static int launch_variant(const GemmArgs& g0, hipStream_t st) {
     case 2: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 2>(g, st);   // 256x128, 2-stage
     case 3: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3>(g, st);   // 256x128, 3-stage
     case 4: return launch_cfg<TOUT, CPLX, CONJ, 2, 4, 3>(g, st);   // 128x256, 3-stage
+    case 7: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3, 1>(g, st);   // 256x128, 3-stage, interleaved LDS-DMA
     case 0: return launch_cfg<TOUT, CPLX, CONJ, 2, 2, 2>(g, st);   // 128x128, 2-stage
-    default: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3>(g, st);  // 256x128, 3-stage (default)
+    default: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3, 1>(g, st);  // = 7 (default)
   }
 }
 
@@ -433,7 +520,7 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   if (!aligned16(g.a_r) || !aligned16(g.b_r)) return CPLXAMD_ESHAPE;
   if (CPLX && (!aligned16(g.a_i) || !aligned16(g.b_i))) return CPLXAMD_ESHAPE;
   if (g.M <= 0 || g.N <= 0) return 0;
-  if (out_dtype == CPLXAMD_F32 && g.ws && g.ldc == g.N && (g.N & 3) == 0 && gemm_variant() == 3) {
+  if (out_dtype == CPLXAMD_F32 && g.ws && g.ldc == g.N && (g.N & 3) == 0 && (gemm_variant() == 3 || gemm_variant() == 7)) {
     const int splits = plan_splits(g.M, g.N, g.K);
     if (splits > 1 && g.ws_bytes >= gemm_bf16_ws_bytes(g.M, g.N, g.K, CPLX))
       return launch_gemm_bf16_splitk<CPLX>(g, splits, st);
