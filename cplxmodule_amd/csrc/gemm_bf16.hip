@@ -1,6 +1,8 @@
-// bf16 complex / real GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16), "NT" form:
-//   C[m,n] = sum_k A[m,k] * op(B[n,k]) (+ bias[n]),  A and B K-contiguous (planar re / im),
-//   fp32 accumulation, bf16 or fp32 output.
+// bf16 complex / real GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16):
+//   C[m,n] = sum_k A[m,k] * op(B[n,k]) (+ bias[n]),  planar re / im, fp32 accumulation,
+//   bf16 or fp32 output.  Each operand may be stored K-contiguous ([rows][K], "N") or
+//   K-major ([K][rows], "T"): forward = (N,N), dgrad = (N,T) with the weight as stored,
+//   wgrad = (T,T) with the activations / gradients as stored -- no transposed copies.
 //
 // Complex 4M in ONE K-loop: each staged (Ar, Ai, Br, Bi) tile set feeds four MFMA chains
 //   Cr += Ar Br ; Cr += (-Ai) Bi ; Ci += Ar Bi ; Ci += Ai Br
@@ -8,20 +10,25 @@
 // issues 4 separate GEMMs + 2 elementwise passes, cplx.py:641-646).  The sign flip for the
 // Ai Bi product (and for conj(B), used by dgrad / wgrad) is an XOR on the packed bf16 fragment.
 //
-// Structure: (64*WM) x (64*WN) output tile per workgroup of WM*WN waves, each wave owning a 64x64
-// sub-tile = 2x2 MFMA tiles x {re, im} (128 accumulator registers); BK = 32.  Operand tiles go
-// global -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip) into a ring of
-// STAGES buffers:
-//   STAGES = 2: issue tile t+1, compute tile t, __syncthreads (carries vmcnt(0))      ["2-phase"]
-//   STAGES = 3: tiles t+1 and t+2 stay in flight across the (raw) barrier; the wait for tile t
-//               is a COUNTED s_waitcnt vmcnt(loads per tile) (cdna_hip_programming.md T3/T4).
-// LDS image of a [rows][32 k] bf16 plane: 64-B rows, the four 16-B chunks of a row XOR-swizzled
-// with (row >> 2) & 3 so that each ds_read_b128 lane group touches 16 distinct 16-B bank slots;
-// the LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane global SOURCE
-// address and again on the read (rule 21 of the guide).
-// Tile order: XCD-aware (block b runs on XCD b % 8 -> each XCD gets a contiguous range of the
-// grouped tile order, GROUP_M row-panels x all column-panels per group) so that the 32-64 tiles
-// resident on one XCD share A / B panels in that XCD's private L2.
+// Structure (profiles/r01_gemm_variants.md has the variant study):
+//  * 256 x 128 output tile, 8 waves, each wave a 64 x 64 sub-tile = 2x2 MFMA tiles x {re, im}
+//    = 128 accumulator registers; BK = 32.
+//  * operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into a ring
+//    of 3 stages (144 KiB); tiles t+1, t+2 stay in flight across the raw s_barrier, the wait for
+//    tile t is a COUNTED s_waitcnt vmcnt (cdna_hip_programming.md T3/T4); the 6 LDS-DMA pieces of
+//    tile t+2 are spread between the MFMA groups of tile t instead of issued as one burst.
+//  * LDS images (the LDS-DMA writes lane-linearly, so every swizzle is applied to the per-lane
+//    global SOURCE address and again on the read -- rule 21 of the guide):
+//      "N" operand: [rows][32 k], 64-B rows, 16-B chunk index XOR (row >> 2) & 3; fragments by
+//                   ds_read_b128 (16 distinct bank slots per lane group);
+//      "T" operand: [32 k][rows], 64-B segment index XOR (k & 3); fragments by two
+//                   ds_read_b64_tr_b16 (hardware 4 x 16 transpose: lane m of a 16-lane group
+//                   addresses T[kb + (m >> 2)][rb + 4 (m & 3)] and receives T[kb..kb+3][rb + m]).
+//  * tile order: XCD-contiguous ranges of a grouped order (GROUP_M row panels x all column
+//    panels) so the tiles resident on one XCD share A / B panels in that XCD's private L2.
+//  * accumulator tiles are kept transposed (B fragment as the first MFMA operand) so each lane
+//    owns 4 consecutive output columns: 8-byte (bf16) / 16-byte (fp32) stores.
+//  * few output tiles + long K (wgrad at batch 2^20): split-K into fp32 slabs + a reduce kernel.
 #include <stdlib.h>
 
 #include "gemm.h"
@@ -29,10 +36,20 @@
 namespace cplxamd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int GROUP_M = 4;
+constexpr int BK = 32, WM = 4, WN = 2, BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN, STAGES = 3;
+
+template <bool CPLX>
+struct Cfg {
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
+  static constexpr int SMEM = STAGES * STAGE_BYTES;
+  static constexpr int PA = BM * 4 / NT, PB = BN * 4 / NT;     // LDS-DMA pieces per plane
+  static constexpr int LOADS = (CPLX ? 2 : 1) * (PA + PB);      // ... per thread per K tile
+};
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -40,45 +57,54 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Stage one [ROWS x 32] bf16 plane tile: ROWS*4 16-B chunks spread over NT threads.
-// LDS chunk p holds global chunk (row = p >> 2, kc = (p & 3) ^ ((row >> 2) & 3)).
-template <int ROWS, int NT>
-__device__ __forceinline__ void stage_plane(const bf16_t* base, int64_t ld, int row0, int rows,
-                                            int k0, char* lds_plane) {
-  const int tid = threadIdx.x;
-  const int wave_chunk = (tid >> 6) * 64;
-  constexpr int PER = ROWS * 4 / NT;
-  static_assert(PER >= 1 && ROWS * 4 % NT == 0, "tile / thread-count mismatch");
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int p = j * NT + tid;
-    const int row = p >> 2;
-    const int kc = (p & 3) ^ ((row >> 2) & 3);
-    int grow = row0 + row;
-    grow = grow < rows ? grow : rows - 1;  // clamp: out-of-range rows are never stored
-    const bf16_t* src = base + (int64_t)grow * ld + k0 + kc * 8;
-    glds16(src, lds_plane + (j * NT + wave_chunk) * 16);
-  }
-}
-
-// One LDS-DMA instruction (piece j of a plane tile), so that the K loop can spread the pieces of
-// tile t+2 between the MFMAs of tile t instead of issuing them in one burst.
-template <int NT>
+// One LDS-DMA instruction: piece j (of ROWS*4/NT) of a plane tile.
+//  !T: chunk p = j*NT + tid holds (row = p >> 2, kc = (p & 3) ^ ((row >> 2) & 3)) of [rows][K]
+//   T: chunk p holds (k = p / (ROWS/8), c = (p % (ROWS/8)) ^ ((k & 3) << 2)) of [K][rows]
+template <int ROWS, bool T>
 __device__ __forceinline__ void stage_piece(const bf16_t* base, int64_t ld, int row0, int rows,
                                             int k0, char* lds_plane, int j) {
   const int tid = threadIdx.x;
   const int wave_chunk = (tid >> 6) * 64;
   const int p = j * NT + tid;
-  const int row = p >> 2;
-  const int kc = (p & 3) ^ ((row >> 2) & 3);
-  int grow = row0 + row;
-  grow = grow < rows ? grow : rows - 1;
-  glds16(base + (int64_t)grow * ld + k0 + kc * 8, lds_plane + (j * NT + wave_chunk) * 16);
+  const bf16_t* src;
+  if (!T) {
+    const int row = p >> 2;
+    const int kc = (p & 3) ^ ((row >> 2) & 3);
+    int grow = row0 + row;
+    grow = grow < rows ? grow : rows - 1;      // clamp: out-of-range rows are never stored
+    src = base + (int64_t)grow * ld + k0 + kc * 8;
+  } else {
+    constexpr int CPR = ROWS / 8;              // 16-B chunks per k row
+    const int k = p / CPR;
+    const int c = (p % CPR) ^ ((k & 3) << 2);
+    int col = row0 + c * 8;
+    col = col + 8 <= rows ? col : rows - 8;    // clamp (rows % 8 == 0 is required)
+    src = base + (int64_t)(k0 + k) * ld + col;
+  }
+  glds16(src, lds_plane + (j * NT + wave_chunk) * 16);
 }
 
-__device__ __forceinline__ bf16x8 lds_frag(const char* lds_plane, int row, int kc) {
+// 8 consecutive k of matrix row `row` (k chunk kc of 4) from an "N" image
+__device__ __forceinline__ bf16x8 frag_n(const char* lds_plane, int row, int kc) {
   const int off = row * 64 + ((kc ^ ((row >> 2) & 3)) << 4);
   return *reinterpret_cast<const bf16x8*>(lds_plane + off);
+}
+
+// same fragment from a "T" image [32 k][ROWS]: two hardware-transposed 4 x 16 reads.
+// rb: first row of this lane's 16-row block, kb: first k of the 8, m = lane & 15.
+template <int ROWS>
+__device__ __forceinline__ bf16x8 frag_t(const char* lds_plane, int rb, int kb, int m) {
+  const int r = rb + 4 * (m & 3);
+  s16x4 v[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = kb + 4 * h + (m >> 2);
+    const int off = k * (ROWS * 2) + (((r >> 3) ^ ((k & 3) << 2)) << 4) + (r & 7) * 2;
+    v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(lds_plane + off));
+  }
+  const s16x8 both = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, both);
 }
 
 __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
@@ -91,23 +117,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool CPLX, int WM, int WN, int STAGES>
-struct Cfg {
-  static constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
-  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-  static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
-  static constexpr int SMEM = STAGES * STAGE_BYTES;
-  // LDS-DMA instructions each thread issues per K tile
-  static constexpr int LOADS = (CPLX ? 2 : 1) * (BM * 4 / NT + BN * 4 / NT);
-};
-
-template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES, int SCHED = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using C = Cfg<CPLX, WM, WN, STAGES>;
-  constexpr int BM = C::BM, BN = C::BN, NT = C::NT;
+  using C = Cfg<CPLX>;
 
-  // ---- XCD-aware grouped tile order ------------------------------------------------------
+  // ---- tile coordinates: split-K slice, XCD-contiguous grouped order ------------------------
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   int lin = blockIdx.x, split = 0;
@@ -116,10 +131,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   if (g.order == 0) {            // natural: consecutive blocks walk N
     bm = lin / tiles_n; bn = lin - bm * tiles_n;
   } else {
-    if (g.order == 1) {          // each XCD gets a contiguous range of the grouped order
-      const int q = ntiles >> 3, r = ntiles & 7, xcd = lin & 7, idx = lin >> 3;
-      lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective
-    }
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = lin & 7, idx = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective
     const int GM = g.group_m;
     const int per_group = GM * tiles_n;
     const int grp = lin / per_group, in_grp = lin - grp * per_group;
@@ -132,9 +145,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = (wid / WN) * 64, wn = (wid % WN) * 64;
   const int l31 = lane & 31, lk = lane >> 5;
+  const int l15 = lane & 15, lg = (lane >> 4) & 1;   // "T" reads: 16-lane group geometry
 
   const bf16_t* Ar = (const bf16_t*)g.a_r; const bf16_t* Ai = (const bf16_t*)g.a_i;
   const bf16_t* Br = (const bf16_t*)g.b_r; const bf16_t* Bi = (const bf16_t*)g.b_i;
+  const int64_t lda = TA ? g.a_cs : g.a_rs, ldb = TB ? g.b_cs : g.b_rs;
 
   f32x16 acc_r[2][2], acc_i[2][2];
 #pragma unroll
@@ -146,38 +161,51 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     }
 
   const int kbase = split * g.kchunk;
-  auto stage = [&](int buf, int k0) {
+  // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
+  auto stage_q = [&](int buf, int k0, int q) {
     k0 += kbase;
     char* s = smem + buf * C::STAGE_BYTES;
-    stage_plane<BM, NT>(Ar, g.a_rs, m0, g.M, k0, s);
-    stage_plane<BN, NT>(Br, g.b_rs, n0, g.N, k0, s + C::A_BYTES);
-    if (CPLX) {
-      stage_plane<BM, NT>(Ai, g.a_rs, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES);
-      stage_plane<BN, NT>(Bi, g.b_rs, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES);
-    }
+    if (q < C::PA) stage_piece<BM, TA>(Ar, lda, m0, g.M, k0, s, q);
+    else if (q < C::PA + C::PB) stage_piece<BN, TB>(Br, ldb, n0, g.N, k0, s + C::A_BYTES, q - C::PA);
+    else if (q < 2 * C::PA + C::PB)
+      stage_piece<BM, TA>(Ai, lda, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES, q - C::PA - C::PB);
+    else
+      stage_piece<BN, TB>(Bi, ldb, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES, q - 2 * C::PA - C::PB);
+  };
+  auto stage_all = [&](int buf, int k0) {
+#pragma unroll
+    for (int q = 0; q < C::LOADS; ++q) stage_q(buf, k0, q);
   };
 
-  // fragments of BOTH K sub-steps are requested up front (16 ds_read_b128), so the second
-  // half's LDS latency hides behind the first half's 16 MFMAs
-  auto compute = [&](int buf) {
+  auto a_frag = [&](const char* plane, int i, int ks) -> bf16x8 {
+    if (TA) return frag_t<BM>(plane, wm + i * 32 + 16 * lg, ks * 16 + 8 * lk, l15);
+    return frag_n(plane, wm + i * 32 + l31, ks * 2 + lk);
+  };
+  auto b_frag = [&](const char* plane, int j, int ks) -> bf16x8 {
+    if (TB) return frag_t<BN>(plane, wn + j * 32 + 16 * lg, ks * 16 + 8 * lk, l15);
+    return frag_n(plane, wn + j * 32 + l31, ks * 2 + lk);
+  };
+
+  // tile in ring slot `buf`: all fragments of both K sub-steps are requested up front, then
+  // 32 MFMAs; one LDS-DMA piece of the tile at knext after each (i, j) MFMA group
+  auto compute = [&](int buf, int nbuf, int knext, bool do_stage, bool do_mfma) {
     const char* sA = smem + buf * C::STAGE_BYTES;
     const char* sB = sA + C::A_BYTES;
     const char* sAi = sB + C::B_BYTES;
     const char* sBi = sAi + C::A_BYTES;
     bf16x8 ar[2][2], br[2][2], ai[2][2], bi[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kc = ks * 2 + lk;
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ar[ks][i] = lds_frag(sA, wm + i * 32 + l31, kc);
-        br[ks][i] = lds_frag(sB, wn + i * 32 + l31, kc);
+        ar[ks][i] = a_frag(sA, i, ks);
+        br[ks][i] = b_frag(sB, i, ks);
         if (CPLX) {
-          ai[ks][i] = lds_frag(sAi, wm + i * 32 + l31, kc);
-          bi[ks][i] = lds_frag(sBi, wn + i * 32 + l31, kc);
+          ai[ks][i] = a_frag(sAi, i, ks);
+          bi[ks][i] = b_frag(sBi, i, ks);
         }
       }
-    }
+    int q = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 nai[2];
@@ -190,78 +218,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          // operands swapped (B fragment first): the accumulator holds the TRANSPOSED 32x32
-          // tile, i.e. lane <-> output row, registers <-> 4-column groups -> 8/16-byte stores
-          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
-          if (CPLX) {
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
-            if (CONJ) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
-            } else {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+          if (do_mfma) {
+            // B fragment first: the accumulator holds the TRANSPOSED 32x32 tile
+            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+            if (CPLX) {
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+              if (CONJ) {
+                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+              } else {
+                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+              }
             }
           }
-        }
-    }
-  };
-
-  // piece q (0 .. LOADS-1) of the tile at k0 into ring slot buf
-  auto stage_q = [&](int buf, int k0, int q) {
-    k0 += kbase;
-    char* s = smem + buf * C::STAGE_BYTES;
-    constexpr int PA = BM * 4 / NT, PB = BN * 4 / NT;      // pieces per A / B plane
-    if (q < PA) stage_piece<NT>(Ar, g.a_rs, m0, g.M, k0, s, q);
-    else if (q < PA + PB) stage_piece<NT>(Br, g.b_rs, n0, g.N, k0, s + C::A_BYTES, q - PA);
-    else if (q < 2 * PA + PB) stage_piece<NT>(Ai, g.a_rs, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES, q - PA - PB);
-    else stage_piece<NT>(Bi, g.b_rs, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES, q - 2 * PA - PB);
-  };
-
-  // compute(cur) with the LDS-DMA pieces of the tile at knext spread between the MFMAs
-  auto compute_interleaved = [&](int buf, int nbuf, int knext, bool do_stage) {
-    const char* sA = smem + buf * C::STAGE_BYTES;
-    const char* sB = sA + C::A_BYTES;
-    const char* sAi = sB + C::B_BYTES;
-    const char* sBi = sAi + C::A_BYTES;
-    bf16x8 ar[2][2], br[2][2], ai[2][2], bi[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kc = ks * 2 + lk;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ar[ks][i] = lds_frag(sA, wm + i * 32 + l31, kc);
-        br[ks][i] = lds_frag(sB, wn + i * 32 + l31, kc);
-        if (CPLX) {
-          ai[ks][i] = lds_frag(sAi, wm + i * 32 + l31, kc);
-          bi[ks][i] = lds_frag(sBi, wn + i * 32 + l31, kc);
-        }
-      }
-    }
-    int q = 0;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 nai[2];
-      if (CPLX) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
-          if (CPLX) {
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
-            if (CONJ) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
-            } else {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
-            }
-          }
-          // one LDS-DMA piece after each (i, j) group of MFMAs until the tile is fully requested
           if (q < C::LOADS) {
             __builtin_amdgcn_sched_barrier(0);
             if (do_stage) stage_q(nbuf, knext, q);
@@ -274,36 +244,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
 
   const int klen = g.splits > 1 ? ((g.K - kbase) < g.kchunk ? (g.K - kbase) : g.kchunk) : g.K;
   const int nt = klen / BK;
-  if (STAGES == 2) {
-    stage(0, 0);
-    __syncthreads();  // the workgroup barrier carries vmcnt(0) for the in-flight LDS-DMA
-    for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BK);
-      compute(t & 1);
-      __syncthreads();
-    }
-  } else {
-    // 3-deep ring: tiles t+1, t+2 in flight while tile t is consumed; one raw barrier per tile.
-    stage(0, 0);
-    if (nt > 1) stage(1, BK);
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-      if (g.dbg & 1) wait_vmcnt<0>(); else if (t + 1 < nt) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();           // tile t landed for every wave; buffer (t-1)%3 free
-      int nxt = cur + 2; nxt = nxt >= 3 ? nxt - 3 : nxt;
-      if (SCHED == 0) {            // burst issue of the next tile's LDS-DMA, then compute
-        if (t + 2 < nt && !(g.dbg & 1)) stage(nxt, (t + 2) * BK);
-        if (!(g.dbg & 2)) compute(cur);
-      } else {                     // LDS-DMA pieces spread between the MFMA groups
-        compute_interleaved(cur, nxt, (t + 2) * BK, t + 2 < nt && !(g.dbg & 1));
-      }
-      cur = cur + 1 == 3 ? 0 : cur + 1;
-    }
+  stage_all(0, 0);
+  if (nt > 1) stage_all(1, BK);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    // own LDS-DMA of tile t landed (tile t+1 may stay in flight), then every wave's did
+    if ((g.dbg & 1) || t + 1 >= nt) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();
+    __builtin_amdgcn_s_barrier();        // ... and ring slot (t-1) % 3 is free for tile t+2
+    int nxt = cur + 2; nxt = nxt >= 3 ? nxt - 3 : nxt;
+    compute(cur, nxt, (t + 2) * BK, t + 2 < nt && !(g.dbg & 1), !(g.dbg & 2));
+    cur = cur + 1 == 3 ? 0 : cur + 1;
   }
 
-  // epilogue.  Transposed 32x32 C/D layout: output row = lane & 31, output columns
-  // 8 q + 4 (lane >> 5) + {0..3} for register group q = r >> 2: one 8-B (bf16) / 16-B (fp32)
-  // store per group instead of four scalar ones.
+  // ---- epilogue.  Transposed 32x32 C/D layout: output row = lane & 31, output columns
+  // 8 q + 4 (lane >> 5) + {0..3} for register group q: one 8-B (bf16) / 16-B (fp32) store each.
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
   TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
   if (g.splits > 1) {  // fp32 partial slabs [split][plane][M][ldc]; bias / emul applied by the reducer
@@ -311,8 +265,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     cr = reinterpret_cast<TOUT*>(g.ws) + (int64_t)split * (CPLX ? 2 : 1) * slab;
     ci = cr + slab;
   }
-  const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.c_r) & 15) == 0 &&
-                      (!CPLX || (reinterpret_cast<uintptr_t>(g.c_i) & 15) == 0) &&
+  const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
+                      (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
                       (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -381,65 +335,57 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// read-only tuning choice (set once from the environment; DESIGN.md "GEMM variants")
-static int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CPLXAMD_GEMM_VARIANT");
-    v = e ? atoi(e) : 7;
-  }
-  return v;
-}
-
-template <typename TOUT, bool CPLX, bool CONJ, int WM, int WN, int STAGES, int SCHED = 0>
-static int launch_cfg(const GemmArgs& g, hipStream_t st) {
-  using C = Cfg<CPLX, WM, WN, STAGES>;
-  const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
-  if (tiles > 0x7fffffff) return CPLXAMD_ESHAPE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES, SCHED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  gemm_bf16_kernel<TOUT, CPLX, CONJ, WM, WN, STAGES, SCHED><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
-  CPLXAMD_CHECK_LAUNCH();
-  return 0;
-}
-
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 
-template <typename TOUT, bool CPLX, bool CONJ>
-static int launch_variant(const GemmArgs& g0, hipStream_t st) {
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+static int launch_kernel(const GemmArgs& g0, hipStream_t st) {
+  using C = Cfg<CPLX>;
+  // read-only tuning knobs, set once from the environment (A/B experiments only)
   static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 4),
-                   sp = env_int("CPLXAMD_GEMM_SETPRIO", 0);
+                   dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
-  g.order = order; g.group_m = gm > 0 ? gm : 1; g.setprio = sp;
-  static const int dbg = env_int("CPLXAMD_GEMM_DBG", 0);
-  g.dbg = dbg;
-  if (!CPLX) {
-    static const int rv = env_int("CPLXAMD_RGEMM_VARIANT", 0);
-    if (rv == 1) return launch_cfg<TOUT, CPLX, CONJ, 4, 4, 3>(g, st);   // real: 256x256, 16 waves
-    if (rv == 2) return launch_cfg<TOUT, CPLX, CONJ, 4, 4, 2>(g, st);
+  g.order = order; g.group_m = gm > 0 ? gm : 1; g.dbg = dbg;
+  const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (tiles * g.splits > 0x7fffffff) return CPLXAMD_ESHAPE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
   }
-  switch (gemm_variant()) {
-    case 1: return launch_cfg<TOUT, CPLX, CONJ, 2, 2, 3>(g, st);   // 128x128, 3-stage
-    case 2: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 2>(g, st);   // 256x128, 2-stage
-    case 3: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3>(g, st);   // 256x128, 3-stage
-    case 4: return launch_cfg<TOUT, CPLX, CONJ, 2, 4, 3>(g, st);   // 128x256, 3-stage
-    case 7: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3, 1>(g, st);   // 256x128, 3-stage, interleaved LDS-DMA
-    case 0: return launch_cfg<TOUT, CPLX, CONJ, 2, 2, 2>(g, st);   // 128x128, 2-stage
-    default: return launch_cfg<TOUT, CPLX, CONJ, 4, 2, 3, 1>(g, st);  // = 7 (default)
-  }
+  gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)(tiles * g.splits)), NT, C::SMEM, st>>>(g);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
 }
 
-// split-K plan for the default 256x128 tile: use it when the tile count leaves CUs idle
+template <typename TOUT, bool CPLX, bool CONJ>
+static int launch_layout(const GemmArgs& g, bool ta, bool tb, hipStream_t st) {
+  if (ta) return tb ? launch_kernel<TOUT, CPLX, CONJ, true, true>(g, st)
+                    : launch_kernel<TOUT, CPLX, CONJ, true, false>(g, st);
+  return tb ? launch_kernel<TOUT, CPLX, CONJ, false, true>(g, st)
+            : launch_kernel<TOUT, CPLX, CONJ, false, false>(g, st);
+}
+
+template <bool CPLX>
+static int launch_dtype(const GemmArgs& g, int out_dtype, bool ta, bool tb, hipStream_t st) {
+  if (out_dtype != CPLXAMD_BF16 && out_dtype != CPLXAMD_F32) return CPLXAMD_EINVAL;
+  const bool f32 = out_dtype == CPLXAMD_F32;
+  if constexpr (CPLX) {
+    if (g.conj_b)
+      return f32 ? launch_layout<float, true, true>(g, ta, tb, st)
+                 : launch_layout<bf16_t, true, true>(g, ta, tb, st);
+  }
+  return f32 ? launch_layout<float, CPLX, false>(g, ta, tb, st)
+             : launch_layout<bf16_t, CPLX, false>(g, ta, tb, st);
+}
+
+// split-K plan: use it when the tile count leaves CUs idle and K is long
 static int plan_splits(int M, int N, int K) {
-  const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
+  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles >= 192 || K < 64 * BK) return 1;
   int s = (int)(256 / tiles);
   const int maxs = K / (32 * BK);          // >= 32 K tiles per split
@@ -488,19 +434,17 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* slab
 }
 
 template <bool CPLX>
-static int launch_gemm_bf16_splitk(const GemmArgs& g0, int splits, hipStream_t st) {
+static int launch_splitk(const GemmArgs& g0, int splits, bool ta, bool tb, hipStream_t st) {
   GemmArgs g = g0;
   g.splits = splits;
   g.kchunk = ((g.K / BK + splits - 1) / splits) * BK;
-  const bool conj = CPLX && g.conj_b;
-  // slabs use ldc = N (dense); the kernel writes float partials, no bias / emul / accumulate
+  // slabs are dense (ldc = N) float partials, no bias / emul / accumulate
   GemmArgs k = g;
   k.ldc = g.N; k.bias_r = k.bias_i = nullptr; k.emul = nullptr; k.accumulate = 0;
-  const int rc = conj ? launch_variant<float, CPLX, true>(k, st) : launch_variant<float, CPLX, false>(k, st);
+  const int rc = launch_dtype<CPLX>(k, CPLXAMD_F32, ta, tb, st);
   if (rc) return rc;
   const int64_t slab = (int64_t)g.M * g.N, stride = (CPLX ? 2 : 1) * slab;
   const int grid = stream_grid(slab >> 2, 256);
-  if (g.ldc != g.N) return CPLXAMD_ESHAPE;
   gemm_slab_reduce_kernel<<<grid, 256, 0, st>>>((const float*)g.ws, splits, stride, g.M, g.N, g.ldc,
                                                 g.bias_r, g.emul, g.accumulate, (float*)g.c_r);
   CPLXAMD_CHECK_LAUNCH();
@@ -515,22 +459,23 @@ static int launch_gemm_bf16_splitk(const GemmArgs& g0, int splits, hipStream_t s
 
 template <bool CPLX>
 int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
-  if (g.a_cs != 1 || g.b_cs != 1 || g.K < BK || (g.K % BK) != 0) return CPLXAMD_ESHAPE;
-  if ((g.a_rs % 8) != 0 || (g.b_rs % 8) != 0) return CPLXAMD_ESHAPE;
+  // operand layouts: K-contiguous rows ("N", *_cs == 1) or K-major ("T", *_rs == 1)
+  bool ta, tb;
+  if (g.a_cs == 1) ta = false; else if (g.a_rs == 1) ta = true; else return CPLXAMD_ESHAPE;
+  if (g.b_cs == 1) tb = false; else if (g.b_rs == 1) tb = true; else return CPLXAMD_ESHAPE;
+  if (g.K < BK || (g.K % BK) != 0) return CPLXAMD_ESHAPE;
+  const int64_t lda = ta ? g.a_cs : g.a_rs, ldb = tb ? g.b_cs : g.b_rs;
+  if ((lda % 8) != 0 || (ldb % 8) != 0) return CPLXAMD_ESHAPE;
+  if ((ta && ((g.M % 8) != 0 || g.M < 8)) || (tb && ((g.N % 8) != 0 || g.N < 8))) return CPLXAMD_ESHAPE;
   if (!aligned16(g.a_r) || !aligned16(g.b_r)) return CPLXAMD_ESHAPE;
   if (CPLX && (!aligned16(g.a_i) || !aligned16(g.b_i))) return CPLXAMD_ESHAPE;
   if (g.M <= 0 || g.N <= 0) return 0;
-  if (out_dtype == CPLXAMD_F32 && g.ws && g.ldc == g.N && (g.N & 3) == 0 && (gemm_variant() == 3 || gemm_variant() == 7)) {
+  if (out_dtype == CPLXAMD_F32 && g.ws && g.ldc == g.N && (g.N & 3) == 0) {
     const int splits = plan_splits(g.M, g.N, g.K);
     if (splits > 1 && g.ws_bytes >= gemm_bf16_ws_bytes(g.M, g.N, g.K, CPLX))
-      return launch_gemm_bf16_splitk<CPLX>(g, splits, st);
+      return launch_splitk<CPLX>(g, splits, ta, tb, st);
   }
-  const bool conj = CPLX && g.conj_b;
-  if (out_dtype == CPLXAMD_BF16)
-    return conj ? launch_variant<bf16_t, CPLX, true>(g, st) : launch_variant<bf16_t, CPLX, false>(g, st);
-  if (out_dtype == CPLXAMD_F32)
-    return conj ? launch_variant<float, CPLX, true>(g, st) : launch_variant<float, CPLX, false>(g, st);
-  return CPLXAMD_EINVAL;
+  return launch_dtype<CPLX>(g, out_dtype, ta, tb, st);
 }
 
 template int launch_gemm_bf16<true>(const GemmArgs&, int, hipStream_t);

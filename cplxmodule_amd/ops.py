@@ -253,23 +253,20 @@ def _cplx_linear_fwd(x2r, x2i, wr, wi, bias):
 
 
 def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype):
-    """dX = G conj(W):  dX[b,i] = sum_o G[b,o] conj(W[o,i])."""
+    """dX = G conj(W):  dX[b,i] = sum_o G[b,o] conj(W[o,i]).  The weight is read as stored
+    ([O, I] = K-major for this product): no transposed copy."""
     B, O = g2r.shape
     I = wr.shape[1]
     if _is_bf16(g2r):
-        wtr, wti = transpose2d(cast(wr, torch.bfloat16)), transpose2d(cast(wi, torch.bfloat16))
-        return cgemm(g2r, g2i, (O, 1), wtr, wti, (O, 1), B, I, O, conj_b=True, out_dtype=out_dtype)
+        wr, wi = cast(wr, torch.bfloat16), cast(wi, torch.bfloat16)
     return cgemm(g2r, g2i, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=out_dtype)
 
 
 def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None):
-    """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]."""
+    """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]; both operands
+    are K-major as stored (the bf16 kernel reads them through ds_read_b64_tr_b16)."""
     B, O = g2r.shape
     I = x2r.shape[1]
-    if _is_bf16(g2r) and B % 32 == 0 and B >= 32:
-        gtr, gti = transpose2d(g2r), transpose2d(g2i)
-        xtr, xti = transpose2d(x2r), transpose2d(x2i)
-        return cgemm(gtr, gti, (B, 1), xtr, xti, (B, 1), O, I, B, conj_b=True, out=out)
     return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True, out=out)
 
 
@@ -277,16 +274,13 @@ def _real_linear_dx(g2, w, out_dtype):
     B, O = g2.shape
     I = w.shape[1]
     if _is_bf16(g2):
-        return rgemm(g2, (O, 1), transpose2d(cast(w, torch.bfloat16)), (O, 1), B, I, O,
-                     out_dtype=out_dtype)
+        w = cast(w, torch.bfloat16)
     return rgemm(g2, (O, 1), w, (1, I), B, I, O, out_dtype=out_dtype)
 
 
 def _real_linear_dw(g2, x2, emul=None, out=None):
     B, O = g2.shape
     I = x2.shape[1]
-    if _is_bf16(g2) and _is_bf16(x2) and B % 32 == 0 and B >= 32:
-        return rgemm(transpose2d(g2), (B, 1), transpose2d(x2), (B, 1), O, I, B, emul=emul, out=out)
     if g2.dtype != x2.dtype:
         g2, x2 = cast(g2, torch.float32), cast(x2, torch.float32)
     return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul, out=out)

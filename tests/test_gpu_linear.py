@@ -81,6 +81,33 @@ def test_cgemm_bf16_vs_oracle(pkg, M, N_, K, conj):
     np.testing.assert_allclose(N(ci16), ref2.imag, rtol=8e-3, atol=8e-3 * scale)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N_,K", [(256, 128, 64), (264, 136, 96), (512, 384, 160), (128, 128, 4096), (40, 24, 32)])
+@pytest.mark.parametrize("conj", (False, True))
+def test_cgemm_bf16_transposed_operands(pkg, M, N_, K, conj, ta, tb):
+    """K-major ("T") operands through the ds_read_b64_tr_b16 path: A given as [K, M] and / or B
+    as [K, N], addressed by strides; asymmetric data so a row / column swap cannot hide."""
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import ops
+    rs = np.random.RandomState(M + 3 * N_ + K)
+    ar, ai = bf16_round(rs.randn(M, K)), bf16_round(rs.randn(M, K) + 0.3)
+    br, bi = bf16_round(rs.randn(N_, K) * 0.5 + 0.1), bf16_round(rs.randn(N_, K))
+    ref = (ar.astype(np.float64) + 1j * ai) @ ((br.astype(np.float64) + 1j * bi).conj() if conj else
+                                              (br.astype(np.float64) + 1j * bi)).T
+    q = lambda a: T(np.ascontiguousarray(a), torch.bfloat16)  # noqa: E731
+    A = (q(ar.T), q(ai.T), (1, M)) if ta else (q(ar), q(ai), (K, 1))
+    Bm = (q(br.T), q(bi.T), (1, N_)) if tb else (q(br), q(bi), (K, 1))
+    cr, ci = ops.cgemm(A[0], A[1], A[2], Bm[0], Bm[1], Bm[2], M, N_, K, conj_b=conj,
+                       out_dtype=torch.float32)
+    scale = float(np.abs(ref).max())
+    tol = (2e-6 * np.sqrt(K) * 4 + 1e-6) * scale
+    np.testing.assert_allclose(N(cr), ref.real, rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(N(ci), ref.imag, rtol=1e-5, atol=tol)
+    c = ops.rgemm(A[0], A[2], Bm[0], Bm[2], M, N_, K)
+    rref = ar.astype(np.float64) @ br.astype(np.float64).T
+    np.testing.assert_allclose(N(c), rref, rtol=1e-5, atol=1e-5 * np.abs(rref).max())
+
+
 @pytest.mark.parametrize("M,N_,K", [(128, 128, 64), (70, 190, 96), (64, 64, 24), (128, 256, 4096)])
 def test_rgemm_bf16_and_f32(pkg, M, N_, K):
     from gpu_util import T, N, bf16_round
