@@ -193,7 +193,7 @@ def main():
                                    f"batch {B} per GPU, LRT fwd + KL + full bwd (BASELINE configs[1] + VD)",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "kl_weight": KLW, "noise": "in-kernel Philox4x32-10"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM, 3 launches/step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM: fwd NN, dgrad NT, wgrad TT = 3 launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,
                          # HBM bytes per launch from rocprofv3 PMC passes of the same kernel / shape

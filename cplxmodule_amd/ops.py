@@ -249,7 +249,8 @@ def _cplx_linear_fwd(x2r, x2i, wr, wi, bias):
     B, I = x2r.shape
     O = wr.shape[0]
     wcr, wci = cast(wr, x2r.dtype), cast(wi, x2r.dtype)
-    return cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
+    yr, yi = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
+    return yr, yi, (wcr, wci)
 
 
 def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype):
@@ -302,7 +303,7 @@ class CplxLinearFn(torch.autograd.Function):
         I, O = wr.shape[1], wr.shape[0]
         x2r, x2i = xr.reshape(-1, I).contiguous(), xi.reshape(-1, I).contiguous()
         bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
-        yr, yi = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
+        yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
         ctx.save_for_backward(x2r, x2i, wr, wi)
         ctx.has_bias = br is not None
         ctx.lead = xr.shape[:-1]
@@ -316,7 +317,7 @@ class CplxLinearFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
         if need[0] or need[1]:
-            dxr, dxi = _cplx_linear_dx(g2r, g2i, _c(wr), _c(wi), x2r.dtype)
+            dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r.dtype)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         if need[2] or need[3]:
             dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
@@ -336,9 +337,10 @@ class CplxLinearLRTFn(torch.autograd.Function):
         x2r, x2i = xr.reshape(-1, I).contiguous(), xi.reshape(-1, I).contiguous()
         B = x2r.shape[0]
         bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
-        mur, mui = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
+        mur, mui, ctx.wc = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
         a = abs2(x2r, x2i)                                   # [B,I], activation dtype
         S = exp(_c(ls2), out_dtype=x2r.dtype)                # [O,I]
+        ctx.S = S
         s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)            # float32 [B,O]
         eps = None
         if eps_r is not None:
@@ -383,9 +385,8 @@ class CplxLinearLRTFn(torch.autograd.Function):
             if need[6]:
                 dls2 = _real_linear_dw(gs2, a, emul=exp(_c(ls2)))  # (gs2^T a) * exp(ls2)
         if need[0] or need[1]:
-            dxr, dxi = _cplx_linear_dx(g2r, g2i, _c(wr), _c(wi), dt)
-            S = exp(_c(ls2), out_dtype=dt)
-            ga = _real_linear_dx(gs2, S, dt)                 # gs2 . S -> [B,I]
+            dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], dt)
+            ga = _real_linear_dx(gs2, ctx.S, dt)             # gs2 . S -> [B,I]
             lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         if handle is not None:
