@@ -11,10 +11,14 @@
 //   * LDS rows are 80 B (64 B of k + 16 B pad): every ds_read_b128 lane group hits 16 distinct
 //     16-B slots.
 // Tile: 64 x 64 outputs per 256-thread block (4 waves, one 32x32 MFMA tile x {re, im} each),
-// BK = 32, single LDS stage, several blocks per CU hide the gather latency.
+// BK = 32, single LDS stage (20 KiB): ~8 blocks per CU hide the gather latency.  (A register-
+// prefetching, double-buffered variant at 4 blocks per CU measured 12 % SLOWER on cfg3: the
+// kernel is bound by gather-instruction issue, not by latency.)
 //
 // Reference semantics: cplx.convnd (cplxmodule/cplx.py:717-800), zero padding, no conjugation
 // in the forward; DGRAD / WGRAD conjugate the weight / input.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cplxamd {
