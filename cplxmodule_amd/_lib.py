@@ -29,8 +29,9 @@ SIGNATURES = {
     "cplxamd_vd_mask": [_P, _P, _P, _F, _P, _P, _P, _L, _P],
     "cplxamd_expi_fwd": [_P, _P, _L, _P],
     "cplxamd_expi_bwd": [_P, _P, _P, _L, _P],
-    "cplxamd_lrt_reparam_fwd": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _P],
-    "cplxamd_lrt_reparam_bwd": [_P, _P, _P, _P, _P, _U, _U, _P, _L, _I, _I, _P],
+    "cplxamd_lrt_reparam_fwd": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _L, _I, _P],
+    "cplxamd_lrt_reparam_bwd": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _I, _P],
+    "cplxamd_philox_advance": [_P, _P, _P],
     "cplxamd_philox_normal": [_P, _P, _U, _U, _L, _P],
     "cplxamd_cgemm": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,
                       _I, _I, _I, _P, _L, _P],

@@ -103,7 +103,8 @@ __device__ __forceinline__ float lrt_std(float s2) { return rn_sqrt(fmaxf(s2, 1e
 template <typename T, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
     const T* mu_r, const T* mu_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
-    uint64_t offset, T* y_r, T* y_i, int64_t n) {
+    uint64_t offset, const uint64_t* state, T* y_r, T* y_i, int64_t n) {
+  if (PHILOX && state) { seed = state[0]; offset = state[1]; }   // device-resident stream position
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kRpThreads;
   for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n4; i += stride) {
@@ -151,7 +152,8 @@ __device__ __forceinline__ float lrt_gs2(float gs, float s2) {
 template <typename T, typename TG, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
     const T* g_r, const T* g_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
-    uint64_t offset, TG* g_s2, int64_t n) {
+    uint64_t offset, const uint64_t* state, TG* g_s2, int64_t n) {
+  if (PHILOX && state) { seed = state[0]; offset = state[1]; }
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kRpThreads;
   for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n4; i += stride) {
@@ -205,14 +207,14 @@ __global__ __launch_bounds__(kRpThreads) void philox_normal_kernel(float* er, fl
 
 template <typename T>
 static int launch_fwd(const void* mu_r, const void* mu_i, const float* s2, const void* eps_r,
-                      const void* eps_i, uint64_t seed, uint64_t offset, void* y_r, void* y_i,
-                      int64_t n, hipStream_t st) {
+                      const void* eps_i, uint64_t seed, uint64_t offset, const uint64_t* state,
+                      void* y_r, void* y_i, int64_t n, hipStream_t st) {
   const int grid = stream_grid(n >> 2, kRpThreads);
   const bool cplx = mu_i != nullptr, philox = eps_r == nullptr;
 #define RP_FWD(C, P)                                                                       \
   reparam_fwd_kernel<T, C, P><<<grid, kRpThreads, 0, st>>>(                                \
       (const T*)mu_r, (const T*)mu_i, s2, (const T*)eps_r, (const T*)eps_i, seed, offset,  \
-      (T*)y_r, (T*)y_i, n)
+      state, (T*)y_r, (T*)y_i, n)
   if (cplx && philox) RP_FWD(true, true);
   else if (cplx) RP_FWD(true, false);
   else if (philox) RP_FWD(false, true);
@@ -224,14 +226,14 @@ static int launch_fwd(const void* mu_r, const void* mu_i, const float* s2, const
 
 template <typename T, typename TG>
 static int launch_bwd(const void* g_r, const void* g_i, const float* s2, const void* eps_r,
-                      const void* eps_i, uint64_t seed, uint64_t offset, void* g_s2, int64_t n,
-                      hipStream_t st) {
+                      const void* eps_i, uint64_t seed, uint64_t offset, const uint64_t* state,
+                      void* g_s2, int64_t n, hipStream_t st) {
   const int grid = stream_grid(n >> 2, kRpThreads);
   const bool cplx = g_i != nullptr, philox = eps_r == nullptr;
 #define RP_BWD(C, P)                                                                      \
   reparam_bwd_kernel<T, TG, C, P><<<grid, kRpThreads, 0, st>>>(                           \
       (const T*)g_r, (const T*)g_i, s2, (const T*)eps_r, (const T*)eps_i, seed, offset,   \
-      (TG*)g_s2, n)
+      state, (TG*)g_s2, n)
   if (cplx && philox) RP_BWD(true, true);
   else if (cplx) RP_BWD(true, false);
   else if (philox) RP_BWD(false, true);
@@ -239,6 +241,15 @@ static int launch_bwd(const void* g_r, const void* g_i, const float* s2, const v
 #undef RP_BWD
   CPLXAMD_CHECK_LAUNCH();
   return 0;
+}
+
+// used[0..1] = state[0..1]; state[1] += 1   (one stochastic forward consumes one offset)
+__global__ void philox_advance_kernel(uint64_t* state, uint64_t* used) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    used[0] = state[0];
+    used[1] = state[1];
+    state[1] = state[1] + 1;
+  }
 }
 
 }  // namespace cplxamd
@@ -249,33 +260,40 @@ extern "C" {
 
 int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
                             const void* eps_r, const void* eps_i, uint64_t seed,
-                            uint64_t offset, void* y_r, void* y_i, int64_t n, int dtype,
-                            void* stream) {
+                            uint64_t offset, const uint64_t* state, void* y_r, void* y_i,
+                            int64_t n, int dtype, void* stream) {
   if (!mu_r || !s2 || !y_r || n < 0) return CPLXAMD_EINVAL;
   if ((mu_i == nullptr) != (y_i == nullptr)) return CPLXAMD_EINVAL;
   if (eps_r && mu_i && !eps_i) return CPLXAMD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32)
-    return launch_fwd<float>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, y_r, y_i, n, st);
+    return launch_fwd<float>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, st);
   if (dtype == CPLXAMD_BF16)
-    return launch_fwd<bf16_t>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, y_r, y_i, n, st);
+    return launch_fwd<bf16_t>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, st);
   return CPLXAMD_EINVAL;
 }
 
 int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
                             const void* eps_r, const void* eps_i, uint64_t seed,
-                            uint64_t offset, void* g_s2, int64_t n, int dtype, int gs2_dtype,
-                            void* stream) {
+                            uint64_t offset, const uint64_t* state, void* g_s2, int64_t n,
+                            int dtype, int gs2_dtype, void* stream) {
   if (!g_r || !s2 || !g_s2 || n < 0) return CPLXAMD_EINVAL;
   if (eps_r && g_i && !eps_i) return CPLXAMD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32 && gs2_dtype == CPLXAMD_F32)
-    return launch_bwd<float, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, g_s2, n, st);
+    return launch_bwd<float, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
   if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_F32)
-    return launch_bwd<bf16_t, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, g_s2, n, st);
+    return launch_bwd<bf16_t, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
   if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_BF16)
-    return launch_bwd<bf16_t, bf16_t>(g_r, g_i, s2, eps_r, eps_i, seed, offset, g_s2, n, st);
+    return launch_bwd<bf16_t, bf16_t>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
   return CPLXAMD_EINVAL;
+}
+
+int cplxamd_philox_advance(uint64_t* state, uint64_t* used, void* stream) {
+  if (!state || !used) return CPLXAMD_EINVAL;
+  philox_advance_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, used);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
 }
 
 int cplxamd_philox_normal(float* eps_r, float* eps_i, uint64_t seed, uint64_t offset,

@@ -70,7 +70,7 @@ class _CplxGaussianMixin:
         if noise.mode == "torch":
             e = cplx.randn(*shape, dtype=like.dtype, device=like.device)
             return e.real, e.imag, 0, 0
-        seed, offset = noise.next()
+        seed, offset = noise.next(like.device)
         return None, None, seed, offset
 
 

@@ -3,6 +3,9 @@
 mode "philox" (default): the kernels generate the noise in registers from the counter-based
 Philox stream (seed, offset) documented in DESIGN.md; nothing is materialised and the backward
 regenerates it.  Each stochastic forward consumes one offset.
+mode "philox-device": the same stream, but (seed, offset) live in a device int64[2] tensor that a
+one-thread kernel advances: nothing about the noise position is baked into kernel arguments, so
+a training step captured in a hipGraph (torch.cuda.CUDAGraph) draws fresh noise on every replay.
 mode "torch": the layers draw the noise with torch.randn on the device in the reference's tape
 layout (one [2, B, O] draw / sqrt 2 for complex layers, cplxmodule/cplx.py:544-550) and hand it
 to the kernels -- bit-compatible with a recorded reference tape, 8-16 B/output more traffic.
@@ -15,6 +18,7 @@ class _NoiseState:
         self.mode = "philox"
         self._seed = None
         self.counter = 0
+        self._dev = {}
 
     @property
     def seed(self):
@@ -22,16 +26,31 @@ class _NoiseState:
 
     def manual_seed(self, seed):
         self._seed, self.counter = int(seed), 0
+        self._dev = {}
 
     def set_mode(self, mode):
-        if mode not in ("philox", "torch"):
-            raise ValueError("noise mode must be 'philox' or 'torch'")
+        if mode not in ("philox", "philox-device", "torch"):
+            raise ValueError("noise mode must be 'philox', 'philox-device' or 'torch'")
         self.mode = mode
 
-    def next(self):
-        """(seed, offset) for one stochastic forward pass."""
+    def next(self, device=None):
+        """(seed, offset) for one stochastic forward pass; in "philox-device" mode a device
+        int64[2] copy of the position (and 0) instead, the device-resident position advanced."""
+        if self.mode == "philox-device":
+            from ... import ops
+            return ops.philox_advance(self.device_state(device)), 0
         self.counter += 1
         return self.seed & 0xFFFFFFFFFFFFFFFF, self.counter
+
+    def device_state(self, device):
+        device = torch.device(device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in self._dev:
+            seed = self.seed & 0xFFFFFFFFFFFFFFFF
+            seed = seed - (1 << 64) if seed >= (1 << 63) else seed      # same 64 bits, as int64
+            self._dev[key] = torch.tensor([seed, self.counter + 1], dtype=torch.int64,
+                                          device=device)
+        return self._dev[key]
 
 
 noise = _NoiseState()

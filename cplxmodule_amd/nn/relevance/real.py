@@ -45,7 +45,7 @@ class _RealGaussianMixin:
     def _draw_noise(self, shape, like):
         if noise.mode == "torch":
             return torch.randn(*shape, dtype=like.dtype, device=like.device), 0, 0
-        seed, offset = noise.next()
+        seed, offset = noise.next(like.device)
         return None, seed, offset
 
 

@@ -148,6 +148,21 @@ def philox_normal(n, seed, offset, device, complex_=False):
     return (er, ei) if complex_ else er
 
 
+def _noise_args(seed, offset):
+    """(seed, offset, device-state pointer): `seed` may be a device int64[2] tensor
+    {seed, offset} (graph-capturable noise position) instead of a host integer."""
+    if isinstance(seed, torch.Tensor):
+        return 0, 0, ptr(seed)
+    return seed, offset, None
+
+
+def philox_advance(state):
+    """Copy the device noise position and advance it by one stochastic forward."""
+    used = torch.empty_like(state)
+    call("cplxamd_philox_advance", ptr(state), ptr(used), stream_ptr())
+    return used
+
+
 def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
     """y = mu + eps * sqrt(max(s2, 1e-8)); eps=(eps_r, eps_i) / eps_r tensor or None (Philox)."""
     require_device(mu_r, mu_i, s2)
@@ -158,8 +173,9 @@ def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
         e_r, e_i = _c(cast(e_r, mu_r.dtype)), (None if e_i is None else _c(cast(e_i, mu_r.dtype)))
     y_r = mu_r if inplace else torch.empty_like(mu_r)
     y_i = None if mu_i is None else (mu_i if inplace else torch.empty_like(mu_i))
-    call("cplxamd_lrt_reparam_fwd", ptr(mu_r), ptr(mu_i), ptr(s2), ptr(e_r), ptr(e_i), seed,
-         offset, ptr(y_r), ptr(y_i), mu_r.numel(), dtype_code(mu_r), stream_ptr())
+    sd, of, st = _noise_args(seed, offset)
+    call("cplxamd_lrt_reparam_fwd", ptr(mu_r), ptr(mu_i), ptr(s2), ptr(e_r), ptr(e_i), sd,
+         of, st, ptr(y_r), ptr(y_i), mu_r.numel(), dtype_code(mu_r), stream_ptr())
     return y_r, y_i
 
 
@@ -171,7 +187,8 @@ def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float3
         e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
         e_r, e_i = _c(cast(e_r, g_r.dtype)), (None if e_i is None else _c(cast(e_i, g_r.dtype)))
     g_s2 = torch.empty_like(s2, dtype=out_dtype)
-    call("cplxamd_lrt_reparam_bwd", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), seed, offset,
+    sd, of, st = _noise_args(seed, offset)
+    call("cplxamd_lrt_reparam_bwd", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,
          ptr(g_s2), g_r.numel(), dtype_code(g_r), dtype_code(g_s2), stream_ptr())
     return g_s2
 

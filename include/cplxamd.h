@@ -99,19 +99,25 @@ int cplxamd_expi_bwd(const float* g, const float* x, float* gx, int64_t n, void*
  * mu_i / y_i / eps_i NULL  => real layer (eps ~ N(0,1)); else eps_r, eps_i ~ N(0,1/2).
  * eps_r NULL => noise from the counter-based Philox4x32-10 stream (seed, offset) defined in
  * DESIGN.md ("noise stream"); the backward regenerates it from the same (seed, offset).
+ * `state` (nullable): device uint64[2] = {seed, offset}; when given it overrides the two host
+ * scalars, so a hipGraph that captured the launch draws fresh noise on every replay
+ * (cplxamd_philox_advance moves the stream position on the device).
  * s2 is float32; mu / y / eps / g have element type `dtype`.
  * ---------------------------------------------------------------------------------- */
 int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
                             const void* eps_r, const void* eps_i, uint64_t seed,
-                            uint64_t offset, void* y_r, void* y_i, int64_t n, int dtype,
-                            void* stream);
+                            uint64_t offset, const uint64_t* state, void* y_r, void* y_i,
+                            int64_t n, int dtype, void* stream);
 
 /* g_s2 = (g_r*eps_r + g_i*eps_i) * 0.5 / sqrt(max(s2,1e-8)) * [s2 >= 1e-8]
  * g_s2 has element type gs2_dtype (float32, or bf16 when it feeds the bf16 GEMMs). */
 int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
                             const void* eps_r, const void* eps_i, uint64_t seed,
-                            uint64_t offset, void* g_s2, int64_t n, int dtype, int gs2_dtype,
-                            void* stream);
+                            uint64_t offset, const uint64_t* state, void* g_s2, int64_t n,
+                            int dtype, int gs2_dtype, void* stream);
+
+/* used[0..1] = state[0..1]; state[1] += 1  (device-resident noise stream position) */
+int cplxamd_philox_advance(uint64_t* state, uint64_t* used, void* stream);
 
 /* Writes the Philox noise itself (float32), for tests: real (eps_i NULL) or complex. */
 int cplxamd_philox_normal(float* eps_r, float* eps_i, uint64_t seed, uint64_t offset,
