@@ -37,6 +37,7 @@ SIGNATURES = {
                       _I, _I, _I, _P, _L, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
+    "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],
     "cplxamd_abs2": [_P, _P, _P, _L, _I, _I, _P],
     "cplxamd_modulus": [_P, _P, _P, _L, _P],
     "cplxamd_exp": [_P, _P, _L, _I, _P],
@@ -63,7 +64,8 @@ SIGNATURES = {
     "cplxamd_bn_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _L, _P],
 }
 _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
-             "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64}
+             "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,
+             "cplxamd_cgemm3m_ws_bytes": c_int64}
 
 _lib = None
 

@@ -278,8 +278,17 @@ def linear(input, weight, bias=None):
     return Cplx(yr, yi)
 
 
-# interchangeable algorithm names of the reference (cplx.py:634-698); one kernel serves them all
-linear_naive = linear_cat = linear_3m = linear
+def linear_3m(input, weight, bias=None):
+    """Gauss's three-product form (cplxmodule/cplx.py:651-672): three real MFMA GEMMs + a fused
+    combine for bf16 activations (operand sums rounded to bf16); float32 runs the exact 4M kernel.
+    Slower than `linear` on MI355X (DESIGN.md "3M vs 4M"), kept for the reference's API."""
+    br, bi = (None, None) if bias is None else (bias.real, bias.imag)
+    yr, yi = ops.CplxLinearFn.apply(input.real, input.imag, weight.real, weight.imag, br, bi, 1)
+    return Cplx(yr, yi)
+
+
+# the remaining algorithm names of the reference (cplx.py:634-698) share the 4M kernel
+linear_naive = linear_cat = linear
 
 
 def matmul(u, v):

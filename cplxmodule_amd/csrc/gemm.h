@@ -16,6 +16,10 @@ struct GemmArgs {
   // and writes slab `split` of the workspace; a second kernel reduces the slabs.
   int splits = 1; int kchunk = 0; void* ws = nullptr; int64_t ws_bytes = 0;
   int dbg = 0;   // ablation bits (CPLXAMD_GEMM_DBG): 1 no LDS-DMA after the prologue, 2 no MFMA
+  // Gauss 3M combine (real bf16 kernel only): this launch computes t3 = (Ar+Ai)(Br+Bi'); with the
+  // dense fp32 slabs t1 = Ar Br and T2 = Ai Bi the epilogue stores
+  //   c_r = t1 - gsign T2 + bias_r,   c_i = t3 - t1 - gsign T2 + bias_i      (gsign = -1: conj(B))
+  const float* g1 = nullptr; const float* g2 = nullptr; float gsign = 1.0f;
 };
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)
@@ -26,6 +30,10 @@ int launch_gemm_generic(const GemmArgs& g, int in_dtype, int out_dtype, hipStrea
 // qualify so that the caller can fall back to the generic kernel.
 template <bool CPLX>
 int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st);
+
+// Gauss 3M (3 real MFMA GEMMs + fused combine) for dense bf16 operands; ESHAPE otherwise
+int launch_gemm_bf16_gauss(const GemmArgs& g, int out_dtype, hipStream_t st);
+int64_t gemm_bf16_gauss_ws_bytes(int M, int N, int K);
 
 // workspace the bf16 path wants for split-K at this shape (0: no split-K)
 int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx);

@@ -11,6 +11,8 @@ int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int o
   return gemm_bf16_ws_bytes(M, N, K, cplx != 0);
 }
 
+int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K) { return gemm_bf16_gauss_ws_bytes(M, N, K); }
+
 int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
                   const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
                   const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
@@ -20,11 +22,13 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
   if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
   if ((bias_r == nullptr) != (bias_i == nullptr)) return CPLXAMD_EINVAL;
   if (accumulate && out_dtype != CPLXAMD_F32) return CPLXAMD_EINVAL;
-  if (algo != 0) return CPLXAMD_ESHAPE;  // 3M: not built yet
+  if (algo != CPLXAMD_ALGO_4M && algo != CPLXAMD_ALGO_3M) return CPLXAMD_EINVAL;
   GemmArgs g{a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, bias_r, bias_i, nullptr,
              c_r, c_i, ldc, M, N, K, conj_b ? 1 : 0, accumulate ? 1 : 0};
   g.ws = ws; g.ws_bytes = ws_bytes;
   hipStream_t st = (hipStream_t)stream;
+  if (algo == CPLXAMD_ALGO_3M)     // Gauss: dense bf16 operands only, never a silent 4M fallback
+    return in_dtype == CPLXAMD_BF16 ? launch_gemm_bf16_gauss(g, out_dtype, st) : CPLXAMD_ESHAPE;
   if (in_dtype == CPLXAMD_BF16) {
     const int rc = launch_gemm_bf16<true>(g, out_dtype, st);
     if (rc != CPLXAMD_ESHAPE) return rc;

@@ -265,8 +265,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
     cr = reinterpret_cast<TOUT*>(g.ws) + (int64_t)split * (CPLX ? 2 : 1) * slab;
     ci = cr + slab;
   }
+  const bool two_planes = CPLX || g.g1;
   const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
-                      (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
+                      (!two_planes || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
+                      (!g.g1 || (g.N & 3) == 0) &&
                       (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -284,6 +286,32 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e) {
           vr.v[e] = acc_r[i][j][4 * q + e];
           vi.v[e] = CPLX ? acc_i[i][j][4 * q + e] : 0.f;
+        }
+        if (!CPLX && g.g1) {                       // Gauss 3M combine (see gemm.h)
+          const int64_t od = (int64_t)row * g.N + col;
+          if (vec_ok && col + 3 < g.N) {
+            const f4 p = ld4(g.g1 + od), t2 = ld4(g.g2 + od);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float q = g.gsign * t2.v[e];
+              vi.v[e] = vr.v[e] - p.v[e] - q;
+              vr.v[e] = p.v[e] - q;
+            }
+            if (g.bias_r) {
+              const f4 b = ld4(g.bias_r + col), c = ld4(g.bias_i + col);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { vr.v[e] += b.v[e]; vi.v[e] += c.v[e]; }
+            }
+            st4(cr + o, vr);
+            st4(ci + o, vi);
+          } else {
+            for (int e = 0; e < 4 && col + e < g.N; ++e) {
+              const float p = g.g1[od + e], q = g.gsign * g.g2[od + e];
+              io<TOUT>::st(cr + o + e, p - q + (g.bias_r ? g.bias_r[col + e] : 0.f));
+              io<TOUT>::st(ci + o + e, vr.v[e] - p - q + (g.bias_i ? g.bias_i[col + e] : 0.f));
+            }
+          }
+          continue;
         }
         if (vec_ok && col + 3 < g.N) {
           if (g.bias_r) {
@@ -476,6 +504,72 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
       return launch_splitk<CPLX>(g, splits, ta, tb, st);
   }
   return launch_dtype<CPLX>(g, out_dtype, ta, tb, st);
+}
+
+// ---- Gauss 3M: t1 = Ar Br, T2 = Ai Bi, t3 = (Ar + Ai)(Br + s Bi) as three real MFMA GEMMs; the
+// combine rides in the third one's epilogue.  25 % fewer MFMAs than 4M, but each real GEMM has half
+// the LDS reuse of the fused 4M loop and the operand sums are rounded to bf16.
+__global__ __launch_bounds__(256) void gauss_sum_kernel(const bf16_t* r, const bf16_t* i, float sign,
+                                                        bf16_t* out, int64_t n8) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n8; c += stride) {
+    const uint4 a = *reinterpret_cast<const uint4*>(r + 8 * c);
+    const uint4 b = *reinterpret_cast<const uint4*>(i + 8 * c);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = __uint_as_float(aw[e] << 16) + sign * __uint_as_float(bw[e] << 16);
+      const float hi = __uint_as_float(aw[e] & 0xffff0000u) + sign * __uint_as_float(bw[e] & 0xffff0000u);
+      ow[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + 8 * c) = uint4{ow[0], ow[1], ow[2], ow[3]};
+  }
+}
+
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+int64_t gemm_bf16_gauss_ws_bytes(int M, int N, int K) {
+  return align256((int64_t)M * K * 2) + align256((int64_t)N * K * 2) + 2 * (int64_t)M * N * 4;
+}
+
+int launch_gemm_bf16_gauss(const GemmArgs& g, int out_dtype, hipStream_t st) {
+  bool ta, tb;
+  if (g.a_cs == 1) ta = false; else if (g.a_rs == 1) ta = true; else return CPLXAMD_ESHAPE;
+  if (g.b_cs == 1) tb = false; else if (g.b_rs == 1) tb = true; else return CPLXAMD_ESHAPE;
+  // dense operands only: the sums are formed over the raw storage
+  if ((ta ? g.a_cs : g.a_rs) != (ta ? g.M : g.K) || (tb ? g.b_cs : g.b_rs) != (tb ? g.N : g.K))
+    return CPLXAMD_ESHAPE;
+  if (g.accumulate || (g.N & 3) || ((int64_t)g.M * g.K & 7) || ((int64_t)g.N * g.K & 7))
+    return CPLXAMD_ESHAPE;
+  if (!g.ws || g.ws_bytes < gemm_bf16_gauss_ws_bytes(g.M, g.N, g.K)) return CPLXAMD_EWS;
+  if ((reinterpret_cast<uintptr_t>(g.ws) & 255) != 0) return CPLXAMD_EALIGN;
+  if (g.M <= 0 || g.N <= 0) return 0;
+  char* w = (char*)g.ws;
+  bf16_t* As = (bf16_t*)w; w += align256((int64_t)g.M * g.K * 2);
+  bf16_t* Bs = (bf16_t*)w; w += align256((int64_t)g.N * g.K * 2);
+  float* t1 = (float*)w; float* t2 = t1 + (int64_t)g.M * g.N;
+  const float s = g.conj_b ? -1.0f : 1.0f;
+  const int64_t na = (int64_t)g.M * g.K / 8, nb = (int64_t)g.N * g.K / 8;
+  gauss_sum_kernel<<<stream_grid(na, 256), 256, 0, st>>>((const bf16_t*)g.a_r, (const bf16_t*)g.a_i,
+                                                        1.0f, As, na);
+  CPLXAMD_CHECK_LAUNCH();
+  gauss_sum_kernel<<<stream_grid(nb, 256), 256, 0, st>>>((const bf16_t*)g.b_r, (const bf16_t*)g.b_i,
+                                                        s, Bs, nb);
+  CPLXAMD_CHECK_LAUNCH();
+  GemmArgs r = g;
+  r.a_i = r.b_i = nullptr; r.bias_r = r.bias_i = nullptr; r.conj_b = 0;
+  r.ws = nullptr; r.ws_bytes = 0; r.ldc = g.N; r.c_i = nullptr;
+  r.c_r = t1;
+  int rc = launch_gemm_bf16<false>(r, CPLXAMD_F32, st);
+  if (rc) return rc;
+  r.a_r = g.a_i; r.b_r = g.b_i; r.c_r = t2;
+  rc = launch_gemm_bf16<false>(r, CPLXAMD_F32, st);
+  if (rc) return rc;
+  GemmArgs f = g;
+  f.a_r = As; f.b_r = Bs; f.a_i = f.b_i = nullptr; f.conj_b = 0; f.ws = nullptr; f.ws_bytes = 0;
+  f.g1 = t1; f.g2 = t2; f.gsign = s;
+  return launch_gemm_bf16<false>(f, out_dtype, st);
 }
 
 template int launch_gemm_bf16<true>(const GemmArgs&, int, hipStream_t);

@@ -109,10 +109,29 @@ def _gemm_ws(M, N, K, cplx, a, c):
     return buf
 
 
+_gauss_ws_cache = {}
+
+
+def _gauss_ws(M, N, K, device):
+    need = int(_lib.load().cplxamd_cgemm3m_ws_bytes(M, N, K))
+    key = (device.type, device.index)
+    buf = _gauss_ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _gauss_ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return buf
+
+
+def gauss_ok(M, N, K):
+    """Shapes the 3M entry accepts (mirrors launch_gemm_bf16_gauss); the layer-level helpers run
+    4M for the rest, the C entry point itself refuses them."""
+    return K >= 32 and K % 32 == 0 and N % 4 == 0 and (M * K) % 8 == 0 and (N * K) % 8 == 0
+
+
 def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False,
-          out_dtype=torch.float32, out=None, accumulate=False):
+          out_dtype=torch.float32, out=None, accumulate=False, algo=0):
     """C[m,n] = sum_k A[m,k] op(B[n,k]) (+ bias[n]) on planar complex operands.
-    `a_strides` / `b_strides` are (row, col) element strides into the given planes."""
+    `a_strides` / `b_strides` are (row, col) element strides into the given planes.
+    algo: 0 = 4M (one fused K loop), 1 = Gauss 3M (dense bf16 operands only)."""
     require_device(ar, ai, br, bi)
     if out is None:
         cr = torch.empty(M, N, dtype=out_dtype, device=ar.device)
@@ -120,10 +139,10 @@ def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False
     else:
         cr, ci = out
     b_r, b_i = (None, None) if bias is None else bias
-    ws = _gemm_ws(M, N, K, True, ar, cr)
+    ws = _gauss_ws(M, N, K, ar.device) if algo == 1 else _gemm_ws(M, N, K, True, ar, cr)
     call("cplxamd_cgemm", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
          b_strides[0], b_strides[1], ptr(b_r), ptr(b_i), ptr(cr), ptr(ci), N, M, N, K,
-         int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), 0, ptr(ws),
+         int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), int(algo), ptr(ws),
          0 if ws is None else ws.numel(), stream_ptr())
     return cr, ci
 
@@ -261,31 +280,34 @@ def _is_bf16(t):
     return t.dtype == torch.bfloat16
 
 
-def _cplx_linear_fwd(x2r, x2i, wr, wi, bias):
+def _cplx_linear_fwd(x2r, x2i, wr, wi, bias, algo=0):
     """[B,I] x [O,I]^T -> [B,O]; weights are cast to the activation dtype (bf16 MFMA path)."""
     B, I = x2r.shape
     O = wr.shape[0]
     wcr, wci = cast(wr, x2r.dtype), cast(wi, x2r.dtype)
-    yr, yi = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
+    yr, yi = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype,
+                   algo=algo if gauss_ok(B, O, I) else 0)
     return yr, yi, (wcr, wci)
 
 
-def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype):
+def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype, algo=0):
     """dX = G conj(W):  dX[b,i] = sum_o G[b,o] conj(W[o,i]).  The weight is read as stored
     ([O, I] = K-major for this product): no transposed copy."""
     B, O = g2r.shape
     I = wr.shape[1]
     if _is_bf16(g2r):
         wr, wi = cast(wr, torch.bfloat16), cast(wi, torch.bfloat16)
-    return cgemm(g2r, g2i, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=out_dtype)
+    return cgemm(g2r, g2i, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=out_dtype,
+                 algo=algo if gauss_ok(B, I, O) and I % 8 == 0 else 0)
 
 
-def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None):
+def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0):
     """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]; both operands
     are K-major as stored (the bf16 kernel reads them through ds_read_b64_tr_b16)."""
     B, O = g2r.shape
     I = x2r.shape[1]
-    return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True, out=out)
+    return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True, out=out,
+                 algo=algo if gauss_ok(O, I, B) and O % 8 == 0 and I % 8 == 0 else 0)
 
 
 def _real_linear_dx(g2, w, out_dtype):
@@ -315,12 +337,14 @@ class CplxLinearFn(torch.autograd.Function):
     """cplx.linear (cplxmodule/cplx.py:634-648) + its backward."""
 
     @staticmethod
-    def forward(ctx, xr, xi, wr, wi, br, bi):
+    def forward(ctx, xr, xi, wr, wi, br, bi, algo=0):
         require_device(xr, xi, wr, wi, br, bi)
         I, O = wr.shape[1], wr.shape[0]
         x2r, x2i = xr.reshape(-1, I).contiguous(), xi.reshape(-1, I).contiguous()
         bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
-        yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
+        # Gauss 3M exists for the bf16 MFMA path only; float32 always runs the exact 4M kernel
+        ctx.algo = algo = algo if _is_bf16(x2r) else 0
+        yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias, algo)
         ctx.save_for_backward(x2r, x2i, wr, wi)
         ctx.has_bias = br is not None
         ctx.lead = xr.shape[:-1]
@@ -334,13 +358,13 @@ class CplxLinearFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
         if need[0] or need[1]:
-            dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r.dtype)
+            dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r.dtype, ctx.algo)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         if need[2] or need[3]:
-            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
+            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i, algo=ctx.algo)
         if ctx.has_bias and (need[4] or need[5]):
             dbr, dbi = colsum(g2r), colsum(g2i)
-        return dxr, dxi, dwr, dwi, dbr, dbi
+        return dxr, dxi, dwr, dwi, dbr, dbi, None
 
 
 class CplxLinearLRTFn(torch.autograd.Function):

@@ -28,6 +28,12 @@ extern "C" {
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
 
+/* complex product algorithm of cplxamd_cgemm */
+enum {
+  CPLXAMD_ALGO_4M = 0,   /* four real products in one K loop     (cplx.py:634-648 linear_naive) */
+  CPLXAMD_ALGO_3M = 1    /* Gauss: three real MFMA GEMMs + combine (cplx.py:651-672 linear_3m)   */
+};
+
 /* KL penalty kinds */
 enum {
   CPLXAMD_KL_REAL_VD = 0,  /* cplxmodule/nn/relevance/real/vd.py:54-76     */
@@ -136,13 +142,18 @@ int cplxamd_philox_normal(float* eps_r, float* eps_i, uint64_t seed, uint64_t of
  * accumulate != 0: C += result (C must then be float32).
  * The MFMA fast path (bf16 inputs, a_cs == b_cs == 1, K % 32 == 0, 16-byte aligned rows) is
  * chosen automatically; everything else runs the generic float32-MFMA kernel.
- * algo: 0 = 4M (four real products), 1 = 3M (Gauss; bf16 fast path only).
+ * algo: CPLXAMD_ALGO_4M, or CPLXAMD_ALGO_3M = Gauss's three products t1 = Ar Br, t2 = Ai Bi,
+ * t3 = (Ar + Ai)(Br + Bi): dense bf16 operands only (ESHAPE otherwise, never a silent 4M), needs
+ * `ws` of cplxamd_cgemm3m_ws_bytes(M, N, K) bytes (256-B aligned), no accumulate.  The operand
+ * sums are rounded to bf16, so the result is NOT bit-identical to 4M.
  * ---------------------------------------------------------------------------------- */
 int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
                   const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
                   const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
                   int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
                   int algo, void* ws, int64_t ws_bytes, void* stream);
+
+int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
 
 /* Optional scratch for split-K (bf16 inputs, float32 output, few output tiles, long K -- e.g. the
  * weight gradient at batch 2^20): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be

@@ -108,6 +108,81 @@ def test_cgemm_bf16_transposed_operands(pkg, M, N_, K, conj, ta, tb):
     np.testing.assert_allclose(N(c), rref, rtol=1e-5, atol=1e-5 * np.abs(rref).max())
 
 
+@pytest.mark.parametrize("lay", ["nn", "nt", "tt"])
+@pytest.mark.parametrize("M,N_,K", [(256, 128, 64), (264, 136, 96), (40, 24, 32), (512, 384, 1024)])
+@pytest.mark.parametrize("conj", (False, True))
+def test_cgemm_gauss_3m(pkg, M, N_, K, conj, lay):
+    """algo = 3M: t1 = Ar Br, t2 = Ai Bi', t3 = (Ar + Ai)(Br + Bi') with the operand sums rounded
+    to bf16, re = t1 - t2, im = t3 - t1 - t2 (Bi' = -Bi for conj).  Checked against exactly that
+    model in float64 (fp32-accumulation tolerance), and against the true product at the looser
+    tolerance the extra bf16 rounding of the sums costs."""
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import ops
+    rs = np.random.RandomState(M + 5 * N_ + K + conj)
+    ar, ai = bf16_round(rs.randn(M, K)), bf16_round(rs.randn(M, K) + 0.3)
+    br, bi = bf16_round(rs.randn(N_, K) * 0.5 + 0.1), bf16_round(rs.randn(N_, K))
+    bias = (rs.randn(N_).astype(np.float32), rs.randn(N_).astype(np.float32))
+    s = -1.0 if conj else 1.0
+    f = lambda a: a.astype(np.float64)  # noqa: E731
+    t1, t2 = f(ar) @ f(br).T, s * (f(ai) @ f(bi).T)
+    t3 = f(bf16_round(ar + ai)) @ f(bf16_round(br + s * bi)).T
+    mr, mi = t1 - t2 + bias[0], t3 - t1 - t2 + bias[1]
+    q = lambda a: T(np.ascontiguousarray(a), torch.bfloat16)  # noqa: E731
+    ta, tb = lay[0] == "t", lay[1] == "t"
+    A = (q(ar.T), q(ai.T), (1, M)) if ta else (q(ar), q(ai), (K, 1))
+    Bm = (q(br.T), q(bi.T), (1, N_)) if tb else (q(br), q(bi), (K, 1))
+    cr, ci = ops.cgemm(A[0], A[1], A[2], Bm[0], Bm[1], Bm[2], M, N_, K, conj_b=conj,
+                       bias=(T(bias[0]), T(bias[1])), out_dtype=torch.float32, algo=1)
+    scale = float(max(np.abs(t1).max(), np.abs(t3).max()))
+    tol = (2e-6 * np.sqrt(K) * 4 + 1e-6) * scale
+    np.testing.assert_allclose(N(cr), mr, rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(N(ci), mi, rtol=1e-5, atol=tol)
+    true = (f(ar) + 1j * f(ai)) @ ((f(br) + 1j * s * f(bi))).T + (bias[0] + 1j * bias[1])
+    err = np.abs((N(cr) + 1j * N(ci)) - true).max()
+    assert err <= 2 ** -8 * np.sqrt(K) * 4 * 1.5 + 1e-3, err      # sums carry a 2^-9 relative rounding
+    c16r, c16i = ops.cgemm(A[0], A[1], A[2], Bm[0], Bm[1], Bm[2], M, N_, K, conj_b=conj,
+                           out_dtype=torch.bfloat16, algo=1)
+    np.testing.assert_allclose(N(c16r), mr - bias[0], rtol=8e-3, atol=8e-3 * scale)
+    np.testing.assert_allclose(N(c16i), mi - bias[1], rtol=8e-3, atol=8e-3 * scale)
+
+
+def test_cgemm_gauss_rejects_what_it_cannot_do(pkg):
+    """3M never degrades silently: float32 operands and strided (non-dense) operands are refused."""
+    from gpu_util import T
+    from cplxmodule_amd import ops
+    from cplxmodule_amd._lib import CplxAmdError
+    a = T(np.ones((64, 64), np.float32))
+    with pytest.raises(CplxAmdError):
+        ops.cgemm(a, a, (64, 1), a, a, (64, 1), 64, 64, 64, algo=1)
+    b = a.bfloat16()
+    with pytest.raises(CplxAmdError):
+        ops.cgemm(b, b, (64, 1), b, b, (64, 1), 64, 64, 32, algo=1)     # lda != K
+
+
+@pytest.mark.parametrize("B,I,O", [(96, 128, 96), (96, 128, 72), (50, 40, 24)])
+def test_linear_3m_layer_fwd_bwd(pkg, B, I, O):
+    """cplx.linear_3m (cplxmodule/cplx.py:669-694) against cplx.linear on bf16 activations:
+    forward and all gradients agree to the bf16-sum rounding (shapes the 3M entry refuses run
+    the 4M kernel at the layer level)."""
+    from gpu_util import DEV
+    from cplxmodule_amd import Cplx, cplx
+    torch.manual_seed(1)
+    w = Cplx(torch.randn(O, I, device=DEV, requires_grad=True), torch.randn(O, I, device=DEV, requires_grad=True))
+    b = Cplx(torch.randn(O, device=DEV, requires_grad=True), torch.randn(O, device=DEV, requires_grad=True))
+    x = Cplx(torch.randn(B, I, device=DEV).bfloat16().requires_grad_(True),
+             torch.randn(B, I, device=DEV).bfloat16().requires_grad_(True))
+    outs = []
+    for fn in (cplx.linear, cplx.linear_3m):
+        for t in (w.real, w.imag, b.real, b.imag, x.real, x.imag):
+            t.grad = None
+        y = fn(x, w, b)
+        torch.autograd.backward((y.real, y.imag), (torch.ones_like(y.real), 0.5 * torch.ones_like(y.imag)))
+        outs.append([y.real.float(), y.imag.float()] + [t.grad.float() for t in (w.real, w.imag, b.real, b.imag, x.real, x.imag)])
+    for a_, b_ in zip(*outs):
+        scale = float(a_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 3e-2 * scale
+
+
 @pytest.mark.parametrize("M,N_,K", [(128, 128, 64), (70, 190, 96), (64, 64, 24), (128, 256, 4096)])
 def test_rgemm_bf16_and_f32(pkg, M, N_, K):
     from gpu_util import T, N, bf16_round
