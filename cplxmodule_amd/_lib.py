@@ -37,6 +37,8 @@ SIGNATURES = {
                       _I, _I, _I, _P, _L, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
+    "cplxamd_nhwc_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],
     "cplxamd_abs2": [_P, _P, _P, _L, _I, _I, _P],
     "cplxamd_modulus": [_P, _P, _P, _L, _P],

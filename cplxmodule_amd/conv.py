@@ -62,9 +62,49 @@ def _repack_dgrad(w, groups):
     return w.view(groups, Co // groups, Cg, KH, KW).permute(0, 2, 1, 3, 4).contiguous()
 
 
+def nhwc_pad(x, ph, pw):
+    """planar NCHW bf16 -> zero-padded channels-last [B, H+2ph, W+2pw, C]."""
+    B, C, H, W = x.shape
+    out = torch.empty(B, H + 2 * ph, W + 2 * pw, C, dtype=torch.bfloat16, device=x.device)
+    call("cplxamd_nhwc_pad", ptr(x), ptr(out), B, C, H, W, ph, pw, stream_ptr())
+    return out
+
+
+def _rows_ok(geom, C, ph, pw):
+    """Shapes the shifted-row kernel (csrc/conv_nhwc.hip) takes: stride 1, groups 1, C % 32 == 0."""
+    B, H, W = geom[0], geom[3], geom[4]
+    return (geom[7] == 1 and geom[8] == 1 and geom[13] == 1 and C % 32 == 0 and ph >= 0 and pw >= 0
+            and (geom[6] - 1) * geom[12] <= 32 and B * (H + 2 * ph) * (W + 2 * pw) < 2 ** 31)
+
+
+def _pack_rows(w, swap):
+    """[Co, Ci, KH, KW] -> [KH][KW][C/16][N][16] for the shifted-row kernel: (C, N) = (Ci, Co) for
+    the forward, (Co, Ci) with both spatial dims flipped for the data gradient (`swap`)."""
+    if swap:
+        w = w.flip(2, 3).transpose(0, 1)
+    N, C, KH, KW = w.shape
+    return w.reshape(N, C // 16, 16, KH, KW).permute(3, 4, 1, 0, 2).contiguous()
+
+
+def _conv_rows(xr, xi, wpr, wpi, br, bi, yr, yi, C, Cout, geom, ph, pw, conj):
+    """One launch of the shifted-row kernel on (padded copies of) xr / xi."""
+    xpr = nhwc_pad(xr, ph, pw)
+    xpi = None if xi is None else nhwc_pad(xi, ph, pw)
+    B, Hp, Wp = xpr.shape[0], xpr.shape[1], xpr.shape[2]
+    return try_call("cplxamd_conv2d_nhwc", ptr(xpr), ptr(xpi), ptr(wpr), ptr(wpi), ptr(br), ptr(bi),
+                    ptr(yr), ptr(yi), B, Hp, Wp, C, Cout, geom[5], geom[6], geom[11], geom[12],
+                    int(conj), dtype_code(yr), stream_ptr())
+
+
 def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape):
     yr = torch.empty(out_shape, dtype=xr.dtype, device=xr.device)
     yi = None if xi is None else torch.empty_like(yr)
+    if xr.dtype == torch.bfloat16 and _rows_ok(geom, geom[1], geom[9], geom[10]):
+        wpr = _pack_rows(wr, False)
+        wpi = None if wi is None else _pack_rows(wi, False)
+        if _conv_rows(xr, xi, wpr, wpi, br, bi, yr, yi, geom[1], geom[2], geom, geom[9], geom[10],
+                      False):
+            return yr, yi
     if xr.dtype == torch.bfloat16 and try_call(
             "cplxamd_conv2d_bf16_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
             ptr(yi), geom, ptr(_ktab(geom, 0, xr.device)), stream_ptr()):
@@ -77,6 +117,15 @@ def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape):
 def conv_dgrad(gr, gi, wr, wi, geom, x_shape):
     dxr = torch.empty(x_shape, dtype=gr.dtype, device=gr.device)
     dxi = None if gi is None else torch.empty_like(dxr)
+    # full correlation of the padded output gradient with the flipped, conjugated weight
+    qh, qw = (geom[5] - 1) * geom[11] - geom[9], (geom[6] - 1) * geom[12] - geom[10]
+    ggeom = list(geom)
+    ggeom[3], ggeom[4] = gr.shape[2], gr.shape[3]
+    if gr.dtype == torch.bfloat16 and _rows_ok(ggeom, geom[2], qh, qw):
+        wdr = _pack_rows(wr, True)
+        wdi = None if wi is None else _pack_rows(wi, True)
+        if _conv_rows(gr, gi, wdr, wdi, None, None, dxr, dxi, geom[2], geom[1], geom, qh, qw, True):
+            return dxr, dxi
     if gr.dtype == torch.bfloat16 and geom[7] == 1 and geom[8] == 1:
         wtr = _repack_dgrad(wr, geom[13])
         wti = None if wi is None else _repack_dgrad(wi, geom[13])

@@ -232,6 +232,25 @@ int64_t cplxamd_conv2d_bf16_wgrad_ws_bytes(const int* geom, int cplx);
 int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, const void* xi,
                               const float* emul, float* dwr, float* dwi, const int* geom,
                               const int* ktab, void* ws, int64_t ws_bytes, void* stream);
+
+/* bf16 convolution, stride 1, groups 1, as ONE shifted-row MFMA GEMM over a zero-padded
+ * channels-last copy of the input (conv_nhwc.hip): no gathers, operands move by LDS-DMA.
+ *   cplxamd_nhwc_pad : planar NCHW bf16 x[B,C,H,W] -> out[B, H+2*pad_h, W+2*pad_w, C] (C % 8 == 0)
+ *   cplxamd_conv2d_nhwc : y[b,co,ho,wo] = sum_{kh,kw,c} xp[b, ho+kh*dil_h, wo+kw*dil_w, c] *
+ *                         op(w[co, kh, kw, c]) (+ bias[co]),  Ho = Hp-(KH-1)*dil_h, Wo likewise;
+ *       xp_* padded channels-last bf16, w_* bf16 [KH][KW][C/16][Cout][16] (C % 32 == 0,
+ *       (KW-1)*dil_w <= 32), y_* planar NCHW of out_dtype; xp_i == NULL: real convolution;
+ *       conj_w: use conj(w).
+ * Forward: w[kh][kw][c/16][co][c%16] = weight[co][c][kh][kw].  Data gradient: the same call on the
+ * output gradient padded by (K-1)*dil - pad, with the roles of the two channel dimensions swapped,
+ * the kernel flipped in both spatial dimensions, and conj_w = 1.
+ * Replaces the same reference code as cplxamd_conv2d_fwd / _dgrad (cplx.py:717-838). */
+int cplxamd_nhwc_pad(const void* x, void* out, int B, int C, int H, int W, int pad_h, int pad_w,
+                     void* stream);
+int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, const void* w_i,
+                        const float* bias_r, const float* bias_i, void* y_r, void* y_i, int B,
+                        int Hp, int Wp, int C, int Cout, int KH, int KW, int dil_h, int dil_w,
+                        int conj_w, int out_dtype, void* stream);
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);

@@ -125,6 +125,10 @@ def test_conv_bf16_and_larger_vs_oracle():
     dict(B=2, Ci=64, Co=64, H=12, W=13, k=3, stride=1, padding=2, dilation=2, groups=2),
     dict(B=2, Ci=32, Co=32, H=15, W=14, k=(3, 1), stride=2, padding=(1, 0), dilation=1, groups=1),
     dict(B=1, Ci=64, Co=96, H=9, W=9, k=1, stride=1, padding=0, dilation=1, groups=1),
+    # shifted-row kernel (conv_nhwc.hip) for forward AND dgrad: Ci % 32 == Co % 32 == 0
+    dict(B=3, Ci=32, Co=160, H=23, W=19, k=3, stride=1, padding=(2, 1), dilation=(2, 1), groups=1),
+    dict(B=2, Ci=64, Co=32, H=14, W=37, k=(3, 2), stride=1, padding=(1, 0), dilation=1, groups=1),
+    dict(B=5, Ci=96, Co=64, H=11, W=10, k=(1, 5), stride=1, padding=(0, 4), dilation=1, groups=1),
 ])
 def test_conv_bf16_fast_path_vs_oracle(cfg):
     """Shapes that take the bf16-MFMA conv kernels (K % 32 == 0): forward, dgrad (incl. the
@@ -156,3 +160,36 @@ def test_conv_bf16_fast_path_vs_oracle(cfg):
     got = dict(dxr=txr.grad, dxi=txi.grad, dwr=twr.grad, dwi=twi.grad, dbr=tbr.grad, dbi=tbi.grad)
     for n, t in got.items():
         np.testing.assert_allclose(N(t), bw[n], rtol=2e-2, atol=2e-2 * np.abs(bw[n]).max(), err_msg=n)
+
+
+@pytest.mark.parametrize("B,C,H,W,ph,pw", [(2, 64, 9, 13, 0, 0), (3, 40, 7, 70, 2, 1), (1, 136, 5, 4, 1, 3)])
+def test_nhwc_pad_exact(B, C, H, W, ph, pw):
+    """cplxamd_nhwc_pad is a pure data movement: identical to permute + zero pad."""
+    from gpu_util import DEV
+    from cplxmodule_amd import conv
+    torch.manual_seed(0)
+    x = torch.randn(B, C, H, W, device=DEV).bfloat16()
+    got = conv.nhwc_pad(x, ph, pw)
+    ref = torch.nn.functional.pad(x.float(), (pw, pw, ph, ph)).permute(0, 2, 3, 1).contiguous()
+    assert got.shape == ref.shape
+    assert torch.equal(got.float(), ref)
+
+
+def test_real_conv_bf16_rows_kernel_vs_oracle():
+    """Real convolution (and its dgrad) through the shifted-row kernel."""
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import conv
+    rs = np.random.RandomState(11)
+    B, Ci, Co, H, W = 2, 32, 64, 16, 18
+    x, w = bf16_round(rs.randn(B, Ci, H, W)), bf16_round(rs.randn(Co, Ci, 3, 3) * 0.1)
+    b = rs.randn(Co).astype(np.float32)
+    tx, tw, tb = T(x, torch.bfloat16).requires_grad_(True), T(w).requires_grad_(True), T(b).requires_grad_(True)
+    y = conv.RealConv2dFn.apply(tx, tw, tb, 1, 1, 1, 1)
+    f = np.float64
+    ref = orc.real_conv2d(x.astype(f), w.astype(f), padding=1) + b.astype(f)[None, :, None, None]
+    np.testing.assert_allclose(N(y), ref, rtol=1e-2, atol=1e-2 * np.abs(ref).max())
+    g = bf16_round(rs.randn(*ref.shape))
+    (y * T(g, torch.bfloat16)).sum().backward()
+    dx, dw = orc.real_conv2d_bwd(g.astype(f), x.astype(f), w.astype(f), padding=1)
+    for n, t, r in (("dx", tx.grad, dx), ("dw", tw.grad, dw), ("db", tb.grad, g.astype(f).sum((0, 2, 3)))):
+        np.testing.assert_allclose(N(t), r, rtol=2e-2, atol=2e-2 * np.abs(r).max(), err_msg=n)
