@@ -20,8 +20,8 @@
 //
 // The K loop of a convolution is short (KH * C / 32 = 6 stages for 3x3 x 64 channels), so the
 // per-tile prologue (first stage latency) and epilogue weigh as much as the main loop.  Hence:
-//  * 256-row x 64-channel tiles, 4 waves x (64 x 64), 2-stage ring = 72 KiB LDS, so TWO workgroups
-//    share a CU and one's epilogue / prologue overlaps the other's MFMAs;
+//  * 256-row x 64-channel tiles, 4 waves x (64 x 64), 2-stage ring = 76 KiB LDS, so TWO workgroups
+//    share a CU (128-row tiles with four workgroups per CU measured 6 % slower) and one's epilogue / prologue overlaps the other's MFMAs;
 //  * the epilogue transposes the accumulators through LDS and writes each channel's 256 pixels as
 //    one contiguous run (the direct MFMA C layout would scatter 16-B pieces over 32 channel planes:
 //    measured 1.06 ms of a 3.06 ms kernel).
@@ -41,7 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace cn {
 
-constexpr int BK = 32, BM = 256, BN = 64, NT = 256;
+constexpr int BK = 32, BM = 256, BN = 64, NT = BM;
 constexpr int MAX_EXTRA = 32;                       // (KW-1)*dil_w rows of halo at most
 constexpr int OUT_LD = BM + 8;                      // epilogue image [channel][pixel], padded rows
 
@@ -53,6 +53,7 @@ struct Args {
   int64_t rows;                 // B * Hp * Wp
   int B, Hp, Wp, C, Cout, KH, KW, dil_h, dil_w, Ho, Wo;
   int srows;                    // staged input rows per tile: BM + (KW-1)*dil_w
+  int npieces;                  // LDS-DMA pieces per stage that carry data (the rest go to a dump slot)
   int dbg;                      // ablation bit (CPLXAMD_CONV_DBG): 4 no stores
 };
 
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
   const int nk = g.KH * cpt;                      // stages: (kh, channel chunk)
   const int nA = g.srows * 4;                     // 16-B chunks per plane
   const int plane_bytes = nA * 16;
-  constexpr int stage_bytes = NPC * NT * 16;      // [A_r | A_i] padded to whole pieces
+  const int stage_bytes = g.npieces * NT * 16;    // [A_r | A_i] padded to whole pieces
+  char* const dump = smem + 2 * stage_bytes;      // where the (fixed-count) surplus pieces land
 
   f32x16 acc_r[2][2], acc_i[2][2];
 #pragma unroll
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
     grow = grow < g.rows ? grow : g.rows - 1;                    // rows past the end feed dropped outputs
     const bf16_t* base = plane ? g.x_i : g.x_r;
     glds16(base + grow * g.C + c0 + (((c & 3) ^ ((row >> 2) & 3)) << 3),
-           smem + buf * stage_bytes + (q * NT + wave_chunk) * 16);
+           q < g.npieces ? smem + buf * stage_bytes + (q * NT + wave_chunk) * 16 : dump + wave_chunk * 16);
   };
 
   // weight fragments of (stage kt, tap kw, K sub-step ks) straight from global memory
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
   TOUT* yi = reinterpret_cast<TOUT*>(g.y_i);
   const int64_t plane_sz = (int64_t)g.Ho * g.Wo;
   // this thread's 8 pixels (same for every channel it stores)
-  const int m8 = (tid & 31) * 8;
+  constexpr int MT = BM / 8, NR = NT / MT;                      // threads per pixel row, channels per sweep
+  const int m8 = (tid % MT) * 8;
   int64_t off[8];
   bool ok[8];
   {
@@ -280,8 +283,8 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
       const TOUT* src = img_lds + (PASSES == 2 ? 0 : pl) * BN * OUT_LD;
       TOUT* out = pl ? yi : yr;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int n = (tid >> 5) + 8 * r;
+      for (int r = 0; r < BN / NR; ++r) {
+        const int n = tid / MT + NR * r;
         if (n0 + n >= g.Cout) continue;
         const TOUT* p = src + n * OUT_LD + m8;
         TOUT* o = out + (int64_t)(n0 + n) * plane_sz;
@@ -359,8 +362,8 @@ static int launch_conj(const Args& g0, bool conj, hipStream_t st) {
   Args g = g0;
   static const int dbg = getenv("CPLXAMD_CONV_DBG") ? atoi(getenv("CPLXAMD_CONV_DBG")) : 0;
   g.dbg = dbg;
-  constexpr int NPC = (CPLX ? 2 : 1) * (BM + MAX_EXTRA) * 4 / NT + 1;
-  int smem = 2 * NPC * NT * 16;
+  g.npieces = ((CPLX ? 2 : 1) * g.srows * 4 + NT - 1) / NT;
+  int smem = (2 * g.npieces + 1) * NT * 16;
   const int out_img = (sizeof(TOUT) == 2 ? (CPLX ? 2 : 1) : 1) * BN * OUT_LD * (int)sizeof(TOUT);
   smem = smem > out_img ? smem : out_img;
   const int64_t tiles = ((g.rows + BM - 1) / BM) * ((g.Cout + BN - 1) / BN);
@@ -424,7 +427,7 @@ int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, con
   if (B == 0) return 0;
   cn::Args g{(const bf16_t*)xp_r, (const bf16_t*)xp_i, (const bf16_t*)w_r, (const bf16_t*)w_i,
              bias_r, bias_i, y_r, y_i, rows, B, Hp, Wp, C, Cout, KH, KW, dil_h, dil_w, Ho, Wo,
-             cn::BM + (KW - 1) * dil_w, 0};
+             cn::BM + (KW - 1) * dil_w, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = out_dtype == CPLXAMD_F32;
   if (cplx)
