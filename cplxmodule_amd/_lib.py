@@ -37,7 +37,9 @@ SIGNATURES = {
                       _I, _I, _I, _P, _L, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
-    "cplxamd_nhwc_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cplxamd_nhwc_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cplxamd_conv2d_nhwc_wgrad_ws_bytes": [_I] * 8,
+    "cplxamd_conv2d_nhwc_wgrad": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
     "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],
     "cplxamd_abs2": [_P, _P, _P, _L, _I, _I, _P],
@@ -67,7 +69,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,
-             "cplxamd_cgemm3m_ws_bytes": c_int64}
+             "cplxamd_cgemm3m_ws_bytes": c_int64,
+             "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64}
 
 _lib = None
 

@@ -62,12 +62,18 @@ def _repack_dgrad(w, groups):
     return w.view(groups, Co // groups, Cg, KH, KW).permute(0, 2, 1, 3, 4).contiguous()
 
 
-def nhwc_pad(x, ph, pw):
-    """planar NCHW bf16 -> zero-padded channels-last [B, H+2ph, W+2pw, C]."""
+def nhwc_pad(x, ph, pw, Hp=None, Wp=None, tail_rows=0):
+    """planar NCHW bf16 -> zero-padded channels-last [B, Hp, Wp, C] (default: symmetric padding).
+    tail_rows: extra zero rows of C appended after the last image (the wgrad kernel's K padding)."""
     B, C, H, W = x.shape
-    out = torch.empty(B, H + 2 * ph, W + 2 * pw, C, dtype=torch.bfloat16, device=x.device)
-    call("cplxamd_nhwc_pad", ptr(x), ptr(out), B, C, H, W, ph, pw, stream_ptr())
-    return out
+    Hp = H + 2 * ph if Hp is None else Hp
+    Wp = W + 2 * pw if Wp is None else Wp
+    rows = B * Hp * Wp
+    buf = torch.empty(rows + tail_rows, C, dtype=torch.bfloat16, device=x.device)
+    call("cplxamd_nhwc_pad", ptr(x), ptr(buf), B, C, H, W, ph, pw, Hp, Wp, stream_ptr())
+    if tail_rows:
+        buf[rows:].zero_()
+    return buf[:rows].view(B, Hp, Wp, C)
 
 
 def _rows_ok(geom, C, ph, pw):
@@ -137,9 +143,37 @@ def conv_dgrad(gr, gi, wr, wi, geom, x_shape):
     return dxr, dxi
 
 
+def _wgrad_rows(gr, gi, xr, xi, geom, w_shape, emul):
+    """Weight gradient on channels-last copies (csrc/conv_nhwc_wgrad.hip); False if not eligible."""
+    B, Ci, Co, KH, KW = geom[0], geom[1], geom[2], geom[5], geom[6]
+    if not (_rows_ok(geom, 32, geom[9], geom[10]) and Ci % 8 == 0 and Co % 8 == 0 and KW <= 4):
+        return None
+    cplx = gi is not None
+    Hp, Wp = geom[3] + 2 * geom[9], geom[4] + 2 * geom[10]
+    xtail = 32 + (KH - 1) * geom[11] * Wp + (KW - 1) * geom[12]
+    xpr = nhwc_pad(xr, geom[9], geom[10], tail_rows=xtail)
+    xpi = nhwc_pad(xi, geom[9], geom[10], tail_rows=xtail) if cplx else None
+    tail = (-(B * Hp * Wp)) % 32
+    gpr = nhwc_pad(gr, 0, 0, Hp, Wp, tail_rows=tail)
+    gpi = nhwc_pad(gi, 0, 0, Hp, Wp, tail_rows=tail) if cplx else None
+    nbytes = int(_lib.load().cplxamd_conv2d_nhwc_wgrad_ws_bytes(B, Hp, Wp, Ci, Co, KH, KW, int(cplx)))
+    ws = _scratch(gr.device, nbytes)
+    dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)
+    dwi = torch.empty_like(dwr) if cplx else None
+    if try_call("cplxamd_conv2d_nhwc_wgrad", ptr(gpr), ptr(gpi), ptr(xpr), ptr(xpi), ptr(emul),
+                ptr(dwr), ptr(dwi), B, Hp, Wp, Ci, Co, KH, KW, geom[11], geom[12], ptr(ws),
+                ws.numel(), stream_ptr()):
+        return dwr, dwi
+    return None
+
+
 def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
     lib = _lib.load()
     cplx = gi is not None
+    if gr.dtype == torch.bfloat16:
+        out = _wgrad_rows(gr, gi, xr, xi, geom, w_shape, emul)
+        if out is not None:
+            return out
     if gr.dtype == torch.bfloat16:
         nbytes = int(lib.cplxamd_conv2d_bf16_wgrad_ws_bytes(geom, int(cplx)))
         ws = _scratch(gr.device, nbytes)

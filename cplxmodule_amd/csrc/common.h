@@ -39,6 +39,23 @@ template <> struct io<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// One LDS-DMA instruction (global_load_lds_dwordx4): every lane moves the 16 bytes at its global
+// address straight into LDS at  lds_wave_base + lane * 16  (no VGPR round trip).
+// Issued as inline asm ON PURPOSE: the compiler treats the builtin as an LDS store that may alias
+// every later ds_read and inserts `s_waitcnt vmcnt(0)` in front of those reads, which silently
+// turns a multi-stage ring into a fully synchronous copy (found in the ISA of the round-1 kernels:
+// a vmcnt(0) right behind every counted wait).  With the asm form the compiler does not track the
+// transfer at all; the kernels order LDS-DMA writes against reads themselves with counted
+// `s_waitcnt vmcnt(N)` + `s_barrier`.  M0 carries the wave-uniform LDS byte address (the low 32
+// bits of a flat LDS pointer are the LDS offset); the compiler itself never uses M0 on gfx9+.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, const void* lds_wave_base) {
+  const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :
+               : "s"(m0), "v"(gsrc)
+               : "memory");
+}
+
 // 4-wide vector access (16 B for float, 8 B for bf16)
 struct f4 { float v[4]; };
 __device__ __forceinline__ f4 ld4(const float* p) {

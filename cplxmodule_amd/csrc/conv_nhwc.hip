@@ -58,8 +58,7 @@ struct Args {
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  lds_dma16(gsrc, lds_wave_base);     // common.h: inline asm, invisible to the compiler's waitcnt pass
 }
 
 // 8 consecutive k of LDS row `row` (16-B chunk kc of 4); chunk slots XOR-swizzled per row group
@@ -310,6 +309,8 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
 constexpr int TP = 64;
 struct __attribute__((packed, aligned(2))) bf4_t { bf16_t v[4]; };
 
+// (ph, pw) = rows / columns of zeros before the image; the rest of the Hp x Wp grid after it is
+// zero too.
 __global__ __launch_bounds__(256) void nhwc_pad_kernel(const bf16_t* __restrict__ x,
                                                        bf16_t* __restrict__ out, int B, int C, int H,
                                                        int W, int ph, int pw, int Hp, int Wp) {
@@ -390,13 +391,13 @@ using namespace cplxamd;
 extern "C" {
 
 int cplxamd_nhwc_pad(const void* x, void* out, int B, int C, int H, int W, int pad_h, int pad_w,
-                     void* stream) {
-  if (!x || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0)
+                     int Hp, int Wp, void* stream) {
+  if (!x || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 ||
+      Hp < H + pad_h || Wp < W + pad_w)
     return CPLXAMD_EINVAL;
   if (C % 8) return CPLXAMD_ESHAPE;
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return CPLXAMD_EALIGN;
   if (B == 0) return 0;
-  const int Hp = H + 2 * pad_h, Wp = W + 2 * pad_w;
   const int ctiles = (C + cn::TP - 1) / cn::TP;
   if ((int64_t)B * ctiles > 65535 || Hp > 65535) return CPLXAMD_ESHAPE;
   dim3 grid((Wp + cn::TP - 1) / cn::TP, Hp, B * ctiles);

@@ -52,9 +52,7 @@ struct Cfg {
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(
-      (const __attribute__((address_space(1))) void*)gsrc,
-      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  lds_dma16(gsrc, lds_wave_base);     // common.h: inline asm, invisible to the compiler's waitcnt pass
 }
 
 // One LDS-DMA instruction: piece j (of ROWS*4/NT) of a plane tile.

@@ -235,7 +235,8 @@ int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, co
 
 /* bf16 convolution, stride 1, groups 1, as ONE shifted-row MFMA GEMM over a zero-padded
  * channels-last copy of the input (conv_nhwc.hip): no gathers, operands move by LDS-DMA.
- *   cplxamd_nhwc_pad : planar NCHW bf16 x[B,C,H,W] -> out[B, H+2*pad_h, W+2*pad_w, C] (C % 8 == 0)
+ *   cplxamd_nhwc_pad : planar NCHW bf16 x[B,C,H,W] -> out[B, Hp, Wp, C] (C % 8 == 0) with the image at
+ *       rows pad_h.., columns pad_w.. and zeros elsewhere (Hp >= H + pad_h, Wp >= W + pad_w)
  *   cplxamd_conv2d_nhwc : y[b,co,ho,wo] = sum_{kh,kw,c} xp[b, ho+kh*dil_h, wo+kw*dil_w, c] *
  *                         op(w[co, kh, kw, c]) (+ bias[co]),  Ho = Hp-(KH-1)*dil_h, Wo likewise;
  *       xp_* padded channels-last bf16, w_* bf16 [KH][KW][C/16][Cout][16] (C % 32 == 0,
@@ -246,11 +247,25 @@ int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, co
  * the kernel flipped in both spatial dimensions, and conj_w = 1.
  * Replaces the same reference code as cplxamd_conv2d_fwd / _dgrad (cplx.py:717-838). */
 int cplxamd_nhwc_pad(const void* x, void* out, int B, int C, int H, int W, int pad_h, int pad_w,
-                     void* stream);
+                     int Hp, int Wp, void* stream);
 int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, const void* w_i,
                         const float* bias_r, const float* bias_i, void* y_r, void* y_i, int B,
                         int Hp, int Wp, int C, int Cout, int KH, int KW, int dil_h, int dil_w,
                         int conj_w, int out_dtype, void* stream);
+
+/* Weight gradient on the same channels-last copies (conv_nhwc_wgrad.hip):
+ *   dw[co, ci, kh, kw] = sum_r gp[r][co] * conj(xp[r + kh*dil_h*Wp + kw*dil_w][ci]) (* emul, real only)
+ * over the rows r = (b, hp, wp) of the padded input grid.  gp_*: the output gradient laid on that
+ * grid by cplxamd_nhwc_pad(g, .., pad_h = 0, pad_w = 0, Hp, Wp).  Both buffers carry ZERO tail rows
+ * after the last image so that the kernel never clamps a row: gp up to a multiple of 32 rows, xp
+ * 32 + (KH-1)*dil_h*Wp + (KW-1)*dil_w rows.  Ci % 8 == Co % 8 == 0, KW <= 4.  dw_* float32
+ * [Co, Ci, KH, KW]; ws >= cplxamd_conv2d_nhwc_wgrad_ws_bytes. */
+int64_t cplxamd_conv2d_nhwc_wgrad_ws_bytes(int B, int Hp, int Wp, int Ci, int Co, int KH, int KW,
+                                           int cplx);
+int cplxamd_conv2d_nhwc_wgrad(const void* gp_r, const void* gp_i, const void* xp_r, const void* xp_i,
+                              const float* emul, float* dw_r, float* dw_i, int B, int Hp, int Wp,
+                              int Ci, int Co, int KH, int KW, int dil_h, int dil_w, void* ws,
+                              int64_t ws_bytes, void* stream);
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);
