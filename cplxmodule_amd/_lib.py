@@ -40,7 +40,7 @@ SIGNATURES = {
     "cplxamd_nhwc_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "cplxamd_conv2d_nhwc_wgrad_ws_bytes": [_I] * 8,
     "cplxamd_conv2d_nhwc_wgrad": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
-    "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
+    "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_L] + [_I] * 5 + [_P],
     "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],
     "cplxamd_abs2": [_P, _P, _P, _L, _I, _I, _P],
     "cplxamd_modulus": [_P, _P, _P, _L, _P],

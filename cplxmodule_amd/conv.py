@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, ops
-from ._lib import call, try_call, dtype_code, ptr, require_device, stream_ptr
+from ._lib import CplxAmdError, call, try_call, dtype_code, ptr, require_device, stream_ptr
 from .cplx import Cplx
 
 _ws_cache = {}
@@ -62,25 +62,76 @@ def _repack_dgrad(w, groups):
     return w.view(groups, Co // groups, Cg, KH, KW).permute(0, 2, 1, 3, 4).contiguous()
 
 
-def nhwc_pad(x, ph, pw, Hp=None, Wp=None, tail_rows=0):
-    """planar NCHW bf16 -> zero-padded channels-last [B, Hp, Wp, C] (default: symmetric padding).
-    tail_rows: extra zero rows of C appended after the last image (the wgrad kernel's K padding)."""
+def nhwc_pad(x, ph, pw, Hp=None, Wp=None, head_rows=0, tail_rows=0):
+    """planar NCHW bf16 -> zero-padded channels-last grid [B, Hp, Wp, C] (default: symmetric
+    padding), inside a buffer with `head_rows` / `tail_rows` extra zero rows of C before / after
+    the grid (the kernels index rows relative to the grid and never clamp inside those)."""
     B, C, H, W = x.shape
     Hp = H + 2 * ph if Hp is None else Hp
     Wp = W + 2 * pw if Wp is None else Wp
     rows = B * Hp * Wp
-    buf = torch.empty(rows + tail_rows, C, dtype=torch.bfloat16, device=x.device)
-    call("cplxamd_nhwc_pad", ptr(x), ptr(buf), B, C, H, W, ph, pw, Hp, Wp, stream_ptr())
+    buf = torch.empty(head_rows + rows + tail_rows, C, dtype=torch.bfloat16, device=x.device)
+    grid = buf[head_rows:head_rows + rows]
+    call("cplxamd_nhwc_pad", ptr(x), ptr(grid), B, C, H, W, ph, pw, Hp, Wp, stream_ptr())
+    if head_rows:
+        buf[:head_rows].zero_()
     if tail_rows:
-        buf[rows:].zero_()
-    return buf[:rows].view(B, Hp, Wp, C)
+        buf[head_rows + rows:].zero_()
+    return grid.view(B, Hp, Wp, C)
 
 
-def _rows_ok(geom, C, ph, pw):
-    """Shapes the shifted-row kernel (csrc/conv_nhwc.hip) takes: stride 1, groups 1, C % 32 == 0."""
-    B, H, W = geom[0], geom[3], geom[4]
-    return (geom[7] == 1 and geom[8] == 1 and geom[13] == 1 and C % 32 == 0 and ph >= 0 and pw >= 0
-            and (geom[6] - 1) * geom[12] <= 32 and B * (H + 2 * ph) * (W + 2 * pw) < 2 ** 31)
+# ---- eligibility of the channels-last ("rows") kernels: stride 1, groups 1, bf16 ------------- #
+def _grid(geom):
+    return geom[3] + 2 * geom[9], geom[4] + 2 * geom[10]             # Hp, Wp of the input grid
+
+
+def _rows_base_ok(geom):
+    Hp, Wp = _grid(geom)
+    return (geom[7] == 1 and geom[8] == 1 and geom[13] == 1 and (geom[6] - 1) * geom[12] <= 32
+            and geom[0] * Hp * Wp < 2 ** 31)
+
+
+def _rows_fwd_ok(geom):
+    return _rows_base_ok(geom) and geom[1] % 32 == 0
+
+
+def _rows_dgrad_ok(geom):
+    return _rows_base_ok(geom) and geom[2] % 32 == 0
+
+
+def _rows_wgrad_ok(geom, cplx):
+    Hp, Wp = _grid(geom)
+    KH, KW = geom[5], geom[6]
+    span = geom[0] * Hp * Wp + 64 + KH * geom[11] * Wp
+    if not (_rows_base_ok(geom) and geom[1] % 8 == 0 and geom[2] % 8 == 0
+            and span * max(geom[1], geom[2]) < 2 ** 31):
+        return False
+    if KH == 1 and KW == 1:
+        return True                      # 1x1: the (T, T) GEMM of the linear layer on the two grids
+    # KW waves stage 32 + 32 + (KW-1)*dil_w rows of 8 chunks per plane in at most 8 pieces each
+    chunks = (2 if cplx else 1) * 8 * (64 + (KW - 1) * geom[12])
+    return KW <= 4 and -(-chunks // (64 * KW)) <= 8
+
+
+def _shift_rows(geom):
+    """Largest tap shift in grid rows: (KH-1)*dil_h*Wp + (KW-1)*dil_w."""
+    return (geom[5] - 1) * geom[11] * _grid(geom)[1] + (geom[6] - 1) * geom[12]
+
+
+def input_grid(xr, xi, geom):
+    """Channels-last copy of the (padded) input: read by the forward and by the weight gradient."""
+    tail = 32 + _shift_rows(geom)
+    return (nhwc_pad(xr, geom[9], geom[10], tail_rows=tail),
+            None if xi is None else nhwc_pad(xi, geom[9], geom[10], tail_rows=tail))
+
+
+def grad_grid(gr, gi, geom):
+    """The output gradient laid top-left on the input's padded grid: read by the data gradient
+    (backwards, hence the zero head rows) and by the weight gradient (zero tail up to 32 rows)."""
+    Hp, Wp = _grid(geom)
+    head, tail = _shift_rows(geom), 32 + (-(geom[0] * Hp * Wp)) % 32
+    return (nhwc_pad(gr, 0, 0, Hp, Wp, head_rows=head, tail_rows=tail),
+            None if gi is None else nhwc_pad(gi, 0, 0, Hp, Wp, head_rows=head, tail_rows=tail))
 
 
 def _pack_rows(w, swap):
@@ -92,45 +143,45 @@ def _pack_rows(w, swap):
     return w.reshape(N, C // 16, 16, KH, KW).permute(3, 4, 1, 0, 2).contiguous()
 
 
-def _conv_rows(xr, xi, wpr, wpi, br, bi, yr, yi, C, Cout, geom, ph, pw, conj):
-    """One launch of the shifted-row kernel on (padded copies of) xr / xi."""
-    xpr = nhwc_pad(xr, ph, pw)
-    xpi = None if xi is None else nhwc_pad(xi, ph, pw)
-    B, Hp, Wp = xpr.shape[0], xpr.shape[1], xpr.shape[2]
-    return try_call("cplxamd_conv2d_nhwc", ptr(xpr), ptr(xpi), ptr(wpr), ptr(wpi), ptr(br), ptr(bi),
-                    ptr(yr), ptr(yi), B, Hp, Wp, C, Cout, geom[5], geom[6], geom[11], geom[12],
-                    int(conj), dtype_code(yr), stream_ptr())
-
-
-def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape):
+def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape, keep_grid=False):
+    """-> (yr, yi) or, with keep_grid, (yr, yi, xp): xp = the channels-last input copies when the
+    rows kernel ran (the caller keeps them for the weight gradient), else None."""
     yr = torch.empty(out_shape, dtype=xr.dtype, device=xr.device)
     yi = None if xi is None else torch.empty_like(yr)
-    if xr.dtype == torch.bfloat16 and _rows_ok(geom, geom[1], geom[9], geom[10]):
+    done = lambda xp: (yr, yi, xp) if keep_grid else (yr, yi)  # noqa: E731
+    if xr.dtype == torch.bfloat16 and _rows_fwd_ok(geom):
+        xp = input_grid(xr, xi, geom)
+        Hp, Wp = _grid(geom)
         wpr = _pack_rows(wr, False)
         wpi = None if wi is None else _pack_rows(wi, False)
-        if _conv_rows(xr, xi, wpr, wpi, br, bi, yr, yi, geom[1], geom[2], geom, geom[9], geom[10],
-                      False):
-            return yr, yi
+        if try_call("cplxamd_conv2d_nhwc", ptr(xp[0]), ptr(xp[1]), ptr(wpr), ptr(wpi), ptr(br),
+                    ptr(bi), ptr(yr), ptr(yi), geom[0], Hp, Wp, geom[1], geom[2], geom[5], geom[6],
+                    geom[11], geom[12], 0, 0, 0, 0, out_shape[2], out_shape[3], dtype_code(yr),
+                    stream_ptr()):
+            return done(xp)
     if xr.dtype == torch.bfloat16 and try_call(
             "cplxamd_conv2d_bf16_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
             ptr(yi), geom, ptr(_ktab(geom, 0, xr.device)), stream_ptr()):
-        return yr, yi
+        return done(None)
     call("cplxamd_conv2d_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
          ptr(yi), geom, dtype_code(xr), stream_ptr())
-    return yr, yi
+    return done(None)
 
 
-def conv_dgrad(gr, gi, wr, wi, geom, x_shape):
+def conv_dgrad(gr, gi, wr, wi, geom, x_shape, gp=None):
+    """gp: grad_grid(gr, gi, geom) if the caller already made it (shared with conv_wgrad)."""
     dxr = torch.empty(x_shape, dtype=gr.dtype, device=gr.device)
     dxi = None if gi is None else torch.empty_like(dxr)
-    # full correlation of the padded output gradient with the flipped, conjugated weight
-    qh, qw = (geom[5] - 1) * geom[11] - geom[9], (geom[6] - 1) * geom[12] - geom[10]
-    ggeom = list(geom)
-    ggeom[3], ggeom[4] = gr.shape[2], gr.shape[3]
-    if gr.dtype == torch.bfloat16 and _rows_ok(ggeom, geom[2], qh, qw):
+    if gr.dtype == torch.bfloat16 and _rows_dgrad_ok(geom):
+        # dX[h, w] sits at grid position (h + ph, w + pw) and reads the gradient grid backwards
+        gp = grad_grid(gr, gi, geom) if gp is None else gp
+        Hp, Wp = _grid(geom)
         wdr = _pack_rows(wr, True)
         wdi = None if wi is None else _pack_rows(wi, True)
-        if _conv_rows(gr, gi, wdr, wdi, None, None, dxr, dxi, geom[2], geom[1], geom, qh, qw, True):
+        if try_call("cplxamd_conv2d_nhwc", ptr(gp[0]), ptr(gp[1]), ptr(wdr), ptr(wdi), None, None,
+                    ptr(dxr), ptr(dxi), geom[0], Hp, Wp, geom[2], geom[1], geom[5], geom[6],
+                    geom[11], geom[12], 1, -_shift_rows(geom), geom[9], geom[10], x_shape[2],
+                    x_shape[3], dtype_code(dxr), stream_ptr()):
             return dxr, dxi
     if gr.dtype == torch.bfloat16 and geom[7] == 1 and geom[8] == 1:
         wtr = _repack_dgrad(wr, geom[13])
@@ -143,37 +194,46 @@ def conv_dgrad(gr, gi, wr, wi, geom, x_shape):
     return dxr, dxi
 
 
-def _wgrad_rows(gr, gi, xr, xi, geom, w_shape, emul):
-    """Weight gradient on channels-last copies (csrc/conv_nhwc_wgrad.hip); False if not eligible."""
+def _wgrad_rows(gp, xp, geom, w_shape, emul):
+    """Weight gradient on the channels-last grids (csrc/conv_nhwc_wgrad.hip)."""
     B, Ci, Co, KH, KW = geom[0], geom[1], geom[2], geom[5], geom[6]
-    if not (_rows_ok(geom, 32, geom[9], geom[10]) and Ci % 8 == 0 and Co % 8 == 0 and KW <= 4):
-        return None
-    cplx = gi is not None
-    Hp, Wp = geom[3] + 2 * geom[9], geom[4] + 2 * geom[10]
-    xtail = 32 + (KH - 1) * geom[11] * Wp + (KW - 1) * geom[12]
-    xpr = nhwc_pad(xr, geom[9], geom[10], tail_rows=xtail)
-    xpi = nhwc_pad(xi, geom[9], geom[10], tail_rows=xtail) if cplx else None
-    tail = (-(B * Hp * Wp)) % 32
-    gpr = nhwc_pad(gr, 0, 0, Hp, Wp, tail_rows=tail)
-    gpi = nhwc_pad(gi, 0, 0, Hp, Wp, tail_rows=tail) if cplx else None
+    cplx = gp[1] is not None
+    Hp, Wp = _grid(geom)
+    dev = gp[0].device
+    if KH == 1 and KW == 1:
+        # dW[co, ci] = sum_r G[r, co] conj(X[r, ci]): exactly the linear layer's weight gradient on
+        # [rows, C] operands (both grids carry >= 32 zero tail rows, so K rounds up to 32 freely)
+        K = -(-(B * Hp * Wp) // 32) * 32
+        flat = lambda t, C: torch.as_strided(t, (K, C), (C, 1))  # noqa: E731
+        if cplx:
+            dwr, dwi = ops._cplx_linear_dw(flat(gp[0], Co), flat(gp[1], Co), flat(xp[0], Ci),
+                                           flat(xp[1], Ci))
+            return dwr.view(w_shape), dwi.view(w_shape)
+        em = None if emul is None else emul.reshape(Co, Ci)
+        return ops._real_linear_dw(flat(gp[0], Co), flat(xp[0], Ci), emul=em).view(w_shape), None
     nbytes = int(_lib.load().cplxamd_conv2d_nhwc_wgrad_ws_bytes(B, Hp, Wp, Ci, Co, KH, KW, int(cplx)))
-    ws = _scratch(gr.device, nbytes)
-    dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)
+    ws = _scratch(dev, nbytes)
+    dwr = torch.empty(w_shape, dtype=torch.float32, device=dev)
     dwi = torch.empty_like(dwr) if cplx else None
-    if try_call("cplxamd_conv2d_nhwc_wgrad", ptr(gpr), ptr(gpi), ptr(xpr), ptr(xpi), ptr(emul),
+    if try_call("cplxamd_conv2d_nhwc_wgrad", ptr(gp[0]), ptr(gp[1]), ptr(xp[0]), ptr(xp[1]), ptr(emul),
                 ptr(dwr), ptr(dwi), B, Hp, Wp, Ci, Co, KH, KW, geom[11], geom[12], ptr(ws),
                 ws.numel(), stream_ptr()):
         return dwr, dwi
     return None
 
 
-def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
+def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None, xp=None, gp=None):
+    """xr / xi may be None when xp (input_grid) is given; gp: a grad_grid shared with conv_dgrad."""
     lib = _lib.load()
     cplx = gi is not None
-    if gr.dtype == torch.bfloat16:
-        out = _wgrad_rows(gr, gi, xr, xi, geom, w_shape, emul)
+    if gr.dtype == torch.bfloat16 and _rows_wgrad_ok(geom, cplx):
+        xp = input_grid(xr, xi, geom) if xp is None else xp
+        gp = grad_grid(gr, gi, geom) if gp is None else gp
+        out = _wgrad_rows(gp, xp, geom, w_shape, emul)
         if out is not None:
             return out
+    if xr is None:
+        raise CplxAmdError("conv_wgrad: the channels-last kernel refused a shape it was planned for")
     if gr.dtype == torch.bfloat16:
         nbytes = int(lib.cplxamd_conv2d_bf16_wgrad_ws_bytes(geom, int(cplx)))
         ws = _scratch(gr.device, nbytes)
@@ -190,6 +250,15 @@ def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
     call("cplxamd_conv2d_wgrad", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul), ptr(dwr), ptr(dwi),
          geom, dtype_code(gr), ptr(ws), ws.numel(), stream_ptr())
     return dwr, dwi
+
+
+def _shared_grad_grid(gr, gi, geom, need_dx, need_dw):
+    """One gradient grid for both backward kernels (None if neither takes the rows path)."""
+    if gr.dtype != torch.bfloat16:
+        return None
+    if (need_dx and _rows_dgrad_ok(geom)) or (need_dw and _rows_wgrad_ok(geom, gi is not None)):
+        return grad_grid(gr, gi, geom)
+    return None
 
 
 def chansum(g):
@@ -212,9 +281,11 @@ class CplxConv2dFn(torch.autograd.Function):
         wcr, wci = ops.cast(wr.contiguous(), xr.dtype), ops.cast(wi.contiguous(), xr.dtype)
         geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
-        yr, yi = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape)
-        ctx.save_for_backward(xr, xi, wcr, wci)
-        ctx.geom, ctx.has_bias, ctx.wshape = geom, br is not None, wr.shape
+        yr, yi, xp = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape, keep_grid=True)
+        # keep the channels-last input for the weight gradient instead of the planar one
+        ctx.grid = xp is not None and _rows_wgrad_ok(geom, True)
+        ctx.save_for_backward(*(xp if ctx.grid else (xr, xi)), wcr, wci)
+        ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, br is not None, wr.shape, xr.shape
         return yr, yi
 
     @staticmethod
@@ -223,10 +294,14 @@ class CplxConv2dFn(torch.autograd.Function):
         gr, gi = gr.contiguous(), gi.contiguous()
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
+        gp = _shared_grad_grid(gr, gi, ctx.geom, need[0] or need[1], need[2] or need[3])
         if need[0] or need[1]:
-            dxr, dxi = conv_dgrad(gr, gi, wcr, wci, ctx.geom, xr.shape)
+            dxr, dxi = conv_dgrad(gr, gi, wcr, wci, ctx.geom, ctx.xshape, gp=gp)
         if need[2] or need[3]:
-            dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape)
+            if ctx.grid:
+                dwr, dwi = conv_wgrad(gr, gi, None, None, ctx.geom, ctx.wshape, xp=(xr, xi), gp=gp)
+            else:
+                dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape, gp=gp)
         if ctx.has_bias and (need[4] or need[5]):
             dbr, dbi = chansum(gr), chansum(gi)
         return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
@@ -239,9 +314,11 @@ class RealConv2dFn(torch.autograd.Function):
         x = x.contiguous()
         wc = ops.cast(w.contiguous(), x.dtype)
         geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
-        y, _ = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom, oshape)
-        ctx.save_for_backward(x, wc)
-        ctx.geom, ctx.has_bias, ctx.wshape = geom, b is not None, w.shape
+        y, _, xp = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom,
+                            oshape, keep_grid=True)
+        ctx.grid = xp is not None and _rows_wgrad_ok(geom, False)
+        ctx.save_for_backward(xp[0] if ctx.grid else x, wc)
+        ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, b is not None, w.shape, x.shape
         return y
 
     @staticmethod
@@ -250,10 +327,14 @@ class RealConv2dFn(torch.autograd.Function):
         g = g.contiguous()
         need = ctx.needs_input_grad
         dx = dw = db = None
+        gp = _shared_grad_grid(g, None, ctx.geom, need[0], need[1])
         if need[0]:
-            dx, _ = conv_dgrad(g, None, wc, None, ctx.geom, x.shape)
+            dx, _ = conv_dgrad(g, None, wc, None, ctx.geom, ctx.xshape, gp=gp)
         if need[1]:
-            dw, _ = conv_wgrad(g, None, x, None, ctx.geom, ctx.wshape)
+            if ctx.grid:
+                dw, _ = conv_wgrad(g, None, None, None, ctx.geom, ctx.wshape, xp=(x, None), gp=gp)
+            else:
+                dw, _ = conv_wgrad(g, None, x, None, ctx.geom, ctx.wshape, gp=gp)
         if ctx.has_bias and need[2]:
             db = chansum(g)
         return dx, dw, db, None, None, None, None

@@ -51,7 +51,9 @@ struct Args {
   const float* bias_r; const float* bias_i;
   void* y_r; void* y_i;
   int64_t rows;                 // B * Hp * Wp
-  int B, Hp, Wp, C, Cout, KH, KW, dil_h, dil_w, Ho, Wo;
+  int B, Hp, Wp, C, Cout, KH, KW, dil_h, dil_w, Ho, Wo;   // Ho x Wo: extent of the output image
+  int64_t row_bias;             // added to every input row index (<= 0: the data gradient reads backwards)
+  int oh, ow;                   // grid position of output pixel (0, 0)
   int srows;                    // staged input rows per tile: BM + (KW-1)*dil_w
   int npieces;                  // LDS-DMA pieces per stage that carry data (the rest go to a dump slot)
   int dbg;                      // ablation bit (CPLXAMD_CONV_DBG): 4 no stores
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
     const int plane = c >= nA;
     c -= plane * nA;
     const int row = c >> 2;
-    int64_t grow = m0 + row + (int64_t)kh * g.dil_h * g.Wp;
+    int64_t grow = m0 + row + g.row_bias + (int64_t)kh * g.dil_h * g.Wp;
     grow = grow < g.rows ? grow : g.rows - 1;                    // rows past the end feed dropped outputs
     const bf16_t* base = plane ? g.x_i : g.x_r;
     glds16(base + grow * g.C + c0 + (((c & 3) ^ ((row >> 2) & 3)) << 3),
@@ -243,8 +245,9 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
     uint32_t hp = rem / (uint32_t)g.Wp, wp = rem - hp * (uint32_t)g.Wp;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      ok[e] = m + e < g.rows && b < (uint32_t)g.B && hp < (uint32_t)g.Ho && wp < (uint32_t)g.Wo;
-      off[e] = (int64_t)b * g.Cout * plane_sz + (int64_t)hp * g.Wo + wp;
+      const uint32_t ho = hp - (uint32_t)g.oh, wo = wp - (uint32_t)g.ow;   // wraps when before the image
+      ok[e] = m + e < g.rows && b < (uint32_t)g.B && ho < (uint32_t)g.Ho && wo < (uint32_t)g.Wo;
+      off[e] = (int64_t)b * g.Cout * plane_sz + (int64_t)ho * g.Wo + wo;
       if (++wp >= (uint32_t)g.Wp) { wp = 0; if (++hp >= (uint32_t)g.Hp) { hp = 0; ++b; } }
     }
   }
@@ -410,7 +413,8 @@ int cplxamd_nhwc_pad(const void* x, void* out, int B, int C, int H, int W, int p
 int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, const void* w_i,
                         const float* bias_r, const float* bias_i, void* y_r, void* y_i, int B,
                         int Hp, int Wp, int C, int Cout, int KH, int KW, int dil_h, int dil_w,
-                        int conj_w, int out_dtype, void* stream) {
+                        int conj_w, int64_t row_bias, int oh, int ow, int Hout, int Wout,
+                        int out_dtype, void* stream) {
   if (!xp_r || !w_r || !y_r) return CPLXAMD_EINVAL;
   const bool cplx = xp_i != nullptr;
   if (cplx && (!w_i || !y_i)) return CPLXAMD_EINVAL;
@@ -419,8 +423,9 @@ int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, con
     return CPLXAMD_EINVAL;
   if (out_dtype != CPLXAMD_BF16 && out_dtype != CPLXAMD_F32) return CPLXAMD_EINVAL;
   if (C % 32 || (KW - 1) * dil_w > cn::MAX_EXTRA) return CPLXAMD_ESHAPE;
-  const int Ho = Hp - (KH - 1) * dil_h, Wo = Wp - (KW - 1) * dil_w;
-  if (Ho <= 0 || Wo <= 0) return CPLXAMD_ESHAPE;
+  if (Hout <= 0 || Wout <= 0 || oh < 0 || ow < 0 || oh + Hout > Hp || ow + Wout > Wp || row_bias > 0)
+    return CPLXAMD_EINVAL;
+  const int Ho = Hout, Wo = Wout;
   const int64_t rows = (int64_t)B * Hp * Wp;
   if (rows >= ((int64_t)1 << 31) || (int64_t)Hp * Wp >= ((int64_t)1 << 31)) return CPLXAMD_ESHAPE;
   auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -428,7 +433,7 @@ int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, con
   if (B == 0) return 0;
   cn::Args g{(const bf16_t*)xp_r, (const bf16_t*)xp_i, (const bf16_t*)w_r, (const bf16_t*)w_i,
              bias_r, bias_i, y_r, y_i, rows, B, Hp, Wp, C, Cout, KH, KW, dil_h, dil_w, Ho, Wo,
-             cn::BM + (KW - 1) * dil_w, 0, 0};
+             row_bias, oh, ow, cn::BM + (KW - 1) * dil_w, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = out_dtype == CPLXAMD_F32;
   if (cplx)

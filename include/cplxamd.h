@@ -237,21 +237,27 @@ int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, co
  * channels-last copy of the input (conv_nhwc.hip): no gathers, operands move by LDS-DMA.
  *   cplxamd_nhwc_pad : planar NCHW bf16 x[B,C,H,W] -> out[B, Hp, Wp, C] (C % 8 == 0) with the image at
  *       rows pad_h.., columns pad_w.. and zeros elsewhere (Hp >= H + pad_h, Wp >= W + pad_w)
- *   cplxamd_conv2d_nhwc : y[b,co,ho,wo] = sum_{kh,kw,c} xp[b, ho+kh*dil_h, wo+kw*dil_w, c] *
- *                         op(w[co, kh, kw, c]) (+ bias[co]),  Ho = Hp-(KH-1)*dil_h, Wo likewise;
- *       xp_* padded channels-last bf16, w_* bf16 [KH][KW][C/16][Cout][16] (C % 32 == 0,
- *       (KW-1)*dil_w <= 32), y_* planar NCHW of out_dtype; xp_i == NULL: real convolution;
- *       conj_w: use conj(w).
- * Forward: w[kh][kw][c/16][co][c%16] = weight[co][c][kh][kw].  Data gradient: the same call on the
- * output gradient padded by (K-1)*dil - pad, with the roles of the two channel dimensions swapped,
- * the kernel flipped in both spatial dimensions, and conj_w = 1.
+ *   cplxamd_conv2d_nhwc : with r(b, i, j) the flattened row index of grid position (i, j) of image b,
+ *         y[b, co, ho, wo] = sum_{kh,kw,c} xp[r(b, ho + oh, wo + ow) + row_bias + kh*dil_h*Wp + kw*dil_w][c]
+ *                                          * op(w[co, kh, kw, c]) (+ bias[co])      ho < Hout, wo < Wout
+ *       xp_* channels-last bf16 grid [B, Hp, Wp, C], w_* bf16 [KH][KW][C/16][Cout][16] (C % 32 == 0,
+ *       (KW-1)*dil_w <= 32), y_* planar NCHW [B, Cout, Hout, Wout] of out_dtype; xp_i == NULL: real
+ *       convolution; conj_w: use conj(w).  row_bias <= 0; the buffer must hold -row_bias zero rows
+ *       before the grid (rows past its end are never multiplied into a stored output).
+ * Forward (input padded by (ph, pw)): row_bias = oh = ow = 0, Hout = Hp-(KH-1)*dil_h,
+ * w[kh][kw][c/16][co][c%16] = weight[co][c][kh][kw].  Data gradient: xp = the output gradient laid
+ * top-left on the INPUT's padded grid (cplxamd_nhwc_pad(g, pad 0, Hp, Wp)), the roles of the two
+ * channel dimensions swapped, the kernel flipped in both spatial dimensions, conj_w = 1,
+ * row_bias = -((KH-1)*dil_h*Wp + (KW-1)*dil_w), (oh, ow) = (ph, pw), (Hout, Wout) = (H, W): the same
+ * gradient grid then also feeds cplxamd_conv2d_nhwc_wgrad.
  * Replaces the same reference code as cplxamd_conv2d_fwd / _dgrad (cplx.py:717-838). */
 int cplxamd_nhwc_pad(const void* x, void* out, int B, int C, int H, int W, int pad_h, int pad_w,
                      int Hp, int Wp, void* stream);
 int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, const void* w_i,
                         const float* bias_r, const float* bias_i, void* y_r, void* y_i, int B,
                         int Hp, int Wp, int C, int Cout, int KH, int KW, int dil_h, int dil_w,
-                        int conj_w, int out_dtype, void* stream);
+                        int conj_w, int64_t row_bias, int oh, int ow, int Hout, int Wout,
+                        int out_dtype, void* stream);
 
 /* Weight gradient on the same channels-last copies (conv_nhwc_wgrad.hip):
  *   dw[co, ci, kh, kw] = sum_r gp[r][co] * conj(xp[r + kh*dil_h*Wp + kw*dil_w][ci]) (* emul, real only)

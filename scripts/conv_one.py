@@ -27,6 +27,6 @@ def timeit(fn, iters=10, warm=3):
 
 flop = 8.0 * B * Co * oshape[2] * oshape[3] * C * K * K
 t = timeit(lambda: conv.conv_fwd(xr, xi, wr, wi, None, None, geom, oshape))
-tp = timeit(lambda: (conv.nhwc_pad(xr, 0, 0), conv.nhwc_pad(xi, 0, 0)))
+tp = timeit(lambda: conv.input_grid(xr, xi, geom))
 print(f"dbg={os.environ.get('CPLXAMD_CONV_DBG', '0')} fwd {t:.3f} ms (pad passes {tp:.3f} ms) -> kernel ~{t - tp:.3f} ms = "
       f"{flop / (t - tp) / 1e9:.0f} TF/s")

@@ -27,6 +27,6 @@ def timeit(fn, iters=10, warm=3):
 
 flop = 8.0 * B * Co * oshape[2] * oshape[3] * C * K * K
 t = timeit(lambda: conv.conv_wgrad(gr, gi, xr, xi, geom, (Co, C, K, K)))
-tp = 2 * timeit(lambda: (conv.nhwc_pad(xr, 0, 0), conv.nhwc_pad(xi, 0, 0)))
+tp = timeit(lambda: (conv.input_grid(xr, xi, geom), conv.grad_grid(gr, gi, geom)))
 print(f"dbg={os.environ.get('CPLXAMD_CONV_DBG', '0')} wgrad {t:.3f} ms (4 pad passes ~{tp:.3f} ms) -> kernel ~{t - tp:.3f} ms = "
       f"{flop / (t - tp) / 1e9:.0f} TF/s")
