@@ -225,9 +225,21 @@ __global__ __launch_bounds__(256) void chansum_partial(const T* x, int64_t B, in
   __shared__ double red[4];
   const int c = blockIdx.x;
   double acc = 0.0;
+  // 8 elements per lane and load (16-B for bf16, 2 x 16-B for f32; planes are only element-aligned,
+  // the packed struct makes the compiler emit unaligned-tolerant dwordx4 loads); float partial of
+  // the 8, double across iterations
+  struct __attribute__((packed, aligned(sizeof(T)))) V8 { T v[8]; };
   for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
     const T* pl = x + (b * C + c) * S;
-    for (int64_t s = threadIdx.x; s < S; s += 256) acc += (double)io<T>::ld(pl + s);
+    const int64_t S8 = S & ~(int64_t)7;
+    for (int64_t s = (int64_t)threadIdx.x * 8; s < S8; s += 256 * 8) {
+      const V8 v = *reinterpret_cast<const V8*>(pl + s);
+      float p = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p += io<T>::ld(&v.v[e]);
+      acc += (double)p;
+    }
+    for (int64_t s = S8 + threadIdx.x; s < S; s += 256) acc += (double)io<T>::ld(pl + s);
   }
   const double t = block_sum<double, 256>(acc, red);
   if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * C + c] = t;

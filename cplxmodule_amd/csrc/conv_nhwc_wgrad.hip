@@ -246,23 +246,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_kernel(Args g) {
 }
 
 // dW[co][ci][kh][kw] (plane pl) = sum_split slab[split][kh][kw][pl][tco][tci][co % 64][ci % 64] (* emul)
+// one thread per slab element (coalesced reads of every split), scattered 4-B write into dW
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* ws, int splits, int KH,
                                                                 int KW, int planes, int pl, int Co,
                                                                 int Ci, int tco, int tci,
                                                                 const float* emul, float* dw) {
-  const int64_t n = (int64_t)Co * Ci * KH * KW;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  // i = ((co * Ci + ci) * KH + kh) * KW + kw
-  const int kw = (int)(i % KW);
-  const int kh = (int)((i / KW) % KH);
-  const int ci = (int)((i / ((int64_t)KW * KH)) % Ci);
-  const int co = (int)(i / ((int64_t)KW * KH * Ci));
-  const int64_t per_split = (int64_t)KH * KW * planes * tco * tci * (TC * TC);
-  const int64_t o = ((((int64_t)(kh * KW + kw) * planes + pl) * tco + co / TC) * tci + ci / TC) * (TC * TC) +
-                    (co % TC) * TC + (ci % TC);
+  const int64_t per_plane = (int64_t)tco * tci * (TC * TC);
+  const int64_t n = (int64_t)KH * KW * per_plane;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int tap = (int)(j / per_plane);
+  int64_t r = j - (int64_t)tap * per_plane;
+  const int t = (int)(r / (TC * TC));
+  r -= (int64_t)t * (TC * TC);
+  const int co = (t / tci) * TC + (int)(r / TC), ci = (t % tci) * TC + (int)(r % TC);
+  if (co >= Co || ci >= Ci) return;
+  const int64_t per_split = (int64_t)KH * KW * planes * per_plane;
+  const int64_t o = ((int64_t)tap * planes + pl) * per_plane + (int64_t)t * (TC * TC) + r;
   float acc = 0.f;
   for (int s = 0; s < splits; ++s) acc += ws[(int64_t)s * per_split + o];
+  const int64_t i = ((int64_t)co * Ci + ci) * KH * KW + tap;        // tap = kh * KW + kw
   dw[i] = emul ? acc * emul[i] : acc;
 }
 
@@ -334,7 +337,7 @@ int cplxamd_conv2d_nhwc_wgrad(const void* gp_r, const void* gp_i, const void* xp
   else
     cw::conv_wgrad_nhwc_kernel<false><<<grid, NT, smem, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
-  const int rgrid = (int)((n + 255) / 256);
+  const int rgrid = (int)(((int64_t)KH * KW * tco * tci * cw::TC * cw::TC + 255) / 256);
   cw::wgrad_slab_reduce_kernel<<<rgrid, 256, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 0, Co, Ci,
                                                      tco, tci, emul, dw_r);
   CPLXAMD_CHECK_LAUNCH();
