@@ -247,13 +247,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_kernel(Args g) {
 
 // dW[co][ci][kh][kw] (plane pl) = sum_split slab[split][kh][kw][pl][tco][tci][co % 64][ci % 64] (* emul)
 // one thread per slab element (coalesced reads of every split), scattered 4-B write into dW
-__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* ws, int splits, int KH,
+__global__ __launch_bounds__(64) void wgrad_slab_reduce_kernel(const float* ws, int splits, int KH,
                                                                 int KW, int planes, int pl, int Co,
                                                                 int Ci, int tco, int tci,
                                                                 const float* emul, float* dw) {
   const int64_t per_plane = (int64_t)tco * tci * (TC * TC);
   const int64_t n = (int64_t)KH * KW * per_plane;
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (j >= n) return;
   const int tap = (int)(j / per_plane);
   int64_t r = j - (int64_t)tap * per_plane;
@@ -263,8 +263,15 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* ws,
   if (co >= Co || ci >= Ci) return;
   const int64_t per_split = (int64_t)KH * KW * planes * per_plane;
   const int64_t o = ((int64_t)tap * planes + pl) * per_plane + (int64_t)t * (TC * TC) + r;
-  float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += ws[(int64_t)s * per_split + o];
+  // fixed summation order (deterministic), 8 loads in flight per thread
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] += ws[(int64_t)(s + u) * per_split + o];
+  }
+  for (; s < splits; ++s) a8[0] += ws[(int64_t)s * per_split + o];
+  const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   const int64_t i = ((int64_t)co * Ci + ci) * KH * KW + tap;        // tap = kh * KW + kw
   dw[i] = emul ? acc * emul[i] : acc;
 }
@@ -337,12 +344,12 @@ int cplxamd_conv2d_nhwc_wgrad(const void* gp_r, const void* gp_i, const void* xp
   else
     cw::conv_wgrad_nhwc_kernel<false><<<grid, NT, smem, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
-  const int rgrid = (int)(((int64_t)KH * KW * tco * tci * cw::TC * cw::TC + 255) / 256);
-  cw::wgrad_slab_reduce_kernel<<<rgrid, 256, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 0, Co, Ci,
+  const int rgrid = (int)(((int64_t)KH * KW * tco * tci * cw::TC * cw::TC + 63) / 64);
+  cw::wgrad_slab_reduce_kernel<<<rgrid, 64, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 0, Co, Ci,
                                                      tco, tci, emul, dw_r);
   CPLXAMD_CHECK_LAUNCH();
   if (cplx) {
-    cw::wgrad_slab_reduce_kernel<<<rgrid, 256, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 1, Co,
+    cw::wgrad_slab_reduce_kernel<<<rgrid, 64, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 1, Co,
                                                        Ci, tco, tci, nullptr, dw_i);
     CPLXAMD_CHECK_LAUNCH();
   }

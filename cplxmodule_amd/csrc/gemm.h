@@ -15,7 +15,7 @@ struct GemmArgs {
   // split-K (bf16 kernel, fp32 output): block (split, tile) covers K range [split*kchunk, ...)
   // and writes slab `split` of the workspace; a second kernel reduces the slabs.
   int splits = 1; int kchunk = 0; void* ws = nullptr; int64_t ws_bytes = 0;
-  int dbg = 0;   // ablation bits (CPLXAMD_GEMM_DBG): 1 no LDS-DMA after the prologue, 2 no MFMA
+  int dbg = 0;   // ablation bits (CPLXAMD_GEMM_DBG): 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no barrier
   // Gauss 3M combine (real bf16 kernel only): this launch computes t3 = (Ar+Ai)(Br+Bi'); with the
   // dense fp32 slabs t1 = Ar Br and T2 = Ai Bi the epilogue stores
   //   c_r = t1 - gsign T2 + bias_r,   c_i = t3 - t1 - gsign T2 + bias_i      (gsign = -1: conj(B))

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
   for (int t = 0; t < nt; ++t) {
     // own LDS-DMA of tile t landed (tile t+1 may stay in flight), then every wave's did
     if ((g.dbg & 1) || t + 1 >= nt) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();
-    __builtin_amdgcn_s_barrier();        // ... and ring slot (t-1) % 3 is free for tile t+2
+    if (!(g.dbg & 4)) __builtin_amdgcn_s_barrier();        // ... and ring slot (t-1) % 3 is free for tile t+2
     int nxt = cur + 2; nxt = nxt >= 3 ? nxt - 3 : nxt;
     compute(cur, nxt, (t + 2) * BK, t + 2 < nt && !(g.dbg & 1), !(g.dbg & 2));
     cur = cur + 1 == 3 ? 0 : cur + 1;
