@@ -58,6 +58,8 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const void* lds_wave
 
 // 4-wide vector access (16 B for float, 8 B for bf16)
 struct f4 { float v[4]; };
+// two f4 halves = 8 elements: one 16-B access for bf16, two for float (needs 16-B alignment of p)
+struct f8 { f4 h[2]; };
 __device__ __forceinline__ f4 ld4(const float* p) {
   float4 t = *reinterpret_cast<const float4*>(p);
   return f4{{t.x, t.y, t.z, t.w}};
@@ -75,6 +77,27 @@ __device__ __forceinline__ void st4(bf16_t* p, const f4& a) {
   t.x = (uint32_t)f32_to_bf16(a.v[0]) | ((uint32_t)f32_to_bf16(a.v[1]) << 16);
   t.y = (uint32_t)f32_to_bf16(a.v[2]) | ((uint32_t)f32_to_bf16(a.v[3]) << 16);
   *reinterpret_cast<uint2*>(p) = t;
+}
+__device__ __forceinline__ f8 ld8(const float* p) { return f8{{ld4(p), ld4(p + 4)}}; }
+__device__ __forceinline__ void st8(float* p, const f8& a) { st4(p, a.h[0]); st4(p + 4, a.h[1]); }
+__device__ __forceinline__ f8 ld8(const bf16_t* p) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+  f8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r.h[e >> 1].v[(e & 1) * 2] = __uint_as_float(w[e] << 16);
+    r.h[e >> 1].v[(e & 1) * 2 + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+  return r;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const f8& a) {
+  uint32_t w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    w[e] = (uint32_t)f32_to_bf16(a.h[e >> 1].v[(e & 1) * 2]) |
+           ((uint32_t)f32_to_bf16(a.h[e >> 1].v[(e & 1) * 2 + 1]) << 16);
+  *reinterpret_cast<uint4*>(p) = uint4{w[0], w[1], w[2], w[3]};
 }
 
 // ---- correctly rounded float32 primitives ---------------------------------------------------

@@ -34,8 +34,10 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi,
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
-    const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+    // one 32x32->64 product each (v_mad_u64_u32) instead of a mul_lo + mul_hi pair
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t lo0 = (uint32_t)p0, hi0 = (uint32_t)(p0 >> 32);
+    const uint32_t lo1 = (uint32_t)p1, hi1 = (uint32_t)(p1 >> 32);
     c0 = hi1 ^ c1 ^ k0;
     c1 = lo1;
     c2 = hi0 ^ c3 ^ k1;
@@ -100,35 +102,47 @@ __device__ __forceinline__ void noise_one(int64_t e, uint64_t seed, uint64_t off
 
 __device__ __forceinline__ float lrt_std(float s2) { return rn_sqrt(fmaxf(s2, 1e-8f)); }
 
+// bf16 activations: the result is rounded to 8 bits of mantissa anyway, so the 1-ulp hardware
+// sqrt / rsq replace the correctly rounded sqrt and division (20 VALU ops per output less; the
+// float32 path keeps the reference's exact arithmetic)
+template <typename T> __device__ __forceinline__ float lrt_std_t(float s2) {
+  if (sizeof(T) == 2) return __builtin_amdgcn_sqrtf(fmaxf(s2, 1e-8f));
+  return lrt_std(s2);
+}
+
 template <typename T, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
     const T* mu_r, const T* mu_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
     uint64_t offset, const uint64_t* state, T* y_r, T* y_i, int64_t n) {
   if (PHILOX && state) { seed = state[0]; offset = state[1]; }   // device-resident stream position
-  const int64_t n4 = n >> 2;
+  // 8 outputs per thread and iteration: all loads first (one 16-B access per bf16 plane, two per
+  // float32 plane), then 2 x 4 outputs; the tail (< 8 elements) is done one element per thread
+  const int64_t n8 = n >> 3;
   const int64_t stride = (int64_t)gridDim.x * kRpThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n4; i += stride) {
-    const f4 s = ld4(s2 + 4 * i);
-    const f4 mr = ld4(mu_r + 4 * i);
-    f4 mi, er, ei, yr, yi;
-    if (CPLX) mi = ld4(mu_i + 4 * i);
-    if (PHILOX) {
-      noise_vec<CPLX>(i, seed, offset, er, ei);
-    } else {
-      er = ld4(eps_r + 4 * i);
-      if (CPLX) ei = ld4(eps_i + 4 * i);
+  for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n8; i += stride) {
+    const f8 s = ld8(s2 + 8 * i);
+    const f8 mr = ld8(mu_r + 8 * i);
+    f8 mi, er, ei, yr, yi;
+    if (CPLX) mi = ld8(mu_i + 8 * i);
+    if (!PHILOX) {
+      er = ld8(eps_r + 8 * i);
+      if (CPLX) ei = ld8(eps_i + 8 * i);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float sd = lrt_std(s.v[j]);
-      yr.v[j] = mr.v[j] + er.v[j] * sd;
-      if (CPLX) yi.v[j] = mi.v[j] + ei.v[j] * sd;
+    for (int h = 0; h < 2; ++h) {
+      if (PHILOX) noise_vec<CPLX>(2 * i + h, seed, offset, er.h[h], ei.h[h]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sd = lrt_std_t<T>(s.h[h].v[j]);
+        yr.h[h].v[j] = mr.h[h].v[j] + er.h[h].v[j] * sd;
+        if (CPLX) yi.h[h].v[j] = mi.h[h].v[j] + ei.h[h].v[j] * sd;
+      }
     }
-    st4(y_r + 4 * i, yr);
-    if (CPLX) st4(y_i + 4 * i, yi);
+    st8(y_r + 8 * i, yr);
+    if (CPLX) st8(y_i + 8 * i, yi);
   }
   if (blockIdx.x == 0) {
-    const int64_t e = (n4 << 2) + threadIdx.x;
+    const int64_t e = (n8 << 3) + threadIdx.x;
     if (e < n) {
       float er, ei = 0.0f;
       if (PHILOX) {
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
         er = io<T>::ld(eps_r + e);
         if (CPLX) ei = io<T>::ld(eps_i + e);
       }
-      const float sd = lrt_std(s2[e]);
+      const float sd = lrt_std_t<T>(s2[e]);
       io<T>::st(y_r + e, io<T>::ld(mu_r + e) + er * sd);
       if (CPLX) io<T>::st(y_i + e, io<T>::ld(mu_i + e) + ei * sd);
     }
@@ -148,35 +162,41 @@ __device__ __forceinline__ float lrt_gs2(float gs, float s2) {
   // torch.clamp passes the gradient AT the boundary
   return s2 >= 1e-8f ? (gs * 0.5f) / lrt_std(s2) : 0.0f;
 }
+template <typename T> __device__ __forceinline__ float lrt_gs2_t(float gs, float s2) {
+  if (sizeof(T) == 2) return s2 >= 1e-8f ? (gs * 0.5f) * __builtin_amdgcn_rsqf(s2) : 0.0f;
+  return lrt_gs2(gs, s2);
+}
 
 template <typename T, typename TG, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
     const T* g_r, const T* g_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
     uint64_t offset, const uint64_t* state, TG* g_s2, int64_t n) {
   if (PHILOX && state) { seed = state[0]; offset = state[1]; }
-  const int64_t n4 = n >> 2;
+  const int64_t n8 = n >> 3;
   const int64_t stride = (int64_t)gridDim.x * kRpThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n4; i += stride) {
-    const f4 s = ld4(s2 + 4 * i);
-    const f4 gr = ld4(g_r + 4 * i);
-    f4 gi, er, ei, o;
-    if (CPLX) gi = ld4(g_i + 4 * i);
-    if (PHILOX) {
-      noise_vec<CPLX>(i, seed, offset, er, ei);
-    } else {
-      er = ld4(eps_r + 4 * i);
-      if (CPLX) ei = ld4(eps_i + 4 * i);
+  for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n8; i += stride) {
+    const f8 s = ld8(s2 + 8 * i);
+    const f8 gr = ld8(g_r + 8 * i);
+    f8 gi, er, ei, o;
+    if (CPLX) gi = ld8(g_i + 8 * i);
+    if (!PHILOX) {
+      er = ld8(eps_r + 8 * i);
+      if (CPLX) ei = ld8(eps_i + 8 * i);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float gs = gr.v[j] * er.v[j];
-      if (CPLX) gs = gs + gi.v[j] * ei.v[j];
-      o.v[j] = lrt_gs2(gs, s.v[j]);
+    for (int h = 0; h < 2; ++h) {
+      if (PHILOX) noise_vec<CPLX>(2 * i + h, seed, offset, er.h[h], ei.h[h]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gs = gr.h[h].v[j] * er.h[h].v[j];
+        if (CPLX) gs = gs + gi.h[h].v[j] * ei.h[h].v[j];
+        o.h[h].v[j] = lrt_gs2_t<T>(gs, s.h[h].v[j]);
+      }
     }
-    st4(g_s2 + 4 * i, o);
+    st8(g_s2 + 8 * i, o);
   }
   if (blockIdx.x == 0) {
-    const int64_t e = (n4 << 2) + threadIdx.x;
+    const int64_t e = (n8 << 3) + threadIdx.x;
     if (e < n) {
       float er, ei = 0.0f;
       if (PHILOX) {
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
       }
       float gs = io<T>::ld(g_r + e) * er;
       if (CPLX) gs = gs + io<T>::ld(g_i + e) * ei;
-      io<TG>::st(g_s2 + e, lrt_gs2(gs, s2[e]));
+      io<TG>::st(g_s2 + e, lrt_gs2_t<T>(gs, s2[e]));
     }
   }
 }
@@ -209,7 +229,7 @@ template <typename T>
 static int launch_fwd(const void* mu_r, const void* mu_i, const float* s2, const void* eps_r,
                       const void* eps_i, uint64_t seed, uint64_t offset, const uint64_t* state,
                       void* y_r, void* y_i, int64_t n, hipStream_t st) {
-  const int grid = stream_grid(n >> 2, kRpThreads);
+  const int grid = stream_grid(n >> 3, kRpThreads);
   const bool cplx = mu_i != nullptr, philox = eps_r == nullptr;
 #define RP_FWD(C, P)                                                                       \
   reparam_fwd_kernel<T, C, P><<<grid, kRpThreads, 0, st>>>(                                \
@@ -228,7 +248,7 @@ template <typename T, typename TG>
 static int launch_bwd(const void* g_r, const void* g_i, const float* s2, const void* eps_r,
                       const void* eps_i, uint64_t seed, uint64_t offset, const uint64_t* state,
                       void* g_s2, int64_t n, hipStream_t st) {
-  const int grid = stream_grid(n >> 2, kRpThreads);
+  const int grid = stream_grid(n >> 3, kRpThreads);
   const bool cplx = g_i != nullptr, philox = eps_r == nullptr;
 #define RP_BWD(C, P)                                                                      \
   reparam_bwd_kernel<T, TG, C, P><<<grid, kRpThreads, 0, st>>>(                           \
@@ -256,6 +276,8 @@ __global__ void philox_advance_kernel(uint64_t* state, uint64_t* used) {
 
 using namespace cplxamd;
 
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 extern "C" {
 
 int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
@@ -263,6 +285,8 @@ int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
                             uint64_t offset, const uint64_t* state, void* y_r, void* y_i,
                             int64_t n, int dtype, void* stream) {
   if (!mu_r || !s2 || !y_r || n < 0) return CPLXAMD_EINVAL;
+  if (!al16(mu_r) || !al16(mu_i) || !al16(s2) || !al16(eps_r) || !al16(eps_i) || !al16(y_r) || !al16(y_i))
+    return CPLXAMD_EALIGN;
   if ((mu_i == nullptr) != (y_i == nullptr)) return CPLXAMD_EINVAL;
   if (eps_r && mu_i && !eps_i) return CPLXAMD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -279,6 +303,8 @@ int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
                             int dtype, int gs2_dtype, void* stream) {
   if (!g_r || !s2 || !g_s2 || n < 0) return CPLXAMD_EINVAL;
   if (eps_r && g_i && !eps_i) return CPLXAMD_EINVAL;
+  if (!al16(g_r) || !al16(g_i) || !al16(s2) || !al16(eps_r) || !al16(eps_i) || !al16(g_s2))
+    return CPLXAMD_EALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32 && gs2_dtype == CPLXAMD_F32)
     return launch_bwd<float, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);

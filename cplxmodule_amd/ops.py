@@ -182,14 +182,20 @@ def philox_advance(state):
     return used
 
 
+def _al16(t):
+    """The streaming kernels move 16 bytes per lane: re-home the rare view that is not aligned."""
+    return t if t is None or t.data_ptr() % 16 == 0 else t.clone()
+
+
 def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
     """y = mu + eps * sqrt(max(s2, 1e-8)); eps=(eps_r, eps_i) / eps_r tensor or None (Philox)."""
     require_device(mu_r, mu_i, s2)
-    mu_r, mu_i, s2 = _c(mu_r), _c(mu_i), _f32(_c(s2))
+    mu_r, mu_i, s2 = _al16(_c(mu_r)), _al16(_c(mu_i)), _al16(_f32(_c(s2)))
     e_r = e_i = None
     if eps is not None:
         e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
         e_r, e_i = _c(cast(e_r, mu_r.dtype)), (None if e_i is None else _c(cast(e_i, mu_r.dtype)))
+        e_r, e_i = _al16(e_r), _al16(e_i)
     y_r = mu_r if inplace else torch.empty_like(mu_r)
     y_i = None if mu_i is None else (mu_i if inplace else torch.empty_like(mu_i))
     sd, of, st = _noise_args(seed, offset)
@@ -200,11 +206,12 @@ def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
 
 def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float32):
     require_device(g_r, g_i, s2)
-    g_r, g_i, s2 = _c(g_r), _c(g_i), _f32(_c(s2))
+    g_r, g_i, s2 = _al16(_c(g_r)), _al16(_c(g_i)), _al16(_f32(_c(s2)))
     e_r = e_i = None
     if eps is not None:
         e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
         e_r, e_i = _c(cast(e_r, g_r.dtype)), (None if e_i is None else _c(cast(e_i, g_r.dtype)))
+        e_r, e_i = _al16(e_r), _al16(e_i)
     g_s2 = torch.empty_like(s2, dtype=out_dtype)
     sd, of, st = _noise_args(seed, offset)
     call("cplxamd_lrt_reparam_bwd", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,

@@ -108,7 +108,8 @@ int cplxamd_expi_bwd(const float* g, const float* x, float* gx, int64_t n, void*
  * `state` (nullable): device uint64[2] = {seed, offset}; when given it overrides the two host
  * scalars, so a hipGraph that captured the launch draws fresh noise on every replay
  * (cplxamd_philox_advance moves the stream position on the device).
- * s2 is float32; mu / y / eps / g have element type `dtype`.
+ * s2 is float32; mu / y / eps / g have element type `dtype`; every pointer 16-byte aligned
+ * (CPLXAMD_EALIGN otherwise).
  * ---------------------------------------------------------------------------------- */
 int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
                             const void* eps_r, const void* eps_i, uint64_t seed,
