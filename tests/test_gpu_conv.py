@@ -193,3 +193,42 @@ def test_real_conv_bf16_rows_kernel_vs_oracle():
     dx, dw = orc.real_conv2d_bwd(g.astype(f), x.astype(f), w.astype(f), padding=1)
     for n, t, r in (("dx", tx.grad, dx), ("dw", tw.grad, dw), ("db", tb.grad, g.astype(f).sum((0, 2, 3)))):
         np.testing.assert_allclose(N(t), r, rtol=2e-2, atol=2e-2 * np.abs(r).max(), err_msg=n)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_conv_bf16_rows_kernels_random_shapes(seed):
+    """Property test of the channels-last kernels (forward, data gradient, weight gradient, bias
+    gradient) on random stride-1 / groups-1 geometries against the exact float32 kernels run on
+    the same bf16-rounded operands: odd image sizes, rectangular / dilated kernels, asymmetric
+    padding, channel counts that are not multiples of the 64-wide tiles, rows % 256 != 0."""
+    from gpu_util import DEV
+    from cplxmodule_amd import Cplx, cplx
+    rs = np.random.RandomState(100 + seed)
+    B = int(rs.randint(1, 5))
+    Ci, Co = int(rs.choice([32, 64, 96])), int(rs.choice([32, 40, 64, 72, 160]))
+    kh, kw = int(rs.randint(1, 4)), int(rs.randint(1, 5))
+    dh, dw = int(rs.randint(1, 3)), int(rs.randint(1, 3))
+    ph, pw = int(rs.randint(0, 3)), int(rs.randint(0, 3))
+    H = int(rs.randint((kh - 1) * dh + 1, 30)) + 2
+    W = int(rs.randint((kw - 1) * dw + 1, 40)) + 2
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16().to(DEV)  # noqa: E731
+    xr, xi = mk(B, Ci, H, W), mk(B, Ci, H, W)
+    wr, wi = (mk(Co, Ci, kh, kw).float() * 0.1).bfloat16().float(), (mk(Co, Ci, kh, kw).float() * 0.1).bfloat16().float()
+    br, bi = mk(Co).float(), mk(Co).float()
+    kw_ = dict(stride=1, padding=(ph, pw), dilation=(dh, dw))
+    outs = []
+    for dt in (torch.bfloat16, torch.float32):
+        leaves = [t.to(dt).clone().requires_grad_(True) for t in (xr, xi)] + \
+                 [t.clone().requires_grad_(True) for t in (wr, wi, br, bi)]
+        y = cplx.conv2d(Cplx(leaves[0], leaves[1]), Cplx(leaves[2], leaves[3]), Cplx(leaves[4], leaves[5]), **kw_)
+        gg = torch.Generator(device="cpu").manual_seed(1000 + seed)
+        gr = torch.randn(y.real.shape, generator=gg).bfloat16().to(DEV)
+        gi = torch.randn(y.real.shape, generator=gg).bfloat16().to(DEV)
+        torch.autograd.backward((y.real, y.imag), (gr.to(dt), gi.to(dt)))
+        outs.append([y.real.float(), y.imag.float()] + [t.grad.float() for t in leaves])
+    names = ["yr", "yi", "dxr", "dxi", "dwr", "dwi", "dbr", "dbi"]
+    for n, a, b in zip(names, *outs):
+        scale = float(b.detach().abs().max()) + 1e-6
+        tol = 2e-2 if n[0] in "yd" and n[1] in "rix" else 1e-3   # bf16-rounded outputs vs fp32-accumulated grads
+        assert float((a.detach() - b.detach()).abs().max()) <= tol * scale, (n, seed, B, Ci, Co, kh, kw, dh, dw, ph, pw, H, W)
