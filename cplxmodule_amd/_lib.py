@@ -5,7 +5,7 @@ ABI version, or a kernel is asked to run on a non-HIP tensor, this module raises
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
+from ctypes import c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 
 import torch
 
@@ -16,7 +16,7 @@ ABI_VERSION = 1
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3}
 
-_P, _I, _L, _U, _F = c_void_p, c_int, c_int64, c_uint64, c_float
+_P, _I, _L, _U, _F, _D = c_void_p, c_int, c_int64, c_uint64, c_float, c_double
 
 # name -> argtypes; restype is int unless listed in _RESTYPES
 SIGNATURES = {
@@ -37,6 +37,11 @@ SIGNATURES = {
                       _I, _I, _I, _P, _L, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
+    "cplxamd_deinterleave": [_P, _P, _P, _L, _I, _P],
+    "cplxamd_interleave": [_P, _P, _P, _L, _I, _P],
+    "cplxamd_modrelu_fwd": [_P, _P, _P, _F, _I, _P, _P, _L, _I, _P],
+    "cplxamd_modrelu_bwd": [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _L, _I, _P],
+    "cplxamd_cplx_dropout": [_P, _P, _P, _P, _D, _U, _U, _P, _L, _I, _P],
     "cplxamd_nhwc_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "cplxamd_conv2d_nhwc_wgrad_ws_bytes": [_I] * 8,
     "cplxamd_conv2d_nhwc_wgrad": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],

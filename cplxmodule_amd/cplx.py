@@ -346,9 +346,13 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
 
 
 def from_interleaved_real(input, copy=True, dim=-1):
-    """[..., 2D] interleaved (re, im) -> Cplx [..., D]  (cplxmodule/cplx.py:451-455)."""
-    shape = list(input.shape)
+    """[..., 2D] interleaved (re, im) -> Cplx [..., D]  (cplxmodule/cplx.py:451-455).  copy=True along
+    the last dim on the GPU is one de-interleaving kernel pass (csrc/layout.hip) instead of two
+    strided copies; copy=False returns strided views like the reference."""
     dim = dim % input.dim()
+    if copy and dim == input.dim() - 1 and input.is_cuda and input.dtype in (torch.float32, torch.bfloat16):
+        return Cplx(*ops.DeinterleaveFn.apply(input))
+    shape = list(input.shape)
     shape[dim:dim + 1] = [shape[dim] // 2, 2]
     pair = input.reshape(shape)
     re, im = pair.select(dim + 1, 0), pair.select(dim + 1, 1)
@@ -359,10 +363,15 @@ from_real = from_interleaved_real
 
 
 def to_interleaved_real(input, flatten=True, dim=-1):
-    """Cplx [..., D] -> real [..., 2D] interleaved (cplxmodule/cplx.py:466-470)."""
-    dim = dim % input.dim() + 1
-    out = torch.stack([input.real, input.imag], dim=dim)
-    return out.flatten(dim - 1, dim) if flatten else out
+    """Cplx [..., D] -> real [..., 2D] interleaved (cplxmodule/cplx.py:466-470); last dim on the GPU:
+    one interleaving kernel pass."""
+    d = dim % input.dim()
+    re, im = input.real, input.imag
+    if d == input.dim() - 1 and re.is_cuda and re.dtype in (torch.float32, torch.bfloat16):
+        out = ops.InterleaveFn.apply(re, im)
+        return out if flatten else out.view(*re.shape, 2)
+    out = torch.stack([re, im], dim=d + 1)
+    return out.flatten(d, d + 1) if flatten else out
 
 
 to_real = to_interleaved_real
@@ -375,3 +384,20 @@ def from_concatenated_real(input, copy=True, dim=-1):
 
 def to_concatenated_real(input, flatten=None, dim=-1):
     return torch.cat([input.real, input.imag], dim=dim)
+
+
+def modrelu(input, threshold=0.5):
+    """Soft-threshold of the modulus, phase kept: z * relu(1 - threshold / max(|z|, 1e-5))
+    (cplxmodule/cplx.py:565-616; note the reference's flipped sign convention).  `threshold` is a
+    float or a (learnable) tensor broadcastable to the input."""
+    return Cplx(*ops.ModReluFn.apply(input.real, input.imag, threshold))
+
+
+def dropout(input, p=0.5, training=True):
+    """Complex dropout: real and imaginary parts of an element are dropped together
+    (cplxmodule/nn/modules/extra.py:7-25); the Bernoulli stream is the package's Philox stream."""
+    if not training or p == 0.0:
+        return input
+    from .nn.relevance.noise import noise
+    seed, offset = noise.next(input.real.device)
+    return Cplx(*ops.CplxDropoutFn.apply(input.real, input.imag, p, seed, offset))

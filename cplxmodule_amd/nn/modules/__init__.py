@@ -2,3 +2,10 @@ from .base import CplxToCplx, CplxParameter  # noqa: F401
 from .linear import CplxLinear  # noqa: F401
 from .conv import CplxConv2d  # noqa: F401
 from .batchnorm import CplxBatchNorm1d, CplxBatchNorm2d, CplxBatchNorm3d  # noqa: F401
+from .casting import AsTypeCplx, TensorToCplx, CplxToTensor  # noqa: F401
+from .casting import InterleavedRealToCplx, ConcatenatedRealToCplx  # noqa: F401
+from .casting import CplxToInterleavedReal, CplxToConcatenatedReal  # noqa: F401
+from .casting import CplxToInterleavedReal as CplxToReal  # noqa: F401
+from .casting import InterleavedRealToCplx as RealToCplx  # noqa: F401
+from .activation import CplxModReLU, CplxAdaptiveModReLU, CplxModulus, CplxAngle  # noqa: F401
+from .extra import CplxDropout  # noqa: F401

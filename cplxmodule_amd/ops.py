@@ -574,3 +574,105 @@ class ExpiFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         call("cplxamd_expi_bwd", ptr(g), ptr(x), ptr(gx), x.numel(), stream_ptr())
         return gx
+
+
+# ------------------------------------------------------------------------------------------ #
+#  layout converters, modReLU, complex dropout (csrc/layout.hip)        #
+# ------------------------------------------------------------------------------------------ #
+class DeinterleaveFn(torch.autograd.Function):
+    """x[..., 2D] -> (re[..., D], im[..., D]) in one pass; backward = interleave of the gradients."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_device(x)
+        x = _al16(_c(x))
+        shape = (*x.shape[:-1], x.shape[-1] // 2)
+        re, im = torch.empty(shape, dtype=x.dtype, device=x.device), torch.empty(shape, dtype=x.dtype, device=x.device)
+        call("cplxamd_deinterleave", ptr(x), ptr(re), ptr(im), re.numel(), dtype_code(x), stream_ptr())
+        return re, im
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        return InterleaveFn.apply(gr, gi)
+
+
+class InterleaveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, re, im):
+        require_device(re, im)
+        re, im = _al16(_c(re)), _al16(_c(im))
+        out = torch.empty((*re.shape[:-1], 2 * re.shape[-1]), dtype=re.dtype, device=re.device)
+        call("cplxamd_interleave", ptr(re), ptr(im), ptr(out), re.numel(), dtype_code(re), stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return DeinterleaveFn.apply(g)
+
+
+def _tau_args(tau, like):
+    """(device pointer, value, numel) of a modReLU threshold: python float -> by value; 1-element
+    tensor -> read on the device; anything else -> broadcast to the activation's shape."""
+    if not isinstance(tau, torch.Tensor):
+        return None, float(tau), 0, None
+    t = _f32(tau)
+    if t.numel() == 1:
+        return t, 0.0, 1, t
+    t = _al16(t.expand(like.shape).contiguous())
+    return t, 0.0, t.numel(), t
+
+
+class ModReluFn(torch.autograd.Function):
+    """cplx.modrelu (cplxmodule/cplx.py:565-616) fused with its backward."""
+
+    @staticmethod
+    def forward(ctx, zr, zi, tau):
+        require_device(zr, zi)
+        zr, zi = _al16(_c(zr)), _al16(_c(zi))
+        tp, tv, tn, keep = _tau_args(tau, zr)
+        yr, yi = torch.empty_like(zr), torch.empty_like(zi)
+        call("cplxamd_modrelu_fwd", ptr(zr), ptr(zi), ptr(tp), tv, tn, ptr(yr), ptr(yi), zr.numel(),
+             dtype_code(zr), stream_ptr())
+        ctx.save_for_backward(zr, zi, *([keep] if keep is not None else []))
+        ctx.tau = (tv, tn, tau.shape if isinstance(tau, torch.Tensor) else None)
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        zr, zi, *rest = ctx.saved_tensors
+        tv, tn, tshape = ctx.tau
+        tp = rest[0] if rest else None
+        gr, gi = _al16(_c(gr)), _al16(_c(gi))
+        dzr, dzi = torch.empty_like(zr), torch.empty_like(zi)
+        want_tau = tshape is not None and ctx.needs_input_grad[2]
+        dtau = torch.empty(zr.shape, dtype=torch.float32, device=zr.device) if want_tau else None
+        call("cplxamd_modrelu_bwd", ptr(zr), ptr(zi), ptr(tp), tv, tn, ptr(gr), ptr(gi), ptr(dzr),
+             ptr(dzi), ptr(dtau), zr.numel(), dtype_code(zr), stream_ptr())
+        if want_tau:
+            dtau = dtau.sum_to_size(tshape) if len(tshape) else dtau.sum()
+        return dzr, dzi, dtau
+
+
+class CplxDropoutFn(torch.autograd.Function):
+    """One keep / drop decision per complex element (nn/modules/extra.py:7-25); the mask is a
+    function of (seed, offset) and is regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, xr, xi, p, seed, offset):
+        require_device(xr, xi)
+        xr, xi = _al16(_c(xr)), _al16(_c(xi))
+        ctx.p, ctx.seed, ctx.offset = p, seed, offset
+        return CplxDropoutFn._run(xr, xi, p, seed, offset)
+
+    @staticmethod
+    def _run(xr, xi, p, seed, offset):
+        yr, yi = torch.empty_like(xr), torch.empty_like(xi)
+        sd, of, st = _noise_args(seed, offset)
+        call("cplxamd_cplx_dropout", ptr(xr), ptr(xi), ptr(yr), ptr(yi), float(p), sd, of, st, xr.numel(),
+             dtype_code(xr), stream_ptr())
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        dr, di = CplxDropoutFn._run(_al16(_c(gr)), _al16(_c(gi)), ctx.p, ctx.seed, ctx.offset)
+        return dr, di, None, None, None

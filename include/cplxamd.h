@@ -297,6 +297,30 @@ int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* x
                    const float* saved, float* dweight, float* dbias, int training, int dtype,
                    void* ws, int64_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * layout converters and the non-GEMM layers either side of the path.
+ *   cplxamd_deinterleave / _interleave : x[2n] <-> (re[n], im[n])   cplx.py:451-470
+ *       (from_interleaved_real(copy=True) / to_interleaved_real along the last dim)
+ *   cplxamd_modrelu_fwd / _bwd : y = z * relu(1 - tau / max(|z|, 1e-5))   cplx.py:565-616
+ *       tau: tau_numel == 0 -> the value `tau_value`; 1 -> read from the device pointer (a
+ *       learnable scalar, no host sync); n -> one threshold per element (pre-broadcast).
+ *       bwd writes dz and, if dtau != NULL, the elementwise d/dtau (float32 [n]; the caller
+ *       sums it down to the parameter's shape).
+ *   cplxamd_cplx_dropout : y = x * keep / (1 - p), ONE Bernoulli(1 - p) draw per complex element
+ *       (nn/modules/extra.py:7-25); keep comes from the Philox4x32-10 stream (seed, offset) or
+ *       the device pair `state`; applying it to the gradient is the backward.
+ * All planes contiguous, 16-byte aligned, n = number of complex elements.
+ * ---------------------------------------------------------------------------------- */
+int cplxamd_deinterleave(const void* x, void* re, void* im, int64_t n, int dtype, void* stream);
+int cplxamd_interleave(const void* re, const void* im, void* out, int64_t n, int dtype, void* stream);
+int cplxamd_modrelu_fwd(const void* zr, const void* zi, const float* tau, float tau_value, int tau_numel,
+                        void* yr, void* yi, int64_t n, int dtype, void* stream);
+int cplxamd_modrelu_bwd(const void* zr, const void* zi, const float* tau, float tau_value, int tau_numel,
+                        const void* gr, const void* gi, void* dzr, void* dzi, float* dtau, int64_t n,
+                        int dtype, void* stream);
+int cplxamd_cplx_dropout(const void* xr, const void* xi, void* yr, void* yi, double p, uint64_t seed,
+                         uint64_t offset, const uint64_t* state, int64_t n, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

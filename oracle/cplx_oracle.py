@@ -519,3 +519,59 @@ def cplx_batch_norm_bwd(gr, gi, xr, xi, running_mean, running_var, weight=None,
     out["dxi"] = (gzu * R + gzv * Wd + (2 * gD / N) * cv + (gB / N) * cu
                   - (R * sgu + Wd * sgv) / N)
     return out
+
+
+# --------------------------------------------------------------------------- #
+#  layout converters, modReLU, complex dropout           #
+# --------------------------------------------------------------------------- #
+def from_interleaved_real(x):
+    """cplxmodule/cplx.py:451-455 along the last dim: x[..., 2k] + i x[..., 2k+1]."""
+    return x[..., 0::2].copy(), x[..., 1::2].copy()
+
+
+def to_interleaved_real(re, im, flatten=True):
+    """cplxmodule/cplx.py:466-470 along the last dim."""
+    out = np.stack([re, im], axis=-1)
+    return out.reshape(*re.shape[:-1], -1) if flatten else out
+
+
+def from_concatenated_real(x):
+    """cplxmodule/cplx.py:458-461."""
+    d = x.shape[-1] // 2
+    return x[..., :d].copy(), x[..., d:].copy()
+
+
+def modrelu(zr, zi, tau):
+    """cplxmodule/cplx.py:613-615: z * relu(1 - tau / clamp(|z|, min=1e-5)); tau broadcasts."""
+    dt = zr.dtype
+    m = np.maximum(cplx_abs(zr, zi), np.asarray(1e-5, dt))
+    s = np.maximum(np.asarray(1.0, dt) - np.asarray(tau, dt) / m, np.asarray(0.0, dt))
+    return zr * s, zi * s
+
+
+def modrelu_bwd(gr, gi, zr, zi, tau):
+    """Hand-derived gradients of ``modrelu``: with dot = g . z,
+    dz = g s + z dot tau / m^3 (active branch, |z| >= 1e-5: clamp passes the gradient at the
+    boundary), dtau = -dot / m (active branch), summed down to tau's shape by the caller."""
+    dt = zr.dtype
+    tau = np.broadcast_to(np.asarray(tau, dt), zr.shape)
+    az = cplx_abs(zr, zi)
+    m = np.maximum(az, np.asarray(1e-5, dt))
+    pre = np.asarray(1.0, dt) - tau / m
+    active = pre > 0
+    s = np.where(active, pre, 0).astype(dt)
+    dot = gr * zr + gi * zi
+    k = np.where(active & (az >= 1e-5), dot * tau / (m * m * m), 0).astype(dt)
+    return dict(dzr=gr * s + zr * k, dzi=gi * s + zi * k,
+                dtau=np.where(active, -dot / m, 0).astype(dt))
+
+
+def cplx_dropout_mask(n, p, seed, offset):
+    """Keep mask of the package's complex dropout (csrc/layout.hip): element e is kept iff word
+    (e & 3) of Philox4x32-10(counter = (e >> 2, offset), key = seed) >= floor(p * 2^32)."""
+    from .philox import philox4x32_10
+    groups = (n + 3) // 4
+    words = philox4x32_10(np.arange(groups, dtype=np.uint64), int(offset), int(seed))
+    t = p * 4294967296.0
+    thresh = np.uint32(0xFFFFFFFF) if t >= 4294967295.0 else np.uint32(int(t))
+    return (words.reshape(-1)[:n] >= thresh)

@@ -395,11 +395,58 @@ def gen_api():
     save("api", d)
 
 
+def gen_extras():
+    """layout converters, modReLU (+ learnable thresholds), CplxDropout."""
+    from cplxmodule.nn import CplxModReLU, CplxAdaptiveModReLU, CplxDropout  # noqa: F401
+    d = {}
+    for tag, dt in DT.items():
+        torch.manual_seed(11)
+        # modReLU: generic values, values inside the dead zone, on the clamp and exact zeros
+        zr, zi = leaf(6, 5, 8, dtype=dt), leaf(6, 5, 8, dtype=dt)
+        with torch.no_grad():
+            zr[0, 0, :4] *= 1e-6
+            zi[0, 0, :4] *= 1e-6
+            zr[0, 1, :2] = 0.0
+            zi[0, 1, :2] = 0.0
+            zr[0, 2, :3] *= 0.3
+            zi[0, 2, :3] *= 0.3
+        gr, gi = torch.randn(6, 5, 8, dtype=dt), torch.randn(6, 5, 8, dtype=dt)
+        cases = {"scalar": 0.5, "one": torch.tensor([0.3], dtype=dt, requires_grad=True),
+                 "chan": (torch.rand(5, 1, dtype=dt) * 0.8 - 0.1).requires_grad_(True)}
+        d[f"{tag}_mr_zr"], d[f"{tag}_mr_zi"], d[f"{tag}_mr_gr"], d[f"{tag}_mr_gi"] = npy(zr), npy(zi), npy(gr), npy(gi)
+        for name, tau in cases.items():
+            for t in (zr, zi):
+                t.grad = None
+            y = cplx.modrelu(C(zr, zi), tau)
+            torch.autograd.backward((y.real, y.imag), (gr, gi))
+            k = f"{tag}_mr_{name}_"
+            d[k + "tau"] = np.asarray(tau, dtype=np.float64) if isinstance(tau, float) else npy(tau)
+            d[k + "yr"], d[k + "yi"], d[k + "dzr"], d[k + "dzi"] = npy(y.real), npy(y.imag), npy(zr.grad), npy(zi.grad)
+            if not isinstance(tau, float):
+                d[k + "dtau"] = npy(tau.grad)
+        # layout converters (pure data movement)
+        x = torch.randn(3, 4, 10, dtype=dt)
+        z = cplx.from_interleaved_real(x, True, -1)
+        d[f"{tag}_il_x"], d[f"{tag}_il_re"], d[f"{tag}_il_im"] = npy(x), npy(z.real), npy(z.imag)
+        d[f"{tag}_il_back"] = npy(cplx.to_interleaved_real(z, True, -1))
+        d[f"{tag}_il_stack"] = npy(cplx.to_interleaved_real(z, False, -1))
+        zc = cplx.from_concatenated_real(x, True, -1)
+        d[f"{tag}_cat_re"], d[f"{tag}_cat_im"] = npy(zc.real), npy(zc.imag)
+        d[f"{tag}_cat_back"] = npy(cplx.to_concatenated_real(zc, None, -1))
+    # dropout: the reference drops (re, im) jointly and rescales by 1/(1-p); record one realisation's
+    # invariants (which elements share a fate, the scale) -- the Bernoulli stream itself is torch's.
+    torch.manual_seed(5)
+    layer = CplxDropout(0.3)
+    layer.train()
+    z = C(torch.randn(64, 50), torch.randn(64, 50))
+    y = layer(z)
+    d["do_zr"], d["do_zi"], d["do_yr"], d["do_yi"] = npy(z.real), npy(z.imag), npy(y.real), npy(y.imag)
+    save("extras", d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reproducible summation order
-    gen_linear()
-    gen_lrt_linear()
-    gen_penalty()
-    gen_conv()
-    gen_batchnorm()
-    gen_api()
+    gens = dict(linear=gen_linear, lrt_linear=gen_lrt_linear, penalty=gen_penalty, conv=gen_conv,
+                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras)
+    for name in (sys.argv[1:] or list(gens)):
+        gens[name]()

@@ -1,0 +1,124 @@
+"""SURVEY 8(f) rows 2-3 on the GPU: layout converters, modReLU (+ learnable thresholds), complex
+dropout -- against the reference's golden vectors, the oracle, and their defining properties."""
+import numpy as np
+import pytest
+import torch
+
+import oracle.cplx_oracle as orc
+from gpu_util import DEV, T, N
+
+pytestmark = pytest.mark.gpu
+
+
+def test_layout_converters_golden(golden):
+    from cplxmodule_amd import Cplx, cplx
+    g = golden("extras")
+    x = T(g["f32_il_x"])
+    z = cplx.from_interleaved_real(x, True, -1)
+    assert np.array_equal(N(z.real), g["f32_il_re"]) and np.array_equal(N(z.imag), g["f32_il_im"])
+    assert np.array_equal(N(cplx.to_interleaved_real(z, True, -1)), g["f32_il_back"])
+    assert np.array_equal(N(cplx.to_interleaved_real(z, False, -1)), g["f32_il_stack"])
+    zc = cplx.from_concatenated_real(x, True, -1)
+    assert np.array_equal(N(zc.real), g["f32_cat_re"])
+    assert np.array_equal(N(cplx.to_concatenated_real(zc)), g["f32_cat_back"])
+    v = cplx.from_interleaved_real(x, False, -1)               # views, like the reference
+    assert v.real.data_ptr() == x.data_ptr() and np.array_equal(N(v.imag), g["f32_il_im"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(7, 3, 10), (1, 2), (5, 4096), (3, 1023 * 2)])
+def test_interleave_roundtrip_and_grad(dtype, shape):
+    from cplxmodule_amd import cplx
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=DEV).to(dtype).requires_grad_(True)
+    z = cplx.from_interleaved_real(x, True, -1)
+    assert torch.equal(z.real, x.detach()[..., 0::2]) and torch.equal(z.imag, x.detach()[..., 1::2])
+    back = cplx.to_interleaved_real(z, True, -1)
+    assert torch.equal(back, x.detach())
+    w = torch.randn(*shape, device=DEV).to(dtype)
+    (back * w).sum().backward()
+    assert torch.equal(x.grad, w)                              # both converters are permutations
+
+
+@pytest.mark.parametrize("case", ["scalar", "one", "chan"])
+def test_modrelu_golden(golden, case):
+    from cplxmodule_amd import Cplx, cplx
+    g = golden("extras")
+    zr, zi = T(g["f32_mr_zr"]).requires_grad_(True), T(g["f32_mr_zi"]).requires_grad_(True)
+    k = f"f32_mr_{case}_"
+    tau = float(g[k + "tau"]) if case == "scalar" else T(g[k + "tau"]).requires_grad_(True)
+    y = cplx.modrelu(Cplx(zr, zi), tau)
+    np.testing.assert_allclose(N(y.real), g[k + "yr"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(N(y.imag), g[k + "yi"], rtol=1e-6, atol=1e-7)
+    torch.autograd.backward((y.real, y.imag), (T(g["f32_mr_gr"]), T(g["f32_mr_gi"])))
+    np.testing.assert_allclose(N(zr.grad), g[k + "dzr"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(N(zi.grad), g[k + "dzi"], rtol=2e-5, atol=2e-5)
+    if case != "scalar":
+        np.testing.assert_allclose(N(tau.grad), g[k + "dtau"], rtol=1e-4, atol=1e-4)
+
+
+def test_modrelu_large_vs_oracle_and_layers():
+    from cplxmodule_amd import Cplx, nn
+    rs = np.random.RandomState(0)
+    zr, zi = rs.randn(33, 1001).astype(np.float32), rs.randn(33, 1001).astype(np.float32)
+    layer = nn.CplxModReLU(0.7)
+    y = layer(Cplx(T(zr), T(zi)))
+    yr, yi = orc.modrelu(zr, zi, 0.7)
+    np.testing.assert_allclose(N(y.real), yr, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(N(y.imag), yi, rtol=1e-6, atol=1e-7)
+    yb = layer(Cplx(T(zr, torch.bfloat16), T(zi, torch.bfloat16)))
+    np.testing.assert_allclose(N(yb.real), yr, rtol=2e-2, atol=2e-2)
+    learn = nn.CplxModReLU(None).to(DEV)                       # learnable scalar threshold
+    ada = nn.CplxAdaptiveModReLU(1001).to(DEV)
+    for m in (learn, ada):
+        out = m(Cplx(T(zr), T(zi)))
+        (out.real.sum() + out.imag.sum()).backward()
+        assert m.threshold.grad is not None and m.threshold.grad.shape == m.threshold.shape
+        assert torch.isfinite(m.threshold.grad).all()
+    assert repr(ada) == "CplxAdaptiveModReLU(1001)"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cplx_dropout_properties(dtype):
+    """Joint fate of (re, im), 1 / (1 - p) rescale, keep rate, the oracle's mask bit for bit, the
+    same mask in backward, identity in eval mode."""
+    from cplxmodule_amd import Cplx, nn
+    from cplxmodule_amd.nn.relevance import noise
+    noise.manual_seed(21)
+    n = (257, 130)
+    torch.manual_seed(1)
+    zr = (torch.rand(*n, device=DEV) + 0.5).to(dtype).requires_grad_(True)
+    zi = (torch.rand(*n, device=DEV) + 0.5).to(dtype).requires_grad_(True)
+    layer = nn.CplxDropout(0.3)
+    y = layer(Cplx(zr, zi))
+    keep = N(y.real) != 0
+    assert np.array_equal(keep, N(y.imag) != 0)
+    want = orc.cplx_dropout_mask(zr.numel(), 0.3, seed=21, offset=noise.counter).reshape(n)
+    assert np.array_equal(keep, want)
+    assert abs(keep.mean() - 0.7) < 0.02
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(N(y.real)[keep], N(zr)[keep] / 0.7, rtol=tol)
+    torch.autograd.backward((y.real, y.imag), (torch.ones_like(y.real), torch.ones_like(y.imag)))
+    np.testing.assert_allclose(N(zr.grad), keep / 0.7, rtol=tol)
+    np.testing.assert_allclose(N(zi.grad), keep / 0.7, rtol=tol)
+    y2 = layer(Cplx(zr, zi))                                   # next call: a fresh mask
+    assert not np.array_equal(N(y2.real) != 0, keep)
+    layer.eval()
+    out = layer(Cplx(zr, zi))
+    assert out.real is zr and out.imag is zi
+
+
+def test_extras_throughput_smoke():
+    """Single-pass kernels: sanity-check they run at streaming speed on a large tensor."""
+    from cplxmodule_amd import Cplx, cplx
+    x = torch.randn(8192, 8192, device=DEV)
+    z = cplx.from_interleaved_real(x, True, -1)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        y = cplx.modrelu(z, 0.5)
+    e.record()
+    torch.cuda.synchronize()
+    gbps = 5 * 16 * z.real.numel() / (s.elapsed_time(e) * 1e-3) / 1e9
+    assert gbps > 1500, gbps

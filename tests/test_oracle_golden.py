@@ -215,3 +215,58 @@ def test_batchnorm_functional(golden, tag):
                                  None, True, 1e-3)
     close(bw["dxr"], g[k + "dxr"], tag, 100)
     close(bw["dxi"], g[k + "dxi"], tag, 100)
+
+
+# ---- converters, modReLU, dropout ------------------------------------- #
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_oracle_layout_converters(golden, tag):
+    g = golden("extras")
+    x = g[f"{tag}_il_x"]
+    re, im = orc.from_interleaved_real(x)
+    assert np.array_equal(re, g[f"{tag}_il_re"]) and np.array_equal(im, g[f"{tag}_il_im"])
+    assert np.array_equal(orc.to_interleaved_real(re, im), g[f"{tag}_il_back"])
+    assert np.array_equal(orc.to_interleaved_real(re, im, flatten=False), g[f"{tag}_il_stack"])
+    cr, ci = orc.from_concatenated_real(x)
+    assert np.array_equal(cr, g[f"{tag}_cat_re"]) and np.array_equal(ci, g[f"{tag}_cat_im"])
+    assert np.array_equal(np.concatenate([cr, ci], -1), g[f"{tag}_cat_back"])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("case", ["scalar", "one", "chan"])
+def test_oracle_modrelu(golden, tag, case):
+    g = golden("extras")
+    zr, zi, gr, gi = (g[f"{tag}_mr_{k}"] for k in ("zr", "zi", "gr", "gi"))
+    k = f"{tag}_mr_{case}_"
+    tau = g[k + "tau"].astype(zr.dtype)
+    tau_b = tau if tau.ndim != 1 or tau.shape[0] != 1 else tau[0]
+    yr, yi = orc.modrelu(zr, zi, tau_b)
+    tol = dict(rtol=1e-6, atol=1e-7) if tag == "f32" else dict(rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(yr, g[k + "yr"], **tol)
+    np.testing.assert_allclose(yi, g[k + "yi"], **tol)
+    bw = orc.modrelu_bwd(gr, gi, zr, zi, tau_b)
+    gtol = dict(rtol=2e-5, atol=2e-5) if tag == "f32" else dict(rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(bw["dzr"], g[k + "dzr"], **gtol)
+    np.testing.assert_allclose(bw["dzi"], g[k + "dzi"], **gtol)
+    if case != "scalar":
+        want = g[k + "dtau"]
+        got = bw["dtau"].sum() if want.size == 1 else bw["dtau"].sum(axis=(0, 2), keepdims=False).reshape(want.shape)
+        np.testing.assert_allclose(np.asarray(got).reshape(want.shape), want,
+                                   **(dict(rtol=1e-4, atol=1e-4) if tag == "f32" else gtol))
+
+
+def test_reference_dropout_contract(golden):
+    """What the reference's CplxDropout guarantees (the property our Philox version must share):
+    real and imaginary parts share their fate, survivors are scaled by 1 / (1 - p)."""
+    g = golden("extras")
+    zr, zi, yr, yi = g["do_zr"], g["do_zi"], g["do_yr"], g["do_yi"]
+    kept_r, kept_i = yr != 0, yi != 0
+    assert np.array_equal(kept_r, kept_i)
+    np.testing.assert_allclose(yr[kept_r], zr[kept_r] / 0.7, rtol=1e-6)
+    np.testing.assert_allclose(yi[kept_i], zi[kept_i] / 0.7, rtol=1e-6)
+    assert 0.6 < kept_r.mean() < 0.8
+
+
+def test_oracle_dropout_mask_rate():
+    m = orc.cplx_dropout_mask(200003, 0.3, seed=7, offset=3)
+    assert m.shape == (200003,) and abs(m.mean() - 0.7) < 5e-3
+    assert not np.array_equal(m, orc.cplx_dropout_mask(200003, 0.3, seed=7, offset=4))
