@@ -37,6 +37,8 @@ SIGNATURES = {
                       _I, _I, _I, _P, _L, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
+    "cplxamd_cplx_maxpool2d_fwd": [_P, _P, _P, _P, _P, _P, _I, _P],
+    "cplxamd_cplx_maxpool2d_bwd": [_P, _P, _P, _P, _P, _P, _I, _P],
     "cplxamd_deinterleave": [_P, _P, _P, _L, _I, _P],
     "cplxamd_interleave": [_P, _P, _P, _L, _I, _P],
     "cplxamd_modrelu_fwd": [_P, _P, _P, _F, _I, _P, _P, _L, _I, _P],

@@ -401,3 +401,26 @@ def dropout(input, p=0.5, training=True):
     from .nn.relevance.noise import noise
     seed, offset = noise.next(input.real.device)
     return Cplx(*ops.CplxDropoutFn.apply(input.real, input.imag, p, seed, offset))
+
+
+def _pair2(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def max_pool2d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False):
+    """Complex max pooling on [B, C, H, W]: the element of largest modulus in each window keeps
+    both its parts (cplxmodule/cplx.py:1114-1175, 1183-1190)."""
+    k = _pair2(kernel_size)
+    s = k if stride is None else _pair2(stride)
+    return Cplx(*ops.CplxMaxPool2dFn.apply(input.real, input.imag, k, s, _pair2(padding),
+                                           _pair2(dilation), bool(ceil_mode)))
+
+
+def max_pool1d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False):
+    """[B, C, L] (cplxmodule/cplx.py:1178-1181): the 2-d kernel on a height-1 image."""
+    first = lambda v: v if isinstance(v, int) else v[0]  # noqa: E731
+    k = first(kernel_size)
+    s = k if stride is None else first(stride)
+    z = Cplx(input.real.unsqueeze(2), input.imag.unsqueeze(2))
+    out = max_pool2d(z, (1, k), (1, s), (0, first(padding)), (1, first(dilation)), ceil_mode)
+    return Cplx(out.real.squeeze(2), out.imag.squeeze(2))

@@ -9,3 +9,4 @@ from .casting import CplxToInterleavedReal as CplxToReal  # noqa: F401
 from .casting import InterleavedRealToCplx as RealToCplx  # noqa: F401
 from .activation import CplxModReLU, CplxAdaptiveModReLU, CplxModulus, CplxAngle  # noqa: F401
 from .extra import CplxDropout  # noqa: F401
+from .pooling import CplxMaxPool1d, CplxMaxPool2d  # noqa: F401

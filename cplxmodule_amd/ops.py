@@ -676,3 +676,47 @@ class CplxDropoutFn(torch.autograd.Function):
     def backward(ctx, gr, gi):
         dr, di = CplxDropoutFn._run(_al16(_c(gr)), _al16(_c(gi)), ctx.p, ctx.seed, ctx.offset)
         return dr, di, None, None, None
+
+
+def _pool_out(L, k, s, p, d, ceil_mode):
+    """torch's pooling output size (incl. the ceil_mode rule that the last window must start
+    inside the input or its left padding)."""
+    num = L + 2 * p - d * (k - 1) - 1
+    o = (-(-num // s) if ceil_mode else num // s) + 1
+    if ceil_mode and (o - 1) * s >= L + p:
+        o -= 1
+    return o
+
+
+class CplxMaxPool2dFn(torch.autograd.Function):
+    """cplx.max_pool2d (cplxmodule/cplx.py:1114-1175, 1183-1190) as one kernel + gather backward."""
+
+    @staticmethod
+    def forward(ctx, zr, zi, kernel, stride, padding, dilation, ceil_mode):
+        import ctypes
+        require_device(zr, zi)
+        zr, zi = _c(zr), _c(zi)
+        B, C, H, W = zr.shape
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw) = kernel, stride, padding, dilation
+        if ph > kh // 2 or pw > kw // 2:
+            raise RuntimeError("pad should be at most half of effective kernel size")
+        Ho, Wo = _pool_out(H, kh, sh, ph, dh, ceil_mode), _pool_out(W, kw, sw, pw, dw, ceil_mode)
+        pool = (ctypes.c_int * 14)(B, C, H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw)
+        yr = torch.empty(B, C, Ho, Wo, dtype=zr.dtype, device=zr.device)
+        yi = torch.empty_like(yr)
+        idx = torch.empty(B, C, Ho, Wo, dtype=torch.int32, device=zr.device)
+        call("cplxamd_cplx_maxpool2d_fwd", ptr(zr), ptr(zi), ptr(yr), ptr(yi), ptr(idx), pool,
+             dtype_code(zr), stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.pool, ctx.in_shape = pool, zr.shape
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        (idx,) = ctx.saved_tensors
+        gr, gi = _c(gr), _c(gi)
+        dzr = torch.empty(ctx.in_shape, dtype=gr.dtype, device=gr.device)
+        dzi = torch.empty_like(dzr)
+        call("cplxamd_cplx_maxpool2d_bwd", ptr(gr), ptr(gi), ptr(idx), ptr(dzr), ptr(dzi), ctx.pool,
+             dtype_code(gr), stream_ptr())
+        return dzr, dzi, None, None, None, None, None

@@ -321,6 +321,15 @@ int cplxamd_modrelu_bwd(const void* zr, const void* zi, const float* tau, float 
 int cplxamd_cplx_dropout(const void* xr, const void* xi, void* yr, void* yi, double p, uint64_t seed,
                          uint64_t offset, const uint64_t* state, int64_t n, int dtype, void* stream);
 
+/* Complex abs-max pooling (cplx.max_poolnd, cplx.py:1114-1175): in every window the element of
+ * largest modulus keeps both its parts (first maximum in row-major window order, as torch).
+ * pool = int[14]: B, C, H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw.  idx: int32 [B, C, Ho, Wo],
+ * the selected position h * W + w, written by fwd and read by bwd (a deterministic gather). */
+int cplxamd_cplx_maxpool2d_fwd(const void* zr, const void* zi, void* yr, void* yi, int32_t* idx,
+                               const int* pool, int dtype, void* stream);
+int cplxamd_cplx_maxpool2d_bwd(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi,
+                               const int* pool, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

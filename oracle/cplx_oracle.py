@@ -575,3 +575,56 @@ def cplx_dropout_mask(n, p, seed, offset):
     t = p * 4294967296.0
     thresh = np.uint32(0xFFFFFFFF) if t >= 4294967295.0 else np.uint32(int(t))
     return (words.reshape(-1)[:n] >= thresh)
+
+
+def _pool_out(L, k, s, p, d, ceil_mode):
+    num = L + 2 * p - d * (k - 1) - 1
+    o = (-(-num // s) if ceil_mode else num // s) + 1
+    if ceil_mode and (o - 1) * s >= L + p:
+        o -= 1
+    return o
+
+
+def cplx_max_pool2d(zr, zi, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False):
+    """cplx.max_poolnd (cplxmodule/cplx.py:1114-1175): argmax of |z| per window (first maximum in
+    row-major window order, as F.max_pool2d), both parts gathered.  Returns (yr, yi, idx)."""
+    (kh, kw), (ph, pw), (dh, dw) = _pair(kernel_size), _pair(padding), _pair(dilation)
+    sh, sw = (kh, kw) if stride is None else _pair(stride)
+    B, C, H, W = zr.shape
+    Ho, Wo = _pool_out(H, kh, sh, ph, dh, ceil_mode), _pool_out(W, kw, sw, pw, dw, ceil_mode)
+    mod = cplx_abs(zr, zi)
+    yr, yi = np.zeros((B, C, Ho, Wo), zr.dtype), np.zeros((B, C, Ho, Wo), zr.dtype)
+    idx = np.zeros((B, C, Ho, Wo), np.int64)
+    for oh in range(Ho):
+        for ow in range(Wo):
+            best = np.full((B, C), -np.inf)
+            sel = np.full((B, C), -1, np.int64)
+            for i in range(kh):
+                h = oh * sh - ph + i * dh
+                if not 0 <= h < H:
+                    continue
+                for j in range(kw):
+                    w = ow * sw - pw + j * dw
+                    if not 0 <= w < W:
+                        continue
+                    m = mod[:, :, h, w]
+                    take = (sel < 0) | (m > best)
+                    best = np.where(take, m, best)
+                    sel = np.where(take, h * W + w, sel)
+            idx[:, :, oh, ow] = sel
+    flat_r, flat_i = zr.reshape(B, C, -1), zi.reshape(B, C, -1)
+    yr = np.take_along_axis(flat_r, idx.reshape(B, C, -1), -1).reshape(B, C, Ho, Wo)
+    yi = np.take_along_axis(flat_i, idx.reshape(B, C, -1), -1).reshape(B, C, Ho, Wo)
+    return yr, yi, idx
+
+
+def cplx_max_pool2d_bwd(gr, gi, idx, in_shape):
+    """Scatter-add of the output gradients to the selected positions."""
+    B, C, H, W = in_shape
+    dzr, dzi = np.zeros((B, C, H * W), gr.dtype), np.zeros((B, C, H * W), gr.dtype)
+    fi = idx.reshape(B, C, -1)
+    for b in range(B):
+        for c in range(C):
+            np.add.at(dzr[b, c], fi[b, c], gr[b, c].reshape(-1))
+            np.add.at(dzi[b, c], fi[b, c], gi[b, c].reshape(-1))
+    return dzr.reshape(in_shape), dzi.reshape(in_shape)

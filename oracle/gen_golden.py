@@ -433,6 +433,28 @@ def gen_extras():
         zc = cplx.from_concatenated_real(x, True, -1)
         d[f"{tag}_cat_re"], d[f"{tag}_cat_im"] = npy(zc.real), npy(zc.imag)
         d[f"{tag}_cat_back"] = npy(cplx.to_concatenated_real(zc, None, -1))
+    # abs-max pooling (values, gradients); one case has ties (a constant block)
+    torch.manual_seed(13)
+    pools = {"k2": dict(kernel_size=2), "k3s2p1": dict(kernel_size=3, stride=2, padding=1),
+             "rect": dict(kernel_size=(3, 2), stride=(2, 1), padding=(1, 0), dilation=(1, 2), ceil_mode=True)}
+    for tag, dt in DT.items():
+        zr, zi = leaf(2, 3, 9, 11, dtype=dt), leaf(2, 3, 9, 11, dtype=dt)
+        with torch.no_grad():
+            zr[0, 0, :4, :4] = 1.0
+            zi[0, 0, :4, :4] = -1.0
+        d[f"{tag}_mp_zr"], d[f"{tag}_mp_zi"] = npy(zr), npy(zi)
+        for name, kw in pools.items():
+            for t in (zr, zi):
+                t.grad = None
+            y = cplx.max_pool2d(C(zr, zi), **kw)
+            gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+            torch.autograd.backward((y.real, y.imag), (gr, gi))
+            k = f"{tag}_mp_{name}_"
+            d[k + "yr"], d[k + "yi"], d[k + "gr"], d[k + "gi"] = npy(y.real), npy(y.imag), npy(gr), npy(gi)
+            d[k + "dzr"], d[k + "dzi"] = npy(zr.grad), npy(zi.grad)
+        x1r, x1i = leaf(2, 4, 17, dtype=dt), leaf(2, 4, 17, dtype=dt)
+        y1 = cplx.max_pool1d(C(x1r, x1i), 3, 2, 1)
+        d[f"{tag}_mp1_zr"], d[f"{tag}_mp1_zi"], d[f"{tag}_mp1_yr"], d[f"{tag}_mp1_yi"] = npy(x1r), npy(x1i), npy(y1.real), npy(y1.imag)
     # dropout: the reference drops (re, im) jointly and rescales by 1/(1-p); record one realisation's
     # invariants (which elements share a fate, the scale) -- the Bernoulli stream itself is torch's.
     torch.manual_seed(5)

@@ -122,3 +122,36 @@ def test_extras_throughput_smoke():
     torch.cuda.synchronize()
     gbps = 5 * 16 * z.real.numel() / (s.elapsed_time(e) * 1e-3) / 1e9
     assert gbps > 1500, gbps
+
+
+POOLS = {"k2": dict(kernel_size=2), "k3s2p1": dict(kernel_size=3, stride=2, padding=1),
+         "rect": dict(kernel_size=(3, 2), stride=(2, 1), padding=(1, 0), dilation=(1, 2), ceil_mode=True)}
+
+
+@pytest.mark.parametrize("name", list(POOLS))
+def test_max_pool2d_golden(golden, name):
+    """Selection (incl. ties), values and gradients (overlapping windows) against the reference."""
+    from cplxmodule_amd import Cplx, cplx
+    g = golden("extras")
+    zr, zi = T(g["f32_mp_zr"]).requires_grad_(True), T(g["f32_mp_zi"]).requires_grad_(True)
+    k = f"f32_mp_{name}_"
+    y = cplx.max_pool2d(Cplx(zr, zi), **POOLS[name])
+    assert np.array_equal(N(y.real), g[k + "yr"]) and np.array_equal(N(y.imag), g[k + "yi"])
+    torch.autograd.backward((y.real, y.imag), (T(g[k + "gr"]), T(g[k + "gi"])))
+    np.testing.assert_allclose(N(zr.grad), g[k + "dzr"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(N(zi.grad), g[k + "dzi"], rtol=1e-6, atol=1e-6)
+
+
+def test_max_pool1d_and_layers(golden):
+    from cplxmodule_amd import Cplx, nn
+    g = golden("extras")
+    z = Cplx(T(g["f32_mp1_zr"]), T(g["f32_mp1_zi"]))
+    y = nn.CplxMaxPool1d(3, 2, 1)(z)
+    assert np.array_equal(N(y.real), g["f32_mp1_yr"]) and np.array_equal(N(y.imag), g["f32_mp1_yi"])
+    rs = np.random.RandomState(4)
+    zr, zi = rs.randn(3, 5, 31, 29).astype(np.float32), rs.randn(3, 5, 31, 29).astype(np.float32)
+    layer = nn.CplxMaxPool2d(3, stride=2, padding=1, ceil_mode=True)
+    out = layer(Cplx(T(zr), T(zi)))
+    yr, yi, _ = orc.cplx_max_pool2d(zr, zi, 3, 2, 1, 1, True)
+    assert np.array_equal(N(out.real), yr) and np.array_equal(N(out.imag), yi)
+    assert "kernel_size=3" in repr(layer)

@@ -270,3 +270,21 @@ def test_oracle_dropout_mask_rate():
     m = orc.cplx_dropout_mask(200003, 0.3, seed=7, offset=3)
     assert m.shape == (200003,) and abs(m.mean() - 0.7) < 5e-3
     assert not np.array_equal(m, orc.cplx_dropout_mask(200003, 0.3, seed=7, offset=4))
+
+
+POOLS = {"k2": dict(kernel_size=2), "k3s2p1": dict(kernel_size=3, stride=2, padding=1),
+         "rect": dict(kernel_size=(3, 2), stride=(2, 1), padding=(1, 0), dilation=(1, 2), ceil_mode=True)}
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("name", list(POOLS))
+def test_oracle_max_pool2d(golden, tag, name):
+    g = golden("extras")
+    zr, zi = g[f"{tag}_mp_zr"], g[f"{tag}_mp_zi"]
+    k = f"{tag}_mp_{name}_"
+    yr, yi, idx = orc.cplx_max_pool2d(zr, zi, **POOLS[name])
+    assert np.array_equal(yr, g[k + "yr"]) and np.array_equal(yi, g[k + "yi"])
+    dzr, dzi = orc.cplx_max_pool2d_bwd(g[k + "gr"], g[k + "gi"], idx, zr.shape)
+    tol = dict(rtol=1e-6, atol=1e-6) if tag == "f32" else dict(rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(dzr, g[k + "dzr"], **tol)
+    np.testing.assert_allclose(dzi, g[k + "dzi"], **tol)
