@@ -97,7 +97,17 @@ __device__ __forceinline__ float kl_value(float t) {
     return fmaf(0.5f, softplus_f(t), kK1 * sigmoid_f(fmaf(kK3, t, -kK2)));
   if (KIND == CPLXAMD_KL_REAL_ARD) return 0.5f * softplus_f(t);
   if (KIND == CPLXAMD_KL_CPLX_VD) return cplx_vd_value(t);
+  // extensions/complex.py:113-117: softplus(t) + 0.57810 sigmoid(1.36526 t - 1.45926)
+  if (KIND == CPLXAMD_KL_CPLX_VD_APPROX)
+    return fmaf(0.57810f, sigmoid_f(fmaf(1.36526f, t, -1.45926f)), softplus_f(t));
+  // extensions/complex.py:43-46: log|w| - ls2 - Ei(-e^t)/2 = (f_vd(t) - gamma)/2 - ls2/2; the
+  // -ls2/2 term is added by the kernel (kl_ls2_term)
+  if (KIND == CPLXAMD_KL_CPLX_VD_SCALEFREE) return 0.5f * (cplx_vd_value(t) - kEulerGamma);
   return softplus_f(t);
+}
+// part of the penalty that depends on log_sigma2 directly (not through t): c * ls2
+template <int KIND> __device__ __forceinline__ constexpr float kl_ls2_term() {
+  return KIND == CPLXAMD_KL_CPLX_VD_SCALEFREE ? -0.5f : 0.0f;
 }
 
 // f'(t)
@@ -109,6 +119,11 @@ __device__ __forceinline__ float kl_slope(float t) {
   }
   if (KIND == CPLXAMD_KL_REAL_ARD) return 0.5f * softplus_grad_f(t);
   if (KIND == CPLXAMD_KL_CPLX_VD) return -expm1f(-expf(t));  // 1 - exp(-e^t)
+  if (KIND == CPLXAMD_KL_CPLX_VD_APPROX) {
+    const float su = sigmoid_f(fmaf(1.36526f, t, -1.45926f));
+    return fmaf(0.57810f * 1.36526f, su * (1.0f - su), softplus_grad_f(t));
+  }
+  if (KIND == CPLXAMD_KL_CPLX_VD_SCALEFREE) return -0.5f * expm1f(-expf(t));
   return softplus_grad_f(t);
 }
 
@@ -148,7 +163,8 @@ struct KlArgs {
 
 template <int KIND, bool VALUE, bool GRAD>
 __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
-  constexpr bool CPLX = (KIND == CPLXAMD_KL_CPLX_VD || KIND == CPLXAMD_KL_CPLX_ARD);
+  constexpr bool CPLX = KIND >= CPLXAMD_KL_CPLX_VD;
+  constexpr float kLs = kl_ls2_term<KIND>();
   __shared__ double red[kKlThreads / 64];
   const int64_t n4 = a.n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kKlThreads;
@@ -170,12 +186,12 @@ __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
       float theta;
       const float t = -log_alpha_of<CPLX, false>(ls.v[j], wr.v[j], wi.v[j], theta);
       if (VALUE) {
-        val.v[j] = kl_value<KIND>(t);
+        val.v[j] = kl_value<KIND>(t) + kLs * ls.v[j];
         part += val.v[j];
       }
       if (GRAD) {
         const float fp = kl_slope<KIND>(t) * ge.v[j] * gs;
-        d_ls.v[j] = -fp;
+        d_ls.v[j] = kLs * ge.v[j] * gs - fp;
         weight_grad<CPLX>(fp, wr.v[j], wi.v[j], theta, d_wr.v[j], d_wi.v[j]);
       }
     }
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
       float theta;
       const float t = -log_alpha_of<CPLX, false>(ls, wr, wi, theta);
       if (VALUE) {
-        const float v = kl_value<KIND>(t);
+        const float v = kl_value<KIND>(t) + kLs * ls;
         acc += (double)v;
         if (a.out_elem) a.out_elem[i] = v;
       }
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
         const float fp = kl_slope<KIND>(t) * ge * gs;
         float gwr, gwi;
         weight_grad<CPLX>(fp, wr, wi, theta, gwr, gwi);
-        if (a.g_ls2) a.g_ls2[i] = -fp;
+        if (a.g_ls2) a.g_ls2[i] = kLs * ge * gs - fp;
         if (a.g_wr) a.g_wr[i] = gwr;
         if (CPLX && a.g_wi) a.g_wi[i] = gwi;
       }
@@ -244,6 +260,12 @@ static int launch_kl(int kind, const KlArgs& a, int grid, hipStream_t st) {
     case CPLXAMD_KL_CPLX_ARD:
       kl_kernel<CPLXAMD_KL_CPLX_ARD, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
       break;
+    case CPLXAMD_KL_CPLX_VD_APPROX:
+      kl_kernel<CPLXAMD_KL_CPLX_VD_APPROX, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
+      break;
+    case CPLXAMD_KL_CPLX_VD_SCALEFREE:
+      kl_kernel<CPLXAMD_KL_CPLX_VD_SCALEFREE, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
+      break;
     default:
       return CPLXAMD_EINVAL;
   }
@@ -252,7 +274,7 @@ static int launch_kl(int kind, const KlArgs& a, int grid, hipStream_t st) {
 }
 
 static bool kl_args_ok(const float* wr, const float* wi, const float* ls2, int kind, int64_t n) {
-  if (!wr || !ls2 || n < 0 || kind < 0 || kind > 3) return false;
+  if (!wr || !ls2 || n < 0 || kind < 0 || kind > CPLXAMD_KL_CPLX_VD_SCALEFREE) return false;
   const bool cplx = kind >= CPLXAMD_KL_CPLX_VD;
   return cplx ? wi != nullptr : true;
 }

@@ -3,3 +3,4 @@ from .noise import noise  # noqa: F401
 from .real import LinearVD, LinearARD, Conv2dVD, Conv2dARD  # noqa: F401
 from .complex import CplxLinearVD, CplxLinearARD, CplxConv2dVD, CplxConv2dARD  # noqa: F401
 from .complex import torch_expi  # noqa: F401
+from . import extensions  # noqa: F401

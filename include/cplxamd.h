@@ -39,7 +39,10 @@ enum {
   CPLXAMD_KL_REAL_VD = 0,  /* cplxmodule/nn/relevance/real/vd.py:54-76     */
   CPLXAMD_KL_REAL_ARD = 1, /* cplxmodule/nn/relevance/real/ard.py:10-39    */
   CPLXAMD_KL_CPLX_VD = 2,  /* cplxmodule/nn/relevance/complex/vd.py:95-99  */
-  CPLXAMD_KL_CPLX_ARD = 3  /* cplxmodule/nn/relevance/complex/ard.py:9-39  */
+  CPLXAMD_KL_CPLX_ARD = 3, /* cplxmodule/nn/relevance/complex/ard.py:9-39  */
+  /* SURVEY 8(f) row 4, cplxmodule/nn/relevance/extensions/complex.py: */
+  CPLXAMD_KL_CPLX_VD_APPROX = 4,    /* :113-117 softplus-sigmoid approximation          */
+  CPLXAMD_KL_CPLX_VD_SCALEFREE = 5  /* :43-46   log|w| - log_sigma2 - Ei(-1/alpha) / 2  */
 };
 
 /* error codes (negative; positive values are hipError_t) */

@@ -28,6 +28,7 @@ EULER_GAMMA = float(np.euler_gamma)
 K1, K2, K3 = 0.63576, 1.87320, 1.48695
 
 KINDS = ("real_vd", "real_ard", "cplx_vd", "cplx_ard")
+EXT_KINDS = ("cplx_vd_approx", "cplx_vd_scalefree")   # nn/relevance/extensions/complex.py
 
 
 # --------------------------------------------------------------------------- #
@@ -217,6 +218,12 @@ def penalty(kind, log_sigma2, wr, wi=None):
             return np.asarray(EULER_GAMMA, dt) + t - expi(-np.exp(t))
     if kind == "cplx_ard":
         return softplus(t)
+    if kind == "cplx_vd_approx":      # extensions/complex.py:113-117
+        return softplus(t) + np.asarray(0.57810, dt) * sigmoid(np.asarray(1.36526, dt) * t - np.asarray(1.45926, dt))
+    if kind == "cplx_vd_scalefree":   # extensions/complex.py:43-46 (t = 2 log|w| - log_sigma2)
+        log_abs_w = (t + log_sigma2) / 2
+        with np.errstate(over="ignore"):
+            return log_abs_w - log_sigma2 - np.asarray(0.5, dt) * expi(-np.exp(t))
     raise ValueError(kind)
 
 
@@ -234,6 +241,12 @@ def penalty_dt(kind, t):
             return -np.expm1(-np.exp(t))
     if kind == "cplx_ard":
         return softplus_grad(t)
+    if kind == "cplx_vd_approx":
+        su = sigmoid(np.asarray(1.36526, dt) * t - np.asarray(1.45926, dt))
+        return softplus_grad(t) + np.asarray(0.57810 * 1.36526, dt) * su * (1 - su)
+    if kind == "cplx_vd_scalefree":   # the part through t; the direct -ls2/2 term is in penalty_bwd
+        with np.errstate(over="ignore"):
+            return -np.expm1(-np.exp(t)) / 2
     raise ValueError(kind)
 
 
@@ -245,6 +258,8 @@ def penalty_bwd(kind, g, log_sigma2, wr, wi=None):
     fp = g * penalty_dt(kind, t)
     eps0 = np.asarray(1e-12, dt)
     out = dict(dlog_sigma2=-fp)
+    if kind == "cplx_vd_scalefree":
+        out["dlog_sigma2"] = -fp - g * np.asarray(0.5, dt)
     with np.errstate(divide="ignore", invalid="ignore"):
         if wi is None:
             theta = np.abs(wr)

@@ -433,6 +433,25 @@ def gen_extras():
         zc = cplx.from_concatenated_real(x, True, -1)
         d[f"{tag}_cat_re"], d[f"{tag}_cat_im"] = npy(zc.real), npy(zc.imag)
         d[f"{tag}_cat_back"] = npy(cplx.to_concatenated_real(zc, None, -1))
+    # extension penalties: value + gradients on the mixed-regime parameters
+    from cplxmodule.nn.relevance.extensions import complex as ext
+    for tag, dt in DT.items():
+        torch.manual_seed(17)
+        for name, cls in (("cplx_vd_approx", ext.CplxLinearVDApprox), ("cplx_vd_scalefree", ext.CplxLinearVDScaleFree)):
+            layer = cls(24, 20).to(dt)
+            wr, wi, ls2 = _mixed_vd_params(20, 24, dt)
+            with torch.no_grad():
+                layer.weight.real.copy_(wr)
+                layer.weight.imag.copy_(wi)
+                layer.log_sigma2.copy_(ls2)
+            g = torch.randn(20, 24, dtype=dt)
+            pen = layer.penalty
+            (pen * g).sum().backward()
+            k = f"{tag}_ext_{name}_"
+            d[k + "wr"], d[k + "wi"], d[k + "ls2"], d[k + "g"] = npy(wr), npy(wi), npy(ls2), npy(g)
+            d[k + "pen"] = npy(pen)
+            d[k + "dls2"] = npy(layer.log_sigma2.grad)
+            d[k + "dwr"], d[k + "dwi"] = npy(layer.weight.real.grad), npy(layer.weight.imag.grad)
     # abs-max pooling (values, gradients); one case has ties (a constant block)
     torch.manual_seed(13)
     pools = {"k2": dict(kernel_size=2), "k3s2p1": dict(kernel_size=3, stride=2, padding=1),

@@ -203,3 +203,38 @@ def test_reparam_philox_fwd_bwd_consistent(ops):
     np.testing.assert_allclose(N(gs2), 0.5 * (gr * N(yr) + gi * N(yi)), rtol=1e-5, atol=1e-6)
     y = ops.reparam_fwd(T(mu), None, T(s2), None, seed=77, offset=6)[0]
     np.testing.assert_allclose(N(y), philox.real_noise(n, 77, 6), atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", orc.EXT_KINDS)
+def test_extension_penalties_gpu(golden, ops, kind):
+    """SURVEY 8(f) row 4 (extensions/complex.py): values, sum, gradients and the layer classes."""
+    from gpu_util import T, N, DEV
+    from cplxmodule_amd.nn.relevance import extensions as ext
+    g = golden("extras")
+    k = f"f32_ext_{kind}_"
+    wr, wi, ls2, up = g[k + "wr"], g[k + "wi"], g[k + "ls2"], g[k + "g"]
+    elem, tot = ops.kl_fwd(kind, T(wr), T(wi), T(ls2), elementwise=True)
+    ref = g[k + "pen"]
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(N(elem)[fin], ref[fin], rtol=1e-5, atol=4e-6)
+    o64 = orc.penalty(kind, ls2.astype(np.float64), wr.astype(np.float64), wi.astype(np.float64))
+    fin64 = np.isfinite(o64)
+    np.testing.assert_allclose(N(elem)[fin64], o64[fin64], rtol=3e-6, atol=5e-7)
+    g_ls2, g_wr, g_wi = ops.kl_bwd(kind, T(wr), T(wi), T(ls2), g_elem=T(up))
+    o = orc.penalty_bwd(kind, up.astype(np.float64), ls2.astype(np.float64), wr.astype(np.float64),
+                        wi.astype(np.float64))
+    theta = orc.cplx_abs(wr, wi)
+    with np.errstate(divide="ignore"):
+        amp = np.where(theta > 0, 2 / (theta + 1e-12), 0)
+    eps = np.finfo(np.float32).eps
+    for got, key, a in ((g_ls2, "dlog_sigma2", 1.0), (g_wr, "dwr", amp), (g_wi, "dwi", amp)):
+        err = np.abs(N(got).astype(np.float64) - o[key])
+        bound = 2e-5 * np.abs(o[key]) + 8 * eps * np.maximum(a, 1.0)
+        assert (err <= bound).all(), (kind, key, float((err - bound).max()))
+    cls = dict(cplx_vd_approx=ext.CplxLinearVDApprox, cplx_vd_scalefree=ext.CplxLinearVDScaleFree)[kind]
+    layer = cls(24, 20).to(DEV)
+    with torch.no_grad():
+        layer.weight.real.copy_(T(wr)); layer.weight.imag.copy_(T(wi)); layer.log_sigma2.copy_(T(ls2))
+    np.testing.assert_allclose(N(layer.penalty)[fin], ref[fin], rtol=1e-5, atol=4e-6)
+    conv_cls = dict(cplx_vd_approx=ext.CplxConv2dVDApprox, cplx_vd_scalefree=ext.CplxConv2dVDScaleFree)[kind]
+    assert conv_cls(4, 4, 3).to(DEV).penalty.shape == (4, 4, 3, 3)

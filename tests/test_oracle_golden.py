@@ -288,3 +288,28 @@ def test_oracle_max_pool2d(golden, tag, name):
     tol = dict(rtol=1e-6, atol=1e-6) if tag == "f32" else dict(rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(dzr, g[k + "dzr"], **tol)
     np.testing.assert_allclose(dzi, g[k + "dzi"], **tol)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("kind", orc.EXT_KINDS)
+def test_extension_penalties(golden, tag, kind):
+    """CplxLinearVDApprox / VDScaleFree penalties of the reference."""
+    g = golden("extras")
+    k = f"{tag}_ext_{kind}_"
+    wr, wi, ls2, up = g[k + "wr"], g[k + "wi"], g[k + "ls2"], g[k + "g"]
+    pen, ref = orc.penalty(kind, ls2, wr, wi), g[k + "pen"]
+    fin = np.isfinite(ref)
+    np.testing.assert_array_equal(np.isfinite(pen), fin)
+    close(pen[fin], ref[fin], tag, 8)
+    bw = orc.penalty_bwd(kind, up, ls2, wr, wi)
+    eps = np.finfo(ls2.dtype).eps
+    theta = orc.cplx_abs(wr, wi)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        amp = np.where(theta > 0, 2 / (theta + 1e-12), 0)
+    rt = 2e-5 if tag == "f32" else 1e-10
+    for n, m, a in (("dlog_sigma2", "dls2", 1.0), ("dwr", "dwr", amp), ("dwi", "dwi", amp)):
+        r = g[k + m]
+        ok = np.isfinite(r)
+        err = np.abs(bw[n] - r)
+        bound = rt * np.abs(r) + 8 * eps * np.maximum(a, 1.0)
+        assert (err[ok] <= (bound[ok] if np.ndim(bound) else bound)).all(), (n, err[ok].max())
