@@ -35,6 +35,8 @@
 //  * few output tiles + long K (wgrad at batch 2^20): split-K into fp32 slabs + a reduce kernel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm.h"
 
 namespace cplxamd {
@@ -44,10 +46,17 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32, WM = 4, WN = 2, BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN, STAGES = 3;
+constexpr int BK = 32, NT = 512, STAGES = 3;
 
+// complex: 256 x 128 tile, 4 x 2 waves of 64 x 64 (2 x 2 MFMA tiles x {re, im} = 128 accumulators);
+// real: 256 x 256 tile, 2 x 4 waves of 128 x 64 (4 x 2 MFMA tiles = 128 accumulators) -- with one
+// MFMA chain per staged byte instead of four, the real kernel needs the larger tile to keep the
+// LDS-DMA pieces and ds_reads per MFMA where the complex kernel has them.
 template <bool CPLX>
 struct Cfg {
+  static constexpr int IB = CPLX ? 2 : 4;                       // 32-row MFMA blocks per wave
+  static constexpr int WM = CPLX ? 4 : 2, WN = CPLX ? 2 : 4;    // waves along M / N
+  static constexpr int BM = 32 * IB * WM, BN = 64 * WN;
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
   static constexpr int SMEM = STAGES * STAGE_BYTES;
@@ -125,6 +134,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
   using C = Cfg<CPLX>;
 
   // ---- tile coordinates: split-K slice, XCD-contiguous grouped order ------------------------
+  constexpr int BM = C::BM, BN = C::BN, IB = C::IB;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   int lin = blockIdx.x, split = 0;
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
   const int m0 = bm * BM, n0 = bn * BN;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = (wid / WN) * 64, wn = (wid % WN) * 64;
+  const int wm = (wid / C::WN) * (32 * IB), wn = (wid % C::WN) * 64;
   const int l31 = lane & 31, lk = lane >> 5;
   const int l15 = lane & 15, lg = (lane >> 4) & 1;   // "T" reads: 16-lane group geometry
 
@@ -153,13 +163,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
   const bf16_t* Br = (const bf16_t*)g.b_r; const bf16_t* Bi = (const bf16_t*)g.b_i;
   const int64_t lda = TA ? g.a_cs : g.a_rs, ldb = TB ? g.b_cs : g.b_rs;
 
-  f32x16 acc_r[2][2], acc_i[2][2];
+  f32x16 acc_r[IB][2], acc_i[CPLX ? IB : 1][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IB; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       acc_r[i][j] = f32x16{0};
-      acc_i[i][j] = f32x16{0};
+      if (CPLX) acc_i[i][j] = f32x16{0};
     }
 
   const int kbase = split * g.kchunk;
@@ -195,29 +205,31 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
     const char* sB = sA + C::A_BYTES;
     const char* sAi = sB + C::B_BYTES;
     const char* sBi = sAi + C::A_BYTES;
-    bf16x8 ar[2][2], br[2][2], ai[2][2], bi[2][2];
+    bf16x8 ar[2][IB], br[2][2], ai[2][IB], bi[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < IB; ++i) {
         ar[ks][i] = a_frag(sA, i, ks);
-        br[ks][i] = b_frag(sB, i, ks);
-        if (CPLX) {
-          ai[ks][i] = a_frag(sAi, i, ks);
-          bi[ks][i] = b_frag(sBi, i, ks);
-        }
+        if (CPLX) ai[ks][i] = a_frag(sAi, i, ks);
       }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        br[ks][j] = b_frag(sB, j, ks);
+        if (CPLX) bi[ks][j] = b_frag(sBi, j, ks);
+      }
+    }
     int q = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 nai[2];
+      bf16x8 nai[IB];
       if (CPLX) {
         // no conj: re -= Ai Bi, im += Ar Bi ; conj(B): re += Ai Bi, im -= Ar Bi
 #pragma unroll
-        for (int i = 0; i < 2; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
+        for (int i = 0; i < IB; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (do_mfma) {
@@ -265,33 +277,34 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
     //   S1 read F[1] <- (tile t, ks 1)           S2 16 MFMAs on F[0] + second half of tile t+2's pieces
     //   S3 lgkmcnt(0), vmcnt (tile t+1 landed), s_barrier   (slot of tile t is free: all in registers)
     //   S4 read F[0] <- (tile t+1, ks 0)         S5 16 MFMAs on F[1] + first half of tile t+3's pieces
-    bf16x8 ar[2][2], br[2][2], ai[2][2], bi[2][2];           // [ks][block]
+    bf16x8 ar[2][IB], br[2][2], ai[2][IB], bi[2][2];         // [ks][block]
     auto read_half = [&](int buf, int ks) {
       const char* sA = smem + buf * C::STAGE_BYTES;
       const char* sB = sA + C::A_BYTES;
       const char* sAi = sB + C::B_BYTES;
       const char* sBi = sAi + C::A_BYTES;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < IB; ++i) {
         ar[ks][i] = a_frag(sA, i, ks);
-        br[ks][i] = b_frag(sB, i, ks);
-        if (CPLX) {
-          ai[ks][i] = a_frag(sAi, i, ks);
-          bi[ks][i] = b_frag(sBi, i, ks);
-        }
+        if (CPLX) ai[ks][i] = a_frag(sAi, i, ks);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        br[ks][j] = b_frag(sB, j, ks);
+        if (CPLX) bi[ks][j] = b_frag(sBi, j, ks);
       }
     };
     constexpr int H = (C::LOADS + 1) / 2;                     // pieces issued in S5; the rest in S2
     auto mfma_half = [&](int ks, int slot, int tile, int q0, int q1) {
-      bf16x8 nai[2];
+      bf16x8 nai[IB];
       if (CPLX) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
+        for (int i = 0; i < IB; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
       }
       int q = q0;
       const bool live = tile < nt && !(g.dbg & 1);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (!(g.dbg & 2)) {
@@ -353,10 +366,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
                       (!two_planes || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
                       (!g.g1 || (g.N & 3) == 0) &&
                       (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  // one 32-row block of the wave tile; `i` is a compile-time constant (an `#pragma unroll`ed loop
+  // over i was left rolled by the compiler for some of the 128-row real variants, which sent the
+  // whole accumulator array to scratch)
+  auto store_block = [&](auto I) {
+    constexpr int i = decltype(I)::value;
     const int row = m0 + wm + i * 32 + l31;
-    if (row >= g.M) continue;
+    if (row >= g.M) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           vr.v[e] = acc_r[i][j][4 * q + e];
-          vi.v[e] = CPLX ? acc_i[i][j][4 * q + e] : 0.f;
+          vi.v[e] = CPLX ? acc_i[CPLX ? i : 0][j][4 * q + e] : 0.f;
         }
         if (!CPLX && g.g1) {                       // Gauss 3M combine (see gemm.h)
           const int64_t od = (int64_t)row * g.N + col;
@@ -441,6 +457,12 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
         }
       }
     }
+  };
+  store_block(std::integral_constant<int, 0>{});
+  store_block(std::integral_constant<int, 1>{});
+  if constexpr (IB == 4) {
+    store_block(std::integral_constant<int, 2>{});
+    store_block(std::integral_constant<int, 3>{});
   }
 }
 
@@ -459,7 +481,7 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
                    dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
   g.order = order; g.group_m = gm > 0 ? gm : 1; g.dbg = dbg;
-  const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   if (tiles * g.splits > 0x7fffffff) return CPLXAMD_ESHAPE;
   static bool attr_set = false;
   if (!attr_set) {
@@ -502,8 +524,9 @@ static int launch_dtype(const GemmArgs& g, int out_dtype, bool ta, bool tb, hipS
 }
 
 // split-K plan: use it when the tile count leaves CUs idle and K is long
-static int plan_splits(int M, int N, int K) {
-  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+static int plan_splits(int M, int N, int K, bool cplx) {
+  const int bm = cplx ? Cfg<true>::BM : Cfg<false>::BM, bn = cplx ? Cfg<true>::BN : Cfg<false>::BN;
+  const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   if (tiles >= 192 || K < 64 * BK) return 1;
   int s = (int)(256 / tiles);
   const int maxs = K / (32 * BK);          // >= 32 K tiles per split
@@ -513,7 +536,7 @@ static int plan_splits(int M, int N, int K) {
 }
 
 int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx) {
-  const int s = plan_splits(M, N, K);
+  const int s = plan_splits(M, N, K, cplx);
   return s > 1 ? (int64_t)s * (cplx ? 2 : 1) * M * N * (int64_t)sizeof(float) : 0;
 }
 
@@ -589,7 +612,7 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   if (CPLX && (!aligned16(g.a_i) || !aligned16(g.b_i))) return CPLXAMD_ESHAPE;
   if (g.M <= 0 || g.N <= 0) return 0;
   if (out_dtype == CPLXAMD_F32 && g.ws && g.ldc == g.N && (g.N & 3) == 0) {
-    const int splits = plan_splits(g.M, g.N, g.K);
+    const int splits = plan_splits(g.M, g.N, g.K, CPLX);
     if (splits > 1 && g.ws_bytes >= gemm_bf16_ws_bytes(g.M, g.N, g.K, CPLX))
       return launch_splitk<CPLX>(g, splits, ta, tb, st);
   }
