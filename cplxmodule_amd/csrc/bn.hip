@@ -150,18 +150,22 @@ __device__ __forceinline__ Whiten inv_sqrt_2x2(double a, double b, double d) {
   return Whiten{(d + s) / t, -b / t, (a + s) / t};
 }
 
-// forward finalize: one thread per feature
-__global__ void bn_fwd_finalize(const double* partial, int chunks, int F, double count,
+// forward finalize: one wave per feature (lanes stride over the chunk partials, wave reduction,
+// lane 0 does the per-feature algebra)
+__global__ __launch_bounds__(64) void bn_fwd_finalize(const double* partial, int chunks, int F, double count,
                                 const float* weight, const float* bias, float* running_mean,
                                 float* running_var, int training, float momentum, float eps,
                                 float* saved, float* coef) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
+  const int f = blockIdx.x;
   double mu, mv, vuu, vuv, vvv;
+  double s[5] = {0, 0, 0, 0, 0};
   if (training) {
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int c = 0; c < chunks; ++c)
+    for (int c = threadIdx.x; c < chunks; c += 64)
       for (int j = 0; j < 5; ++j) s[j] += partial[((int64_t)c * F + f) * 5 + j];
+    for (int j = 0; j < 5; ++j) s[j] = wave_sum(s[j]);
+  }
+  if (threadIdx.x != 0) return;
+  if (training) {
     mu = s[0] / count; mv = s[1] / count;
     vuu = s[2] / count - mu * mu + (double)eps;
     vvv = s[3] / count - mv * mv + (double)eps;
@@ -194,14 +198,15 @@ __global__ void bn_fwd_finalize(const double* partial, int chunks, int F, double
   c[6] = (float)b0; c[7] = (float)b1;
 }
 
-__global__ void bn_bwd_finalize(const double* partial, int chunks, int F, double count,
+__global__ __launch_bounds__(64) void bn_bwd_finalize(const double* partial, int chunks, int F, double count,
                                 const float* weight, const float* saved, int training,
                                 float* dweight, float* dbias, float* coef) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
+  const int f = blockIdx.x;
   double s[6] = {0, 0, 0, 0, 0, 0};
-  for (int c = 0; c < chunks; ++c)
+  for (int c = threadIdx.x; c < chunks; c += 64)
     for (int j = 0; j < 6; ++j) s[j] += partial[((int64_t)c * F + f) * 6 + j];
+  for (int j = 0; j < 6; ++j) s[j] = wave_sum(s[j]);
+  if (threadIdx.x != 0) return;
   const double Sgu = s[0], Sgv = s[1], Suu = s[2], Suv = s[3], Svu = s[4], Svv = s[5];
   const double p = saved[2 * F + f], q = saved[3 * F + f], w = saved[4 * F + f];
   double w00 = 1, w01 = 0, w10 = 0, w11 = 1;
@@ -352,12 +357,11 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
     CPLXAMD_CHECK_LAUNCH();
   }
   const double count = (double)B * (double)S;
-  const int fb = (F + 127) / 128;
   if (!BWD)
-    bn_fwd_finalize<<<fb, 128, 0, st>>>(partial, g.chunks, F, count, weight, bias, running_mean,
+    bn_fwd_finalize<<<F, 64, 0, st>>>(partial, g.chunks, F, count, weight, bias, running_mean,
                                         running_var, training, momentum, eps, saved, coef);
   else
-    bn_bwd_finalize<<<fb, 128, 0, st>>>(partial, g.chunks, F, count, weight, saved, training,
+    bn_bwd_finalize<<<F, 64, 0, st>>>(partial, g.chunks, F, count, weight, saved, training,
                                         dweight, dbias, coef);
   CPLXAMD_CHECK_LAUNCH();
   if (S > 1) {

@@ -208,12 +208,28 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 }
 
 // out[i] = (sum_s slab[s][i]) (* emul[i])
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* slabs, int splits, int64_t n,
-                                                       const float* emul, float* out) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+// out[i] = (sum_s slab[s][i]) (* emul[i]).  Block = 64 consecutive elements x 16 split lanes (one wave
+// per split lane, coalesced 256-B reads, 4 loads in flight per thread), fixed summation order.
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* slabs, int splits, int64_t n,
+                                                        const float* emul, float* out) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    int s = sl;
+    for (; s + 48 < splits; s += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += slabs[(int64_t)(s + 16 * u) * n + i];
+    }
+    for (; s < splits; s += 16) a[0] += slabs[(int64_t)s * n + i];
+  }
+  red[sl][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+  if (sl == 0 && i < n) {
     float acc = 0.f;
-    for (int s = 0; s < splits; ++s) acc += slabs[(int64_t)s * n + i];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) acc += red[w][lane];
     out[i] = emul ? acc * emul[i] : acc;
   }
 }
@@ -244,12 +260,13 @@ __global__ __launch_bounds__(256) void chansum_partial(const T* x, int64_t B, in
   const double t = block_sum<double, 256>(acc, red);
   if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * C + c] = t;
 }
-__global__ void chansum_final(const double* partial, int chunks, int C, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one wave per channel: lanes stride over the chunk partials, then a wave reduction
+__global__ __launch_bounds__(64) void chansum_final(const double* partial, int chunks, int C, float* out) {
+  const int c = blockIdx.x;
   double acc = 0.0;
-  for (int j = 0; j < chunks; ++j) acc += partial[(int64_t)j * C + c];
-  out[c] = (float)acc;
+  for (int j = threadIdx.x; j < chunks; j += 64) acc += partial[(int64_t)j * C + c];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[c] = (float)acc;
 }
 
 static bool conv_geom_ok(const ConvP& p) {
@@ -336,7 +353,7 @@ int cplxamd_conv2d_wgrad_splits(const int* geom) {
   if (fill_geom(geom, p)) return 0;
   const int64_t K = (int64_t)p.B * p.Ho * p.Wo;
   const int64_t tiles = (int64_t)((p.Cog + CBM - 1) / CBM) * (((int64_t)p.Cg * p.KH * p.KW + CBN - 1) / CBN) * p.G;
-  int64_t s = (2048 + tiles - 1) / tiles;
+  int64_t s = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU; more only adds slab traffic
   const int64_t maxs = (K + 4 * CBK - 1) / (4 * CBK);
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
@@ -372,11 +389,11 @@ int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const v
   else if (dtype == CPLXAMD_BF16) rc = conv_launch<bf16_t, MODE_WGRAD>(a, cplx, st);
   else return CPLXAMD_EINVAL;
   if (rc) return rc;
-  const int grid = stream_grid(wsz, 256);
-  slab_sum_kernel<<<grid, 256, 0, st>>>((const float*)a.yr, a.splits, wsz, emul, dwr);
+  const int sgrid = (int)((wsz + 63) / 64);
+  slab_sum_kernel<<<sgrid, 1024, 0, st>>>((const float*)a.yr, a.splits, wsz, emul, dwr);
   CPLXAMD_CHECK_LAUNCH();
   if (cplx) {
-    slab_sum_kernel<<<grid, 256, 0, st>>>((const float*)a.yi, a.splits, wsz, nullptr, dwi);
+    slab_sum_kernel<<<sgrid, 1024, 0, st>>>((const float*)a.yi, a.splits, wsz, nullptr, dwi);
     CPLXAMD_CHECK_LAUNCH();
   }
   return 0;
@@ -396,7 +413,7 @@ int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int 
   else
     return CPLXAMD_EINVAL;
   CPLXAMD_CHECK_LAUNCH();
-  chansum_final<<<(C + 127) / 128, 128, 0, st>>>((const double*)ws, chunks, C, out);
+  chansum_final<<<C, 64, 0, st>>>((const double*)ws, chunks, C, out);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }

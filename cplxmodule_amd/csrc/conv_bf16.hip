@@ -328,12 +328,28 @@ int conv_bf16_launch(const ConvFArgs& a, bool cplx, bool check, hipStream_t st) 
   return 0;
 }
 
-__global__ __launch_bounds__(256) void slab_sum2_kernel(const float* slabs, int splits, int64_t n,
+// out[i] = (sum_s slab[s][i]) (* emul[i]).  Block = 64 consecutive elements x 16 split lanes (one wave
+// per split lane, coalesced 256-B reads, 4 loads in flight per thread), fixed summation order.
+__global__ __launch_bounds__(1024) void slab_sum2_kernel(const float* slabs, int splits, int64_t n,
                                                         const float* emul, float* out) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    int s = sl;
+    for (; s + 48 < splits; s += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += slabs[(int64_t)(s + 16 * u) * n + i];
+    }
+    for (; s < splits; s += 16) a[0] += slabs[(int64_t)s * n + i];
+  }
+  red[sl][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+  if (sl == 0 && i < n) {
     float acc = 0.f;
-    for (int s = 0; s < splits; ++s) acc += slabs[(int64_t)s * n + i];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) acc += red[w][lane];
     out[i] = emul ? acc * emul[i] : acc;
   }
 }
@@ -353,7 +369,7 @@ static int wgrad_splits(const ConvFP& p) {
   const int64_t K = (int64_t)p.B * p.Ho * p.Wo;
   const int64_t tiles = (int64_t)((p.Cog + FBM - 1) / FBM) *
                         (((int64_t)p.Cg * p.KH * p.KW + FBN - 1) / FBN) * p.G;
-  int64_t s = (2048 + tiles - 1) / tiles;
+  int64_t s = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU; more only adds slab traffic
   const int64_t maxs = (K + 8 * FBK - 1) / (8 * FBK);
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
@@ -473,11 +489,11 @@ int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, co
     rc = conv_bf16_launch<FMODE_WGRAD>(a, cplx, check, st);
   }
   if (rc) return rc;
-  const int grid = stream_grid(wsz, 256);
-  slab_sum2_kernel<<<grid, 256, 0, st>>>((const float*)a.yr, a.splits, wsz, emul, dwr);
+  const int sgrid = (int)((wsz + 63) / 64);
+  slab_sum2_kernel<<<sgrid, 1024, 0, st>>>((const float*)a.yr, a.splits, wsz, emul, dwr);
   CPLXAMD_CHECK_LAUNCH();
   if (cplx) {
-    slab_sum2_kernel<<<grid, 256, 0, st>>>((const float*)a.yi, a.splits, wsz, nullptr, dwi);
+    slab_sum2_kernel<<<sgrid, 1024, 0, st>>>((const float*)a.yi, a.splits, wsz, nullptr, dwi);
     CPLXAMD_CHECK_LAUNCH();
   }
   return 0;

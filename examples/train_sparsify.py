@@ -51,7 +51,44 @@ class Net(torch.nn.Module):
         return abs(z)                       # logits = modulus of the 10 complex outputs
 
 
-def train(model, x, y, steps, klw, lr, wrap):
+def train_graph(model, x, y, steps, klw, lr):
+    """The whole step -- forward, loss + KL, backward, Adam -- captured once in a hipGraph and
+    replayed: the model is launch-bound (tens of small kernels per layer), so this is where a HIP
+    graph replaces what a tracing compiler would be used for.  The LRT noise position lives on the
+    device ("philox-device"), so every replay draws fresh noise."""
+    rel.noise.set_mode("philox-device")
+    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True)
+    model.train()
+
+    def step():
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        kl = sum(rel.penalties(model), torch.zeros((), device=y.device))
+        (loss + klw * kl).backward()
+        opt.step()
+        return loss.detach(), kl.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    hist = []
+    with torch.cuda.stream(side):
+        for _ in range(3):                                  # warm-up: allocator, caches, Adam state
+            opt.zero_grad(set_to_none=True)
+            hist.append(step())
+    torch.cuda.current_stream().wait_stream(side)
+    opt.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    for _ in range(steps - 3):
+        g.replay()
+        hist.append((out[0].clone(), out[1].clone()))       # no host sync inside the loop
+    rel.noise.set_mode("philox")
+    return [(float(a), float(b)) for a, b in hist]
+
+
+def train(model, x, y, steps, klw, lr, wrap, graph=False):
+    if graph and not wrap:
+        return train_graph(model, x, y, steps, klw, lr)
     par = dp.DataParallel(model) if wrap else None
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     model.train()
@@ -77,6 +114,8 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=8)
     ap.add_argument("--klw", type=float, default=2e-3)
     ap.add_argument("--threshold", type=float, default=1.0)
+    ap.add_argument("--graph", action="store_true", help="capture each phase's training step in a hipGraph")
+    ap.add_argument("--time", action="store_true", help="print the wall time of the three phases")
     a = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -88,12 +127,15 @@ def main(argv=None):
     torch.manual_seed(0)
     x, y = synthetic_complex_mnist(a.batch, dev, seed=100 + rank)
 
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     dense = Net(nn.CplxLinear, a.width).to(dev)
-    h1 = train(dense, x, y, a.steps, 0.0, 2e-3, world > 1)
+    h1 = train(dense, x, y, a.steps, 0.0, 2e-3, world > 1, a.graph)
 
     ard = Net(rel.CplxLinearARD, a.width).to(dev)
     ard.load_state_dict(dense.state_dict(), strict=False)
-    h2 = train(ard, x, y, 2 * a.steps, a.klw, 5e-3, world > 1)
+    h2 = train(ard, x, y, 2 * a.steps, a.klw, 5e-3, world > 1, a.graph)
     sp = sparsity(ard, hard=True, threshold=a.threshold)
 
     masks = rel.compute_ard_masks(ard, hard=False, threshold=a.threshold)
@@ -101,7 +143,9 @@ def main(argv=None):
     fine = Net(masked.CplxLinearMasked, a.width).to(dev)
     fine.load_state_dict(state, strict=False)
     masked.deploy_masks(fine, state_dict=masks)
-    h3 = train(fine, x, y, a.steps, 0.0, 1e-3, world > 1)
+    h3 = train(fine, x, y, a.steps, 0.0, 1e-3, world > 1, a.graph)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
 
     fine.eval()
     with torch.no_grad():
@@ -112,6 +156,9 @@ def main(argv=None):
               f"sparsity@{a.threshold} {sp:.3f}")
         print(f"masked loss {h3[0][0]:.3f} -> {h3[-1][0]:.3f}   train acc {acc:.3f}   "
               f"kept {int(masks['head.mask'].sum())}/{masks['head.mask'].numel()} head weights")
+        if a.time:
+            print(f"{4 * a.steps} steps in {elapsed:.2f} s = {1e3 * elapsed / (4 * a.steps):.2f} ms/step "
+                  f"({'hipGraph replay' if a.graph else 'eager'})")
     if world > 1:
         dist.destroy_process_group()
     return dict(dense=h1, ard=h2, masked=h3, sparsity=sp, acc=acc, masks=masks)
