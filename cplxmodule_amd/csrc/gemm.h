@@ -26,6 +26,8 @@ struct GemmArgs {
 template <bool CPLX>
 int launch_gemm_generic(const GemmArgs& g, int in_dtype, int out_dtype, hipStream_t st);
 
+int64_t gemm_generic_ws_bytes(int M, int N, int K, bool cplx);   // split-K scratch (0: none)
+
 // bf16 MFMA fast path (gemm_bf16.hip); returns CPLXAMD_ESHAPE when the arguments do not
 // qualify so that the caller can fall back to the generic kernel.
 template <bool CPLX>

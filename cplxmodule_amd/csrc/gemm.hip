@@ -7,8 +7,11 @@ extern "C" {
 
 /* scratch the bf16 path wants for split-K at this shape (0 = none) */
 int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype) {
-  if (in_dtype != CPLXAMD_BF16 || out_dtype != CPLXAMD_F32) return 0;
-  return gemm_bf16_ws_bytes(M, N, K, cplx != 0);
+  // the generic kernel is the fallback of every bf16 shape as well: ask for the larger of the two
+  const int64_t gen = gemm_generic_ws_bytes(M, N, K, cplx != 0);
+  if (in_dtype != CPLXAMD_BF16 || out_dtype != CPLXAMD_F32) return gen;
+  const int64_t fast = gemm_bf16_ws_bytes(M, N, K, cplx != 0);
+  return fast > gen ? fast : gen;
 }
 
 int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K) { return gemm_bf16_gauss_ws_bytes(M, N, K); }

@@ -96,10 +96,8 @@ _gemm_ws_cache = {}
 
 
 def _gemm_ws(M, N, K, cplx, a, c):
-    """Split-K scratch (only asked for by few-tile / long-K bf16 -> fp32 GEMMs, e.g. wgrad)."""
-    if a.dtype != torch.bfloat16 or c.dtype != torch.float32:
-        return None
-    need = int(_lib.load().cplxamd_gemm_ws_bytes(M, N, K, int(cplx), 1, 0))
+    """Split-K scratch (asked for by few-tile / long-K GEMMs: wgrad at large batch, small heads)."""
+    need = int(_lib.load().cplxamd_gemm_ws_bytes(M, N, K, int(cplx), dtype_code(a), dtype_code(c)))
     if need == 0:
         return None
     key = (a.device.type, a.device.index)

@@ -159,9 +159,9 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
 
 int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
 
-/* Optional scratch for split-K (bf16 inputs, float32 output, few output tiles, long K -- e.g. the
- * weight gradient at batch 2^20): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be
- * NULL (no split-K). */
+/* Optional scratch for split-K (few output tiles, long K -- e.g. the weight gradient at batch
+ * 2^20, or a 10-output head): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be NULL
+ * (no split-K).  With split-K the float32 result is a sum of per-split partial sums. */
 int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype);
 
 /* real GEMM; emul (nullable, float32 [M,N] with leading dimension ldc): C = (A B^T) * emul. */

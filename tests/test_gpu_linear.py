@@ -362,3 +362,33 @@ def test_philox_layer_statistics(pkg):
     assert abs(float(ratio) - 1.0) < 0.02          # E|eps|^2 = 1
     assert float((y1.real - y2.real).abs().mean()) > 1e-3
     assert abs(float(d1[0].mean())) < 5e-3 * float(s2.mean().sqrt())
+
+
+@pytest.mark.parametrize("M,N_,K", [(256, 10, 1568), (10, 1568, 256), (64, 64, 1000), (70, 130, 4100), (3, 5, 777)])
+@pytest.mark.parametrize("conj", (False, True))
+def test_cgemm_f32_generic_split_k(pkg, M, N_, K, conj):
+    """Few output tiles + long K: the exact-f32 kernel splits K into slabs (incl. a K that is not a
+    multiple of the 16-wide K tile, and splits whose range is empty) -- against float64."""
+    from gpu_util import T, N
+    from cplxmodule_amd import ops
+    rs = np.random.RandomState(M + N_ + K)
+    ar, ai = rs.randn(M, K).astype(np.float32), rs.randn(M, K).astype(np.float32)
+    br, bi = rs.randn(N_, K).astype(np.float32), rs.randn(N_, K).astype(np.float32)
+    bias = (rs.randn(N_).astype(np.float32), rs.randn(N_).astype(np.float32))
+    f = np.float64
+    b64 = br.astype(f) + 1j * bi
+    ref = (ar.astype(f) + 1j * ai) @ (b64.conj() if conj else b64).T + (bias[0] + 1j * bias[1])
+    cr, ci = ops.cgemm(T(ar), T(ai), (K, 1), T(br), T(bi), (K, 1), M, N_, K, bias=(T(bias[0]), T(bias[1])),
+                       conj_b=conj)
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(N(cr), ref.real, rtol=1e-5, atol=2e-6 * np.sqrt(K) * scale / 10)
+    np.testing.assert_allclose(N(ci), ref.imag, rtol=1e-5, atol=2e-6 * np.sqrt(K) * scale / 10)
+    # K-major B operand (the dgrad layout) and a real GEMM with emul through the same path
+    cr2, ci2 = ops.cgemm(T(ar), T(ai), (K, 1), T(np.ascontiguousarray(br.T)), T(np.ascontiguousarray(bi.T)),
+                         (1, N_), M, N_, K, conj_b=conj)
+    ref2 = ref - (bias[0] + 1j * bias[1])
+    np.testing.assert_allclose(N(cr2), ref2.real, rtol=1e-5, atol=2e-6 * np.sqrt(K) * scale / 10)
+    em = rs.rand(M, N_).astype(np.float32)
+    c = ops.rgemm(T(ar), (K, 1), T(br), (K, 1), M, N_, K, emul=T(em))
+    rref = (ar.astype(f) @ br.astype(f).T) * em
+    np.testing.assert_allclose(N(c), rref, rtol=1e-5, atol=2e-6 * np.sqrt(K) * np.abs(rref).max() / 10)
