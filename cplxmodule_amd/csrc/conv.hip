@@ -101,11 +101,16 @@ __device__ __forceinline__ int64_t b_offset(const ConvP& p, int g, int64_t n, in
   }
 }
 
+// One thread's 4 elements of a [64 x CBK] operand tile: gather global -> registers (fetch), then
+// registers -> LDS as d[k][r] (commit).  Split so that the gathers of tile t+1 are in flight while
+// the MFMAs of tile t run (the K loop is double-buffered in LDS).
+struct ConvRegs { float r[4], i[4]; };
+
 template <typename T, bool CPLX, int MODE, bool IS_A, bool KFAST>
-__device__ __forceinline__ void stage(float (*dr)[CLD], float (*di)[CLD], const void* sr,
-                                      const void* si, const ConvP& p, int g, int64_t row0,
-                                      int64_t rows, int64_t k0, int64_t kend) {
+__device__ __forceinline__ ConvRegs fetch(const void* sr, const void* si, const ConvP& p, int g,
+                                          int64_t row0, int64_t rows, int64_t k0, int64_t kend) {
   const int t = threadIdx.x;
+  ConvRegs o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int r, k;
@@ -120,16 +125,30 @@ __device__ __forceinline__ void stage(float (*dr)[CLD], float (*di)[CLD], const 
         if (CPLX) vi = ldv<T>(si, off);
       }
     }
-    dr[k][r] = vr;
-    if (CPLX) di[k][r] = vi;
+    o.r[j] = vr;
+    o.i[j] = vi;
+  }
+  return o;
+}
+
+template <bool CPLX, bool KFAST>
+__device__ __forceinline__ void commit(float (*dr)[CLD], float (*di)[CLD], const ConvRegs& o) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int r, k;
+    if (KFAST) { k = t & 15; r = (t >> 4) + 16 * j; }
+    else { r = t & 63; k = (t >> 6) + 4 * j; }
+    dr[k][r] = o.r[j];
+    if (CPLX) di[k][r] = o.i[j];
   }
 }
 
 // T: element type of the activations / gradients; TW: element type of the weight operand
 template <typename T, bool CPLX, int MODE>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
-  __shared__ float As_r[CBK][CLD], Bs_r[CBK][CLD];
-  __shared__ float As_i[CPLX ? CBK : 1][CLD], Bs_i[CPLX ? CBK : 1][CLD];
+  __shared__ float As_r[2][CBK][CLD], Bs_r[2][CBK][CLD];
+  __shared__ float As_i[CPLX ? 2 : 1][CPLX ? CBK : 1][CLD], Bs_i[CPLX ? 2 : 1][CPLX ? CBK : 1][CLD];
   const ConvP& p = a.p;
   const int g = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
   const int64_t m0 = (int64_t)blockIdx.y * CBM, n0 = (int64_t)blockIdx.x * CBN;
@@ -140,32 +159,37 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   if (kend > a.K) kend = a.K;
   // conjugation: DGRAD conj(W) is the A operand, WGRAD conj(X) is the B operand
   const float sa = (MODE == MODE_DGRAD) ? -1.f : 1.f, sb = (MODE == MODE_WGRAD) ? -1.f : 1.f;
+  constexpr bool BK_FAST = MODE == MODE_WGRAD;   // B: pixels fastest (FWD, DGRAD) or k (= pixels) fastest
 
   f32x16 acc_r = {0}, acc_i = {0};
-  for (int64_t k0 = kbeg; k0 < kend; k0 += CBK) {
+  ConvRegs ra, rb;
+  auto fetch_both = [&](int64_t k0) {
     // A: weights (FWD: k contiguous; DGRAD: gathered) / grad-out (WGRAD: k contiguous)
-    stage<T, CPLX, MODE, true, true>(As_r, As_i, MODE == MODE_WGRAD ? a.xr : a.wr,
-                                     MODE == MODE_WGRAD ? a.xi : a.wi, p, g, m0, a.M, k0, kend);
-    // B: gathered activations: pixels fastest (FWD, DGRAD) or k (= pixels) fastest (WGRAD)
-    if (MODE == MODE_WGRAD)
-      stage<T, CPLX, MODE, false, true>(Bs_r, Bs_i, a.wr, a.wi, p, g, n0, a.N, k0, kend);
-    else
-      stage<T, CPLX, MODE, false, false>(Bs_r, Bs_i, a.xr, a.xi, p, g, n0, a.N, k0, kend);
-    __syncthreads();
+    ra = fetch<T, CPLX, MODE, true, true>(MODE == MODE_WGRAD ? a.xr : a.wr, MODE == MODE_WGRAD ? a.xi : a.wi,
+                                          p, g, m0, a.M, k0, kend);
+    if (MODE == MODE_WGRAD) rb = fetch<T, CPLX, MODE, false, true>(a.wr, a.wi, p, g, n0, a.N, k0, kend);
+    else rb = fetch<T, CPLX, MODE, false, false>(a.xr, a.xi, p, g, n0, a.N, k0, kend);
+  };
+  if (kbeg < kend) fetch_both(kbeg);
+  int buf = 0;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += CBK, buf ^= 1) {
+    commit<CPLX, true>(As_r[buf], As_i[CPLX ? buf : 0], ra);
+    commit<CPLX, BK_FAST>(Bs_r[buf], Bs_i[CPLX ? buf : 0], rb);
+    __syncthreads();                         // tile visible; the other buffer is free again
+    if (k0 + CBK < kend) fetch_both(k0 + CBK);
 #pragma unroll
     for (int kk = 0; kk < CBK; kk += 2) {
-      const float ar = As_r[kk + lk][wm + l31];
-      const float br = Bs_r[kk + lk][wn + l31];
+      const float ar = As_r[buf][kk + lk][wm + l31];
+      const float br = Bs_r[buf][kk + lk][wn + l31];
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, acc_r, 0, 0, 0);
       if (CPLX) {
-        const float ai = sa * As_i[kk + lk][wm + l31];
-        const float bi = sb * Bs_i[kk + lk][wn + l31];
+        const float ai = sa * As_i[buf][kk + lk][wm + l31];
+        const float bi = sb * Bs_i[buf][kk + lk][wn + l31];
         acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, acc_r, 0, 0, 0);
         acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, acc_i, 0, 0, 0);
         acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, acc_i, 0, 0, 0);
       }
     }
-    __syncthreads();
   }
 
   // epilogue: col = lane & 31 runs along N, rows (M) across registers
