@@ -196,10 +196,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM: fwd NN, dgrad NT, wgrad TT = 3 launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,
-                         # HBM bytes per launch from rocprofv3 PMC passes of the same kernel / shape
-                         # (profiles/r01_gemm_variants.md): FETCH_SIZE 524,850 KiB x 2 (gfx950
-                         # correction) + WRITE_SIZE 195,840 KiB; algorithmic minimum 320 MB
-                         "traffic": 1.275e9 if B == BATCH else None, "flop_per_launch": flops,
+                         # HBM bytes per launch from separate rocprofv3 --pmc passes of the same kernel /
+                         # shape (scripts/pmc_gemm.sh, profiles/r01_gemm_variants.md): FETCH_SIZE
+                         # 528,699 KiB x 2 (gfx950 correction) + WRITE_SIZE 416,787 KiB (calibrated 1:1
+                         # on a streaming write in the same run); algorithmic minimum 320 MB
+                         "traffic": 1.51e9 if B == BATCH else None, "flop_per_launch": flops,
                          "avg_launch_ms": round(gemm_ms, 4) if gemm_ms else None},
             "hbm_kernels_GBps": {
                 "kl_fwd(12B/elt)": round(12 * nw / (kl_f * 1e-3) / 1e9, 1) if kl_f else None,
