@@ -27,7 +27,9 @@
 //    measured 1.06 ms of a 3.06 ms kernel).
 // Measured history (cfg3, B=64, forward): gather kernel (conv_bf16.hip) 3.82 ms; 512-row tiles with
 // one stage per tap 3.35 ms; kernel-row stages 2.34 ms; with weights staged through LDS at BK = 16
-// and a 3-stage ring 3.04 ms (32-B rows halve the LDS-DMA efficiency).
+// and a 3-stage ring 3.04 ms (32-B rows halve the LDS-DMA efficiency).  On the final structure
+// (1.65 ms): 128 x 32 wave tiles (half the weight-fragment loads) 1.68 ms; A fragments prefetched one
+// tap ahead 2.26 ms (32 spilled registers) -- neither is kept.
 #include <stdlib.h>
 
 #include <type_traits>
