@@ -1,7 +1,6 @@
 """Real <-> complex layout layers (reference: cplxmodule/nn/modules/casting.py:7-150).
 The interleaved converters run as single-pass kernels (csrc/layout.hip) when they copy along the
 last dimension on the GPU; the others are views / one torch op, as in the reference."""
-import torch
 
 from ... import cplx
 from .base import BaseRealToCplx, BaseCplxToReal
