@@ -7,6 +7,7 @@ from .casting import InterleavedRealToCplx, ConcatenatedRealToCplx  # noqa: F401
 from .casting import CplxToInterleavedReal, CplxToConcatenatedReal  # noqa: F401
 from .casting import CplxToInterleavedReal as CplxToReal  # noqa: F401
 from .casting import InterleavedRealToCplx as RealToCplx  # noqa: F401
-from .activation import CplxModReLU, CplxAdaptiveModReLU, CplxModulus, CplxAngle  # noqa: F401
+from .activation import CplxModReLU, CplxAdaptiveModReLU  # noqa: F401
+from .casting import CplxModulus, CplxAngle  # noqa: F401
 from .extra import CplxDropout  # noqa: F401
 from .pooling import CplxMaxPool1d, CplxMaxPool2d  # noqa: F401

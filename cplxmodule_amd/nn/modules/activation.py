@@ -1,46 +1,39 @@
-"""Complex activations (reference: cplxmodule/nn/modules/activation.py:8-62)."""
+"""modReLU layers.  API counterpart of cplxmodule/nn/modules/activation.py:8-50;
+the arithmetic is one fused kernel pair (csrc/layout.hip: modrelu_fwd / modrelu_bwd), including
+the gradient of a learnable threshold."""
 import torch
 
 from ... import cplx
-from .base import CplxToCplx, BaseCplxToReal
+from .base import CplxToCplx
 
 
-class CplxModReLU(CplxToCplx):
-    """z -> (|z| - tau)_+ z / |z|; a non-float `threshold` (e.g. None) makes tau a learnable scalar
-    initialised U(0, 0.25) as in the reference (activation.py:21-25)."""
+class _SoftThresholdModulus(CplxToCplx):
+    """z -> max(|z| - tau, 0) * z / |z|, tau = `self.threshold` (float, or a Parameter that is
+    broadcast against the input)."""
+
+    def forward(self, input):
+        return cplx.modrelu(input, self.threshold)
+
+
+class CplxModReLU(_SoftThresholdModulus):
+    """Fixed threshold when given a float; anything else (e.g. `None`) asks for ONE learnable
+    threshold, drawn from U(0, 1/4) like the reference does."""
 
     def __init__(self, threshold=0.5):
         super().__init__()
-        if not isinstance(threshold, float):
-            threshold = torch.nn.Parameter(torch.rand(1) * 0.25)
-        self.threshold = threshold
-
-    def forward(self, input):
-        return cplx.modrelu(input, self.threshold)
+        learn = not isinstance(threshold, float)
+        self.threshold = torch.nn.Parameter(torch.rand(1).mul_(0.25)) if learn else threshold
 
 
-class CplxAdaptiveModReLU(CplxToCplx):
-    """modReLU with a learnable threshold tensor of shape `dim` (broadcast against the input),
-    initialised N(0, 0.02^2) (activation.py:46-49)."""
+class CplxAdaptiveModReLU(_SoftThresholdModulus):
+    """A learnable threshold tensor of shape `dim` (default: one value), N(0, 0.02^2) at init;
+    `CplxAdaptiveModReLU(d)` thresholds every feature of a [..., d] input separately,
+    `CplxAdaptiveModReLU(c, 1, 1)` every channel of a [B, c, H, W] input."""
 
     def __init__(self, *dim):
         super().__init__()
-        self.dim = dim if dim else (1,)
-        self.threshold = torch.nn.Parameter(torch.randn(*self.dim) * 0.02)
-
-    def forward(self, input):
-        return cplx.modrelu(input, self.threshold)
+        self.dim = tuple(dim) or (1,)
+        self.threshold = torch.nn.Parameter(torch.randn(*self.dim).mul_(0.02))
 
     def __repr__(self):
-        body = repr(self.dim)[1:-1] if len(self.dim) > 1 else repr(self.dim[0])
-        return f"{self.__class__.__name__}({body})"
-
-
-class CplxModulus(BaseCplxToReal):
-    def forward(self, input):
-        return abs(input)
-
-
-class CplxAngle(BaseCplxToReal):
-    def forward(self, input):
-        return input.angle
+        return f"{type(self).__name__}({', '.join(map(str, self.dim))})"

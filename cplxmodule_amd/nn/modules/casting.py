@@ -67,3 +67,17 @@ class CplxToTensor(BaseCplxToReal):
 
     def forward(self, input):
         return cplx.to_interleaved_real(input, False, -1)
+
+
+class CplxModulus(BaseCplxToReal):
+    """|z| (one kernel: cplxamd_modulus)."""
+
+    def forward(self, input):
+        return abs(input)
+
+
+class CplxAngle(BaseCplxToReal):
+    """arg z."""
+
+    def forward(self, input):
+        return input.angle
