@@ -138,8 +138,22 @@ def call(name, *args):
         raise CplxAmdError(f"{name} failed: {what}")
 
 
+_empty_anchor = {}
+
+
 def ptr(t):
-    return None if t is None else c_void_p(t.data_ptr())
+    """Device pointer of a tensor for the C ABI (None -> NULL).  An EMPTY tensor has no storage
+    (data_ptr() == 0), which the library would reject as a missing argument; it gets the address
+    of a small per-device anchor instead -- with zero elements nothing is read or written there."""
+    if t is None:
+        return None
+    p = t.data_ptr()
+    if p == 0 and t.numel() == 0 and t.is_cuda:
+        key = t.device.index
+        if key not in _empty_anchor:
+            _empty_anchor[key] = torch.zeros(64, dtype=torch.float32, device=t.device)
+        p = _empty_anchor[key].data_ptr()
+    return c_void_p(p)
 
 
 def stream_ptr():

@@ -264,6 +264,8 @@ def _shared_grad_grid(gr, gi, geom, need_dx, need_dw):
 def chansum(g):
     """sum over (batch, spatial) per channel of an NCHW tensor -> float32 [C]."""
     B, C = g.shape[0], g.shape[1]
+    if g.numel() == 0:
+        return torch.zeros(C, dtype=torch.float32, device=g.device)
     S = g.numel() // (B * C)
     out = torch.empty(C, dtype=torch.float32, device=g.device)
     ws = _scratch(g.device, 64 * C * 8)

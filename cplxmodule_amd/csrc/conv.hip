@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64) void chansum_final(const double* partial, int c
 }
 
 static bool conv_geom_ok(const ConvP& p) {
-  return p.B > 0 && p.Ci > 0 && p.Co > 0 && p.G > 0 && p.Ci % p.G == 0 && p.Co % p.G == 0 &&
+  return p.B >= 0 && p.Ci > 0 && p.Co > 0 && p.G > 0 && p.Ci % p.G == 0 && p.Co % p.G == 0 &&
          p.KH > 0 && p.KW > 0 && p.sh > 0 && p.sw > 0 && p.dh > 0 && p.dw > 0 && p.Ho > 0 &&
          p.Wo > 0 && p.Cg == p.Ci / p.G && p.Cog == p.Co / p.G;
 }
@@ -346,6 +346,7 @@ int cplxamd_conv2d_fwd(const void* xr, const void* xi, const void* wr, const voi
   if (rc) return rc;
   a.xr = xr; a.xi = xi; a.wr = wr; a.wi = wi; a.bias_r = bias_r; a.bias_i = bias_i;
   a.yr = yr; a.yi = yi;
+  if (a.p.B == 0) return 0;                                   // empty batch: nothing to write
   a.M = a.p.Cog; a.N = (int64_t)a.p.B * a.p.Ho * a.p.Wo; a.K = (int64_t)a.p.Cg * a.p.KH * a.p.KW;
   a.splits = 1; a.kchunk = a.K;
   hipStream_t st = (hipStream_t)stream;
@@ -363,6 +364,7 @@ int cplxamd_conv2d_dgrad(const void* gr, const void* gi, const void* wr, const v
   int rc = fill_geom(geom, a.p);
   if (rc) return rc;
   a.xr = gr; a.xi = gi; a.wr = wr; a.wi = wi; a.yr = dxr; a.yi = dxi;
+  if (a.p.B == 0) return 0;
   a.M = a.p.Cg; a.N = (int64_t)a.p.B * a.p.H * a.p.W; a.K = (int64_t)a.p.Cog * a.p.KH * a.p.KW;
   a.splits = 1; a.kchunk = a.K;
   hipStream_t st = (hipStream_t)stream;
@@ -401,8 +403,13 @@ int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const v
   ConvArgs a{};
   int rc = fill_geom(geom, a.p);
   if (rc) return rc;
-  if (ws_bytes < cplxamd_conv2d_wgrad_ws_bytes(geom, cplx)) return CPLXAMD_EWS;
   const int64_t wsz = (int64_t)a.p.Co * a.p.Cg * a.p.KH * a.p.KW;
+  if (a.p.B == 0) {                                            // empty batch: the gradient is zero
+    hipError_t e = hipMemsetAsync(dwr, 0, wsz * sizeof(float), (hipStream_t)stream);
+    if (e == hipSuccess && cplx) e = hipMemsetAsync(dwi, 0, wsz * sizeof(float), (hipStream_t)stream);
+    return (int)e;
+  }
+  if (ws_bytes < cplxamd_conv2d_wgrad_ws_bytes(geom, cplx)) return CPLXAMD_EWS;
   a.splits = cplxamd_conv2d_wgrad_splits(geom);
   a.xr = gr; a.xi = gi; a.wr = xr; a.wi = xi;
   a.yr = ws; a.yi = (float*)ws + (int64_t)a.splits * wsz;

@@ -48,3 +48,34 @@ def test_train_sparsify_pipeline():
     assert 0.0 <= out["sparsity"] <= 1.0
     assert set(out["masks"]["head.mask"].unique().tolist()) <= {0.0, 1.0}
     assert np.isfinite(out["masked"][-1][0])
+
+
+def test_empty_batches_everywhere():
+    """Empty inputs (the reference's torch ops accept them): forward shapes, zero parameter
+    gradients, no kernel is asked to touch a NULL pointer."""
+    import torch
+    from gpu_util import DEV
+    from cplxmodule_amd import Cplx, cplx, nn
+    from cplxmodule_amd.nn import relevance as rel
+    z = lambda *s, dt=torch.float32: Cplx(torch.randn(*s, device=DEV).to(dt), torch.randn(*s, device=DEV).to(dt))  # noqa: E731
+    for dt in (torch.float32, torch.bfloat16):
+        lin = nn.CplxLinear(32, 16).to(DEV)
+        assert lin(z(0, 32, dt=dt)).real.shape == (0, 16)
+        vd = rel.CplxLinearVD(32, 16).to(DEV)
+        x = z(0, 32, dt=dt)
+        x.real.requires_grad_(True)
+        y = vd(x)
+        (y.real.float().sum() + y.imag.float().sum() + 0 * sum(rel.penalties(vd))).backward()
+        assert x.real.grad.shape == (0, 32)
+        assert float(vd.weight.real.grad.abs().max()) == 0.0 and float(vd.bias.real.grad.abs().max()) == 0.0
+        conv = nn.CplxConv2d(32, 64, 3, padding=1).to(DEV)
+        xc = z(0, 32, 8, 8, dt=dt)
+        xc.real.requires_grad_(True)
+        out = conv(xc)
+        assert out.real.shape == (0, 64, 8, 8)
+        (out.real.float().sum() + out.imag.float().sum()).backward()
+        assert float(conv.weight.real.grad.abs().max()) == 0.0
+    assert cplx.modrelu(z(0, 5), 0.5).real.shape == (0, 5)
+    assert cplx.from_interleaved_real(torch.randn(0, 8, device=DEV)).real.shape == (0, 4)
+    assert cplx.max_pool2d(z(0, 3, 8, 8), 2).real.shape == (0, 3, 4, 4)
+    assert cplx.dropout(z(0, 4), 0.5).imag.shape == (0, 4)
