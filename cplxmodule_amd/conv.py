@@ -477,3 +477,66 @@ def real_conv2d_layer(layer, input, eps=None):
         eps, seed, offset = layer._draw_noise(oshape, input)
     return RealConv2dLRTFn.apply(input, layer.weight, layer.bias, layer.log_sigma2, eps, seed,
                                  offset, *args)
+
+
+# ------------------------------------------------------------------------------------------ #
+#  1-d convolution: the 2-d kernels on a height-1 image (cplx.conv1d, cplxmodule/cplx.py:803-819) #
+# ------------------------------------------------------------------------------------------ #
+def _one(v):
+    return v if isinstance(v, int) else v[0]
+
+
+class _Lift1d:
+    """A 1-d conv layer seen as the equivalent 2-d one: weights / log_sigma2 get a unit height
+    (views: gradients flow back to the 3-d parameters), the 1-d hyper-parameters become (1, s),
+    (0, p), (1, d).  Everything else is the wrapped layer's."""
+
+    def __init__(self, layer):
+        self._layer = layer
+
+    def __getattr__(self, name):
+        return getattr(self._layer, name)
+
+    @property
+    def weight(self):
+        w = self._layer.weight
+        return Cplx(w.real.unsqueeze(2), w.imag.unsqueeze(2)) if isinstance(w, Cplx) else w.unsqueeze(2)
+
+    @property
+    def log_sigma2(self):
+        return self._layer.log_sigma2.unsqueeze(2)
+
+    stride = property(lambda self: (1, _one(self._layer.stride)))
+    padding = property(lambda self: (0, _one(self._layer.padding)))
+    dilation = property(lambda self: (1, _one(self._layer.dilation)))
+
+
+def _up(x):
+    return Cplx(x.real.unsqueeze(2), x.imag.unsqueeze(2)) if isinstance(x, Cplx) else x.unsqueeze(2)
+
+
+def _down(y):
+    return Cplx(y.real.squeeze(2), y.imag.squeeze(2)) if isinstance(y, Cplx) else y.squeeze(2)
+
+
+def cplx_conv1d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                padding_mode="zeros"):
+    """Complex 1-d cross-correlation on [B, C, L]."""
+    if padding_mode == "circular":
+        p = _one(padding)
+        pads = ((p + 1) // 2, p // 2)
+        input = Cplx(F.pad(input.real, pads, mode="circular"), F.pad(input.imag, pads, mode="circular"))
+        padding = 0
+    elif padding_mode != "zeros":
+        raise ValueError("padding_mode must be 'zeros' or 'circular'.")
+    w2 = Cplx(weight.real.unsqueeze(2), weight.imag.unsqueeze(2))
+    y = cplx_conv2d(_up(input), w2, bias, (1, _one(stride)), (0, _one(padding)), (1, _one(dilation)), groups)
+    return _down(y)
+
+
+def cplx_conv1d_lrt(layer, input, eps=None):
+    return _down(cplx_conv2d_lrt(_Lift1d(layer), _up(input), None if eps is None else _up(eps)))
+
+
+def real_conv1d_layer(layer, input, eps=None):
+    return _down(real_conv2d_layer(_Lift1d(layer), _up(input), None if eps is None else _up(eps)))

@@ -345,6 +345,13 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
     return conv.cplx_conv2d(input, weight, bias, stride, padding, dilation, groups, padding_mode)
 
 
+def conv1d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, padding_mode="zeros"):
+    """Complex 1-d cross-correlation on [B, C, L] (cplxmodule/cplx.py:803-819): the 2-d kernels on a
+    height-1 image."""
+    from . import conv
+    return conv.cplx_conv1d(input, weight, bias, stride, padding, dilation, groups, padding_mode)
+
+
 def from_interleaved_real(input, copy=True, dim=-1):
     """[..., 2D] interleaved (re, im) -> Cplx [..., D]  (cplxmodule/cplx.py:451-455).  copy=True along
     the last dim on the GPU is one de-interleaving kernel pass (csrc/layout.hip) instead of two

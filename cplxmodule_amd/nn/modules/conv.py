@@ -1,7 +1,7 @@
-"""CplxConv2d: complex 2-d cross-correlation layer (cplxmodule/nn/modules/conv.py:11-92, 147-196)."""
+"""CplxConv1d / CplxConv2d: complex cross-correlation layers (cplxmodule/nn/modules/conv.py:11-196)."""
 import math
 
-from torch.nn.modules.utils import _pair
+from torch.nn.modules.utils import _pair, _single
 
 from .base import CplxToCplx, CplxParameter
 from .. import init
@@ -55,3 +55,32 @@ class CplxConv2d(CplxToCplx):
         if self.padding_mode != "zeros":
             s += f", padding_mode='{self.padding_mode}'"
         return s
+
+
+class CplxConv1d(CplxConv2d):
+    """[B, C, L] complex convolution; weight [out, in / groups, k].  Runs the 2-d kernels on a
+    height-1 image (cplx.conv1d)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        CplxToCplx.__init__(self)
+        if in_channels % groups != 0:
+            raise ValueError("in_channels must be divisible by groups")
+        if out_channels % groups != 0:
+            raise ValueError("out_channels must be divisible by groups")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _single(kernel_size), _single(stride)
+        self.padding, self.dilation = _single(padding), _single(dilation)
+        self.transposed, self.output_padding = False, _single(0)
+        self.groups, self.padding_mode = groups, padding_mode
+        self.weight = CplxParameter(
+            cplx.Cplx.empty(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = CplxParameter(cplx.Cplx.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def forward(self, input):
+        return cplx.conv1d(input, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.groups, self.padding_mode)

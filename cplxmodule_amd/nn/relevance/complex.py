@@ -11,7 +11,7 @@ from .base import BaseARD
 from .noise import noise
 from ..utils.sparsity import SparsityStats
 from ..modules.linear import CplxLinear
-from ..modules.conv import CplxConv2d
+from ..modules.conv import CplxConv1d, CplxConv2d
 from ... import ops, cplx
 
 
@@ -124,4 +124,28 @@ class CplxConv2dVD(CplxConv2dGaussian, SparsityStats, BaseARD):
 
 
 class CplxConv2dARD(CplxConv2dVD):
+    _kl_kind = "cplx_ard"
+
+
+class CplxConv1dGaussian(_CplxGaussianMixin, CplxConv1d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                         dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode)
+        if self.padding_mode != "zeros":
+            raise ValueError(f"Only `zeros` padding mode is supported. Got `{self.padding_mode}`.")
+        self._init_variational()
+
+    def forward(self, input, eps=None):
+        if not self.training:
+            return super().forward(input)
+        from ... import conv
+        return conv.cplx_conv1d_lrt(self, input, eps)
+
+
+class CplxConv1dVD(CplxConv1dGaussian, SparsityStats, BaseARD):
+    _kl_kind = "cplx_vd"
+
+
+class CplxConv1dARD(CplxConv1dVD):
     _kl_kind = "cplx_ard"

@@ -94,3 +94,25 @@ class Conv2dVD(Conv2dGaussian, SparsityStats, BaseARD):
 
 class Conv2dARD(Conv2dVD):
     _kl_kind = "real_ard"
+
+
+class Conv1dGaussian(_RealGaussianMixin, torch.nn.Conv1d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                         dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode)
+        if self.padding_mode != "zeros":
+            raise ValueError(f"Only `zeros` padding mode is supported. Got `{self.padding_mode}`.")
+        self._init_variational()
+
+    def forward(self, input, eps=None):
+        from ... import conv
+        return conv.real_conv1d_layer(self, input, eps)
+
+
+class Conv1dVD(Conv1dGaussian, SparsityStats, BaseARD):
+    _kl_kind = "real_vd"
+
+
+class Conv1dARD(Conv1dVD):
+    _kl_kind = "real_ard"

@@ -452,6 +452,23 @@ def gen_extras():
             d[k + "pen"] = npy(pen)
             d[k + "dls2"] = npy(layer.log_sigma2.grad)
             d[k + "dwr"], d[k + "dwi"] = npy(layer.weight.real.grad), npy(layer.weight.imag.grad)
+    # 1-d complex convolution (cplx.conv1d): zeros and circular padding, values + gradients
+    for tag, dt in DT.items():
+        torch.manual_seed(19)
+        for name, kw in (("s2p1", dict(stride=2, padding=1)), ("d2", dict(dilation=2)),
+                         ("circ", dict(padding=3, padding_mode="circular")), ("g2", dict(groups=2, padding=2))):
+            xr, xi = leaf(3, 4, 21, dtype=dt), leaf(3, 4, 21, dtype=dt)
+            cg = 2 if name == "g2" else 4
+            wr, wi = leaf(6, cg, 3, dtype=dt, scale=0.3), leaf(6, cg, 3, dtype=dt, scale=0.3)
+            br, bi = leaf(6, dtype=dt), leaf(6, dtype=dt)
+            y = cplx.conv1d(C(xr, xi), C(wr, wi), C(br, bi), **kw)
+            gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+            torch.autograd.backward((y.real, y.imag), (gr, gi))
+            k = f"{tag}_c1_{name}_"
+            for n, t in dict(xr=xr, xi=xi, wr=wr, wi=wi, br=br, bi=bi, yr=y.real, yi=y.imag, gr=gr, gi=gi).items():
+                d[k + n] = npy(t)
+            for n, t in dict(dxr=xr, dxi=xi, dwr=wr, dwi=wi, dbr=br, dbi=bi).items():
+                d[k + n] = npy(t.grad)
     # abs-max pooling (values, gradients); one case has ties (a constant block)
     torch.manual_seed(13)
     pools = {"k2": dict(kernel_size=2), "k3s2p1": dict(kernel_size=3, stride=2, padding=1),

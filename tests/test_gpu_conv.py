@@ -232,3 +232,65 @@ def test_conv_bf16_rows_kernels_random_shapes(seed):
         scale = float(b.detach().abs().max()) + 1e-6
         tol = 2e-2 if n[0] in "yd" and n[1] in "rix" else 1e-3   # bf16-rounded outputs vs fp32-accumulated grads
         assert float((a.detach() - b.detach()).abs().max()) <= tol * scale, (n, seed, B, Ci, Co, kh, kw, dh, dw, ph, pw, H, W)
+
+
+C1_CASES = {"s2p1": dict(stride=2, padding=1), "d2": dict(dilation=2),
+            "circ": dict(padding=3, padding_mode="circular"), "g2": dict(groups=2, padding=2)}
+
+
+@pytest.mark.parametrize("name", list(C1_CASES))
+def test_conv1d_golden(golden, name):
+    """cplx.conv1d (the 2-d kernels on a height-1 image) against the reference: values and every
+    gradient, zeros / circular padding, stride, dilation, groups."""
+    from gpu_util import T, N
+    from cplxmodule_amd import Cplx, cplx
+    g = golden("extras")
+    k = f"f32_c1_{name}_"
+    lv = {n: T(g[k + n]).requires_grad_(True) for n in ("xr", "xi", "wr", "wi", "br", "bi")}
+    y = cplx.conv1d(Cplx(lv["xr"], lv["xi"]), Cplx(lv["wr"], lv["wi"]), Cplx(lv["br"], lv["bi"]), **C1_CASES[name])
+    np.testing.assert_allclose(N(y.real), g[k + "yr"], **_tol(g[k + "yr"], 2e-5))
+    np.testing.assert_allclose(N(y.imag), g[k + "yi"], **_tol(g[k + "yi"], 2e-5))
+    torch.autograd.backward((y.real, y.imag), (T(g[k + "gr"]), T(g[k + "gi"])))
+    for n in ("xr", "xi", "wr", "wi", "br", "bi"):
+        np.testing.assert_allclose(N(lv[n].grad), g[k + "d" + n], **_tol(g[k + "d" + n], 5e-5), err_msg=n)
+
+
+def test_conv1d_layers_and_lrt():
+    """CplxConv1d / CplxConv1dVD / Conv1dARD: state-dict layout, eval = mean path, training = the
+    2-d LRT on the lifted tensors (same noise position => same bits), penalties, masks."""
+    from gpu_util import DEV
+    from cplxmodule_amd import Cplx, nn
+    from cplxmodule_amd.nn import relevance as rel
+    torch.manual_seed(3)
+    l1 = rel.CplxConv1dVD(8, 12, 5, stride=2, padding=2).to(DEV)
+    l2 = rel.CplxConv2dVD(8, 12, (1, 5), stride=(1, 2), padding=(0, 2)).to(DEV)
+    with torch.no_grad():
+        for a, b in ((l1.weight.real, l2.weight.real), (l1.weight.imag, l2.weight.imag), (l1.log_sigma2, l2.log_sigma2)):
+            a.uniform_(-0.3, 0.3)
+            b.copy_(a.unsqueeze(2))
+        l1.log_sigma2.sub_(4.0); l2.log_sigma2.sub_(4.0)
+        l2.bias.real.copy_(l1.bias.real); l2.bias.imag.copy_(l1.bias.imag)
+    assert list(l1.state_dict()) == ["log_sigma2", "weight.imag", "weight.real", "bias.imag", "bias.real"]
+    x = Cplx(torch.randn(4, 8, 33, device=DEV, requires_grad=True), torch.randn(4, 8, 33, device=DEV))
+    x2 = Cplx(x.real.detach().unsqueeze(2).requires_grad_(True), x.imag.unsqueeze(2))
+    for mode in ("eval", "train"):
+        getattr(l1, mode)(); getattr(l2, mode)()
+        rel.noise.manual_seed(4)
+        y1 = l1(x)
+        rel.noise.manual_seed(4)
+        y2 = l2(x2)
+        assert y1.real.shape == (4, 12, 17)
+        assert torch.equal(y1.real, y2.real.squeeze(2)) and torch.equal(y1.imag, y2.imag.squeeze(2))
+    (y1.real.sum() + sum(rel.penalties(l1))).backward()
+    (y2.real.sum() + sum(rel.penalties(l2))).backward()
+    assert torch.allclose(l1.log_sigma2.grad, l2.log_sigma2.grad.squeeze(2), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(l1.weight.real.grad, l2.weight.real.grad.squeeze(2), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(x.real.grad, x2.real.grad.squeeze(2), rtol=1e-6, atol=1e-7)
+    assert rel.compute_ard_masks(l1, hard=True, threshold=0.0)["mask"].shape == (12, 8, 5)
+    r = rel.Conv1dARD(8, 12, 3, padding=1).to(DEV)
+    xr = torch.randn(4, 8, 20, device=DEV)
+    assert r(xr).shape == (4, 12, 20)
+    r.eval()
+    assert torch.allclose(r(xr), torch.nn.functional.conv1d(xr, r.weight, r.bias, padding=1), rtol=1e-4, atol=1e-5)
+    c = nn.CplxConv1d(8, 12, 3, padding=2, padding_mode="circular").to(DEV)
+    assert c(Cplx(xr, xr)).real.shape == (4, 12, 20)
