@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int64_t ld_
 
 // out[c] = sum_r in[r, c].  Stage 1: block = 64 column-quads x 4 row lanes over one row chunk,
 // 8-16 B loads per lane, partial[chunk][c]; stage 2 sums the chunks.  (cols % 4 != 0: scalar path.)
-constexpr int kColChunks = 32;
+constexpr int kColChunks = 256;
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* in, int64_t ld, float* partial,
@@ -97,12 +97,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* in, int64_
   int r1 = r0 + rows_per;
   if (r1 > rows) r1 = rows;
   f4 acc = {{0.f, 0.f, 0.f, 0.f}};
-  if (c < cols)
-    for (int r = r0 + ty; r < r1; r += 4) {
+  if (c < cols) {
+    int r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {              // 4 independent loads in flight per thread
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ld4(in + (int64_t)(r + 4 * u) * ld + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc.v[j] += (v[0].v[j] + v[1].v[j]) + (v[2].v[j] + v[3].v[j]);
+    }
+    for (; r < r1; r += 4) {
       const f4 v = ld4(in + (int64_t)r * ld + c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j];
     }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) red[ty][tx][j] = acc.v[j];
   __syncthreads();
@@ -223,10 +232,12 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
   const bool vec = ws && (cols % 4 == 0) && (ld % 4 == 0) && rows >= 64 &&
                    ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
   if (vec) {
-    int chunks = rows / 64;
+    const int gx = (cols / 4 + 63) / 64;
+    int chunks = (2048 + gx - 1) / gx;            // ~8 blocks per CU
+    if (chunks > rows / 256) chunks = rows / 256; // >= 256 rows per chunk (the final pass is serial in chunks)
     if (chunks > kColChunks) chunks = kColChunks;
     if (chunks < 1) chunks = 1;
-    dim3 grid((cols / 4 + 63) / 64, chunks);
+    dim3 grid(gx, chunks);
     if (dtype == CPLXAMD_F32)
       colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)in, ld, (float*)ws, rows, cols);
     else if (dtype == CPLXAMD_BF16)
