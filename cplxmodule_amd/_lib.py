@@ -46,6 +46,8 @@ SIGNATURES = {
     "cplxamd_modrelu_bwd": [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _L, _I, _P],
     "cplxamd_cplx_dropout": [_P, _P, _P, _P, _D, _U, _U, _P, _L, _I, _P],
     "cplxamd_nhwc_pad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cplxamd_nhwc_pad_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cplxamd_conv2d_nhwc_f32": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_L] + [_I] * 4 + [_P],
     "cplxamd_conv2d_nhwc_wgrad_ws_bytes": [_I] * 8,
     "cplxamd_conv2d_nhwc_wgrad": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
     "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_L] + [_I] * 5 + [_P],

@@ -70,9 +70,10 @@ def nhwc_pad(x, ph, pw, Hp=None, Wp=None, head_rows=0, tail_rows=0):
     Hp = H + 2 * ph if Hp is None else Hp
     Wp = W + 2 * pw if Wp is None else Wp
     rows = B * Hp * Wp
-    buf = torch.empty(head_rows + rows + tail_rows, C, dtype=torch.bfloat16, device=x.device)
+    buf = torch.empty(head_rows + rows + tail_rows, C, dtype=x.dtype, device=x.device)
     grid = buf[head_rows:head_rows + rows]
-    call("cplxamd_nhwc_pad", ptr(x), ptr(grid), B, C, H, W, ph, pw, Hp, Wp, stream_ptr())
+    entry = "cplxamd_nhwc_pad" if x.dtype == torch.bfloat16 else "cplxamd_nhwc_pad_f32"
+    call(entry, ptr(x), ptr(grid), B, C, H, W, ph, pw, Hp, Wp, stream_ptr())
     if head_rows:
         buf[:head_rows].zero_()
     if tail_rows:
@@ -91,12 +92,13 @@ def _rows_base_ok(geom):
             and geom[0] * Hp * Wp < 2 ** 31)
 
 
-def _rows_fwd_ok(geom):
-    return _rows_base_ok(geom) and geom[1] % 32 == 0
+def _rows_fwd_ok(geom, dtype=torch.bfloat16):
+    """bf16 stages hold 32 channels, float32 stages 16."""
+    return _rows_base_ok(geom) and geom[1] % (32 if dtype == torch.bfloat16 else 16) == 0
 
 
-def _rows_dgrad_ok(geom):
-    return _rows_base_ok(geom) and geom[2] % 32 == 0
+def _rows_dgrad_ok(geom, dtype=torch.bfloat16):
+    return _rows_base_ok(geom) and geom[2] % (32 if dtype == torch.bfloat16 else 16) == 0
 
 
 def _rows_wgrad_ok(geom, cplx):
@@ -135,12 +137,14 @@ def grad_grid(gr, gi, geom):
 
 
 def _pack_rows(w, swap):
-    """[Co, Ci, KH, KW] -> [KH][KW][C/16][N][16] for the shifted-row kernel: (C, N) = (Ci, Co) for
-    the forward, (Co, Ci) with both spatial dims flipped for the data gradient (`swap`)."""
+    """[Co, Ci, KH, KW] -> [KH][KW][C/v][N][v] for the shifted-row kernels (v = 16 bf16 or 4 float32 =
+    one MFMA operand load): (C, N) = (Ci, Co) for the forward, (Co, Ci) with both spatial dims
+    flipped for the data gradient (`swap`)."""
     if swap:
         w = w.flip(2, 3).transpose(0, 1)
     N, C, KH, KW = w.shape
-    return w.reshape(N, C // 16, 16, KH, KW).permute(3, 4, 1, 0, 2).contiguous()
+    v = 16 if w.dtype == torch.bfloat16 else 4
+    return w.reshape(N, C // v, v, KH, KW).permute(3, 4, 1, 0, 2).contiguous()
 
 
 def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape, keep_grid=False):
@@ -159,6 +163,15 @@ def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape, keep_grid=False):
                     geom[11], geom[12], 0, 0, 0, 0, out_shape[2], out_shape[3], dtype_code(yr),
                     stream_ptr()):
             return done(xp)
+    if xr.dtype == torch.float32 and _rows_fwd_ok(geom, torch.float32):
+        xp = input_grid(xr, xi, geom)
+        Hp, Wp = _grid(geom)
+        wpr = _pack_rows(wr, False)
+        wpi = None if wi is None else _pack_rows(wi, False)
+        if try_call("cplxamd_conv2d_nhwc_f32", ptr(xp[0]), ptr(xp[1]), ptr(wpr), ptr(wpi), ptr(br),
+                    ptr(bi), ptr(yr), ptr(yi), geom[0], Hp, Wp, geom[1], geom[2], geom[5], geom[6],
+                    geom[11], geom[12], 0, 0, 0, 0, out_shape[2], out_shape[3], stream_ptr()):
+            return done(None)           # float32: the weight gradient still wants the planar input
     if xr.dtype == torch.bfloat16 and try_call(
             "cplxamd_conv2d_bf16_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
             ptr(yi), geom, ptr(_ktab(geom, 0, xr.device)), stream_ptr()):
@@ -172,6 +185,16 @@ def conv_dgrad(gr, gi, wr, wi, geom, x_shape, gp=None):
     """gp: grad_grid(gr, gi, geom) if the caller already made it (shared with conv_wgrad)."""
     dxr = torch.empty(x_shape, dtype=gr.dtype, device=gr.device)
     dxi = None if gi is None else torch.empty_like(dxr)
+    if gr.dtype == torch.float32 and _rows_dgrad_ok(geom, torch.float32):
+        gp = grad_grid(gr, gi, geom) if gp is None else gp
+        Hp, Wp = _grid(geom)
+        wdr = _pack_rows(wr, True)
+        wdi = None if wi is None else _pack_rows(wi, True)
+        if try_call("cplxamd_conv2d_nhwc_f32", ptr(gp[0]), ptr(gp[1]), ptr(wdr), ptr(wdi), None, None,
+                    ptr(dxr), ptr(dxi), geom[0], Hp, Wp, geom[2], geom[1], geom[5], geom[6],
+                    geom[11], geom[12], 1, -_shift_rows(geom), geom[9], geom[10], x_shape[2],
+                    x_shape[3], stream_ptr()):
+            return dxr, dxi
     if gr.dtype == torch.bfloat16 and _rows_dgrad_ok(geom):
         # dX[h, w] sits at grid position (h + ph, w + pw) and reads the gradient grid backwards
         gp = grad_grid(gr, gi, geom) if gp is None else gp

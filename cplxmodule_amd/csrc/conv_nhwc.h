@@ -15,8 +15,8 @@ constexpr int MAX_EXTRA = 32;                       // (KW-1)*dil_w rows of halo
 constexpr int OUT_LD = BM + 8;                      // epilogue image [channel][pixel], padded rows
 
 struct Args {
-  const bf16_t* x_r; const bf16_t* x_i;
-  const bf16_t* w_r; const bf16_t* w_i;
+  const void* x_r; const void* x_i;       // channels-last grid (bf16 or float32, per kernel)
+  const void* w_r; const void* w_i;       // packed weights (same element type)
   const float* bias_r; const float* bias_i;
   void* y_r; void* y_i;
   int64_t rows;                 // B * Hp * Wp

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
     const int row = c >> 2;
     int64_t grow = m0 + row + g.row_bias + (int64_t)kh * g.dil_h * g.Wp;
     grow = grow < g.rows ? grow : g.rows - 1;                    // rows past the end feed dropped outputs
-    const bf16_t* base = plane ? g.x_i : g.x_r;
+    const bf16_t* base = (const bf16_t*)(plane ? g.x_i : g.x_r);
     glds16(base + grow * g.C + c0 + (((c & 3) ^ ((row >> 2) & 3)) << 3),
            q < g.npieces ? smem + buf * stage_bytes + (q * NT + wave_chunk) * 16 : dump + wave_chunk * 16);
   };
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t o = (blk + nrow[j]) * 16 + lk * 8;
-      br[j] = *reinterpret_cast<const bf16x8*>(g.w_r + o);
-      if (CPLX) bi[j] = *reinterpret_cast<const bf16x8*>(g.w_i + o);
+      br[j] = *reinterpret_cast<const bf16x8*>((const bf16_t*)g.w_r + o);
+      if (CPLX) bi[j] = *reinterpret_cast<const bf16x8*>((const bf16_t*)g.w_i + o);
     }
   };
 
@@ -334,7 +334,7 @@ int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, con
   auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (!a16(xp_r) || !a16(w_r) || (cplx && (!a16(xp_i) || !a16(w_i)))) return CPLXAMD_EALIGN;
   if (B == 0) return 0;
-  cn::Args g{(const bf16_t*)xp_r, (const bf16_t*)xp_i, (const bf16_t*)w_r, (const bf16_t*)w_i,
+  cn::Args g{xp_r, xp_i, w_r, w_i,
              bias_r, bias_i, y_r, y_i, rows, B, Hp, Wp, C, Cout, KH, KW, dil_h, dil_w, Ho, Wo,
              row_bias, oh, ow, cn::BM + (KW - 1) * dil_w, 0, 0};
   hipStream_t st = (hipStream_t)stream;

@@ -263,6 +263,16 @@ int cplxamd_conv2d_nhwc(const void* xp_r, const void* xp_i, const void* w_r, con
                         int conj_w, int64_t row_bias, int oh, int ow, int Hout, int Wout,
                         int out_dtype, void* stream);
 
+/* Exact-float32 versions of the two entry points above (conv_nhwc_f32.hip, v_mfma_f32_32x32x2_f32):
+ * float32 grids / outputs, C % 16 == 0, weights packed [KH][KW][C/4][Cout][4]. */
+int cplxamd_nhwc_pad_f32(const void* x, void* out, int B, int C, int H, int W, int pad_h, int pad_w,
+                         int Hp, int Wp, void* stream);
+int cplxamd_conv2d_nhwc_f32(const void* xp_r, const void* xp_i, const void* w_r, const void* w_i,
+                            const float* bias_r, const float* bias_i, void* y_r, void* y_i, int B,
+                            int Hp, int Wp, int C, int Cout, int KH, int KW, int dil_h, int dil_w,
+                            int conj_w, int64_t row_bias, int oh, int ow, int Hout, int Wout,
+                            void* stream);
+
 /* Weight gradient on the same channels-last copies (conv_nhwc_wgrad.hip):
  *   dw[co, ci, kh, kw] = sum_r gp[r][co] * conj(xp[r + kh*dil_h*Wp + kw*dil_w][ci]) (* emul, real only)
  * over the rows r = (b, hp, wp) of the padded input grid.  gp_*: the output gradient laid on that

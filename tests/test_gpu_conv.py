@@ -294,3 +294,36 @@ def test_conv1d_layers_and_lrt():
     assert torch.allclose(r(xr), torch.nn.functional.conv1d(xr, r.weight, r.bias, padding=1), rtol=1e-4, atol=1e-5)
     c = nn.CplxConv1d(8, 12, 3, padding=2, padding_mode="circular").to(DEV)
     assert c(Cplx(xr, xr)).real.shape == (4, 12, 20)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, Ci=32, Co=64, H=14, W=17, k=3, padding=1, dilation=1),
+    dict(B=3, Ci=16, Co=40, H=12, W=11, k=(3, 2), padding=(2, 0), dilation=(2, 1)),
+    dict(B=1, Ci=48, Co=16, H=9, W=20, k=(1, 4), padding=(0, 3), dilation=1),
+    dict(B=2, Ci=64, Co=96, H=10, W=10, k=1, padding=0, dilation=1),
+])
+def test_conv_f32_rows_kernel_vs_oracle(cfg):
+    """The exact-float32 shifted-row kernel (conv_nhwc_f32.hip: forward and data gradient) against
+    the float64 oracle at float32 tolerances (1e-5 relative to the largest output)."""
+    from gpu_util import T, N
+    from cplxmodule_amd import Cplx, cplx
+    rs = np.random.RandomState(cfg["Ci"] * 3 + cfg["Co"])
+    B, Ci, Co, H, W = cfg["B"], cfg["Ci"], cfg["Co"], cfg["H"], cfg["W"]
+    kh, kw = (cfg["k"], cfg["k"]) if isinstance(cfg["k"], int) else cfg["k"]
+    f32 = np.float32
+    xr, xi = rs.randn(B, Ci, H, W).astype(f32), rs.randn(B, Ci, H, W).astype(f32)
+    wr, wi = (rs.randn(Co, Ci, kh, kw) * 0.1).astype(f32), (rs.randn(Co, Ci, kh, kw) * 0.1).astype(f32)
+    br, bi = rs.randn(Co).astype(f32), rs.randn(Co).astype(f32)
+    lv = [T(a).requires_grad_(True) for a in (xr, xi, wr, wi, br, bi)]
+    kw_ = dict(stride=1, padding=cfg["padding"], dilation=cfg["dilation"])
+    y = cplx.conv2d(Cplx(lv[0], lv[1]), Cplx(lv[2], lv[3]), Cplx(lv[4], lv[5]), **kw_)
+    f = np.float64
+    yr, yi = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), br.astype(f), bi.astype(f), **kw_)
+    s = max(np.abs(yr).max(), np.abs(yi).max())
+    np.testing.assert_allclose(N(y.real), yr, rtol=1e-5, atol=1e-5 * s)
+    np.testing.assert_allclose(N(y.imag), yi, rtol=1e-5, atol=1e-5 * s)
+    gr, gi = rs.randn(*yr.shape).astype(f32), rs.randn(*yr.shape).astype(f32)
+    torch.autograd.backward((y.real, y.imag), (T(gr), T(gi)))
+    bw = orc.cplx_conv2d_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), **kw_)
+    for n, t in dict(dxr=lv[0].grad, dxi=lv[1].grad, dwr=lv[2].grad, dwi=lv[3].grad).items():
+        np.testing.assert_allclose(N(t), bw[n], rtol=1e-5, atol=2e-5 * np.abs(bw[n]).max(), err_msg=n)
