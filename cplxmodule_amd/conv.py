@@ -101,17 +101,21 @@ def _rows_dgrad_ok(geom, dtype=torch.bfloat16):
     return _rows_base_ok(geom) and geom[2] % (32 if dtype == torch.bfloat16 else 16) == 0
 
 
-def _rows_wgrad_ok(geom, cplx):
+def _rows_wgrad_ok(geom, cplx, dtype=torch.bfloat16):
     Hp, Wp = _grid(geom)
     KH, KW = geom[5], geom[6]
+    bf16 = dtype == torch.bfloat16
     span = geom[0] * Hp * Wp + 64 + KH * geom[11] * Wp
-    if not (_rows_base_ok(geom) and geom[1] % 8 == 0 and geom[2] % 8 == 0
+    cmul = 8 if bf16 else 4
+    if not (_rows_base_ok(geom) and geom[1] % cmul == 0 and geom[2] % cmul == 0
             and span * max(geom[1], geom[2]) < 2 ** 31):
         return False
     if KH == 1 and KW == 1:
         return True                      # 1x1: the (T, T) GEMM of the linear layer on the two grids
-    # KW waves stage 32 + 32 + (KW-1)*dil_w rows of 8 chunks per plane in at most 8 pieces each
-    chunks = (2 if cplx else 1) * 8 * (64 + (KW - 1) * geom[12])
+    # KW waves stage kr + kr + (KW-1)*dil_w rows (kr = 32 bf16 / 16 float32 rows of 8 / 16 chunks)
+    # per plane in at most 8 pieces each
+    kr, per_row = (32, 8) if bf16 else (16, 16)
+    chunks = (2 if cplx else 1) * per_row * (2 * kr + (KW - 1) * geom[12])
     return KW <= 4 and -(-chunks // (64 * KW)) <= 8
 
 
@@ -171,7 +175,7 @@ def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape, keep_grid=False):
         if try_call("cplxamd_conv2d_nhwc_f32", ptr(xp[0]), ptr(xp[1]), ptr(wpr), ptr(wpi), ptr(br),
                     ptr(bi), ptr(yr), ptr(yi), geom[0], Hp, Wp, geom[1], geom[2], geom[5], geom[6],
                     geom[11], geom[12], 0, 0, 0, 0, out_shape[2], out_shape[3], stream_ptr()):
-            return done(None)           # float32: the weight gradient still wants the planar input
+            return done(xp)
     if xr.dtype == torch.bfloat16 and try_call(
             "cplxamd_conv2d_bf16_fwd", ptr(xr), ptr(xi), ptr(wr), ptr(wi), ptr(br), ptr(bi), ptr(yr),
             ptr(yi), geom, ptr(_ktab(geom, 0, xr.device)), stream_ptr()):
@@ -234,11 +238,12 @@ def _wgrad_rows(gp, xp, geom, w_shape, emul):
             return dwr.view(w_shape), dwi.view(w_shape)
         em = None if emul is None else emul.reshape(Co, Ci)
         return ops._real_linear_dw(flat(gp[0], Co), flat(xp[0], Ci), emul=em).view(w_shape), None
-    nbytes = int(_lib.load().cplxamd_conv2d_nhwc_wgrad_ws_bytes(B, Hp, Wp, Ci, Co, KH, KW, int(cplx)))
+    sfx = "" if gp[0].dtype == torch.bfloat16 else "_f32"
+    nbytes = int(getattr(_lib.load(), f"cplxamd_conv2d_nhwc_wgrad{sfx}_ws_bytes")(B, Hp, Wp, Ci, Co, KH, KW, int(cplx)))
     ws = _scratch(dev, nbytes)
     dwr = torch.empty(w_shape, dtype=torch.float32, device=dev)
     dwi = torch.empty_like(dwr) if cplx else None
-    if try_call("cplxamd_conv2d_nhwc_wgrad", ptr(gp[0]), ptr(gp[1]), ptr(xp[0]), ptr(xp[1]), ptr(emul),
+    if try_call(f"cplxamd_conv2d_nhwc_wgrad{sfx}", ptr(gp[0]), ptr(gp[1]), ptr(xp[0]), ptr(xp[1]), ptr(emul),
                 ptr(dwr), ptr(dwi), B, Hp, Wp, Ci, Co, KH, KW, geom[11], geom[12], ptr(ws),
                 ws.numel(), stream_ptr()):
         return dwr, dwi
@@ -249,7 +254,7 @@ def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None, xp=None, gp=None):
     """xr / xi may be None when xp (input_grid) is given; gp: a grad_grid shared with conv_dgrad."""
     lib = _lib.load()
     cplx = gi is not None
-    if gr.dtype == torch.bfloat16 and _rows_wgrad_ok(geom, cplx):
+    if gr.dtype in (torch.bfloat16, torch.float32) and _rows_wgrad_ok(geom, cplx, gr.dtype):
         xp = input_grid(xr, xi, geom) if xp is None else xp
         gp = grad_grid(gr, gi, geom) if gp is None else gp
         out = _wgrad_rows(gp, xp, geom, w_shape, emul)
@@ -277,9 +282,9 @@ def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None, xp=None, gp=None):
 
 def _shared_grad_grid(gr, gi, geom, need_dx, need_dw):
     """One gradient grid for both backward kernels (None if neither takes the rows path)."""
-    if gr.dtype != torch.bfloat16:
+    if gr.dtype not in (torch.bfloat16, torch.float32):
         return None
-    if (need_dx and _rows_dgrad_ok(geom)) or (need_dw and _rows_wgrad_ok(geom, gi is not None)):
+    if (need_dx and _rows_dgrad_ok(geom, gr.dtype)) or (need_dw and _rows_wgrad_ok(geom, gi is not None, gr.dtype)):
         return grad_grid(gr, gi, geom)
     return None
 
@@ -308,7 +313,7 @@ class CplxConv2dFn(torch.autograd.Function):
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
         yr, yi, xp = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape, keep_grid=True)
         # keep the channels-last input for the weight gradient instead of the planar one
-        ctx.grid = xp is not None and _rows_wgrad_ok(geom, True)
+        ctx.grid = xp is not None and _rows_wgrad_ok(geom, True, xr.dtype)
         ctx.save_for_backward(*(xp if ctx.grid else (xr, xi)), wcr, wci)
         ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, br is not None, wr.shape, xr.shape
         return yr, yi
@@ -341,7 +346,7 @@ class RealConv2dFn(torch.autograd.Function):
         geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
         y, _, xp = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom,
                             oshape, keep_grid=True)
-        ctx.grid = xp is not None and _rows_wgrad_ok(geom, False)
+        ctx.grid = xp is not None and _rows_wgrad_ok(geom, False, x.dtype)
         ctx.save_for_backward(xp[0] if ctx.grid else x, wc)
         ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, b is not None, w.shape, x.shape
         return y

@@ -286,6 +286,160 @@ static int plan_splits(int64_t rows, int KH, int tiles) {
   return (int)s;
 }
 
+
+// ---- exact-float32 variant (v_mfma_f32_32x32x2_f32) -----------------------------------------
+// Same work split (one kernel row per workgroup, one tap per wave, split-K over the rows), but a
+// stage holds KRF = 16 rows of float32 Gp / Xp as [k][64 channels] (256-B rows): the k = 2 MFMA
+// takes one float per lane and operand, read with ds_read_b32 -- 32 consecutive channels per half
+// wave, conflict-free without a swizzle.  128 MFMAs of 64 cycles per stage and wave, 2-stage ring.
+constexpr int KRF = 16;
+
+template <bool CPLX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_f32_kernel(Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = CPLX ? 2 : 1;
+  const int NT = blockDim.x;
+  const int split = blockIdx.x / g.KH, kh = blockIdx.x - split * g.KH;
+  const int co0 = blockIdx.y * TC, ci0 = blockIdx.z * TC;
+  const int tid = threadIdx.x, lane = tid & 63, kw = tid >> 6;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int wave_chunk = kw * 64;
+
+  // stage image: [G_r | G_i | X_r | X_i], 16 chunks of 16 B per row, whole pieces
+  const int nG = KRF * 16, nX = g.xrows * 16;
+  const int stage_bytes = g.npieces * NT * 16;
+  const int64_t t_begin = (int64_t)split * g.tiles_per_split;
+  const int64_t t_all = (g.rows + KRF - 1) / KRF;
+  int64_t t_end = t_begin + g.tiles_per_split;
+  t_end = t_end < t_all ? t_end : t_all;
+  const int nt = (int)(t_end - t_begin);
+  const int64_t xshift = (int64_t)kh * g.dil_h * g.Wp;
+
+  f32x16 acc_r[2][2], acc_i[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc_r[i][j] = f32x16{0};
+      acc_i[i][j] = f32x16{0};
+    }
+
+  // per-thread source pointers for tile t_begin (zero tail rows: no row is ever clamped)
+  const uint64_t g_base = (uint64_t)g.g_r, x_base = (uint64_t)g.x_r;
+  const uint64_t g_delta = CPLX ? (uint64_t)g.g_i - g_base : 0, x_delta = CPLX ? (uint64_t)g.x_i - x_base : 0;
+  uint64_t ptr0[MAXP];
+  uint32_t xbits = 0;
+#pragma unroll
+  for (int q = 0; q < MAXP; ++q) {
+    int c = q * NT + tid;
+    c = c < NP * (nG + nX) ? c : 0;
+    const bool isx = c >= NP * nG;
+    c -= isx ? NP * nG : 0;
+    const int npl = isx ? nX : nG;
+    const bool plane = c >= npl;
+    c -= plane ? npl : 0;
+    const int k = c >> 4, ch = c & 15;
+    const int64_t row = t_begin * KRF + k + (isx ? xshift : 0);
+    const int C_ = isx ? g.Ci : g.Co;
+    int col = (isx ? ci0 : co0) + ch * 4;
+    col = col + 4 <= C_ ? col : C_ - 4;
+    const uint64_t mx = 0 - (uint64_t)isx, mp = 0 - (uint64_t)plane;
+    const uint64_t base = ((x_base & mx) | (g_base & ~mx)) + (((x_delta & mx) | (g_delta & ~mx)) & mp);
+    ptr0[q] = base + 4 * (uint64_t)(row * C_ + col);
+    xbits |= (uint32_t)isx << q;
+  }
+  const uint32_t step_g = KRF * 4 * g.Co, step_x = KRF * 4 * g.Ci;
+  auto stage_q = [&](int buf, int trel, int q) {
+    const uint32_t step = ((xbits >> q) & 1) ? step_x : step_g;
+    lds_dma16(reinterpret_cast<const void*>(ptr0[q] + (uint64_t)trel * step),
+              smem + buf * stage_bytes + (q * NT + wave_chunk) * 16);
+  };
+  auto stage_all = [&](int buf, int trel) {
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+      if (q < g.npieces) stage_q(buf, trel, q);
+  };
+
+  auto compute = [&](int buf, int nbuf, int tnext, bool do_stage) {
+    const float* sGr = reinterpret_cast<const float*>(smem + buf * stage_bytes);
+    const float* sGi = sGr + nG * 4;
+    const float* sXr = sGr + NP * nG * 4;
+    const float* sXi = sXr + nX * 4;
+    const int xk = kw * g.dil_w;
+    int q = 0;
+#pragma unroll
+    for (int s = 0; s < KRF / 2; ++s) {
+      const int k = 2 * s + lk;
+      float ar[2], ai[2], br[2], bi[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ar[i] = sGr[k * TC + i * 32 + l31];
+        br[i] = sXr[(xk + k) * TC + i * 32 + l31];
+        if (CPLX) {
+          ai[i] = sGi[k * TC + i * 32 + l31];
+          bi[i] = sXi[(xk + k) * TC + i * 32 + l31];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // X first: the accumulator holds the tile transposed, row (co) = lane & 31, 4 consecutive ci
+          // per register group.  G conj(X): re = gr xr + gi xi, im = gi xr - gr xi
+          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(br[j], ar[i], acc_r[i][j], 0, 0, 0);
+          if (CPLX) {
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(br[j], ai[i], acc_i[i][j], 0, 0, 0);
+            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bi[j], ai[i], acc_r[i][j], 0, 0, 0);
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bi[j], -ar[i], acc_i[i][j], 0, 0, 0);
+          }
+        }
+      if (q < MAXP) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_stage && q < g.npieces) stage_q(nbuf, tnext, q);
+        __builtin_amdgcn_sched_barrier(0);
+        ++q;
+      }
+    }
+  };
+
+  if (nt > 0) stage_all(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute(t & 1, (t + 1) & 1, t + 1, t + 1 < nt);
+  }
+
+  const int64_t tile = ((((int64_t)(split * g.KH + kh) * g.KW + kw) * NP) * gridDim.y + blockIdx.y) *
+                       gridDim.z + blockIdx.z;
+  float* out_r = g.ws + tile * (TC * TC);
+  float* out_i = out_r + (int64_t)gridDim.y * gridDim.z * (TC * TC);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = (i * 32 + l31) * TC + j * 32 + 8 * q + 4 * lk;
+        f4 vr, vi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vr.v[e] = acc_r[i][j][4 * q + e];
+          vi.v[e] = CPLX ? acc_i[i][j][4 * q + e] : 0.f;
+        }
+        st4(out_r + o, vr);
+        if (CPLX) st4(out_i + o, vi);
+      }
+}
+
+static int plan_splits_f32(int64_t rows, int KH, int tiles) {
+  const int64_t t_all = (rows + KRF - 1) / KRF;
+  int64_t s = 1024 / ((int64_t)KH * tiles);
+  if (s < 1) s = 1;
+  const int64_t maxs = (t_all + 15) / 16;           // >= 16 K tiles per split
+  if (s > maxs) s = maxs;
+  return (int)(s < 1 ? 1 : s);
+}
+
 }  // namespace cw
 }  // namespace cplxamd
 
@@ -351,6 +505,69 @@ int cplxamd_conv2d_nhwc_wgrad(const void* gp_r, const void* gp_i, const void* xp
   if (cplx) {
     cw::wgrad_slab_reduce_kernel<<<rgrid, 64, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 1, Co,
                                                        Ci, tco, tci, nullptr, dw_i);
+    CPLXAMD_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+
+int64_t cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes(int B, int Hp, int Wp, int Ci, int Co, int KH, int KW,
+                                               int cplx) {
+  const int tco = (Co + cw::TC - 1) / cw::TC, tci = (Ci + cw::TC - 1) / cw::TC;
+  const int s = cw::plan_splits_f32((int64_t)B * Hp * Wp, KH, tco * tci);
+  return (int64_t)s * KH * KW * (cplx ? 2 : 1) * tco * tci * cw::TC * cw::TC * (int64_t)sizeof(float);
+}
+
+int cplxamd_conv2d_nhwc_wgrad_f32(const void* gp_r, const void* gp_i, const void* xp_r, const void* xp_i,
+                                  const float* emul, float* dw_r, float* dw_i, int B, int Hp, int Wp,
+                                  int Ci, int Co, int KH, int KW, int dil_h, int dil_w, void* ws,
+                                  int64_t ws_bytes, void* stream) {
+  if (!gp_r || !xp_r || !dw_r || !ws) return CPLXAMD_EINVAL;
+  const bool cplx = gp_i != nullptr;
+  if (cplx && (!xp_i || !dw_i)) return CPLXAMD_EINVAL;
+  if (B < 0 || Hp <= 0 || Wp <= 0 || Ci <= 0 || Co <= 0 || KH <= 0 || KW <= 0 || dil_h <= 0 ||
+      dil_w <= 0)
+    return CPLXAMD_EINVAL;
+  if (Ci % 4 || Co % 4 || KW > 4 || (KW - 1) * dil_w > 32) return CPLXAMD_ESHAPE;
+  const int64_t rows = (int64_t)B * Hp * Wp;
+  if ((rows + 64 + (int64_t)KH * dil_h * Wp) * (Ci > Co ? Ci : Co) >= ((int64_t)1 << 31)) return CPLXAMD_ESHAPE;
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!a16(gp_r) || !a16(xp_r) || !a16(ws) || (cplx && (!a16(gp_i) || !a16(xp_i)))) return CPLXAMD_EALIGN;
+  if (ws_bytes < cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes(B, Hp, Wp, Ci, Co, KH, KW, cplx)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  const int tco = (Co + cw::TC - 1) / cw::TC, tci = (Ci + cw::TC - 1) / cw::TC;
+  if (tco > 65535 || tci > 65535) return CPLXAMD_ESHAPE;
+  const int NP = cplx ? 2 : 1;
+  const int64_t n = (int64_t)Co * Ci * KH * KW;
+  if (B == 0) {
+    hipError_t e = hipMemsetAsync(dw_r, 0, n * sizeof(float), st);
+    if (e == hipSuccess && cplx) e = hipMemsetAsync(dw_i, 0, n * sizeof(float), st);
+    return (int)e;
+  }
+  cw::Args g{(const bf16_t*)gp_r, (const bf16_t*)gp_i, (const bf16_t*)xp_r, (const bf16_t*)xp_i,
+             (float*)ws, rows, Wp, Co, Ci, KH, KW, dil_h, dil_w};
+  g.splits = cw::plan_splits_f32(rows, KH, tco * tci);
+  const int64_t t_all = (rows + cw::KRF - 1) / cw::KRF;
+  g.tiles_per_split = (int)((t_all + g.splits - 1) / g.splits);
+  g.xrows = cw::KRF + (KW - 1) * dil_w;
+  const int NT = 64 * KW;
+  g.npieces = (NP * (cw::KRF * 16 + g.xrows * 16) + NT - 1) / NT;
+  if (g.npieces > cw::MAXP) return CPLXAMD_ESHAPE;
+  g.dbg = 0;
+  const int smem = 2 * g.npieces * NT * 16;
+  dim3 grid(g.splits * KH, tco, tci);
+  if (cplx)
+    cw::conv_wgrad_nhwc_f32_kernel<true><<<grid, NT, smem, st>>>(g);
+  else
+    cw::conv_wgrad_nhwc_f32_kernel<false><<<grid, NT, smem, st>>>(g);
+  CPLXAMD_CHECK_LAUNCH();
+  const int rgrid = (int)(((int64_t)KH * KW * tco * tci * cw::TC * cw::TC + 63) / 64);
+  cw::wgrad_slab_reduce_kernel<<<rgrid, 64, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 0, Co, Ci,
+                                                    tco, tci, emul, dw_r);
+  CPLXAMD_CHECK_LAUNCH();
+  if (cplx) {
+    cw::wgrad_slab_reduce_kernel<<<rgrid, 64, 0, st>>>((const float*)ws, g.splits, KH, KW, NP, 1, Co, Ci,
+                                                      tco, tci, nullptr, dw_i);
     CPLXAMD_CHECK_LAUNCH();
   }
   return 0;

@@ -286,6 +286,13 @@ int cplxamd_conv2d_nhwc_wgrad(const void* gp_r, const void* gp_i, const void* xp
                               const float* emul, float* dw_r, float* dw_i, int B, int Hp, int Wp,
                               int Ci, int Co, int KH, int KW, int dil_h, int dil_w, void* ws,
                               int64_t ws_bytes, void* stream);
+/* exact-float32 version (float32 grids; Ci % 4 == Co % 4 == 0; gp tail up to a multiple of 16 rows) */
+int64_t cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes(int B, int Hp, int Wp, int Ci, int Co, int KH, int KW,
+                                               int cplx);
+int cplxamd_conv2d_nhwc_wgrad_f32(const void* gp_r, const void* gp_i, const void* xp_r, const void* xp_i,
+                                  const float* emul, float* dw_r, float* dw_i, int B, int Hp, int Wp,
+                                  int Ci, int Co, int KH, int KW, int dil_h, int dil_w, void* ws,
+                                  int64_t ws_bytes, void* stream);
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);
