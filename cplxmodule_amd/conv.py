@@ -81,15 +81,22 @@ def nhwc_pad(x, ph, pw, Hp=None, Wp=None, head_rows=0, tail_rows=0):
     return grid.view(B, Hp, Wp, C)
 
 
-# ---- eligibility of the channels-last ("rows") kernels: stride 1, groups 1, bf16 ------------- #
+# ---- eligibility of the channels-last ("rows") kernels: stride 1, groups 1 -------------------- #
+_ROWS_MIN_FLOP = 4e9
+_ROWS_FORCE = False          # tests set this to exercise the kernels on tiny shapes
 def _grid(geom):
     return geom[3] + 2 * geom[9], geom[4] + 2 * geom[10]             # Hp, Wp of the input grid
 
 
 def _rows_base_ok(geom):
+    """stride 1, groups 1, a halo of at most 32 columns -- and enough work to pay for the
+    channels-last copies and the 64-channel tiles: small layers (a few GFLOP, < 32 channels) are
+    launch-bound and stay on the single-launch gather kernels."""
     Hp, Wp = _grid(geom)
+    flop = 8.0 * geom[0] * Hp * Wp * geom[1] * geom[2] * geom[5] * geom[6]
     return (geom[7] == 1 and geom[8] == 1 and geom[13] == 1 and (geom[6] - 1) * geom[12] <= 32
-            and geom[0] * Hp * Wp < 2 ** 31)
+            and geom[0] * Hp * Wp < 2 ** 31 and (flop >= _ROWS_MIN_FLOP and min(geom[1], geom[2]) >= 32
+                                                or _ROWS_FORCE))
 
 
 def _rows_fwd_ok(geom, dtype=torch.bfloat16):
@@ -157,6 +164,8 @@ def conv_fwd(xr, xi, wr, wi, br, bi, geom, out_shape, keep_grid=False):
     yr = torch.empty(out_shape, dtype=xr.dtype, device=xr.device)
     yi = None if xi is None else torch.empty_like(yr)
     done = lambda xp: (yr, yi, xp) if keep_grid else (yr, yi)  # noqa: E731
+    if geom[0] == 0:                       # empty batch: nothing to compute
+        return done(None)
     if xr.dtype == torch.bfloat16 and _rows_fwd_ok(geom):
         xp = input_grid(xr, xi, geom)
         Hp, Wp = _grid(geom)
@@ -189,6 +198,8 @@ def conv_dgrad(gr, gi, wr, wi, geom, x_shape, gp=None):
     """gp: grad_grid(gr, gi, geom) if the caller already made it (shared with conv_wgrad)."""
     dxr = torch.empty(x_shape, dtype=gr.dtype, device=gr.device)
     dxi = None if gi is None else torch.empty_like(dxr)
+    if geom[0] == 0:
+        return dxr, dxi
     if gr.dtype == torch.float32 and _rows_dgrad_ok(geom, torch.float32):
         gp = grad_grid(gr, gi, geom) if gp is None else gp
         Hp, Wp = _grid(geom)
@@ -254,6 +265,9 @@ def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None, xp=None, gp=None):
     """xr / xi may be None when xp (input_grid) is given; gp: a grad_grid shared with conv_dgrad."""
     lib = _lib.load()
     cplx = gi is not None
+    if geom[0] == 0:                       # empty batch: the gradient is zero
+        dwr = torch.zeros(w_shape, dtype=torch.float32, device=gr.device)
+        return dwr, (torch.zeros_like(dwr) if cplx else None)
     if gr.dtype in (torch.bfloat16, torch.float32) and _rows_wgrad_ok(geom, cplx, gr.dtype):
         xp = input_grid(xr, xi, geom) if xp is None else xp
         gp = grad_grid(gr, gi, geom) if gp is None else gp

@@ -9,6 +9,18 @@ from oracle.gen_golden_cases import CONV_CASES
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["rows-forced", "size-gated"])
+def conv_kernel_choice(request):
+    """Every test runs twice: with the channels-last ("rows") kernels forced wherever the geometry
+    allows (they are normally reserved for layers with enough work), and with the default choice,
+    under which these small shapes take the gather kernels."""
+    from cplxmodule_amd import conv
+    old = conv._ROWS_FORCE
+    conv._ROWS_FORCE = request.param == "rows-forced"
+    yield request.param
+    conv._ROWS_FORCE = old
+
+
 def _tol(ref, r=2e-5):
     return dict(rtol=r, atol=r * float(np.abs(ref).max()))
 
