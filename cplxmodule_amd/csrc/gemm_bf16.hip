@@ -477,7 +477,7 @@ template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL>
 static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
   using C = Cfg<CPLX>;
   // read-only tuning knobs, set once from the environment (A/B experiments only)
-  static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 4),
+  static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 2),
                    dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
   g.order = order; g.group_m = gm > 0 ? gm : 1; g.dbg = dbg;
