@@ -134,7 +134,8 @@ __device__ __forceinline__ void philox4(uint64_t ctr_lo, uint64_t ctr_hi, uint64
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
     c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

@@ -38,9 +38,10 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi,
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t lo0 = (uint32_t)p0, hi0 = (uint32_t)(p0 >> 32);
     const uint32_t lo1 = (uint32_t)p1, hi1 = (uint32_t)(p1 >> 32);
-    c0 = hi1 ^ c1 ^ k0;
+    // three-input XOR in one instruction (v_bitop3_b32, truth table 0x96)
+    c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
     c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
+    c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
     c3 = lo0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
