@@ -7,25 +7,28 @@
 // Reference arithmetic: cplx.linear_naive cplx.py:634-648, Cplx.__matmul__ cplx.py:167-174,
 // F.linear in the LRT variance term nn/relevance/complex/base.py:50-54.
 //
-// Tiling: 64x64 outputs per 256-thread block (4 waves as 2x2, one 32x32 MFMA tile each),
-// BK = 16, operands staged k-major in LDS so that every ds_read_b32 is conflict-free.
+// Tiling: 128x128 outputs per 256-thread block (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles x
+// {re, im}), BK = 16, operands staged k-major in LDS (register-prefetched, double-buffered) so
+// that every ds_read_b32 is conflict-free; split-K for few-tile / long-K shapes.
 #include "gemm.h"
 
 namespace cplxamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBM + 1;
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = GBM + 1;
+constexpr int GPLANE = GBK * GLD;                      // floats per staged operand plane
+constexpr int GPER = GBM * GBK / 256;                  // elements per thread and operand plane (8)
 
 template <typename T>
 __device__ __forceinline__ float ldg(const void* p, int64_t off) {
   return io<T>::ld(reinterpret_cast<const T*>(p) + off);
 }
 
-// One thread's 4 elements of a [64 rows x GBK] operand tile: global -> registers (fetch), then
+// One thread's 8 elements of a [128 rows x GBK] operand tile: global -> registers (fetch), then
 // registers -> LDS as dst[k][row] (commit).  Splitting the two lets the loads of tile t+1 fly
 // while the MFMAs of tile t run.
-struct TileRegs { float v[4]; };
+struct TileRegs { float v[GPER]; };
 
 template <typename TIN>
 __device__ __forceinline__ TileRegs fetch_tile(const void* src, int64_t rs, int64_t cs, int row0,
@@ -35,48 +38,55 @@ __device__ __forceinline__ TileRegs fetch_tile(const void* src, int64_t rs, int6
   if (cs == 1 || rs != 1) {  // k fastest across threads
     const int k = t & 15, rb = t >> 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < GPER; ++j) {
       const int gr = row0 + rb + 16 * j, gk = k0 + k;
       o.v[j] = (gr < rows && gk < K) ? ldg<TIN>(src, (int64_t)gr * rs + (int64_t)gk * cs) : 0.0f;
     }
   } else {  // rows fastest across threads
-    const int r = t & 63, kb = t >> 6;
+    const int r = t & 127, kb = t >> 7;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gr = row0 + r, gk = k0 + kb + 4 * j;
+    for (int j = 0; j < GPER; ++j) {
+      const int gr = row0 + r, gk = k0 + kb + 2 * j;
       o.v[j] = (gr < rows && gk < K) ? ldg<TIN>(src, (int64_t)gr * rs + (int64_t)gk * cs) : 0.0f;
     }
   }
   return o;
 }
 
-__device__ __forceinline__ void commit_tile(float (*dst)[GLD], const TileRegs& o, int64_t rs,
-                                            int64_t cs) {
+__device__ __forceinline__ void commit_tile(float* dst, const TileRegs& o, int64_t rs, int64_t cs) {
   const int t = threadIdx.x;
   if (cs == 1 || rs != 1) {
     const int k = t & 15, rb = t >> 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dst[k][rb + 16 * j] = o.v[j];
+    for (int j = 0; j < GPER; ++j) dst[k * GLD + rb + 16 * j] = o.v[j];
   } else {
-    const int r = t & 63, kb = t >> 6;
+    const int r = t & 127, kb = t >> 7;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dst[kb + 4 * j][r] = o.v[j];
+    for (int j = 0; j < GPER; ++j) dst[(kb + 2 * j) * GLD + r] = o.v[j];
   }
 }
 
+// dynamic LDS: [2 buffers][A_r, B_r (, A_i, B_i)][GBK][GLD] floats (66 KiB for the complex kernel)
 template <typename TIN, typename TOUT, bool CPLX>
-__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
-  // two LDS buffers: tile t+1 is committed while other waves may still read tile t
-  __shared__ float As_r[2][GBK][GLD], Bs_r[2][GBK][GLD];
-  __shared__ float As_i[CPLX ? 2 : 1][CPLX ? GBK : 1][GLD], Bs_i[CPLX ? 2 : 1][CPLX ? GBK : 1][GLD];
+__global__ __launch_bounds__(256, 2) void gemm_generic_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  constexpr int NPL = CPLX ? 4 : 2;
+  auto plane = [&](int buf, int which) { return gsm + (buf * NPL + which) * GPLANE; };   // 0 Ar 1 Br 2 Ai 3 Bi
 
   const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;    // 2 x 2 waves, 64 x 64 each = 2 x 2 MFMA tiles
   const int l31 = lane & 31, lk = lane >> 5;
   const float sgn = g.conj_b ? -1.0f : 1.0f;
 
-  f32x16 acc_r = {0}, acc_i = {0};
+  f32x16 acc_r[2][2], acc_i[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc_r[i][j] = f32x16{0};
+      acc_i[i][j] = f32x16{0};
+    }
 
   // split-K: this block covers K range [kb, ke)
   int kb = 0, ke = g.K;
@@ -96,61 +106,77 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
   if (kb < ke) fetch(kb);
   int buf = 0;
   for (int k0 = kb; k0 < ke; k0 += GBK, buf ^= 1) {
-    commit_tile(As_r[buf], ra, g.a_rs, g.a_cs);
-    commit_tile(Bs_r[buf], rb, g.b_rs, g.b_cs);
+    commit_tile(plane(buf, 0), ra, g.a_rs, g.a_cs);
+    commit_tile(plane(buf, 1), rb, g.b_rs, g.b_cs);
     if (CPLX) {
-      commit_tile(As_i[buf], rai, g.a_rs, g.a_cs);
-      commit_tile(Bs_i[buf], rbi, g.b_rs, g.b_cs);
+      commit_tile(plane(buf, 2), rai, g.a_rs, g.a_cs);
+      commit_tile(plane(buf, 3), rbi, g.b_rs, g.b_cs);
     }
     __syncthreads();                       // tile visible; the other buffer is free again
     if (k0 + GBK < ke) fetch(k0 + GBK);     // in flight during the MFMAs below
+    const float* Ar = plane(buf, 0);
+    const float* Br = plane(buf, 1);
+    const float* Ai = plane(buf, CPLX ? 2 : 0);
+    const float* Bi = plane(buf, CPLX ? 3 : 1);
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
-      const float ar = As_r[buf][kk + lk][wm + l31];
-      const float br = Bs_r[buf][kk + lk][wn + l31];
-      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, acc_r, 0, 0, 0);
-      if (CPLX) {
-        const float ai = As_i[buf][kk + lk][wm + l31];
-        const float bi = sgn * Bs_i[buf][kk + lk][wn + l31];
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, acc_r, 0, 0, 0);
-        acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, acc_i, 0, 0, 0);
-        acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, acc_i, 0, 0, 0);
+      float ar[2], br[2], ai[2], bi[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ar[i] = Ar[(kk + lk) * GLD + wm + i * 32 + l31];
+        br[i] = Br[(kk + lk) * GLD + wn + i * 32 + l31];
+        if (CPLX) {
+          ai[i] = Ai[(kk + lk) * GLD + wm + i * 32 + l31];
+          bi[i] = sgn * Bi[(kk + lk) * GLD + wn + i * 32 + l31];
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i], br[j], acc_r[i][j], 0, 0, 0);
+          if (CPLX) {
+            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai[i], bi[j], acc_r[i][j], 0, 0, 0);
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i], bi[j], acc_i[i][j], 0, 0, 0);
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[i], br[j], acc_i[i][j], 0, 0, 0);
+          }
+        }
     }
   }
 
-  // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  const int col = n0 + wn + l31;
-  if (col >= g.N) return;
-  const float b_r = g.bias_r ? g.bias_r[col] : 0.0f;
-  const float b_i = (CPLX && g.bias_i) ? g.bias_i[col] : 0.0f;
+  // C/D layout of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
   TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
-  if (g.splits > 1) {   // fp32 partial slabs [split][plane][M][N]; bias / emul / accumulate: the reducer
-    float* slab = reinterpret_cast<float*>(g.ws) + (int64_t)blockIdx.z * (CPLX ? 2 : 1) * g.M * g.N;
+  float* slab = g.splits > 1 ? reinterpret_cast<float*>(g.ws) + (int64_t)blockIdx.z * (CPLX ? 2 : 1) * g.M * g.N
+                             : nullptr;   // fp32 partial slabs [split][plane][M][N]; bias / emul / accumulate: the reducer
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (row >= g.M) continue;
-      slab[(int64_t)row * g.N + col] = acc_r[r];
-      if (CPLX) slab[(int64_t)g.M * g.N + (int64_t)row * g.N + col] = acc_i[r];
-    }
-    return;
-  }
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn + j * 32 + l31;
+    if (col >= g.N) continue;
+    const float b_r = g.bias_r ? g.bias_r[col] : 0.0f;
+    const float b_i = (CPLX && g.bias_i) ? g.bias_i[col] : 0.0f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-    if (row >= g.M) continue;
-    const int64_t o = (int64_t)row * g.ldc + col;
-    float vr = acc_r[r] + b_r;
-    if (g.emul) vr *= g.emul[o];
-    if (g.accumulate) vr += io<TOUT>::ld(cr + o);
-    io<TOUT>::st(cr + o, vr);
-    if (CPLX) {
-      float vi = acc_i[r] + b_i;
-      if (g.accumulate) vi += io<TOUT>::ld(ci + o);
-      io<TOUT>::st(ci + o, vi);
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        if (slab) {
+          slab[(int64_t)row * g.N + col] = acc_r[i][j][r];
+          if (CPLX) slab[(int64_t)g.M * g.N + (int64_t)row * g.N + col] = acc_i[i][j][r];
+          continue;
+        }
+        const int64_t o = (int64_t)row * g.ldc + col;
+        float vr = acc_r[i][j][r] + b_r;
+        if (g.emul) vr *= g.emul[o];
+        if (g.accumulate) vr += io<TOUT>::ld(cr + o);
+        io<TOUT>::st(cr + o, vr);
+        if (CPLX) {
+          float vi = acc_i[i][j][r] + b_i;
+          if (g.accumulate) vi += io<TOUT>::ld(ci + o);
+          io<TOUT>::st(ci + o, vi);
+        }
+      }
   }
 }
 
@@ -202,17 +228,23 @@ int launch_gemm_generic(const GemmArgs& g0, int in_dtype, int out_dtype, hipStre
     g.kchunk = (((g.K + GBK - 1) / GBK + want - 1) / want) * GBK;   // whole K tiles, covers the tail
   }
   dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.splits);
-  if (in_dtype == CPLXAMD_F32 && out_dtype == CPLXAMD_F32)
-    gemm_generic_kernel<float, float, CPLX><<<grid, 256, 0, st>>>(g);
-  else if (in_dtype == CPLXAMD_BF16 && out_dtype == CPLXAMD_F32)
-    gemm_generic_kernel<bf16_t, float, CPLX><<<grid, 256, 0, st>>>(g);
-  else if (in_dtype == CPLXAMD_BF16 && out_dtype == CPLXAMD_BF16)
-    gemm_generic_kernel<bf16_t, bf16_t, CPLX><<<grid, 256, 0, st>>>(g);
-  else if (in_dtype == CPLXAMD_F32 && out_dtype == CPLXAMD_BF16)
-    gemm_generic_kernel<float, bf16_t, CPLX><<<grid, 256, 0, st>>>(g);
-  else
-    return CPLXAMD_EINVAL;
-  CPLXAMD_CHECK_LAUNCH();
+  constexpr int smem = 2 * (CPLX ? 4 : 2) * GPLANE * (int)sizeof(float);
+  auto go = [&](auto kern) -> int {
+    if (smem > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return (int)e;
+    }
+    kern<<<grid, 256, smem, st>>>(g);
+    CPLXAMD_CHECK_LAUNCH();
+    return 0;
+  };
+  int rc;
+  if (in_dtype == CPLXAMD_F32 && out_dtype == CPLXAMD_F32) rc = go(gemm_generic_kernel<float, float, CPLX>);
+  else if (in_dtype == CPLXAMD_BF16 && out_dtype == CPLXAMD_F32) rc = go(gemm_generic_kernel<bf16_t, float, CPLX>);
+  else if (in_dtype == CPLXAMD_BF16 && out_dtype == CPLXAMD_BF16) rc = go(gemm_generic_kernel<bf16_t, bf16_t, CPLX>);
+  else if (in_dtype == CPLXAMD_F32 && out_dtype == CPLXAMD_BF16) rc = go(gemm_generic_kernel<float, bf16_t, CPLX>);
+  else return CPLXAMD_EINVAL;
+  if (rc) return rc;
   if (g.splits > 1) {
     const int64_t slab = (int64_t)g.M * g.N, stride = (CPLX ? 2 : 1) * slab;
     const int rgrid = stream_grid(slab, 256);
