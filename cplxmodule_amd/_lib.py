@@ -40,6 +40,8 @@ SIGNATURES = {
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
     "cplxamd_cplx_maxpool2d_fwd": [_P, _P, _P, _P, _P, _P, _I, _P],
     "cplxamd_cplx_maxpool2d_bwd": [_P, _P, _P, _P, _P, _P, _I, _P],
+    "cplxamd_bilinear_reduce_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "cplxamd_bilinear_reduce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_deinterleave": [_P, _P, _P, _L, _I, _P],
     "cplxamd_interleave": [_P, _P, _P, _L, _I, _P],
     "cplxamd_modrelu_fwd": [_P, _P, _P, _F, _I, _P, _P, _L, _I, _P],

@@ -291,6 +291,19 @@ def linear_3m(input, weight, bias=None):
 linear_naive = linear_cat = linear
 
 
+def bilinear(input1, input2, weight, bias=None, conjugate=True):
+    """y = x1^H W x2 + b (conjugate=True) or x1^T W x2 + b (cplxmodule/cplx.py:1062-1087):
+    one complex GEMM over the second input with the [O, I1, I2] weight read as [(O I1), I2],
+    then the bilinear reduction kernel over the first input."""
+    br, bi = (None, None) if bias is None else (bias.real, bias.imag)
+    yr, yi = ops.CplxBilinearFn.apply(input1.real, input1.imag, input2.real, input2.imag, weight.real,
+                                      weight.imag, br, bi, bool(conjugate), None, None, None, 0, 0)
+    return Cplx(yr, yi)
+
+
+bilinear_naive = bilinear_cat = bilinear
+
+
 def matmul(u, v):
     """u[..., M, K] @ v[..., K, N]; batch dims of `v` (if any) must equal those of `u`."""
     ur, ui, vr, vi = u.real, u.imag, v.real, v.imag

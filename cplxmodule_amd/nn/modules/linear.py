@@ -1,4 +1,5 @@
-"""CplxLinear: y = x W^T + b in C, on the complex MFMA GEMM (cplxmodule/nn/modules/linear.py:24-64)."""
+"""CplxLinear: y = x W^T + b in C, on the complex MFMA GEMM (cplxmodule/nn/modules/linear.py:24-64);
+CplxBilinear: y = x1^H W x2 + b (linear.py:67-117)."""
 import math
 
 from .base import CplxToCplx, CplxParameter
@@ -32,3 +33,28 @@ class CplxLinear(CplxToCplx):
     def extra_repr(self):
         return (f"in_features={self.in_features}, out_features={self.out_features}, "
                 f"bias={self.bias is not None}")
+
+
+class CplxBilinear(CplxToCplx):
+    """(u, v) -> (u^H A_o v + b_o)_o, or u^T A_o v with `conjugate=False`; weight [out, in1, in2]."""
+
+    def __init__(self, in1_features, in2_features, out_features, bias=True, conjugate=True):
+        super().__init__()
+        self.in1_features, self.in2_features = in1_features, in2_features
+        self.out_features, self.conjugate = out_features, conjugate
+        self.weight = CplxParameter(cplx.Cplx.empty(out_features, in1_features, in2_features))
+        if bias:
+            self.bias = CplxParameter(cplx.Cplx.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    reset_parameters = CplxLinear.reset_parameters
+
+    def forward(self, input1, input2):
+        return cplx.bilinear(input1, input2, self.weight, self.bias, self.conjugate)
+
+    def extra_repr(self):
+        return (f"in1_features={self.in1_features}, in2_features={self.in2_features}, "
+                f"out_features={self.out_features}, bias={self.bias is not None}, "
+                f"conjugate={self.conjugate}")

@@ -10,7 +10,7 @@ import torch
 from .base import BaseARD
 from .noise import noise
 from ..utils.sparsity import SparsityStats
-from ..modules.linear import CplxLinear
+from ..modules.linear import CplxLinear, CplxBilinear
 from ..modules.conv import CplxConv1d, CplxConv2d
 from ... import ops, cplx
 
@@ -100,6 +100,37 @@ class CplxLinearVD(CplxLinearGaussian, SparsityStats, BaseARD):
 
 class CplxLinearARD(CplxLinearVD):
     """Complex linear layer with automatic relevance determination (softplus KL)."""
+    _kl_kind = "cplx_ard"
+
+
+class CplxBilinearGaussian(_CplxGaussianMixin, CplxBilinear):
+    """Bilinear layer with the local reparameterization (complex/base.py:59-84): the variance is the
+    real bilinear form of the squared moduli with exp(log_sigma2) as its weight."""
+
+    def __init__(self, in1_features, in2_features, out_features, bias=True, conjugate=True):
+        super().__init__(in1_features, in2_features, out_features, bias=bias, conjugate=conjugate)
+        self._init_variational()
+
+    def forward(self, input1, input2, eps=None):
+        if not self.training:
+            return super().forward(input1, input2)
+        w, b = self.weight, self.bias
+        if eps is not None:
+            er, ei, seed, offset = eps.real, eps.imag, 0, 0
+        else:
+            er, ei, seed, offset = self._draw_noise((*input1.shape[:-1], self.out_features), input1)
+        br, bi = (None, None) if b is None else (b.real, b.imag)
+        yr, yi = ops.CplxBilinearFn.apply(input1.real, input1.imag, input2.real, input2.imag, w.real,
+                                          w.imag, br, bi, bool(self.conjugate), self.log_sigma2, er, ei,
+                                          seed, offset)
+        return cplx.Cplx(yr, yi)
+
+
+class CplxBilinearVD(CplxBilinearGaussian, SparsityStats, BaseARD):
+    _kl_kind = "cplx_vd"
+
+
+class CplxBilinearARD(CplxBilinearVD):
     _kl_kind = "cplx_ard"
 
 

@@ -74,6 +74,31 @@ class LinearARD(LinearVD):
     _kl_kind = "real_ard"
 
 
+class BilinearGaussian(_RealGaussianMixin, torch.nn.Bilinear):
+    """torch.nn.Bilinear with the local reparameterization (real/base.py:52-77)."""
+
+    def __init__(self, in1_features, in2_features, out_features, bias=True):
+        super().__init__(in1_features, in2_features, out_features, bias=bias)
+        self._init_variational()
+
+    def forward(self, input1, input2, eps=None):
+        if not self.training:
+            return ops.RealBilinearFn.apply(input1, input2, self.weight, self.bias, None, None, 0, 0)
+        seed = offset = 0
+        if eps is None:
+            eps, seed, offset = self._draw_noise((*input1.shape[:-1], self.out_features), input1)
+        return ops.RealBilinearFn.apply(input1, input2, self.weight, self.bias, self.log_sigma2, eps,
+                                        seed, offset)
+
+
+class BilinearVD(BilinearGaussian, SparsityStats, BaseARD):
+    _kl_kind = "real_vd"
+
+
+class BilinearARD(BilinearVD):
+    _kl_kind = "real_ard"
+
+
 class Conv2dGaussian(_RealGaussianMixin, torch.nn.Conv2d):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
                  groups=1, bias=True, padding_mode="zeros"):

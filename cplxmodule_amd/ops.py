@@ -514,6 +514,158 @@ class RealLinearLRTFn(torch.autograd.Function):
         return dx, dw, db, dls2, None, None, None
 
 
+# ------------------------------------------------------------------------------------------ #
+#  bilinear layers: GEMM over the second input, then the reduction kernels of bilinear.hip     #
+# ------------------------------------------------------------------------------------------ #
+def bilinear_reduce_fwd(u, t, bias, B, O, I1, conj):
+    """y[b,o] = sum_i conj?(u[b,i]) t[b,o,i] + bias[o]; u, t, bias: (re, im) pairs, im None = real."""
+    (ur, ui), (tr, ti) = u, t
+    require_device(ur, ui, tr, ti)
+    yr = torch.empty(B, O, dtype=tr.dtype, device=tr.device)
+    yi = None if ti is None else torch.empty_like(yr)
+    br, bi = (None, None) if bias is None else bias
+    call("cplxamd_bilinear_reduce_fwd", ptr(ur), ptr(ui), ptr(tr), ptr(ti), ptr(br), ptr(bi), ptr(yr),
+         ptr(yi), B, O, I1, int(conj), dtype_code(tr), stream_ptr())
+    return yr, yi
+
+
+def bilinear_reduce_bwd(u, t, g, B, O, I1, conj, need_u=True, need_t=True):
+    """-> (dx1_r, dx1_i), (dt_r, dt_i) of bilinear_reduce_fwd (pairs of None where not needed)."""
+    (ur, ui), (tr, ti), (gr, gi) = u, t, g
+    require_device(ur, ui, tr, ti, gr, gi)
+    cplx_ = ui is not None
+    dur = torch.empty_like(ur) if need_u else None
+    dui = torch.empty_like(ur) if need_u and cplx_ else None
+    dtr = torch.empty(B, O * I1, dtype=gr.dtype, device=gr.device) if need_t else None
+    dti = torch.empty_like(dtr) if need_t and cplx_ else None
+    call("cplxamd_bilinear_reduce_bwd", ptr(ur), ptr(ui), ptr(tr), ptr(ti), ptr(gr), ptr(gi), ptr(dur),
+         ptr(dui), ptr(dtr), ptr(dti), B, O, I1, int(conj), dtype_code(gr), stream_ptr())
+    return (dur, dui), (dtr, dti)
+
+
+def _bil_forward(ctx, x1, x2, w, bias, conj, ls2, eps, seed, offset):
+    """Shared forward of the four bilinear Functions.  x1, x2, w, bias, eps: (re, im) pairs with
+    im None for real layers; ls2 None = no noise (plain layer / eval mode)."""
+    cplx_ = x1[1] is not None
+    O, I1, I2 = w[0].shape
+    lead = x1[0].shape[:-1]
+    f1 = tuple(None if p is None else p.reshape(-1, I1).contiguous() for p in x1)
+    f2 = tuple(None if p is None else p.reshape(-1, I2).contiguous() for p in x2)
+    B, dt = f1[0].shape[0], f1[0].dtype
+    wv = tuple(None if p is None else _c(p).view(O * I1, I2) for p in w)
+    fb = None if bias is None else tuple(None if p is None else _f32(_c(p)) for p in bias)
+    if cplx_:
+        tr, ti, wc = _cplx_linear_fwd(f2[0], f2[1], wv[0], wv[1], None)
+    else:
+        wc = (cast(wv[0], dt), None)
+        tr, ti = rgemm(f2[0], (I2, 1), wc[0], (I2, 1), B, O * I1, I2, out_dtype=dt), None
+    yr, yi = bilinear_reduce_fwd(f1, (tr, ti), fb, B, O, I1, conj)
+    s2 = a1 = a2 = tv = None
+    if ls2 is not None:
+        a1, a2 = abs2(f1[0], f1[1], out_dtype=torch.float32), abs2(f2[0], f2[1])
+        S = exp(_c(ls2), out_dtype=dt).view(O * I1, I2)
+        tv = rgemm(a2, (I2, 1), S, (I2, 1), B, O * I1, I2)              # float32 [B, O*I1]
+        s2, _ = bilinear_reduce_fwd((a1, None), (tv, None), None, B, O, I1, False)
+        e = None
+        if eps is not None and eps[0] is not None:
+            e = tuple(None if p is None else p.reshape(B, O) for p in eps)
+            e = e if cplx_ else e[0]
+        yr, yi = reparam_fwd(yr, yi, s2, e, seed, offset, inplace=True)
+    ctx.bil = dict(f1=f1, f2=f2, t=(tr, ti), wc=wc, s2=s2, a1=a1, a2=a2, tv=tv, ls2=ls2, eps=eps,
+                   seed=seed, offset=offset, conj=conj, lead=lead, dims=(B, O, I1, I2),
+                   has_bias=bias is not None)
+    return (yr.view(*lead, O), None if yi is None else yi.view(*lead, O))
+
+
+def _bil_backward(ctx, g, need_x1, need_x2, need_w, need_b, need_ls2):
+    """-> dx1, dx2, dw, db (pairs), dls2.  SURVEY A.1 / A.2 with the weight seen as [(o,i), j]."""
+    st = ctx.bil
+    B, O, I1, I2 = st["dims"]
+    f1, f2, t, wc = st["f1"], st["f2"], st["t"], st["wc"]
+    cplx_ = f1[1] is not None
+    dt = f1[0].dtype
+    g = tuple(None if p is None else p.reshape(B, O).contiguous() for p in g)
+    dx1, dT = bilinear_reduce_bwd(f1, t, g, B, O, I1, st["conj"], need_u=need_x1,
+                                  need_t=need_x2 or need_w)
+    dx2 = dw = (None, None)
+    db = (None, None)
+    dls2 = None
+    if need_x2:
+        if cplx_:
+            dx2 = _cplx_linear_dx(dT[0], dT[1], wc[0], wc[1], dt)
+        else:
+            dx2 = (_real_linear_dx(dT[0], wc[0], dt), None)
+    if need_w:
+        if cplx_:
+            dw = _cplx_linear_dw(dT[0], dT[1], f2[0], f2[1])
+        else:
+            dw = (_real_linear_dw(dT[0], f2[0]), None)
+        dw = tuple(None if p is None else p.view(O, I1, I2) for p in dw)
+    if need_b and st["has_bias"]:
+        db = tuple(None if p is None else colsum(p) for p in g)
+    if st["ls2"] is not None:
+        e = st["eps"]
+        if e is not None and e[0] is not None:
+            e = tuple(None if p is None else p.reshape(B, O) for p in e)
+            e = e if cplx_ else e[0]
+        else:
+            e = None
+        gs2 = reparam_bwd(g[0], g[1], st["s2"], e, st["seed"], st["offset"])       # float32 [B,O]
+        (da1, _), (dtv, _) = bilinear_reduce_bwd((st["a1"], None), (st["tv"], None), (gs2, None), B, O,
+                                                 I1, False, need_u=need_x1, need_t=need_x2 or need_ls2)
+        if need_x1:
+            lrt_dx_accum(dx1[0], dx1[1], f1[0], f1[1], da1)
+        ls2c = _c(st["ls2"])
+        if need_x2:
+            if _is_bf16(f2[0]):
+                da2 = _real_linear_dx(cast(dtv, dt), exp(ls2c, out_dtype=dt).view(O * I1, I2), dt)
+            else:
+                da2 = _real_linear_dx(dtv, exp(ls2c).view(O * I1, I2), dt)
+            lrt_dx_accum(dx2[0], dx2[1], f2[0], f2[1], da2)
+        if need_ls2:
+            dls2 = _real_linear_dw(dtv, st["a2"], emul=exp(ls2c).view(O * I1, I2)).view(O, I1, I2)
+    lead = st["lead"]
+    dx1 = tuple(None if p is None else p.view(*lead, I1) for p in dx1)
+    dx2 = tuple(None if p is None else p.view(*lead, I2) for p in dx2)
+    return dx1, dx2, dw, db, dls2
+
+
+class CplxBilinearFn(torch.autograd.Function):
+    """cplx.bilinear (cplxmodule/cplx.py:1062-1087); with `ls2` also the training-mode forward of
+    CplxBilinearGaussian (nn/relevance/complex/base.py:73-84)."""
+
+    @staticmethod
+    def forward(ctx, x1r, x1i, x2r, x2i, wr, wi, br, bi, conj, ls2, eps_r, eps_i, seed, offset):
+        require_device(x1r, x1i, x2r, x2i, wr, wi, br, bi, ls2, eps_r, eps_i)
+        return _bil_forward(ctx, (x1r, x1i), (x2r, x2i), (wr, wi), None if br is None else (br, bi),
+                            conj, ls2, (eps_r, eps_i), seed, offset)
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        n = ctx.needs_input_grad
+        dx1, dx2, dw, db, dls2 = _bil_backward(ctx, (gr, gi), n[0] or n[1], n[2] or n[3], n[4] or n[5],
+                                               n[6] or n[7], n[9])
+        return dx1[0], dx1[1], dx2[0], dx2[1], dw[0], dw[1], db[0], db[1], None, dls2, None, None, None, None
+
+
+class RealBilinearFn(torch.autograd.Function):
+    """F.bilinear on the GEMM + reduction kernels; with `ls2` the training-mode forward of
+    BilinearGaussian (nn/relevance/real/base.py:66-77)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b, ls2, eps, seed, offset):
+        require_device(x1, x2, w, b, ls2, eps)
+        y, _ = _bil_forward(ctx, (x1, None), (x2, None), (w, None), None if b is None else (b, None),
+                            False, ls2, (eps, None), seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.needs_input_grad
+        dx1, dx2, dw, db, dls2 = _bil_backward(ctx, (g, None), n[0], n[1], n[2], n[3], n[4])
+        return dx1[0], dx2[0], dw[0], db[0], dls2, None, None, None
+
+
 class PenaltyFn(torch.autograd.Function):
     """Elementwise KL penalty tensor (the `.penalty` property of the VD / ARD layers)."""
 

@@ -350,6 +350,21 @@ int cplxamd_cplx_maxpool2d_fwd(const void* zr, const void* zi, void* yr, void* y
 int cplxamd_cplx_maxpool2d_bwd(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi,
                                const int* pool, int dtype, void* stream);
 
+/* Bilinear layers: cplx.bilinear (cplx.py:1062-1087), the variance term of
+ * CplxBilinearGaussian / BilinearGaussian (nn/relevance/complex/base.py:59-84, real/base.py:52-77).
+ *   y[b,o] = sum_i u[b,i] T[b,o,i] + bias[o],   u = conj(x1) if conj_u else x1,
+ * where T[b,(o,i)] = sum_j W[o,i,j] x2[b,j] comes from cplxamd_cgemm / cplxamd_rgemm with the
+ * weight read as stored ([O*I1, I2]).  u: [B, I1], T: [B, O, I1], y, g: [B, O], all contiguous and
+ * of one dtype; bias float32 [O] or NULL.  Real tensors: every imaginary plane NULL.
+ * bwd: dT = g conj(u) (real: g u), du = sum_o g conj(T) mapped back to x1 (conjugated again when
+ * conj_u); either output pair may be NULL (T may then be NULL too when du is not wanted). */
+int cplxamd_bilinear_reduce_fwd(const void* ur, const void* ui, const void* tr, const void* ti,
+                                const float* bias_r, const float* bias_i, void* yr, void* yi, int64_t B,
+                                int O, int I1, int conj_u, int dtype, void* stream);
+int cplxamd_bilinear_reduce_bwd(const void* ur, const void* ui, const void* tr, const void* ti,
+                                const void* gr, const void* gi, void* dx1r, void* dx1i, void* dtr,
+                                void* dti, int64_t B, int O, int I1, int conj_u, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,111 @@ def lrt_real_linear_bwd(g, x, w, log_sigma2, eps, has_bias=True):
 
 
 # --------------------------------------------------------------------------- #
+#  bilinear layers                                                            #
+# --------------------------------------------------------------------------- #
+def real_bilinear(x1, x2, w, b=None):
+    """torch.nn.functional.bilinear: y[b,o] = sum_ij x1[b,i] w[o,i,j] x2[b,j] (+ b[o])."""
+    y = np.einsum("bi,oij,bj->bo", x1, w, x2)
+    return y if b is None else y + b
+
+
+def cplx_bilinear(x1r, x1i, x2r, x2i, wr, wi, br=None, bi=None, conjugate=True):
+    """cplx.bilinear_naive, cplxmodule/cplx.py:1062-1087: four real bilinear forms per weight
+    plane, combined as conj?(x1) (x) x2 = P + iQ,  y = (P Wr - Q Wi) + i (P Wi + Q Wr)."""
+    f = real_bilinear
+    au_r, au_i = f(x1r, x2r, wr), f(x1r, x2r, wi)
+    av_r, av_i = f(x1r, x2i, wr), f(x1r, x2i, wi)
+    bu_r, bu_i = f(x1i, x2r, wr), f(x1i, x2r, wi)
+    bv_r, bv_i = f(x1i, x2i, wr), f(x1i, x2i, wi)
+    if conjugate:
+        pp_r, pp_i, qq_r, qq_i = au_r + bv_r, au_i + bv_i, av_r - bu_r, av_i - bu_i
+    else:
+        pp_r, pp_i, qq_r, qq_i = au_r - bv_r, au_i - bv_i, av_r + bu_r, av_i + bu_i
+    re, im = pp_r - qq_i, pp_i + qq_r
+    if br is not None:
+        re, im = re + br, im + bi
+    return re, im
+
+
+def cplx_bilinear_bwd(gr, gi, x1r, x1i, x2r, x2i, wr, wi, conjugate=True, has_bias=True):
+    """Gradients of `cplx_bilinear` for a real loss (planar convention of SURVEY A.1:
+    d(u v) -> du = g conj(v)).  With u = conj?(x1):  y_o = sum_ij u_i W_oij x2_j."""
+    g = gr + 1j * gi
+    x1 = x1r + 1j * x1i
+    u = np.conj(x1) if conjugate else x1
+    x2 = x2r + 1j * x2i
+    w = wr + 1j * wi
+    du = np.einsum("bo,oij,bj->bi", g, np.conj(w), np.conj(x2))
+    dx1 = np.conj(du) if conjugate else du
+    dx2 = np.einsum("bo,oij,bi->bj", g, np.conj(w), np.conj(u))
+    dw = np.einsum("bo,bi,bj->oij", g, np.conj(u), np.conj(x2))
+    dt = x1r.dtype
+    out = dict(dx1r=dx1.real.astype(dt), dx1i=dx1.imag.astype(dt), dx2r=dx2.real.astype(dt),
+               dx2i=dx2.imag.astype(dt), dwr=dw.real.astype(dt), dwi=dw.imag.astype(dt))
+    if has_bias:
+        out["dbr"], out["dbi"] = gr.sum(0), gi.sum(0)
+    return out
+
+
+def lrt_cplx_bilinear(x1r, x1i, x2r, x2i, wr, wi, br, bi, log_sigma2, eps_r, eps_i, conjugate=True):
+    """CplxBilinearGaussian.forward in training mode,
+    cplxmodule/nn/relevance/complex/base.py:73-84."""
+    mur, mui = cplx_bilinear(x1r, x1i, x2r, x2i, wr, wi, br, bi, conjugate)
+    s2 = real_bilinear(x1r * x1r + x1i * x1i, x2r * x2r + x2i * x2i, np.exp(log_sigma2))
+    sd = np.sqrt(np.maximum(s2, np.asarray(1e-8, s2.dtype)))
+    return mur + eps_r * sd, mui + eps_i * sd, dict(mur=mur, mui=mui, s2=s2)
+
+
+def lrt_cplx_bilinear_bwd(gr, gi, x1r, x1i, x2r, x2i, wr, wi, log_sigma2, eps_r, eps_i,
+                          conjugate=True, has_bias=True):
+    """SURVEY A.2 with the bilinear variance s2 = sum_ij a1_i S_oij a2_j."""
+    dt = x1r.dtype
+    S = np.exp(log_sigma2)
+    a1, a2 = x1r * x1r + x1i * x1i, x2r * x2r + x2i * x2i
+    s2 = real_bilinear(a1, a2, S)
+    lo = np.asarray(1e-8, dt)
+    sd = np.sqrt(np.maximum(s2, lo))
+    gs2 = np.where(s2 >= lo, (gr * eps_r + gi * eps_i) * np.asarray(0.5, dt) / sd, np.asarray(0, dt))
+    out = cplx_bilinear_bwd(gr, gi, x1r, x1i, x2r, x2i, wr, wi, conjugate, has_bias)
+    ga1 = np.einsum("bo,oij,bj->bi", gs2, S, a2)
+    ga2 = np.einsum("bo,oij,bi->bj", gs2, S, a1)
+    out["dx1r"] = out["dx1r"] + 2 * x1r * ga1
+    out["dx1i"] = out["dx1i"] + 2 * x1i * ga1
+    out["dx2r"] = out["dx2r"] + 2 * x2r * ga2
+    out["dx2i"] = out["dx2i"] + 2 * x2i * ga2
+    out["dlog_sigma2"] = np.einsum("bo,bi,bj->oij", gs2, a1, a2) * S
+    return out
+
+
+def lrt_real_bilinear(x1, x2, w, b, log_sigma2, eps):
+    """BilinearGaussian.forward in training mode, cplxmodule/nn/relevance/real/base.py:66-77."""
+    mu = real_bilinear(x1, x2, w, b)
+    s2 = real_bilinear(x1 * x1, x2 * x2, np.exp(log_sigma2))
+    sd = np.sqrt(np.maximum(s2, np.asarray(1e-8, s2.dtype)))
+    return mu + eps * sd, dict(mu=mu, s2=s2)
+
+
+def lrt_real_bilinear_bwd(g, x1, x2, w, log_sigma2, eps, has_bias=True, noise=True):
+    """Gradients of `lrt_real_bilinear` (noise=False: of `real_bilinear` alone)."""
+    dt = x1.dtype
+    out = dict(dx1=np.einsum("bo,oij,bj->bi", g, w, x2), dx2=np.einsum("bo,oij,bi->bj", g, w, x1),
+               dw=np.einsum("bo,bi,bj->oij", g, x1, x2))
+    if has_bias:
+        out["db"] = g.sum(0)
+    if noise:
+        S = np.exp(log_sigma2)
+        a1, a2 = x1 * x1, x2 * x2
+        s2 = real_bilinear(a1, a2, S)
+        lo = np.asarray(1e-8, dt)
+        sd = np.sqrt(np.maximum(s2, lo))
+        gs2 = np.where(s2 >= lo, g * eps * np.asarray(0.5, dt) / sd, np.asarray(0, dt))
+        out["dx1"] = out["dx1"] + 2 * x1 * np.einsum("bo,oij,bj->bi", gs2, S, a2)
+        out["dx2"] = out["dx2"] + 2 * x2 * np.einsum("bo,oij,bi->bj", gs2, S, a1)
+        out["dlog_sigma2"] = np.einsum("bo,bi,bj->oij", gs2, a1, a2) * S
+    return out
+
+
+# --------------------------------------------------------------------------- #
 #  log-alpha, KL penalties, masks                                             #
 # --------------------------------------------------------------------------- #
 def cplx_abs(wr, wi):

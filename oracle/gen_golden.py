@@ -395,6 +395,87 @@ def gen_api():
     save("api", d)
 
 
+def gen_bilinear():
+    """cplx.bilinear (both conjugate modes), CplxBilinearVD / BilinearVD in
+    training mode (noise tape recorded) and eval mode, values + autograd gradients."""
+    d = {}
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        B, I1, I2, O = 13, 9, 11, 7
+        for conj in (True, False):
+            torch.manual_seed(31)
+            x1r, x1i, x2r, x2i = leaf(B, I1, dtype=dt), leaf(B, I1, dtype=dt), leaf(B, I2, dtype=dt), leaf(B, I2, dtype=dt)
+            wr, wi = leaf(O, I1, I2, dtype=dt, scale=0.2), leaf(O, I1, I2, dtype=dt, scale=0.2)
+            br, bi = leaf(O, dtype=dt), leaf(O, dtype=dt)
+            gr, gi = torch.randn(B, O, dtype=dt), torch.randn(B, O, dtype=dt)
+            y = cplx.bilinear(C(x1r, x1i), C(x2r, x2i), C(wr, wi), C(br, bi), conjugate=conj)
+            grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(),
+                                        [x1r, x1i, x2r, x2i, wr, wi, br, bi])
+            k = f"{tag}_fn_{'conj' if conj else 'plain'}_"
+            for nm, t in dict(x1r=x1r, x1i=x1i, x2r=x2r, x2i=x2i, wr=wr, wi=wi, br=br, bi=bi, gr=gr,
+                              gi=gi, yr=y.real, yi=y.imag).items():
+                d[k + nm] = npy(t)
+            for nm, g in zip(["dx1r", "dx1i", "dx2r", "dx2i", "dwr", "dwi", "dbr", "dbi"], grads):
+                d[k + nm] = npy(g)
+        # leading batch dims + no bias, through the layer
+        torch.manual_seed(32)
+        layer = cm.nn.CplxBilinear(I1, I2, O, bias=False, conjugate=True)
+        a, b = cplx.randn(2, 3, I1), cplx.randn(2, 3, I2)
+        y = layer(a, b)
+        for nm, t in dict(x1r=a.real, x1i=a.imag, x2r=b.real, x2i=b.imag, wr=layer.weight.real,
+                          wi=layer.weight.imag, yr=y.real, yi=y.imag).items():
+            d[f"{tag}_layer_{nm}"] = npy(t)
+        # complex VD bilinear: training (tape) + eval
+        torch.manual_seed(33)
+        layer = rel.CplxBilinearVD(I1, I2, O, bias=True, conjugate=True)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        a, b = cplx.randn(B, I1), cplx.randn(B, I2)
+        x1r, x1i = a.real.clone().requires_grad_(True), a.imag.clone().requires_grad_(True)
+        x2r, x2i = b.real.clone().requires_grad_(True), b.imag.clone().requires_grad_(True)
+        gr, gi = torch.randn(B, O), torch.randn(B, O)
+        layer.train()
+        torch.manual_seed(81)
+        y = layer(C(x1r, x1i), C(x2r, x2i))
+        torch.manual_seed(81)
+        tape = torch.randn(2, B, O)
+        ps = [x1r, x1i, x2r, x2i, layer.weight.real, layer.weight.imag, layer.bias.real,
+              layer.bias.imag, layer.log_sigma2]
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), ps)
+        k = f"{tag}_vd_"
+        for nm, t in dict(x1r=x1r, x1i=x1i, x2r=x2r, x2i=x2i, wr=ps[4], wi=ps[5], br=ps[6], bi=ps[7],
+                          ls2=ps[8], gr=gr, gi=gi, tape=tape, yr=y.real, yi=y.imag).items():
+            d[k + nm] = npy(t)
+        for nm, g in zip(["dx1r", "dx1i", "dx2r", "dx2i", "dwr", "dwi", "dbr", "dbi", "dls2"], grads):
+            d[k + nm] = npy(g)
+        layer.eval()
+        y = layer(C(x1r, x1i), C(x2r, x2i))
+        d[k + "yr_eval"], d[k + "yi_eval"] = npy(y.real), npy(y.imag)
+        d[k + "pen"] = npy(layer.penalty)
+        # real VD bilinear
+        torch.manual_seed(34)
+        layer = rel.BilinearVD(I1, I2, O, bias=True)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        x1, x2 = torch.randn(B, I1).requires_grad_(True), torch.randn(B, I2).requires_grad_(True)
+        g = torch.randn(B, O)
+        layer.train()
+        torch.manual_seed(82)
+        y = layer(x1, x2)
+        torch.manual_seed(82)
+        eps = torch.randn(B, O)
+        grads = torch.autograd.grad((y * g).sum(), [x1, x2, layer.weight, layer.bias, layer.log_sigma2])
+        k = f"{tag}_real_"
+        for nm, t in dict(x1=x1, x2=x2, w=layer.weight, b=layer.bias, ls2=layer.log_sigma2, g=g,
+                          eps=eps, y=y, dx1=grads[0], dx2=grads[1], dw=grads[2], db=grads[3],
+                          dls2=grads[4]).items():
+            d[k + nm] = npy(t)
+        layer.eval()
+        d[k + "y_eval"] = npy(layer(x1, x2))
+    torch.set_default_dtype(torch.float32)
+    save("bilinear", d)
+
+
 def gen_extras():
     """layout converters, modReLU (+ learnable thresholds), CplxDropout."""
     from cplxmodule.nn import CplxModReLU, CplxAdaptiveModReLU, CplxDropout  # noqa: F401
@@ -505,6 +586,6 @@ def gen_extras():
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reproducible summation order
     gens = dict(linear=gen_linear, lrt_linear=gen_lrt_linear, penalty=gen_penalty, conv=gen_conv,
-                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras)
+                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear)
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

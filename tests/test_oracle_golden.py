@@ -313,3 +313,44 @@ def test_extension_penalties(golden, tag, kind):
         err = np.abs(bw[n] - r)
         bound = rt * np.abs(r) + 8 * eps * np.maximum(a, 1.0)
         assert (err[ok] <= (bound[ok] if np.ndim(bound) else bound)).all(), (n, err[ok].max())
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("mode", ["conj", "plain"])
+def test_bilinear(golden, tag, mode):
+    g = golden("bilinear")
+    k = f"{tag}_fn_{mode}_"
+    a = [g[k + n] for n in ("x1r", "x1i", "x2r", "x2i", "wr", "wi")]
+    yr, yi = orc.cplx_bilinear(*a, g[k + "br"], g[k + "bi"], conjugate=mode == "conj")
+    close(yr, g[k + "yr"], tag, 30)
+    close(yi, g[k + "yi"], tag, 30)
+    bw = orc.cplx_bilinear_bwd(g[k + "gr"], g[k + "gi"], *a, conjugate=mode == "conj")
+    for n in ("dx1r", "dx1i", "dx2r", "dx2i", "dwr", "dwi", "dbr", "dbi"):
+        close(bw[n], g[k + n], tag, 100)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_lrt_bilinear(golden, tag):
+    g = golden("bilinear")
+    k = f"{tag}_vd_"
+    er, ei = orc.cplx_randn_from_tape(g[k + "tape"])
+    a = [g[k + n] for n in ("x1r", "x1i", "x2r", "x2i", "wr", "wi")]
+    yr, yi, _ = orc.lrt_cplx_bilinear(*a, g[k + "br"], g[k + "bi"], g[k + "ls2"], er, ei)
+    close(yr, g[k + "yr"], tag, 30)
+    close(yi, g[k + "yi"], tag, 30)
+    mur, mui = orc.cplx_bilinear(*a, g[k + "br"], g[k + "bi"])
+    close(mur, g[k + "yr_eval"], tag, 30)
+    close(mui, g[k + "yi_eval"], tag, 30)
+    bw = orc.lrt_cplx_bilinear_bwd(g[k + "gr"], g[k + "gi"], *a, g[k + "ls2"], er, ei)
+    for n in ("dx1r", "dx1i", "dx2r", "dx2i", "dwr", "dwi", "dbr", "dbi"):
+        close(bw[n], g[k + n], tag, 300)
+    close(bw["dlog_sigma2"], g[k + "dls2"], tag, 300)
+    close(orc.penalty("cplx_vd", g[k + "ls2"], g[k + "wr"], g[k + "wi"]), g[k + "pen"], tag, 30)
+    # real layer
+    k = f"{tag}_real_"
+    y, _ = orc.lrt_real_bilinear(g[k + "x1"], g[k + "x2"], g[k + "w"], g[k + "b"], g[k + "ls2"], g[k + "eps"])
+    close(y, g[k + "y"], tag, 30)
+    close(orc.real_bilinear(g[k + "x1"], g[k + "x2"], g[k + "w"], g[k + "b"]), g[k + "y_eval"], tag, 30)
+    bw = orc.lrt_real_bilinear_bwd(g[k + "g"], g[k + "x1"], g[k + "x2"], g[k + "w"], g[k + "ls2"], g[k + "eps"])
+    for n, m in (("dx1", "dx1"), ("dx2", "dx2"), ("dw", "dw"), ("db", "db"), ("dlog_sigma2", "dls2")):
+        close(bw[n], g[k + m], tag, 300)
