@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
-            "cplx_vd_scalefree": 5}
+            "cplx_vd_scalefree": 5, "cplx_vd_bogus": 6}
 
 _P, _I, _L, _U, _F, _D = c_void_p, c_int, c_int64, c_uint64, c_float, c_double
 

@@ -271,6 +271,12 @@ def randn_like(input, dtype=None, device=None, requires_grad=False):
                  device=input.device if device is None else device, requires_grad=requires_grad)
 
 
+def phaseshift(input, phi=0.0):
+    """z exp(i phi), phi in radians (cplxmodule/cplx.py:619-631)."""
+    phi = torch.as_tensor(phi, dtype=input.real.dtype, device=input.real.device)
+    return input * Cplx(torch.cos(phi), torch.sin(phi))
+
+
 def linear(input, weight, bias=None):
     """y = x W^T + b on the complex GEMM kernel (replaces linear_naive, cplxmodule/cplx.py:634-648)."""
     br, bi = (None, None) if bias is None else (bias.real, bias.imag)

@@ -103,6 +103,8 @@ __device__ __forceinline__ float kl_value(float t) {
   // extensions/complex.py:43-46: log|w| - ls2 - Ei(-e^t)/2 = (f_vd(t) - gamma)/2 - ls2/2; the
   // -ls2/2 term is added by the kernel (kl_ls2_term)
   if (KIND == CPLXAMD_KL_CPLX_VD_SCALEFREE) return 0.5f * (cplx_vd_value(t) - kEulerGamma);
+  // extensions/complex.py:142-160: the Ei term reads as 0 in the value, the slope is the exact one
+  if (KIND == CPLXAMD_KL_CPLX_VD_BOGUS) return t;
   return softplus_f(t);
 }
 // part of the penalty that depends on log_sigma2 directly (not through t): c * ls2
@@ -118,7 +120,7 @@ __device__ __forceinline__ float kl_slope(float t) {
     return fmaf(0.5f, softplus_grad_f(t), kK1 * kK3 * su * (1.0f - su));
   }
   if (KIND == CPLXAMD_KL_REAL_ARD) return 0.5f * softplus_grad_f(t);
-  if (KIND == CPLXAMD_KL_CPLX_VD) return -expm1f(-expf(t));  // 1 - exp(-e^t)
+  if (KIND == CPLXAMD_KL_CPLX_VD || KIND == CPLXAMD_KL_CPLX_VD_BOGUS) return -expm1f(-expf(t));  // 1 - exp(-e^t)
   if (KIND == CPLXAMD_KL_CPLX_VD_APPROX) {
     const float su = sigmoid_f(fmaf(1.36526f, t, -1.45926f));
     return fmaf(0.57810f * 1.36526f, su * (1.0f - su), softplus_grad_f(t));
@@ -266,6 +268,9 @@ static int launch_kl(int kind, const KlArgs& a, int grid, hipStream_t st) {
     case CPLXAMD_KL_CPLX_VD_SCALEFREE:
       kl_kernel<CPLXAMD_KL_CPLX_VD_SCALEFREE, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
       break;
+    case CPLXAMD_KL_CPLX_VD_BOGUS:
+      kl_kernel<CPLXAMD_KL_CPLX_VD_BOGUS, VALUE, GRAD><<<grid, kKlThreads, 0, st>>>(a);
+      break;
     default:
       return CPLXAMD_EINVAL;
   }
@@ -274,7 +279,7 @@ static int launch_kl(int kind, const KlArgs& a, int grid, hipStream_t st) {
 }
 
 static bool kl_args_ok(const float* wr, const float* wi, const float* ls2, int kind, int64_t n) {
-  if (!wr || !ls2 || n < 0 || kind < 0 || kind > CPLXAMD_KL_CPLX_VD_SCALEFREE) return false;
+  if (!wr || !ls2 || n < 0 || kind < 0 || kind > CPLXAMD_KL_CPLX_VD_BOGUS) return false;
   const bool cplx = kind >= CPLXAMD_KL_CPLX_VD;
   return cplx ? wi != nullptr : true;
 }

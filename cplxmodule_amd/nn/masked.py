@@ -8,8 +8,8 @@ dense layers (the mask multiply is a weight-sized elementwise op).
 """
 import torch
 
-from .modules.linear import CplxLinear
-from .modules.conv import CplxConv2d
+from .modules.linear import CplxLinear, CplxBilinear
+from .modules.conv import CplxConv1d, CplxConv2d
 from .utils.sparsity import SparsityStats
 from .. import cplx, ops
 
@@ -97,6 +97,45 @@ class CplxConv2dMasked(CplxConv2d, _MaskedStats):
         w = self.weight
         n = self._n_dropped(w.real.numel(), hard)
         return [(id(w.real), n), (id(w.imag), n)]
+
+
+class _CplxMaskedStats(_MaskedStats):
+    def sparsity(self, *, hard=True, **kwargs):
+        w = self.weight
+        n = self._n_dropped(w.real.numel(), hard)
+        return [(id(w.real), n), (id(w.imag), n)]
+
+
+class _RealMaskedStats(_MaskedStats):
+    def sparsity(self, *, hard=True, **kwargs):
+        return [(id(self.weight), self._n_dropped(self.weight.numel(), hard))]
+
+
+class CplxConv1dMasked(CplxConv1d, _CplxMaskedStats):
+    def forward(self, input):
+        return cplx.conv1d(input, self.weight_masked, self.bias, self.stride, self.padding,
+                           self.dilation, self.groups, self.padding_mode)
+
+
+class CplxBilinearMasked(CplxBilinear, _CplxMaskedStats):
+    def forward(self, input1, input2):
+        return cplx.bilinear(input1, input2, self.weight_masked, self.bias, self.conjugate)
+
+
+class BilinearMasked(torch.nn.Bilinear, _RealMaskedStats):
+    def forward(self, input1, input2):
+        return ops.RealBilinearFn.apply(input1, input2, self.weight_masked, self.bias, None, None, 0, 0)
+
+
+class Conv1dMasked(torch.nn.Conv1d, _RealMaskedStats):
+    def forward(self, input):
+        from .. import conv
+        if self.padding_mode != "zeros":
+            raise ValueError("Conv1dMasked supports `zeros` padding only")
+        y = conv.RealConv2dFn.apply(input.unsqueeze(2), self.weight_masked.unsqueeze(2), self.bias,
+                                    (1, self.stride[0]), (0, self.padding[0]), (1, self.dilation[0]),
+                                    self.groups)
+        return y.squeeze(2)
 
 
 class LinearMasked(torch.nn.Linear, _MaskedStats):

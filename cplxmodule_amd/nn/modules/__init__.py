@@ -1,5 +1,7 @@
 from .base import CplxToCplx, CplxParameter  # noqa: F401
 from .linear import CplxLinear, CplxBilinear  # noqa: F401
+from .linear import CplxReal, CplxImag, CplxIdentity, CplxPhaseShift  # noqa: F401
+from .container import CplxSequential  # noqa: F401
 from .conv import CplxConv1d, CplxConv2d  # noqa: F401
 from .batchnorm import CplxBatchNorm1d, CplxBatchNorm2d, CplxBatchNorm3d  # noqa: F401
 from .casting import AsTypeCplx, TensorToCplx, CplxToTensor  # noqa: F401

@@ -2,7 +2,9 @@
 CplxBilinear: y = x1^H W x2 + b (linear.py:67-117)."""
 import math
 
-from .base import CplxToCplx, CplxParameter
+import torch
+
+from .base import CplxToCplx, CplxParameter, BaseCplxToReal
 from .. import init
 from ... import cplx
 
@@ -58,3 +60,29 @@ class CplxBilinear(CplxToCplx):
         return (f"in1_features={self.in1_features}, in2_features={self.in2_features}, "
                 f"out_features={self.out_features}, bias={self.bias is not None}, "
                 f"conjugate={self.conjugate}")
+
+
+class CplxIdentity(torch.nn.Identity, CplxToCplx):
+    pass
+
+
+class CplxReal(BaseCplxToReal):
+    def forward(self, input):
+        return input.real
+
+
+class CplxImag(BaseCplxToReal):
+    def forward(self, input):
+        return input.imag
+
+
+class CplxPhaseShift(CplxToCplx):
+    """z -> z exp(i phi) with a learnable phase of shape `dim`, broadcast against the input
+    (linear.py:120-143); initial phases are N(0, 0.02^2)."""
+
+    def __init__(self, *dim):
+        super().__init__()
+        self.phi = torch.nn.Parameter(torch.randn(*dim) * 0.02)
+
+    def forward(self, input):
+        return cplx.phaseshift(input, self.phi)

@@ -42,7 +42,8 @@ enum {
   CPLXAMD_KL_CPLX_ARD = 3, /* cplxmodule/nn/relevance/complex/ard.py:9-39  */
   /* SURVEY 8(f) row 4, cplxmodule/nn/relevance/extensions/complex.py: */
   CPLXAMD_KL_CPLX_VD_APPROX = 4,    /* :113-117 softplus-sigmoid approximation          */
-  CPLXAMD_KL_CPLX_VD_SCALEFREE = 5  /* :43-46   log|w| - log_sigma2 - Ei(-1/alpha) / 2  */
+  CPLXAMD_KL_CPLX_VD_SCALEFREE = 5, /* :43-46   log|w| - log_sigma2 - Ei(-1/alpha) / 2  */
+  CPLXAMD_KL_CPLX_VD_BOGUS = 6      /* :142-160 value -log_alpha (Ei dropped), exact slope  */
 };
 
 /* error codes (negative; positive values are hipError_t) */

@@ -28,7 +28,7 @@ EULER_GAMMA = float(np.euler_gamma)
 K1, K2, K3 = 0.63576, 1.87320, 1.48695
 
 KINDS = ("real_vd", "real_ard", "cplx_vd", "cplx_ard")
-EXT_KINDS = ("cplx_vd_approx", "cplx_vd_scalefree")   # nn/relevance/extensions/complex.py
+EXT_KINDS = ("cplx_vd_approx", "cplx_vd_scalefree", "cplx_vd_bogus")   # nn/relevance/extensions/complex.py
 
 
 # --------------------------------------------------------------------------- #
@@ -329,6 +329,8 @@ def penalty(kind, log_sigma2, wr, wi=None):
         log_abs_w = (t + log_sigma2) / 2
         with np.errstate(over="ignore"):
             return log_abs_w - log_sigma2 - np.asarray(0.5, dt) * expi(-np.exp(t))
+    if kind == "cplx_vd_bogus":       # extensions/complex.py:142-160: -log_alpha - 0 (forward of Ei dropped)
+        return t
     raise ValueError(kind)
 
 
@@ -341,7 +343,7 @@ def penalty_dt(kind, t):
         return softplus_grad(t) / 2 + np.asarray(K1 * K3, dt) * su * (1 - su)
     if kind == "real_ard":
         return softplus_grad(t) / 2
-    if kind == "cplx_vd":
+    if kind in ("cplx_vd", "cplx_vd_bogus"):
         with np.errstate(over="ignore"):
             return -np.expm1(-np.exp(t))
     if kind == "cplx_ard":

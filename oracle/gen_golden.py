@@ -518,7 +518,8 @@ def gen_extras():
     from cplxmodule.nn.relevance.extensions import complex as ext
     for tag, dt in DT.items():
         torch.manual_seed(17)
-        for name, cls in (("cplx_vd_approx", ext.CplxLinearVDApprox), ("cplx_vd_scalefree", ext.CplxLinearVDScaleFree)):
+        for name, cls in (("cplx_vd_approx", ext.CplxLinearVDApprox), ("cplx_vd_scalefree", ext.CplxLinearVDScaleFree),
+                          ("cplx_vd_bogus", ext.CplxLinearVDBogus)):
             layer = cls(24, 20).to(dt)
             wr, wi, ls2 = _mixed_vd_params(20, 24, dt)
             with torch.no_grad():

@@ -171,3 +171,48 @@ def test_bilinear_empty_batch():
     x1, x2 = cplx.randn(0, 4, device=DEV), cplx.randn(0, 6, device=DEV)
     y = layer(x1, x2)
     assert y.shape == (0, 3)
+
+
+def test_masked_bilinear_and_conv1d_layers():
+    """the masked counterparts added with the bilinear family: weight * mask feeds the same kernels"""
+    from cplxmodule_amd import Cplx, cplx
+    from cplxmodule_amd.nn import masked
+    torch.manual_seed(5)
+    m = masked.CplxBilinearMasked(6, 7, 4).to(DEV)
+    x1, x2 = cplx.randn(9, 6, device=DEV), cplx.randn(9, 7, device=DEV)
+    with pytest.raises(RuntimeError):
+        m(x1, x2)
+    mask = (torch.rand(4, 6, 7, device=DEV) > 0.5).float()
+    m.mask = mask
+    y = m(x1, x2)
+    w = m.weight
+    ref = cplx.bilinear(x1, x2, Cplx(w.real * mask, w.imag * mask), m.bias, True)
+    assert torch.equal(y.real, ref.real) and torch.equal(y.imag, ref.imag)
+    a = [N(p).astype(np.float64) for p in (x1.real, x1.imag, x2.real, x2.imag, w.real * mask, w.imag * mask,
+                                            m.bias.real, m.bias.imag)]
+    yr, _ = orc.cplx_bilinear(*a)
+    np.testing.assert_allclose(N(y.real), yr, **_tol(yr))
+    (n_re, dropped), _ = m.sparsity()
+    assert dropped == float(mask.numel() - mask.sum().item())
+
+    r = masked.BilinearMasked(6, 7, 4).to(DEV)
+    r.mask = mask
+    u, v = torch.randn(9, 6, device=DEV), torch.randn(9, 7, device=DEV)
+    ref = orc.real_bilinear(N(u).astype(np.float64), N(v).astype(np.float64),
+                            N(r.weight * mask).astype(np.float64), N(r.bias).astype(np.float64))
+    np.testing.assert_allclose(N(r(u, v)), ref, **_tol(ref))
+
+    c = masked.CplxConv1dMasked(3, 5, 3, padding=1).to(DEV)
+    cm = (torch.rand(5, 3, 3, device=DEV) > 0.4).float()
+    c.mask = cm
+    z = cplx.randn(2, 3, 11, device=DEV)
+    ref = cplx.conv1d(z, Cplx(c.weight.real * cm, c.weight.imag * cm), c.bias, 1, 1)
+    out = c(z)
+    assert torch.equal(out.real, ref.real) and out.shape == (2, 5, 11)
+
+    rc = masked.Conv1dMasked(3, 5, 3, stride=2).to(DEV)
+    rc.mask = cm
+    xin = torch.randn(2, 3, 11, device=DEV)
+    ref = torch.nn.functional.conv1d(xin.cpu().double(), (rc.weight * cm).detach().cpu().double(),
+                                     rc.bias.detach().cpu().double(), stride=2).numpy()
+    np.testing.assert_allclose(N(rc(xin)), ref, **_tol(ref))

@@ -231,10 +231,12 @@ def test_extension_penalties_gpu(golden, ops, kind):
         err = np.abs(N(got).astype(np.float64) - o[key])
         bound = 2e-5 * np.abs(o[key]) + 8 * eps * np.maximum(a, 1.0)
         assert (err <= bound).all(), (kind, key, float((err - bound).max()))
-    cls = dict(cplx_vd_approx=ext.CplxLinearVDApprox, cplx_vd_scalefree=ext.CplxLinearVDScaleFree)[kind]
+    cls = dict(cplx_vd_approx=ext.CplxLinearVDApprox, cplx_vd_scalefree=ext.CplxLinearVDScaleFree,
+               cplx_vd_bogus=ext.CplxLinearVDBogus)[kind]
     layer = cls(24, 20).to(DEV)
     with torch.no_grad():
         layer.weight.real.copy_(T(wr)); layer.weight.imag.copy_(T(wi)); layer.log_sigma2.copy_(T(ls2))
     np.testing.assert_allclose(N(layer.penalty)[fin], ref[fin], rtol=1e-5, atol=4e-6)
-    conv_cls = dict(cplx_vd_approx=ext.CplxConv2dVDApprox, cplx_vd_scalefree=ext.CplxConv2dVDScaleFree)[kind]
+    conv_cls = dict(cplx_vd_approx=ext.CplxConv2dVDApprox, cplx_vd_scalefree=ext.CplxConv2dVDScaleFree,
+                    cplx_vd_bogus=ext.CplxConv2dVDBogus)[kind]
     assert conv_cls(4, 4, 3).to(DEV).penalty.shape == (4, 4, 3, 3)

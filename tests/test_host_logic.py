@@ -1,0 +1,42 @@
+"""Host-side pieces that need no GPU: views, containers, trivial layers."""
+import pytest
+import torch
+
+
+def test_complex_view_and_containers():
+    """utils.views.complex_view, CplxSequential's type check, the trivial Cplx -> real layers"""
+    import warnings
+    from collections import OrderedDict
+    from cplxmodule_amd import Cplx
+    from cplxmodule_amd.utils import complex_view, fix_dim
+    from cplxmodule_amd import nn as cnn
+    x = torch.arange(24.0).reshape(2, 3, 4).requires_grad_(True)
+    re, im = complex_view(x, -1)
+    assert torch.equal(re, x[..., 0::2]) and torch.equal(im, x[..., 1::2])
+    assert re.data_ptr() == x.data_ptr()                       # views, not copies
+    (re.sum() + 2 * im.sum()).backward()
+    assert torch.equal(x.grad[..., 0::2], torch.ones(2, 3, 2)) and torch.equal(x.grad[..., 1::2], 2 * torch.ones(2, 3, 2))
+    y = torch.arange(12.0).reshape(2, 2, 3)
+    re, im = complex_view(y, 1)                                # size-2 axis is dropped
+    assert re.shape == (2, 3) and torch.equal(im, y[:, 1])
+    re, im = complex_view(y, 1, squeeze=False)
+    assert re.shape == (2, 1, 3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        re, im = complex_view(y, -1)
+    assert re.shape == (2, 2, 1) and any(issubclass(m.category, RuntimeWarning) for m in w)
+    assert fix_dim(-1, 3) == 2
+    with pytest.raises(ValueError):
+        fix_dim(3, 3)
+    z = Cplx(torch.randn(4, 5), torch.randn(4, 5))
+    assert cnn.CplxReal()(z) is z.real and cnn.CplxImag()(z) is z.imag and cnn.CplxIdentity()(z) is z
+    seq = cnn.CplxSequential(cnn.CplxIdentity(), cnn.CplxPhaseShift(5))
+    out = seq(z)
+    phi = seq[1].phi.detach()
+    ref = torch.complex(z.real, z.imag) * torch.exp(1j * phi)
+    assert torch.allclose(out.real, ref.real, atol=1e-6) and torch.allclose(out.imag, ref.imag, atol=1e-6)
+    assert len(cnn.CplxSequential(OrderedDict(a=cnn.CplxIdentity()))) == 1
+    with pytest.raises(TypeError):
+        cnn.CplxSequential(cnn.CplxIdentity(), torch.nn.ReLU())
+    with pytest.raises(TypeError):
+        cnn.CplxSequential(cnn.CplxReal())
