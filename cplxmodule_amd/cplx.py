@@ -371,6 +371,13 @@ def conv1d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
     return conv.cplx_conv1d(input, weight, bias, stride, padding, dilation, groups, padding_mode)
 
 
+def conv3d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, padding_mode="zeros"):
+    """Complex 3-d cross-correlation on [B, C, D, H, W] (cplxmodule/cplx.py:841-857): the sum over
+    the depth taps of 2-d correlations on the conv2d kernels (conv3d.py)."""
+    from .conv3d import cplx_conv3d
+    return cplx_conv3d(input, weight, bias, stride, padding, dilation, groups, padding_mode)
+
+
 def from_interleaved_real(input, copy=True, dim=-1):
     """[..., 2D] interleaved (re, im) -> Cplx [..., D]  (cplxmodule/cplx.py:451-455).  copy=True along
     the last dim on the GPU is one de-interleaving kernel pass (csrc/layout.hip) instead of two
@@ -450,3 +457,9 @@ def max_pool1d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode
     z = Cplx(input.real.unsqueeze(2), input.imag.unsqueeze(2))
     out = max_pool2d(z, (1, k), (1, s), (0, first(padding)), (1, first(dilation)), ceil_mode)
     return Cplx(out.real.squeeze(2), out.imag.squeeze(2))
+
+
+def max_pool3d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False):
+    """[B, C, D, H, W] (cplxmodule/cplx.py:1193-1200): separable, 2-d pool then 1-d pool over depth."""
+    from .conv3d import cplx_max_pool3d
+    return cplx_max_pool3d(input, kernel_size, stride, padding, dilation, ceil_mode)

@@ -9,7 +9,7 @@ dense layers (the mask multiply is a weight-sized elementwise op).
 import torch
 
 from .modules.linear import CplxLinear, CplxBilinear
-from .modules.conv import CplxConv1d, CplxConv2d
+from .modules.conv import CplxConv1d, CplxConv2d, CplxConv3d
 from .utils.sparsity import SparsityStats
 from .. import cplx, ops
 
@@ -136,6 +136,21 @@ class Conv1dMasked(torch.nn.Conv1d, _RealMaskedStats):
                                     (1, self.stride[0]), (0, self.padding[0]), (1, self.dilation[0]),
                                     self.groups)
         return y.squeeze(2)
+
+
+class CplxConv3dMasked(CplxConv3d, _CplxMaskedStats):
+    def forward(self, input):
+        return cplx.conv3d(input, self.weight_masked, self.bias, self.stride, self.padding,
+                           self.dilation, self.groups, self.padding_mode)
+
+
+class Conv3dMasked(torch.nn.Conv3d, _RealMaskedStats):
+    def forward(self, input):
+        from .. import conv3d
+        if self.padding_mode != "zeros":
+            raise ValueError("Conv3dMasked supports `zeros` padding only")
+        return conv3d.real_conv3d(input, self.weight_masked, self.bias, self.stride, self.padding,
+                                  self.dilation, self.groups)
 
 
 class LinearMasked(torch.nn.Linear, _MaskedStats):

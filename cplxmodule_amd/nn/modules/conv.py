@@ -1,7 +1,8 @@
-"""CplxConv1d / CplxConv2d: complex cross-correlation layers (cplxmodule/nn/modules/conv.py:11-196)."""
+"""CplxConv1d / CplxConv2d / CplxConv3d: complex cross-correlation layers
+(cplxmodule/nn/modules/conv.py:11-247)."""
 import math
 
-from torch.nn.modules.utils import _pair, _single
+from torch.nn.modules.utils import _pair, _single, _triple
 
 from .base import CplxToCplx, CplxParameter
 from .. import init
@@ -83,4 +84,32 @@ class CplxConv1d(CplxConv2d):
 
     def forward(self, input):
         return cplx.conv1d(input, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.groups, self.padding_mode)
+
+
+class CplxConv3d(CplxConv2d):
+    """[B, C, D, H, W] complex convolution; weight [out, in / groups, kd, kh, kw] (cplx.conv3d)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        CplxToCplx.__init__(self)
+        if in_channels % groups != 0:
+            raise ValueError("in_channels must be divisible by groups")
+        if out_channels % groups != 0:
+            raise ValueError("out_channels must be divisible by groups")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
+        self.padding, self.dilation = _triple(padding), _triple(dilation)
+        self.transposed, self.output_padding = False, _triple(0)
+        self.groups, self.padding_mode = groups, padding_mode
+        self.weight = CplxParameter(
+            cplx.Cplx.empty(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = CplxParameter(cplx.Cplx.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def forward(self, input):
+        return cplx.conv3d(input, self.weight, self.bias, self.stride, self.padding,
                            self.dilation, self.groups, self.padding_mode)

@@ -31,3 +31,7 @@ class CplxMaxPool1d(_CplxMaxPool):
 
 class CplxMaxPool2d(_CplxMaxPool):
     _pool = staticmethod(cplx.max_pool2d)
+
+
+class CplxMaxPool3d(_CplxMaxPool):
+    _pool = staticmethod(cplx.max_pool3d)

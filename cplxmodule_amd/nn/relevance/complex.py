@@ -11,7 +11,7 @@ from .base import BaseARD
 from .noise import noise
 from ..utils.sparsity import SparsityStats
 from ..modules.linear import CplxLinear, CplxBilinear
-from ..modules.conv import CplxConv1d, CplxConv2d
+from ..modules.conv import CplxConv1d, CplxConv2d, CplxConv3d
 from ... import ops, cplx
 
 
@@ -179,4 +179,28 @@ class CplxConv1dVD(CplxConv1dGaussian, SparsityStats, BaseARD):
 
 
 class CplxConv1dARD(CplxConv1dVD):
+    _kl_kind = "cplx_ard"
+
+
+class CplxConv3dGaussian(_CplxGaussianMixin, CplxConv3d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                         dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode)
+        if self.padding_mode != "zeros":
+            raise ValueError(f"Only `zeros` padding mode is supported. Got `{self.padding_mode}`.")
+        self._init_variational()
+
+    def forward(self, input, eps=None):
+        if not self.training:
+            return super().forward(input)
+        from ... import conv3d
+        return conv3d.cplx_conv3d_lrt(self, input, eps)
+
+
+class CplxConv3dVD(CplxConv3dGaussian, SparsityStats, BaseARD):
+    _kl_kind = "cplx_vd"
+
+
+class CplxConv3dARD(CplxConv3dVD):
     _kl_kind = "cplx_ard"

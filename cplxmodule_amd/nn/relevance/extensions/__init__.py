@@ -11,7 +11,7 @@ from .. import complex as _base
 _KINDS = {"Approx": "cplx_vd_approx", "ScaleFree": "cplx_vd_scalefree", "Bogus": "cplx_vd_bogus"}
 __all__ = []
 
-for _layer in ("Linear", "Bilinear", "Conv1d", "Conv2d"):
+for _layer in ("Linear", "Bilinear", "Conv1d", "Conv2d", "Conv3d"):
     _parent = getattr(_base, f"Cplx{_layer}VD")
     for _suffix, _kind in _KINDS.items():
         _name = f"Cplx{_layer}VD{_suffix}"

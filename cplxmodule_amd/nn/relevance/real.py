@@ -141,3 +141,25 @@ class Conv1dVD(Conv1dGaussian, SparsityStats, BaseARD):
 
 class Conv1dARD(Conv1dVD):
     _kl_kind = "real_ard"
+
+
+class Conv3dGaussian(_RealGaussianMixin, torch.nn.Conv3d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, padding_mode="zeros"):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                         dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode)
+        if self.padding_mode != "zeros":
+            raise ValueError(f"Only `zeros` padding mode is supported. Got `{self.padding_mode}`.")
+        self._init_variational()
+
+    def forward(self, input, eps=None):
+        from ... import conv3d
+        return conv3d.real_conv3d_layer(self, input, eps)
+
+
+class Conv3dVD(Conv3dGaussian, SparsityStats, BaseARD):
+    _kl_kind = "real_vd"
+
+
+class Conv3dARD(Conv3dVD):
+    _kl_kind = "real_ard"

@@ -666,6 +666,59 @@ class RealBilinearFn(torch.autograd.Function):
         return dx1[0], dx2[0], dw[0], db[0], dls2, None, None, None
 
 
+class Abs2Fn(torch.autograd.Function):
+    """|x|^2 (xi None: x^2) as a differentiable op, for variance paths composed from several
+    kernels (conv3d.py)."""
+
+    @staticmethod
+    def forward(ctx, xr, xi):
+        xr, xi = _c(xr), _c(xi)
+        ctx.save_for_backward(xr, xi)
+        return abs2(xr, xi)
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, xi = ctx.saved_tensors
+        dxr = torch.zeros_like(xr)
+        dxi = None if xi is None else torch.zeros_like(xi)
+        lrt_dx_accum(dxr, dxi, xr, xi, _c(g))              # dx = 2 x g
+        return dxr, dxi
+
+
+class ExpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = exp(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.saved_tensors[0]
+
+
+class ReparamFn(torch.autograd.Function):
+    """y = mu + eps sqrt(max(s2, 1e-8)) as a stand-alone differentiable op (the fused layers use
+    the kernels directly); d mu = g, d s2 = reparam_bwd."""
+
+    @staticmethod
+    def forward(ctx, mu_r, mu_i, s2, eps_r, eps_i, seed, offset):
+        require_device(mu_r, mu_i, s2, eps_r, eps_i)
+        eps = None if eps_r is None else ((eps_r, eps_i) if mu_i is not None else eps_r)
+        s2 = _c(s2)
+        ctx.save_for_backward(s2, eps_r, eps_i)
+        ctx.cplx, ctx.seed, ctx.offset = mu_i is not None, seed, offset
+        yr, yi = reparam_fwd(mu_r, mu_i, s2, eps, seed, offset)
+        return (yr.view_as(mu_r), None if yi is None else yi.view_as(mu_r))
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        s2, eps_r, eps_i = ctx.saved_tensors
+        eps = None if eps_r is None else ((eps_r, eps_i) if ctx.cplx else eps_r)
+        gs2 = reparam_bwd(gr, gi if ctx.cplx else None, s2, eps, ctx.seed, ctx.offset)
+        return gr, (gi if ctx.cplx else None), gs2.view_as(s2), None, None, None, None
+
+
 class PenaltyFn(torch.autograd.Function):
     """Elementwise KL penalty tensor (the `.penalty` property of the VD / ARD layers)."""
 

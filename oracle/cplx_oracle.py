@@ -157,6 +157,148 @@ def lrt_real_linear_bwd(g, x, w, log_sigma2, eps, has_bias=True):
 
 
 # --------------------------------------------------------------------------- #
+#  3-d convolution / pooling                                                  #
+# --------------------------------------------------------------------------- #
+def _triple(v):
+    return (v, v, v) if isinstance(v, (int, np.integer)) else tuple(v)
+
+
+def _conv3d_taps(x_shape, w_shape, stride, padding, dilation):
+    (sd, sh, sw), (pd, ph, pw), (dd, dh, dw) = _triple(stride), _triple(padding), _triple(dilation)
+    kd, kh, kw = w_shape[2:]
+    D, H, W = x_shape[2:]
+    Do = (D + 2 * pd - dd * (kd - 1) - 1) // sd + 1
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    taps = []
+    for a in range(kd):
+        for i in range(kh):
+            for j in range(kw):
+                taps.append(((a, i, j), (slice(a * dd, a * dd + sd * (Do - 1) + 1, sd),
+                                         slice(i * dh, i * dh + sh * (Ho - 1) + 1, sh),
+                                         slice(j * dw, j * dw + sw * (Wo - 1) + 1, sw))))
+    return (pd, ph, pw), (Do, Ho, Wo), taps
+
+
+def real_conv3d(x, w, stride=1, padding=0, dilation=1, groups=1):
+    """torch.nn.functional.conv3d (cross-correlation, zero padding), one einsum per kernel tap."""
+    (pd, ph, pw), (Do, Ho, Wo), taps = _conv3d_taps(x.shape, w.shape, stride, padding, dilation)
+    B, C = x.shape[:2]
+    Co, Cg = w.shape[:2]
+    xp = np.pad(x, ((0, 0), (0, 0), (pd, pd), (ph, ph), (pw, pw)))
+    out = np.zeros((B, groups, Co // groups, Do, Ho, Wo), x.dtype)
+    wg = w.reshape(groups, Co // groups, Cg, *w.shape[2:])
+    for (a, i, j), (zs, ys, xs) in taps:
+        v = xp[:, :, zs, ys, xs].reshape(B, groups, Cg, Do, Ho, Wo)
+        out += np.einsum("goc,bgcdhw->bgodhw", wg[:, :, :, a, i, j], v)
+    return out.reshape(B, Co, Do, Ho, Wo)
+
+
+def real_conv3d_bwd(g, x, w, stride=1, padding=0, dilation=1, groups=1):
+    """(dx, dw) of `real_conv3d`: the adjoint of every tap."""
+    (pd, ph, pw), (Do, Ho, Wo), taps = _conv3d_taps(x.shape, w.shape, stride, padding, dilation)
+    B, C, D, H, W = x.shape
+    Co, Cg = w.shape[:2]
+    xp = np.pad(x, ((0, 0), (0, 0), (pd, pd), (ph, ph), (pw, pw)))
+    dxp = np.zeros_like(xp)
+    dw = np.zeros_like(w).reshape(groups, Co // groups, Cg, *w.shape[2:])
+    wg = w.reshape(dw.shape)
+    gg = g.reshape(B, groups, Co // groups, Do, Ho, Wo)
+    for (a, i, j), (zs, ys, xs) in taps:
+        v = xp[:, :, zs, ys, xs].reshape(B, groups, Cg, Do, Ho, Wo)
+        dw[:, :, :, a, i, j] = np.einsum("bgodhw,bgcdhw->goc", gg, v)
+        dxp[:, :, zs, ys, xs] += np.einsum("goc,bgodhw->bgcdhw", wg[:, :, :, a, i, j], gg).reshape(B, C, Do, Ho, Wo)
+    return dxp[:, :, pd: pd + D, ph: ph + H, pw: pw + W], dw.reshape(w.shape)
+
+
+def circular_pad3d(x, padding):
+    """symmetric_circular_padding for 5-d input (cplxmodule/cplx.py:699-712): as in 2-d, the FIRST
+    entry of `padding` wraps the LAST dim."""
+    (wl, wr_), (hl, hr), (dl, dr) = [((p + 1) // 2, p // 2) for p in _triple(padding)]
+    return np.pad(x, ((0, 0), (0, 0), (dl, dr), (hl, hr), (wl, wr_)), mode="wrap")
+
+
+def cplx_conv3d(xr, xi, wr, wi, br=None, bi=None, stride=1, padding=0, dilation=1, groups=1,
+                padding_mode="zeros"):
+    """cplx.conv3d -> convnd, cplxmodule/cplx.py:770-800, 841-857."""
+    if padding_mode == "circular":
+        xr, xi, padding = circular_pad3d(xr, padding), circular_pad3d(xi, padding), 0
+    f = lambda x, w: real_conv3d(x, w, stride, padding, dilation, groups)  # noqa: E731
+    re, im = f(xr, wr) - f(xi, wi), f(xr, wi) + f(xi, wr)
+    if br is not None:
+        re, im = re + br.reshape(-1, 1, 1, 1), im + bi.reshape(-1, 1, 1, 1)
+    return re, im
+
+
+def cplx_conv3d_bwd(gr, gi, xr, xi, wr, wi, stride=1, padding=0, dilation=1, groups=1):
+    """dX = G (*) conj(W), dW = G (*) conj(X) (zeros padding), db = sum G."""
+    b = lambda g, x, w: real_conv3d_bwd(g, x, w, stride, padding, dilation, groups)  # noqa: E731
+    dx_rr, dw_rr = b(gr, xr, wr)
+    dx_ii, dw_ii = b(gi, xi, wr)       # wrt (xi, wr) through the imaginary output
+    dx_ri, dw_ri = b(gr, xi, wi)       # re -= conv(xi, wi)
+    dx_ir, dw_ir = b(gi, xr, wi)       # im += conv(xr, wi)
+    return dict(dxr=dx_rr + dx_ir, dxi=dx_ii - dx_ri, dwr=dw_rr + dw_ii, dwi=dw_ir - dw_ri,
+                dbr=gr.sum((0, 2, 3, 4)), dbi=gi.sum((0, 2, 3, 4)))
+
+
+def lrt_cplx_conv3d(xr, xi, wr, wi, br, bi, log_sigma2, eps_r, eps_i, **kw):
+    """CplxConvNdGaussianMixin._forward_impl with F.conv3d, complex/base.py:120-135."""
+    mur, mui = cplx_conv3d(xr, xi, wr, wi, br, bi, **kw)
+    s2 = real_conv3d(xr * xr + xi * xi, np.exp(log_sigma2), **kw)
+    sd = np.sqrt(np.maximum(s2, np.asarray(1e-8, s2.dtype)))
+    return mur + eps_r * sd, mui + eps_i * sd, dict(mur=mur, mui=mui, s2=s2)
+
+
+def lrt_cplx_conv3d_bwd(gr, gi, xr, xi, wr, wi, log_sigma2, eps_r, eps_i, **kw):
+    dt = xr.dtype
+    S = np.exp(log_sigma2)
+    a = xr * xr + xi * xi
+    s2 = real_conv3d(a, S, **kw)
+    lo = np.asarray(1e-8, dt)
+    sd = np.sqrt(np.maximum(s2, lo))
+    gs2 = np.where(s2 >= lo, (gr * eps_r + gi * eps_i) * np.asarray(0.5, dt) / sd, np.asarray(0, dt))
+    out = cplx_conv3d_bwd(gr, gi, xr, xi, wr, wi, **kw)
+    ga, dS = real_conv3d_bwd(gs2, a, S, **kw)
+    out["dxr"] = out["dxr"] + 2 * xr * ga
+    out["dxi"] = out["dxi"] + 2 * xi * ga
+    out["dlog_sigma2"] = dS * S
+    return out
+
+
+def cplx_max_pool3d(zr, zi, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False):
+    """cplx.max_pool3d (cplxmodule/cplx.py:1114-1175, 1193-1200): direct 3-d window scan, first
+    maximum of |z| in (d, h, w) order.  Returns (yr, yi, flat index into D*H*W)."""
+    k, p, dl = _triple(kernel_size), _triple(padding), _triple(dilation)
+    s = k if stride is None else _triple(stride)
+    B, C, D, H, W = zr.shape
+    osz = [_pool_out(L, k[n], s[n], p[n], dl[n], ceil_mode) for n, L in enumerate((D, H, W))]
+    mod = cplx_abs(zr, zi)
+    idx = np.zeros((B, C, *osz), np.int64)
+    for od in range(osz[0]):
+        for oh in range(osz[1]):
+            for ow in range(osz[2]):
+                best = np.full((B, C), -np.inf)
+                sel = np.full((B, C), -1, np.int64)
+                for a in range(k[0]):
+                    d = od * s[0] - p[0] + a * dl[0]
+                    for i in range(k[1]):
+                        h = oh * s[1] - p[1] + i * dl[1]
+                        for j in range(k[2]):
+                            w = ow * s[2] - p[2] + j * dl[2]
+                            if not (0 <= d < D and 0 <= h < H and 0 <= w < W):
+                                continue
+                            m = mod[:, :, d, h, w]
+                            take = (sel < 0) | (m > best)
+                            best = np.where(take, m, best)
+                            sel = np.where(take, (d * H + h) * W + w, sel)
+                idx[:, :, od, oh, ow] = sel
+    fi = idx.reshape(B, C, -1)
+    yr = np.take_along_axis(zr.reshape(B, C, -1), fi, -1).reshape(idx.shape)
+    yi = np.take_along_axis(zi.reshape(B, C, -1), fi, -1).reshape(idx.shape)
+    return yr, yi, idx
+
+
+# --------------------------------------------------------------------------- #
 #  bilinear layers                                                            #
 # --------------------------------------------------------------------------- #
 def real_bilinear(x1, x2, w, b=None):

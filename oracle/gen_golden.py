@@ -476,6 +476,89 @@ def gen_bilinear():
     save("bilinear", d)
 
 
+from gen_golden_cases import CONV3D_CASES, POOL3D_CASES  # noqa: E402
+
+
+def gen_conv3d():
+    """cplx.conv3d (values + gradients), CplxConv3dVD / Conv3dVD training with a recorded noise tape
+    and eval mode, cplx.max_pool3d."""
+    from cplxmodule.nn import CplxMaxPool3d  # noqa: F401
+    d = {}
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        for name, c in CONV3D_CASES.items():
+            torch.manual_seed(41)
+            xr, xi = leaf(*c["x"], dtype=dt), leaf(*c["x"], dtype=dt)
+            wr, wi = leaf(*c["w"], dtype=dt, scale=0.2), leaf(*c["w"], dtype=dt, scale=0.2)
+            br, bi = leaf(c["w"][0], dtype=dt), leaf(c["w"][0], dtype=dt)
+            y = cplx.conv3d(C(xr, xi), C(wr, wi), C(br, bi), **c["kw"])
+            gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+            grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), [xr, xi, wr, wi, br, bi])
+            k = f"{tag}_{name}_"
+            for nm, t in dict(xr=xr, xi=xi, wr=wr, wi=wi, br=br, bi=bi, gr=gr, gi=gi, yr=y.real, yi=y.imag).items():
+                d[k + nm] = npy(t)
+            for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi"], grads):
+                d[k + nm] = npy(g)
+        # complex VD conv3d
+        torch.manual_seed(42)
+        layer = rel.CplxConv3dVD(3, 4, (2, 3, 2), stride=(1, 2, 1), padding=(1, 1, 0))
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        x = cplx.randn(2, 3, 5, 7, 6)
+        xr, xi = x.real.clone().requires_grad_(True), x.imag.clone().requires_grad_(True)
+        layer.train()
+        torch.manual_seed(91)
+        y = layer(C(xr, xi))
+        torch.manual_seed(91)
+        tape = torch.randn(2, *y.shape)
+        gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+        ps = [xr, xi, layer.weight.real, layer.weight.imag, layer.bias.real, layer.bias.imag, layer.log_sigma2]
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), ps)
+        k = f"{tag}_vd_"
+        for nm, t in dict(xr=xr, xi=xi, wr=ps[2], wi=ps[3], br=ps[4], bi=ps[5], ls2=ps[6], gr=gr, gi=gi,
+                          tape=tape, yr=y.real, yi=y.imag).items():
+            d[k + nm] = npy(t)
+        for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi", "dls2"], grads):
+            d[k + nm] = npy(g)
+        layer.eval()
+        y = layer(C(xr, xi))
+        d[k + "yr_eval"], d[k + "yi_eval"] = npy(y.real), npy(y.imag)
+        # real VD conv3d
+        torch.manual_seed(43)
+        layer = rel.Conv3dVD(3, 4, 2, padding=1)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-10, 1)
+        x = torch.randn(2, 3, 4, 5, 6).requires_grad_(True)
+        layer.train()
+        torch.manual_seed(92)
+        y = layer(x)
+        torch.manual_seed(92)
+        eps = torch.randn(*y.shape)
+        g = torch.randn_like(y)
+        grads = torch.autograd.grad((y * g).sum(), [x, layer.weight, layer.bias, layer.log_sigma2])
+        k = f"{tag}_real_"
+        for nm, t in dict(x=x, w=layer.weight, b=layer.bias, ls2=layer.log_sigma2, g=g, eps=eps, y=y,
+                          dx=grads[0], dw=grads[1], db=grads[2], dls2=grads[3]).items():
+            d[k + nm] = npy(t)
+        layer.eval()
+        d[k + "y_eval"] = npy(layer(x))
+        # abs-max pooling 3-d
+        torch.manual_seed(44)
+        zr, zi = leaf(2, 3, 7, 8, 9, dtype=dt), leaf(2, 3, 7, 8, 9, dtype=dt)
+        d[f"{tag}_mp_zr"], d[f"{tag}_mp_zi"] = npy(zr), npy(zi)
+        for name, kw in POOL3D_CASES.items():
+            for t in (zr, zi):
+                t.grad = None
+            y = cplx.max_pool3d(C(zr, zi), **kw)
+            gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+            torch.autograd.backward((y.real, y.imag), (gr, gi))
+            k = f"{tag}_mp_{name}_"
+            d[k + "yr"], d[k + "yi"], d[k + "gr"], d[k + "gi"] = npy(y.real), npy(y.imag), npy(gr), npy(gi)
+            d[k + "dzr"], d[k + "dzi"] = npy(zr.grad), npy(zi.grad)
+    torch.set_default_dtype(torch.float32)
+    save("conv3d", d)
+
+
 def gen_extras():
     """layout converters, modReLU (+ learnable thresholds), CplxDropout."""
     from cplxmodule.nn import CplxModReLU, CplxAdaptiveModReLU, CplxDropout  # noqa: F401
@@ -587,6 +670,6 @@ def gen_extras():
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reproducible summation order
     gens = dict(linear=gen_linear, lrt_linear=gen_lrt_linear, penalty=gen_penalty, conv=gen_conv,
-                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear)
+                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear, conv3d=gen_conv3d)
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

@@ -9,3 +9,17 @@ CONV_CASES = {
     "circular": (2, 3, 4, 8, 9, 3, 1, (2, 1), 1, 1, "circular"),
     "k1": (3, 8, 8, 5, 5, 1, 1, 0, 1, 1, "zeros"),
 }
+
+CONV3D_CASES = {
+    "base": dict(x=(2, 3, 6, 7, 8), w=(4, 3, 3, 3, 3), kw={}),
+    "s2p1": dict(x=(2, 4, 7, 8, 9), w=(6, 4, 3, 2, 3), kw=dict(stride=(2, 1, 2), padding=(1, 0, 1))),
+    "dil": dict(x=(1, 2, 9, 9, 9), w=(3, 2, 2, 3, 2), kw=dict(dilation=(2, 1, 3))),
+    "groups": dict(x=(2, 4, 5, 6, 6), w=(6, 2, 2, 2, 2), kw=dict(groups=2, padding=1)),
+    "circ": dict(x=(2, 2, 5, 6, 7), w=(3, 2, 3, 3, 3), kw=dict(padding=(2, 1, 3), padding_mode="circular")),
+}
+
+POOL3D_CASES = {
+    "k2": dict(kernel_size=2), "k3s2p1": dict(kernel_size=3, stride=2, padding=1),
+    "mixed": dict(kernel_size=(2, 3, 2), stride=(1, 2, 2), padding=(0, 1, 1), dilation=(2, 1, 1)),
+    "ceil": dict(kernel_size=(2, 3, 2), stride=(2, 2, 3), ceil_mode=True),
+}

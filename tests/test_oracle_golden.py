@@ -354,3 +354,61 @@ def test_lrt_bilinear(golden, tag):
     bw = orc.lrt_real_bilinear_bwd(g[k + "g"], g[k + "x1"], g[k + "x2"], g[k + "w"], g[k + "ls2"], g[k + "eps"])
     for n, m in (("dx1", "dx1"), ("dx2", "dx2"), ("dw", "dw"), ("db", "db"), ("dlog_sigma2", "dls2")):
         close(bw[n], g[k + m], tag, 300)
+
+
+from oracle.gen_golden_cases import CONV3D_CASES, POOL3D_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("case", list(CONV3D_CASES))
+def test_conv3d(golden, tag, case):
+    g = golden("conv3d")
+    k = f"{tag}_{case}_"
+    kw = CONV3D_CASES[case]["kw"]
+    a = [g[k + n] for n in ("xr", "xi", "wr", "wi")]
+    yr, yi = orc.cplx_conv3d(*a, g[k + "br"], g[k + "bi"], **kw)
+    close(yr, g[k + "yr"], tag, 100)
+    close(yi, g[k + "yi"], tag, 100)
+    if kw.get("padding_mode", "zeros") == "zeros":
+        bw = orc.cplx_conv3d_bwd(g[k + "gr"], g[k + "gi"], *a, **kw)
+        for n in ("dxr", "dxi", "dwr", "dwi", "dbr", "dbi"):
+            close(bw[n], g[k + n], tag, 300)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_lrt_conv3d(golden, tag):
+    g = golden("conv3d")
+    k = f"{tag}_vd_"
+    kw = dict(stride=(1, 2, 1), padding=(1, 1, 0))
+    er, ei = orc.cplx_randn_from_tape(g[k + "tape"])
+    a = [g[k + n] for n in ("xr", "xi", "wr", "wi")]
+    yr, yi, _ = orc.lrt_cplx_conv3d(*a, g[k + "br"], g[k + "bi"], g[k + "ls2"], er, ei, **kw)
+    close(yr, g[k + "yr"], tag, 100)
+    close(yi, g[k + "yi"], tag, 100)
+    mur, _ = orc.cplx_conv3d(*a, g[k + "br"], g[k + "bi"], **kw)
+    close(mur, g[k + "yr_eval"], tag, 100)
+    bw = orc.lrt_cplx_conv3d_bwd(g[k + "gr"], g[k + "gi"], *a, g[k + "ls2"], er, ei, **kw)
+    for n, m in (("dxr", "dxr"), ("dxi", "dxi"), ("dwr", "dwr"), ("dwi", "dwi"), ("dbr", "dbr"),
+                 ("dbi", "dbi"), ("dlog_sigma2", "dls2")):
+        close(bw[n], g[k + m], tag, 1000)
+    k = f"{tag}_real_"
+    mu = orc.real_conv3d(g[k + "x"], g[k + "w"], padding=1) + g[k + "b"].reshape(-1, 1, 1, 1)
+    close(mu, g[k + "y_eval"], tag, 100)
+    s2 = orc.real_conv3d(g[k + "x"] ** 2, np.exp(g[k + "ls2"]), padding=1)
+    close(mu + g[k + "eps"] * np.sqrt(np.maximum(s2, 1e-8)), g[k + "y"], tag, 100)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("name", list(POOL3D_CASES))
+def test_oracle_max_pool3d(golden, tag, name):
+    g = golden("conv3d")
+    zr, zi = g[f"{tag}_mp_zr"], g[f"{tag}_mp_zi"]
+    k = f"{tag}_mp_{name}_"
+    yr, yi, idx = orc.cplx_max_pool3d(zr, zi, **POOL3D_CASES[name])
+    assert np.array_equal(yr, g[k + "yr"]) and np.array_equal(yi, g[k + "yi"])
+    B, C = zr.shape[:2]
+    dzr = np.zeros((B, C, zr[0, 0].size), zr.dtype)
+    for b in range(B):
+        for c in range(C):
+            np.add.at(dzr[b, c], idx[b, c].reshape(-1), g[k + "gr"][b, c].reshape(-1))
+    close(dzr.reshape(zr.shape), g[k + "dzr"], tag, 10)
