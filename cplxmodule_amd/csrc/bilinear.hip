@@ -11,19 +11,35 @@
 //         du[b,i]   = sum_o g[b,o] conj(T[b,o,i])               (real: sum_o g T);  dx1 = conj?(du)
 // bwd reads T once and writes dT once (16 B per complex float32 element of T); dT then goes through
 // the dgrad / wgrad GEMMs.  Real tensors pass NULL imaginary planes.
+#include <initializer_list>
+
 #include "common.h"
 
 namespace cplxamd {
 
 constexpr int kBT = 256;
 
+// V elements per lane and load (4 when I1 % 4 == 0: 16-B float / 8-B bf16 loads, else 1)
+template <typename T, int V> struct vecio;
+template <typename T> struct vecio<T, 1> {
+  struct type { float v[1]; };
+  static __device__ __forceinline__ type ld(const T* p) { return type{{io<T>::ld(p)}}; }
+  static __device__ __forceinline__ void st(T* p, const type& a) { io<T>::st(p, a.v[0]); }
+};
+template <typename T> struct vecio<T, 4> {
+  using type = f4;
+  static __device__ __forceinline__ type ld(const T* p) { return ld4(p); }
+  static __device__ __forceinline__ void st(T* p, const type& a) { st4(p, a); }
+};
+
 // GS consecutive lanes reduce one (b, o) row of T; rows are contiguous, so a wave reads 64 / GS
 // consecutive rows = one contiguous run of memory.
-template <typename T, bool CPLX, int GS>
+template <typename T, bool CPLX, int GS, int V>
 __global__ __launch_bounds__(kBT) void bilinear_reduce_fwd_kernel(
     const T* __restrict__ ur, const T* __restrict__ ui, const T* __restrict__ tr, const T* __restrict__ ti,
     const float* __restrict__ bias_r, const float* __restrict__ bias_i, T* __restrict__ yr,
     T* __restrict__ yi, int64_t rows, int O, int I1, float usign) {
+  using IO = vecio<T, V>;
   const int sub = threadIdx.x % GS;
   const int64_t row0 = ((int64_t)blockIdx.x * kBT + threadIdx.x) / GS;
   const int64_t rstride = (int64_t)gridDim.x * (kBT / GS);
@@ -36,16 +52,23 @@ __global__ __launch_bounds__(kBT) void bilinear_reduce_fwd_kernel(
     if (CPLX) {
       const T* u_i = ui + b * I1;
       const T* t_i = ti + row * I1;
-#pragma unroll 4
-      for (int i = sub; i < I1; i += GS) {
-        const float a = io<T>::ld(u_r + i), c = usign * io<T>::ld(u_i + i);
-        const float p = io<T>::ld(t_r + i), q = io<T>::ld(t_i + i);
-        ar += a * p - c * q;
-        ai += a * q + c * p;
+#pragma unroll 2
+      for (int i = sub * V; i < I1; i += GS * V) {
+        const auto a = IO::ld(u_r + i), c = IO::ld(u_i + i), p = IO::ld(t_r + i), q = IO::ld(t_i + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float cs = usign * c.v[e];
+          ar += a.v[e] * p.v[e] - cs * q.v[e];
+          ai += a.v[e] * q.v[e] + cs * p.v[e];
+        }
       }
     } else {
-#pragma unroll 4
-      for (int i = sub; i < I1; i += GS) ar += io<T>::ld(u_r + i) * io<T>::ld(t_r + i);
+#pragma unroll 2
+      for (int i = sub * V; i < I1; i += GS * V) {
+        const auto a = IO::ld(u_r + i), p = IO::ld(t_r + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) ar += a.v[e] * p.v[e];
+      }
     }
 #pragma unroll
     for (int m = GS >> 1; m > 0; m >>= 1) {
@@ -60,64 +83,99 @@ __global__ __launch_bounds__(kBT) void bilinear_reduce_fwd_kernel(
   }
 }
 
-// one thread per (b, i): walks o, reading T[b,o,i] (coalesced over i), writing dT[b,o,i], summing du
-template <typename T, bool CPLX>
+// one thread per (b, V consecutive i): walks o, reading T[b,o,i..] (coalesced over i), writing
+// dT[b,o,i..], summing du
+template <typename T, bool CPLX, int V>
 __global__ __launch_bounds__(kBT) void bilinear_reduce_bwd_kernel(
     const T* __restrict__ ur, const T* __restrict__ ui, const T* __restrict__ tr, const T* __restrict__ ti,
     const T* __restrict__ gr, const T* __restrict__ gi, T* __restrict__ dur, T* __restrict__ dui,
     T* __restrict__ dtr, T* __restrict__ dti, int64_t BI, int O, int I1, float usign) {
-  const int64_t p = (int64_t)blockIdx.x * kBT + threadIdx.x;
+  using IO = vecio<T, V>;
+  const int64_t p = ((int64_t)blockIdx.x * kBT + threadIdx.x) * V;
   if (p >= BI) return;
   const int64_t b = p / I1;
   const int i = (int)(p - b * I1);
-  const float a = io<T>::ld(ur + p), c = CPLX ? usign * io<T>::ld(ui + p) : 0.0f;
+  const auto a = IO::ld(ur + p);
+  auto c = a;
+  if (CPLX) {
+    c = IO::ld(ui + p);
+#pragma unroll
+    for (int e = 0; e < V; ++e) c.v[e] *= usign;
+  }
   const T* g_r = gr + b * O;
   const T* g_i = CPLX ? gi + b * O : nullptr;
   const int64_t base = b * O * I1 + i;
-  float sr = 0.0f, si = 0.0f;
+  float sr[V], si[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) sr[e] = si[e] = 0.0f;
 #pragma unroll 4
   for (int o = 0; o < O; ++o) {
-    const int64_t e = base + (int64_t)o * I1;
+    const int64_t e0 = base + (int64_t)o * I1;
     const float x = io<T>::ld(g_r + o);
-    if (CPLX) {
-      const float y = io<T>::ld(g_i + o);
-      if (tr) {
-        const float m = io<T>::ld(tr + e), n = io<T>::ld(ti + e);
-        sr += x * m + y * n;          // g conj(t)
-        si += y * m - x * n;
+    const float y = CPLX ? io<T>::ld(g_i + o) : 0.0f;
+    if (tr) {
+      const auto m = IO::ld(tr + e0);
+      if (CPLX) {
+        const auto n = IO::ld(ti + e0);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          sr[e] += x * m.v[e] + y * n.v[e];      // g conj(t)
+          si[e] += y * m.v[e] - x * n.v[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) sr[e] += x * m.v[e];
       }
-      if (dtr) {
-        io<T>::st(dtr + e, x * a + y * c);  // g conj(u)
-        io<T>::st(dti + e, y * a - x * c);
+    }
+    if (dtr) {
+      auto dr = a, di = a;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        dr.v[e] = CPLX ? x * a.v[e] + y * c.v[e] : x * a.v[e];   // g conj(u)
+        di.v[e] = y * a.v[e] - x * c.v[e];
       }
-    } else {
-      if (tr) sr += x * io<T>::ld(tr + e);
-      if (dtr) io<T>::st(dtr + e, x * a);
+      IO::st(dtr + e0, dr);
+      if (CPLX) IO::st(dti + e0, di);
     }
   }
   if (dur) {
-    io<T>::st(dur + p, sr);
-    if (CPLX) io<T>::st(dui + p, usign * si);   // x1 = conj?(u)
+    auto o_r = a, o_i = a;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { o_r.v[e] = sr[e]; o_i.v[e] = usign * si[e]; }   // x1 = conj?(u)
+    IO::st(dur + p, o_r);
+    if (CPLX) IO::st(dui + p, o_i);
   }
+}
+
+template <typename T>
+static bool vec4_ok(int I1, std::initializer_list<const void*> ptrs) {
+  if (I1 & 3) return false;
+  for (const void* q : ptrs)
+    if (q && (reinterpret_cast<uintptr_t>(q) & (4 * sizeof(T) - 1))) return false;
+  return true;
 }
 
 template <typename T, bool CPLX>
 static int launch_fwd(const void* ur, const void* ui, const void* tr, const void* ti, const float* br,
                       const float* bi, void* yr, void* yi, int64_t rows, int O, int I1, float usign,
                       hipStream_t st) {
-  // group size: the power of two that gives every lane about 4 elements, 4..64
+  const bool v4 = vec4_ok<T>(I1, {ur, ui, tr, ti});
+  const int V = v4 ? 4 : 1;
+  // group size: the power of two that gives every lane about two loads, 4..64
   int gs = 4;
-  while (gs < 64 && gs * 4 < I1) gs <<= 1;
-#define GO(GS)                                                                                        \
-  bilinear_reduce_fwd_kernel<T, CPLX, GS><<<stream_grid(rows * GS, kBT), kBT, 0, st>>>(                \
+  while (gs < 64 && gs * V * 2 < I1) gs <<= 1;
+#define GO(GS, VV)                                                                                    \
+  bilinear_reduce_fwd_kernel<T, CPLX, GS, VV><<<stream_grid(rows * GS, kBT), kBT, 0, st>>>(            \
       (const T*)ur, (const T*)ui, (const T*)tr, (const T*)ti, br, bi, (T*)yr, (T*)yi, rows, O, I1, usign)
+#define GOV(GS) do { if (v4) GO(GS, 4); else GO(GS, 1); } while (0)
   switch (gs) {
-    case 4: GO(4); break;
-    case 8: GO(8); break;
-    case 16: GO(16); break;
-    case 32: GO(32); break;
-    default: GO(64); break;
+    case 4: GOV(4); break;
+    case 8: GOV(8); break;
+    case 16: GOV(16); break;
+    case 32: GOV(32); break;
+    default: GOV(64); break;
   }
+#undef GOV
 #undef GO
   CPLXAMD_CHECK_LAUNCH();
   return 0;
@@ -164,14 +222,20 @@ int cplxamd_bilinear_reduce_bwd(const void* ur, const void* ui, const void* tr, 
   hipStream_t st = (hipStream_t)stream;
   const float us = (cplx && conj_u) ? -1.0f : 1.0f;
   const int64_t BI = B * I1;
-  const int grid = (int)((BI + kBT - 1) / kBT);
-#define GO(T, C)                                                                                     \
-  bilinear_reduce_bwd_kernel<T, C><<<grid, kBT, 0, st>>>((const T*)ur, (const T*)ui, (const T*)tr,    \
-                                                         (const T*)ti, (const T*)gr, (const T*)gi,   \
-                                                         (T*)dur, (T*)dui, (T*)dtr, (T*)dti, BI, O, I1, us)
-  if (dtype == CPLXAMD_F32) { if (cplx) GO(float, true); else GO(float, false); }
-  else if (dtype == CPLXAMD_BF16) { if (cplx) GO(bf16_t, true); else GO(bf16_t, false); }
+  // the o loop is serial per thread: 4 elements per thread only when that still leaves >= 4096 blocks
+  const bool wide = BI >= ((int64_t)1 << 22);
+#define GO(T, C, V)                                                                                  \
+  bilinear_reduce_bwd_kernel<T, C, V><<<(int)((BI / V + kBT - 1) / kBT), kBT, 0, st>>>(               \
+      (const T*)ur, (const T*)ui, (const T*)tr, (const T*)ti, (const T*)gr, (const T*)gi, (T*)dur,   \
+      (T*)dui, (T*)dtr, (T*)dti, BI, O, I1, us)
+#define GOV(T, C)                                                                                    \
+  do {                                                                                               \
+    if (wide && vec4_ok<T>(I1, {ur, ui, tr, ti, dur, dui, dtr, dti})) GO(T, C, 4); else GO(T, C, 1);         \
+  } while (0)
+  if (dtype == CPLXAMD_F32) { if (cplx) GOV(float, true); else GOV(float, false); }
+  else if (dtype == CPLXAMD_BF16) { if (cplx) GOV(bf16_t, true); else GOV(bf16_t, false); }
   else return CPLXAMD_EINVAL;
+#undef GOV
 #undef GO
   CPLXAMD_CHECK_LAUNCH();
   return 0;

@@ -77,6 +77,17 @@ def main():
     print(f"cast f32->bf16 4096^2: {t*1e6:.1f} us {6*w.numel()/t/1e9:.0f} GB/s")
     t = timeit(lambda: ops.colsum(x))
     print(f"colsum bf16 8192x4096: {t*1e6:.1f} us {x.numel()*2/t/1e9:.0f} GB/s")
+    print("== bilinear reduction (T = [B, O, I1] complex) ==")
+    for dt, nb in ((torch.float32, 4), (torch.bfloat16, 2)):
+        for (B, O, I1) in [(8192, 256, 64), (65536, 64, 16), (1024, 256, 512)]:
+            u = [torch.randn(B, I1, device=dev).to(dt) for _ in range(2)]
+            tt = [torch.randn(B, O * I1, device=dev).to(dt) for _ in range(2)]
+            g = [torch.randn(B, O, device=dev).to(dt) for _ in range(2)]
+            tf = timeit(lambda: ops.bilinear_reduce_fwd(u, tt, None, B, O, I1, True))
+            tb = timeit(lambda: ops.bilinear_reduce_bwd(u, tt, g, B, O, I1, True))
+            n = B * O * I1
+            print(f"bilinear_reduce {dt} B={B} O={O} I1={I1}: fwd {tf*1e6:.1f} us {2*nb*n/tf/1e9:.0f} GB/s | "
+                  f"bwd {tb*1e6:.1f} us {4*nb*n/tb/1e9:.0f} GB/s")
 
 
 if __name__ == "__main__":
