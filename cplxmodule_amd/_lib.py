@@ -10,7 +10,7 @@ from ctypes import c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcplxamd.so")
+LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
 ABI_VERSION = 1
 
 F32, BF16 = 0, 1
