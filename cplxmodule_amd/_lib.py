@@ -36,6 +36,7 @@ SIGNATURES = {
     "cplxamd_philox_normal": [_P, _P, _U, _U, _L, _P],
     "cplxamd_cgemm": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,
                       _I, _I, _I, _P, _L, _P],
+    "cplxamd_cgemm_batched": [_P, _P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
     "cplxamd_cplx_maxpool2d_fwd": [_P, _P, _P, _P, _P, _P, _I, _P],

@@ -324,12 +324,38 @@ def matmul(u, v):
         raise CplxAmdError("batched complex matmul needs identical batch dimensions")
     batch = ur.shape[:-2]
     M, K, N = ur.shape[-2], ur.shape[-1], vr.shape[-1]
-    outs = [_MatmulFn.apply(a.contiguous(), b.contiguous(), c.contiguous(), d.contiguous())
-            for a, b, c, d in zip(ur.reshape(-1, M, K), ui.reshape(-1, M, K),
-                                  vr.reshape(-1, K, N), vi.reshape(-1, K, N))]
-    yr = torch.stack([o[0] for o in outs]).view(*batch, M, N)
-    yi = torch.stack([o[1] for o in outs]).view(*batch, M, N)
-    return Cplx(yr, yi)
+    flat = [t.reshape(-1, *t.shape[-2:]).contiguous() for t in (ur, ui, vr, vi)]
+    nb = flat[0].shape[0]
+    if nb > 65535:                                     # grid.z limit of the batched launch
+        parts = [_BatchedMatmulFn.apply(*(t[lo:lo + 65535] for t in flat)) for lo in range(0, nb, 65535)]
+        yr, yi = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    else:
+        yr, yi = _BatchedMatmulFn.apply(*flat)
+    return Cplx(yr.view(*batch, M, N), yi.view(*batch, M, N))
+
+
+class _BatchedMatmulFn(torch.autograd.Function):
+    """[Z, M, K] @ [Z, K, N] in one batched launch of the generic complex GEMM (blockIdx.z = entry)."""
+
+    @staticmethod
+    def forward(ctx, ar, ai, vr, vi):
+        Z, M, K = ar.shape
+        N = vr.shape[2]
+        if ar.dtype != vr.dtype:
+            raise CplxAmdError("matmul operands must share a dtype")
+        ctx.save_for_backward(ar, ai, vr, vi)
+        return ops.cgemm_batched(ar, ai, (K, 1, M * K), vr, vi, (1, N, K * N), Z, M, N, K)
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        ar, ai, vr, vi = ctx.saved_tensors
+        Z, M, K = ar.shape
+        N = vr.shape[2]
+        gr, gi = gr.contiguous(), gi.contiguous()
+        # dA[m,k] = sum_n G[m,n] conj(V[k,n]);  dV[k,n] = conj(sum_m A[m,k] conj(G[m,n]))
+        dar, dai = ops.cgemm_batched(gr, gi, (N, 1, M * N), vr, vi, (N, 1, K * N), Z, M, K, N, conj_b=True)
+        tr, ti = ops.cgemm_batched(ar, ai, (1, K, M * K), gr, gi, (1, N, M * N), Z, K, N, M, conj_b=True)
+        return dar, dai, tr, -ti
 
 
 class _MatmulFn(torch.autograd.Function):

@@ -20,6 +20,8 @@ struct GemmArgs {
   // dense fp32 slabs t1 = Ar Br and T2 = Ai Bi the epilogue stores
   //   c_r = t1 - gsign T2 + bias_r,   c_i = t3 - t1 - gsign T2 + bias_i      (gsign = -1: conj(B))
   const float* g1 = nullptr; const float* g2 = nullptr; float gsign = 1.0f;
+  // batched (generic kernel only): blockIdx.z = batch entry, operands advance by these element strides
+  int batch = 1; int64_t a_bs = 0, b_bs = 0, c_bs = 0;
 };
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)

@@ -39,6 +39,19 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
   return launch_gemm_generic<true>(g, in_dtype, out_dtype, st);
 }
 
+int cplxamd_cgemm_batched(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs, int64_t a_bs,
+                          const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs, int64_t b_bs,
+                          void* c_r, void* c_i, int64_t ldc, int64_t c_bs, int batch, int M, int N, int K,
+                          int conj_b, int in_dtype, int out_dtype, void* stream) {
+  if (!a_r || !a_i || !b_r || !b_i || !c_r || !c_i) return CPLXAMD_EINVAL;
+  if (batch < 0 || M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
+  if (batch == 0) return 0;
+  GemmArgs g{a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, nullptr, nullptr, nullptr,
+             c_r, c_i, ldc, M, N, K, conj_b ? 1 : 0, 0};
+  g.batch = batch; g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;
+  return launch_gemm_generic<true>(g, in_dtype, out_dtype, (hipStream_t)stream);
+}
+
 int cplxamd_rgemm(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
                   int64_t b_cs, const float* bias, const float* emul, void* c, int64_t ldc,
                   int M, int N, int K, int in_dtype, int out_dtype, int accumulate,

@@ -94,13 +94,19 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(GemmArgs g) {
     kb = blockIdx.z * g.kchunk;
     ke = kb + g.kchunk < g.K ? kb + g.kchunk : g.K;
   }
+  // batched launch: blockIdx.z is the batch entry (split-K is off then)
+  const int64_t bz = g.batch > 1 ? blockIdx.z : 0;
+  const TIN* pa_r = reinterpret_cast<const TIN*>(g.a_r) + bz * g.a_bs;
+  const TIN* pb_r = reinterpret_cast<const TIN*>(g.b_r) + bz * g.b_bs;
+  const TIN* pa_i = CPLX ? reinterpret_cast<const TIN*>(g.a_i) + bz * g.a_bs : nullptr;
+  const TIN* pb_i = CPLX ? reinterpret_cast<const TIN*>(g.b_i) + bz * g.b_bs : nullptr;
   TileRegs ra, rb, rai, rbi;
   auto fetch = [&](int k0) {
-    ra = fetch_tile<TIN>(g.a_r, g.a_rs, g.a_cs, m0, k0, g.M, ke);
-    rb = fetch_tile<TIN>(g.b_r, g.b_rs, g.b_cs, n0, k0, g.N, ke);
+    ra = fetch_tile<TIN>(pa_r, g.a_rs, g.a_cs, m0, k0, g.M, ke);
+    rb = fetch_tile<TIN>(pb_r, g.b_rs, g.b_cs, n0, k0, g.N, ke);
     if (CPLX) {
-      rai = fetch_tile<TIN>(g.a_i, g.a_rs, g.a_cs, m0, k0, g.M, ke);
-      rbi = fetch_tile<TIN>(g.b_i, g.b_rs, g.b_cs, n0, k0, g.N, ke);
+      rai = fetch_tile<TIN>(pa_i, g.a_rs, g.a_cs, m0, k0, g.M, ke);
+      rbi = fetch_tile<TIN>(pb_i, g.b_rs, g.b_cs, n0, k0, g.N, ke);
     }
   };
   if (kb < ke) fetch(kb);
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(GemmArgs g) {
   }
 
   // C/D layout of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
-  TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
+  TOUT* cr = reinterpret_cast<TOUT*>(g.c_r) + bz * g.c_bs;
+  TOUT* ci = reinterpret_cast<TOUT*>(g.c_i) + (CPLX ? bz * g.c_bs : 0);
   float* slab = g.splits > 1 ? reinterpret_cast<float*>(g.ws) + (int64_t)blockIdx.z * (CPLX ? 2 : 1) * g.M * g.N
                              : nullptr;   // fp32 partial slabs [split][plane][M][N]; bias / emul / accumulate: the reducer
 #pragma unroll
@@ -222,12 +228,13 @@ int launch_gemm_generic(const GemmArgs& g0, int in_dtype, int out_dtype, hipStre
   if (g0.M <= 0 || g0.N <= 0) return 0;
   GemmArgs g = g0;
   g.splits = 1;
-  const int want = gemm_generic_splits(g.M, g.N, g.K);
+  const int want = g.batch > 1 ? 1 : gemm_generic_splits(g.M, g.N, g.K);
   if (want > 1 && g.ws && g.ws_bytes >= gemm_generic_ws_bytes(g.M, g.N, g.K, CPLX)) {
     g.splits = want;
     g.kchunk = (((g.K + GBK - 1) / GBK + want - 1) / want) * GBK;   // whole K tiles, covers the tail
   }
-  dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.splits);
+  if (g.batch > 65535) return CPLXAMD_ESHAPE;
+  dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, g.batch > 1 ? g.batch : g.splits);
   constexpr int smem = 2 * (CPLX ? 4 : 2) * GPLANE * (int)sizeof(float);
   auto go = [&](auto kern) -> int {
     if (smem > 64 * 1024) {

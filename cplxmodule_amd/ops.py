@@ -145,6 +145,17 @@ def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False
     return cr, ci
 
 
+def cgemm_batched(ar, ai, a_strides, br, bi, b_strides, batch, M, N, K, conj_b=False, out_dtype=None):
+    """`batch` complex products A[z] B[z]^T in one launch; *_strides = (row, col, batch) in elements."""
+    require_device(ar, ai, br, bi)
+    odt = out_dtype or ar.dtype
+    cr = torch.empty(batch, M, N, dtype=odt, device=ar.device)
+    ci = torch.empty_like(cr)
+    call("cplxamd_cgemm_batched", ptr(ar), ptr(ai), *a_strides, ptr(br), ptr(bi), *b_strides, ptr(cr),
+         ptr(ci), N, M * N, batch, M, N, K, int(conj_b), dtype_code(ar), dtype_code(cr), stream_ptr())
+    return cr, ci
+
+
 def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=torch.float32,
           out=None):
     require_device(a, b, bias, emul)

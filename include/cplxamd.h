@@ -165,6 +165,14 @@ int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
  * (no split-K).  With split-K the float32 result is a sum of per-split partial sums. */
 int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype);
 
+/* Batched complex GEMM (Cplx.__matmul__ on [..., M, K] @ [..., K, N], cplx.py:167-181): `batch`
+ * independent products in ONE launch of the exact-f32 MFMA kernel (any strides, any dtype pair);
+ * entry z reads A + z*a_bs, B + z*b_bs and writes C + z*c_bs (strides in elements).  batch <= 65535. */
+int cplxamd_cgemm_batched(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs, int64_t a_bs,
+                          const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs, int64_t b_bs,
+                          void* c_r, void* c_i, int64_t ldc, int64_t c_bs, int batch, int M, int N, int K,
+                          int conj_b, int in_dtype, int out_dtype, void* stream);
+
 /* real GEMM; emul (nullable, float32 [M,N] with leading dimension ldc): C = (A B^T) * emul. */
 int cplxamd_rgemm(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
                   int64_t b_cs, const float* bias, const float* emul, void* c, int64_t ldc,

@@ -51,6 +51,31 @@ def test_matmul_golden(golden, pkg):
     np.testing.assert_allclose(N(m2.imag), g[k + "mi"][0], **_scale_tol(g[k + "mi"], 1e-5))
 
 
+@pytest.mark.parametrize("batch,M,K,N_", [((3, 5), 17, 9, 6), ((70,), 130, 40, 129), ((1,), 1, 1, 1)])
+def test_batched_matmul_and_grads(pkg, batch, M, K, N_):
+    """Cplx.__matmul__ on [..., M, K] @ [..., K, N]: ONE batched launch; values and gradients against
+    complex128 numpy."""
+    from gpu_util import T, N
+    from cplxmodule_amd import cplx
+    rs = np.random.RandomState(M + K)
+    u = rs.randn(*batch, M, K) + 1j * rs.randn(*batch, M, K)
+    v = rs.randn(*batch, K, N_) + 1j * rs.randn(*batch, K, N_)
+    g = rs.randn(*batch, M, N_) + 1j * rs.randn(*batch, M, N_)
+    f = lambda a: T(np.ascontiguousarray(a).astype(np.float32)).requires_grad_(True)  # noqa: E731
+    ur, ui, vr, vi = f(u.real), f(u.imag), f(v.real), f(v.imag)
+    m = cplx.Cplx(ur, ui) @ cplx.Cplx(vr, vi)
+    ref = u @ v
+    assert m.shape == ref.shape
+    np.testing.assert_allclose(N(m.real), ref.real, **_scale_tol(ref.real, 2e-5))
+    np.testing.assert_allclose(N(m.imag), ref.imag, **_scale_tol(ref.imag, 2e-5))
+    import torch
+    torch.autograd.backward((m.real, m.imag), (T(g.real.astype(np.float32)), T(g.imag.astype(np.float32))))
+    du = g @ np.conj(np.swapaxes(v, -1, -2))            # dU = G V^H, dV = U^H G (planar convention)
+    dv = np.conj(np.swapaxes(u, -1, -2)) @ g
+    for got, want in ((ur.grad, du.real), (ui.grad, du.imag), (vr.grad, dv.real), (vi.grad, dv.imag)):
+        np.testing.assert_allclose(N(got), want, **_scale_tol(want, 3e-5))
+
+
 @pytest.mark.parametrize("M,N_,K", [(128, 128, 32), (256, 384, 64), (200, 136, 96), (1, 5, 32),
                                     (130, 130, 160), (64, 64, 40), (33, 17, 7),
                                     (128, 128, 4096), (260, 132, 2048)])  # last two: split-K
