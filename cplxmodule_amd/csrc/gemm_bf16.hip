@@ -46,10 +46,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32, NT = 512;
-#ifndef CPLXAMD_REAL_STAGES
-#define CPLXAMD_REAL_STAGES 3
-#endif
+constexpr int BK = 32, NT = 512, STAGES = 3;
 
 // complex: 256 x 128 tile, 4 x 2 waves of 64 x 64 (2 x 2 MFMA tiles x {re, im} = 128 accumulators);
 // real: 256 x 256 tile, 2 x 4 waves of 128 x 64 (4 x 2 MFMA tiles = 128 accumulators) -- with one
@@ -62,11 +59,9 @@ struct Cfg {
   static constexpr int BM = 32 * IB * WM, BN = 64 * WN;
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
-  // ring slots: 3 x 48 KiB for the complex tile.  The real tile's stages are 32 KiB, so a fourth
-  // slot fits in the 160 KiB (-DCPLXAMD_REAL_STAGES=4): measured equal within noise (0.306 / 0.314 /
-  // 0.287 ms vs 0.312 / 0.309 / 0.284 ms on the three LRT variance GEMMs), so 3 it stays
-  static constexpr int NS = CPLX ? 3 : CPLXAMD_REAL_STAGES;
-  static constexpr int SMEM = NS * STAGE_BYTES;
+  // (a fourth 32 KiB slot for the real tile fits in 160 KiB; a ring generalised to NS slots measured
+  //  no gain with 4 slots and cost the real kernel 2-5 % with 3 -- profiles/r01_gemm_variants.md)
+  static constexpr int SMEM = STAGES * STAGE_BYTES;
   static constexpr int PA = BM * 4 / NT, PB = BN * 4 / NT;     // LDS-DMA pieces per plane
   static constexpr int LOADS = (CPLX ? 2 : 1) * (PA + PB);      // ... per thread per K tile
 };
@@ -281,9 +276,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
     // Rolling half-tile pipeline: the barrier sits in the MIDDLE of a tile, when the wave still
     // holds the fragments of the tile's second K sub-step in registers, so the MFMA pipe keeps
     // running across the barrier and across the LDS latency of the next tile's first fragments.
-    //   S1 read F[1] <- (tile t, ks 1)           S2 16 MFMAs on F[0] + second half of tile t+NS-1's pieces
+    //   S1 read F[1] <- (tile t, ks 1)           S2 16 MFMAs on F[0] + second half of tile t+2's pieces
     //   S3 lgkmcnt(0), vmcnt (tile t+1 landed), s_barrier   (slot of tile t is free: all in registers)
-    //   S4 read F[0] <- (tile t+1, ks 0)         S5 16 MFMAs on F[1] + first half of tile t+NS's pieces
+    //   S4 read F[0] <- (tile t+1, ks 0)         S5 16 MFMAs on F[1] + first half of tile t+3's pieces
     bf16x8 ar[2][IB], br[2][2], ai[2][IB], bi[2][2];         // [ks][block]
     auto read_half = [&](int buf, int ks) {
       const char* sA = smem + buf * C::STAGE_BYTES;
@@ -335,29 +330,26 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
           }
         }
     };
-    constexpr int NS = C::NS;
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-      if (nt > s) stage_all(s, s * BK);
-    if (nt >= NS - 1) wait_vmcnt<(NS - 2) * C::LOADS>(); else wait_vmcnt<0>();
+    stage_all(0, 0);
+    if (nt > 1) stage_all(1, BK);
+    if (nt > 1) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     read_half(0, 0);
-    if (nt > NS - 1 && !(g.dbg & 1)) {
+    if (nt > 2 && !(g.dbg & 1)) {
 #pragma unroll
-      for (int q = 0; q < H; ++q) stage_q(NS - 1, (NS - 1) * BK, q);
+      for (int q = 0; q < H; ++q) stage_q(2, 2 * BK, q);
     }
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
-      const int nx1 = cur + 1 == NS ? 0 : cur + 1;
-      const int last = cur == 0 ? NS - 1 : cur - 1;           // slot of tile t + NS - 1
+      const int nx1 = cur + 1 == 3 ? 0 : cur + 1;
+      const int nx2 = nx1 + 1 == 3 ? 0 : nx1 + 1;
       read_half(cur, 1);                                      // S1
-      mfma_half(0, last, t + NS - 1, H, C::LOADS);            // S2
+      mfma_half(0, nx2, t + 2, H, C::LOADS);                  // S2
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // S3: this wave's F[1] is in registers
-      // tile t+1 landed; tiles t+2 .. t+NS-1 may stay in flight
-      if ((g.dbg & 1) || t + NS - 1 >= nt) wait_vmcnt<0>(); else wait_vmcnt<(NS - 2) * C::LOADS>();
+      if ((g.dbg & 1) || t + 2 >= nt) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();
       if (!(g.dbg & 4)) __builtin_amdgcn_s_barrier();
       if (t + 1 < nt) read_half(nx1, 0);                      // S4
-      mfma_half(1, cur, t + NS, 0, H);                        // S5 (slot of tile t is free now)
+      mfma_half(1, cur, t + 3, 0, H);                         // S5 (slot of tile t is free now)
       cur = nx1;
     }
   }
