@@ -582,3 +582,83 @@ def cplx_conv1d_lrt(layer, input, eps=None):
 
 def real_conv1d_layer(layer, input, eps=None):
     return _down(real_conv2d_layer(_Lift1d(layer), _up(input), None if eps is None else _up(eps)))
+
+
+# ------------------------------------------------------------------------------------------ #
+#  transposed convolution = the data-gradient kernels run forward                              #
+# ------------------------------------------------------------------------------------------ #
+def _transpose_out_shape(x_shape, w_shape, stride, padding, output_padding, dilation, groups):
+    B, Cin, H, W = x_shape
+    _, Cog, KH, KW = w_shape
+    (sh, sw), (ph, pw), (oh, ow), (dh, dw) = (_pair(v) for v in (stride, padding, output_padding, dilation))
+    return (B, Cog * groups, (H - 1) * sh - 2 * ph + dh * (KH - 1) + oh + 1,
+            (W - 1) * sw - 2 * pw + dw * (KW - 1) + ow + 1)
+
+
+class CplxConvTranspose2dFn(torch.autograd.Function):
+    """y = x (*)^T W + b without conjugation (cplx.conv_transposend_naive, cplxmodule/cplx.py:860-873).
+    The transposed correlation IS the adjoint of `Conv_V`, which the dgrad kernels compute as
+    g -> g (*)^T conj(V); with V = conj(W) that is the forward pass here.  Backward, by the same
+    adjointness:  dx = Conv_V(gy) (the forward conv kernels),  dV = wgrad(g_out = x, input = gy),
+    dW = conj(dV),  db = sum gy."""
+
+    @staticmethod
+    def forward(ctx, xr, xi, wr, wi, br, bi, stride, padding, output_padding, dilation, groups):
+        require_device(xr, xi, wr, wi, br, bi)
+        xr, xi = xr.contiguous(), xi.contiguous()
+        if wr.shape[0] != xr.shape[1]:
+            raise ValueError(f"expected {wr.shape[0]} input channels, got {xr.shape[1]}")
+        yshape = _transpose_out_shape(xr.shape, wr.shape, stride, padding, output_padding, dilation, groups)
+        geom, oshape = _geom(yshape, wr.shape, stride, padding, dilation, groups)
+        if tuple(oshape) != tuple(xr.shape):
+            raise ValueError("output_padding must be smaller than either stride or dilation")
+        vr, vi = ops.cast(wr.contiguous(), xr.dtype), ops.cast((-wi).contiguous(), xr.dtype)
+        yr, yi = conv_dgrad(xr, xi, vr, vi, geom, yshape)
+        if br is not None:
+            yr, yi = yr + br.view(1, -1, 1, 1).to(yr.dtype), yi + bi.view(1, -1, 1, 1).to(yi.dtype)
+        ctx.save_for_backward(xr, xi, vr, vi)
+        ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, br is not None, wr.shape, xr.shape
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        xr, xi, vr, vi = ctx.saved_tensors
+        gr, gi = gr.contiguous(), gi.contiguous()
+        need = ctx.needs_input_grad
+        dxr = dxi = dwr = dwi = dbr = dbi = None
+        if need[0] or need[1]:
+            dxr, dxi = conv_fwd(gr, gi, vr, vi, None, None, ctx.geom, ctx.xshape)
+        if need[2] or need[3]:
+            dwr, dvi = conv_wgrad(xr, xi, gr, gi, ctx.geom, ctx.wshape)
+            dwi = -dvi
+        if ctx.has_bias and (need[4] or need[5]):
+            dbr, dbi = chansum(gr), chansum(gi)
+        return (dxr, dxi, dwr, dwi, dbr, dbi) + (None,) * 5
+
+
+def cplx_conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1,
+                          dilation=1, padding_mode="zeros"):
+    xr, xi = input.real, input.imag
+    if padding_mode == "circular":     # the reference pads the INPUT circularly, then runs padding 0
+        xr, xi, padding = _circular_pad(xr, padding), _circular_pad(xi, padding), 0
+    elif padding_mode != "zeros":
+        raise ValueError("padding_mode must be 'zeros' or 'circular'.")
+    br, bi = (None, None) if bias is None else (bias.real, bias.imag)
+    yr, yi = CplxConvTranspose2dFn.apply(xr, xi, weight.real, weight.imag, br, bi, stride, padding,
+                                         output_padding, dilation, groups)
+    return Cplx(yr, yi)
+
+
+def cplx_conv_transpose1d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1,
+                          dilation=1, padding_mode="zeros"):
+    if padding_mode == "circular":
+        p = _one(padding)
+        pads = ((p + 1) // 2, p // 2)
+        input = Cplx(F.pad(input.real, pads, mode="circular"), F.pad(input.imag, pads, mode="circular"))
+        padding = 0
+    elif padding_mode != "zeros":
+        raise ValueError("padding_mode must be 'zeros' or 'circular'.")
+    w2 = Cplx(weight.real.unsqueeze(2), weight.imag.unsqueeze(2))
+    y = cplx_conv_transpose2d(_up(input), w2, bias, (1, _one(stride)), (0, _one(padding)),
+                              (0, _one(output_padding)), groups, (1, _one(dilation)))
+    return _down(y)

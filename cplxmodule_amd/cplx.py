@@ -404,6 +404,23 @@ def conv3d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
     return cplx_conv3d(input, weight, bias, stride, padding, dilation, groups, padding_mode)
 
 
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1,
+                     dilation=1, padding_mode="zeros"):
+    """Complex 2-d transposed convolution, weight [in, out / groups, kh, kw], no conjugation
+    (cplxmodule/cplx.py:860-1001; the reference's functional default `groups=0` is not kept).  Runs
+    the data-gradient kernels of conv2d as the forward pass."""
+    from . import conv
+    return conv.cplx_conv_transpose2d(input, weight, bias, stride, padding, output_padding, groups,
+                                      dilation, padding_mode)
+
+
+def conv_transpose1d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1,
+                     dilation=1, padding_mode="zeros"):
+    from . import conv
+    return conv.cplx_conv_transpose1d(input, weight, bias, stride, padding, output_padding, groups,
+                                      dilation, padding_mode)
+
+
 def from_interleaved_real(input, copy=True, dim=-1):
     """[..., 2D] interleaved (re, im) -> Cplx [..., D]  (cplxmodule/cplx.py:451-455).  copy=True along
     the last dim on the GPU is one de-interleaving kernel pass (csrc/layout.hip) instead of two

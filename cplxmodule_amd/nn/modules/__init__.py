@@ -3,6 +3,7 @@ from .linear import CplxLinear, CplxBilinear  # noqa: F401
 from .linear import CplxReal, CplxImag, CplxIdentity, CplxPhaseShift  # noqa: F401
 from .container import CplxSequential  # noqa: F401
 from .conv import CplxConv1d, CplxConv2d, CplxConv3d  # noqa: F401
+from .conv import CplxConvTranspose1d, CplxConvTranspose2d  # noqa: F401
 from .batchnorm import CplxBatchNorm1d, CplxBatchNorm2d, CplxBatchNorm3d  # noqa: F401
 from .casting import AsTypeCplx, TensorToCplx, CplxToTensor  # noqa: F401
 from .casting import InterleavedRealToCplx, ConcatenatedRealToCplx  # noqa: F401

@@ -113,3 +113,66 @@ class CplxConv3d(CplxConv2d):
     def forward(self, input):
         return cplx.conv3d(input, self.weight, self.bias, self.stride, self.padding,
                            self.dilation, self.groups, self.padding_mode)
+
+
+class CplxConvTranspose2d(CplxConv2d):
+    """Complex transposed convolution; weight [in, out / groups, kh, kw].  Constructor as the
+    reference's (conv.py:348-380; note its default `bias=None`, i.e. no bias unless asked for).
+    `forward(input, output_size=None)` resolves the output padding like torch's ConvTranspose2d
+    (the reference borrows torch's private helper, whose signature changed in torch 2)."""
+    _nd = 2
+    _fn = staticmethod(cplx.conv_transpose2d)
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 output_padding=0, groups=1, bias=None, padding_mode="zeros"):
+        CplxToCplx.__init__(self)
+        if padding_mode not in ("zeros", "circular"):
+            raise ValueError(f'Only "zeros" or "circular" padding mode are supported by `{type(self).__name__}`')
+        if in_channels % groups != 0:
+            raise ValueError("in_channels must be divisible by groups")
+        if out_channels % groups != 0:
+            raise ValueError("out_channels must be divisible by groups")
+        tup = _pair if self._nd == 2 else _single
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = tup(kernel_size), tup(stride)
+        self.padding, self.dilation = tup(padding), tup(dilation)
+        self.transposed, self.output_padding = True, tup(output_padding)
+        self.groups, self.padding_mode = groups, padding_mode
+        self.weight = CplxParameter(
+            cplx.Cplx.empty(in_channels, out_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = CplxParameter(cplx.Cplx.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def _resolve_output_padding(self, input, output_size):
+        if output_size is None:
+            return self.output_padding
+        want = list(output_size)[-self._nd:]
+        pads = []
+        for n, size in enumerate(want):
+            L = input.shape[2 + n]
+            lo = (L - 1) * self.stride[n] - 2 * self.padding[n] + self.dilation[n] * (self.kernel_size[n] - 1) + 1
+            hi = lo + max(self.stride[n], self.dilation[n]) - 1
+            if not lo <= size <= hi:
+                raise ValueError(f"requested an output size of {tuple(want)}, but valid sizes of dim {n} "
+                                 f"range from {lo} to {hi}")
+            pads.append(size - lo)
+        return tuple(pads)
+
+    def forward(self, input, output_size=None):
+        return type(self)._fn(input, self.weight, self.bias, self.stride, self.padding,
+                              self._resolve_output_padding(input, output_size), self.groups,
+                              self.dilation, self.padding_mode)
+
+    def extra_repr(self):
+        s = super().extra_repr()
+        if any(self.output_padding):
+            s += f", output_padding={self.output_padding}"
+        return s
+
+
+class CplxConvTranspose1d(CplxConvTranspose2d):
+    _nd = 1
+    _fn = staticmethod(cplx.conv_transpose1d)

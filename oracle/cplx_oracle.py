@@ -157,6 +157,45 @@ def lrt_real_linear_bwd(g, x, w, log_sigma2, eps, has_bias=True):
 
 
 # --------------------------------------------------------------------------- #
+#  transposed convolution                                                     #
+# --------------------------------------------------------------------------- #
+def _convt_out_shape(x_shape, w_shape, stride, padding, output_padding, dilation, groups):
+    (sh, sw), (ph, pw), (oh, ow), (dh, dw) = (_pair(v) for v in (stride, padding, output_padding, dilation))
+    B, _, H, W = x_shape
+    _, Cog, kh, kw = w_shape
+    return (B, Cog * groups, (H - 1) * sh - 2 * ph + dh * (kh - 1) + oh + 1,
+            (W - 1) * sw - 2 * pw + dw * (kw - 1) + ow + 1)
+
+
+def real_conv_transpose2d(x, w, stride=1, padding=0, output_padding=0, dilation=1, groups=1):
+    """torch.nn.functional.conv_transpose2d = the adjoint (input gradient) of conv2d with the same
+    weight, evaluated at x; weight [Cin, Cout / groups, kh, kw]."""
+    yshape = _convt_out_shape(x.shape, w.shape, stride, padding, output_padding, dilation, groups)
+    return real_conv2d_bwd(x, np.zeros(yshape, x.dtype), w, stride, padding, dilation, groups)[0]
+
+
+def cplx_conv_transpose2d(xr, xi, wr, wi, br=None, bi=None, stride=1, padding=0, output_padding=0,
+                          dilation=1, groups=1):
+    """cplx.conv_transposend_naive + bias, cplxmodule/cplx.py:860-873, 937-943 (no conjugation)."""
+    t = lambda x, w: real_conv_transpose2d(x, w, stride, padding, output_padding, dilation, groups)  # noqa: E731
+    re, im = t(xr, wr) - t(xi, wi), t(xr, wi) + t(xi, wr)
+    if br is not None:
+        re, im = re + br.reshape(-1, 1, 1), im + bi.reshape(-1, 1, 1)
+    return re, im
+
+
+def cplx_conv_transpose2d_bwd(gr, gi, xr, xi, wr, wi, stride=1, padding=0, output_padding=0, dilation=1,
+                              groups=1):
+    """T_w is the adjoint of Conv_w, so d/dx is Conv_w of the output gradient and d/dw is the conv
+    weight gradient with the roles (output gradient, input) = (x, g)."""
+    c = lambda g, w: real_conv2d(g, w, stride, padding, dilation, groups)  # noqa: E731
+    wg = lambda x, g: real_conv2d_bwd(x, g, wr, stride, padding, dilation, groups)[1]  # noqa: E731
+    return dict(dxr=c(gr, wr) + c(gi, wi), dxi=c(gi, wr) - c(gr, wi),
+                dwr=wg(xr, gr) + wg(xi, gi), dwi=wg(xr, gi) - wg(xi, gr),
+                dbr=gr.sum((0, 2, 3)), dbi=gi.sum((0, 2, 3)))
+
+
+# --------------------------------------------------------------------------- #
 #  3-d convolution / pooling                                                  #
 # --------------------------------------------------------------------------- #
 def _triple(v):

@@ -559,6 +559,35 @@ def gen_conv3d():
     save("conv3d", d)
 
 
+def gen_conv_transpose():
+    """cplx.conv_transpose2d / conv_transpose1d (functional; the reference LAYER does not run on
+    torch >= 2, its functional does): values + autograd gradients."""
+    from gen_golden_cases import CONVT_CASES
+    d = {}
+    for tag, dt in DT.items():
+        for name, c in CONVT_CASES.items():
+            torch.manual_seed(51)
+            xr, xi = leaf(*c["x"], dtype=dt), leaf(*c["x"], dtype=dt)
+            wr, wi = leaf(*c["w"], dtype=dt, scale=0.3), leaf(*c["w"], dtype=dt, scale=0.3)
+            co = c["w"][1] * c["kw"]["groups"]
+            br, bi = leaf(co, dtype=dt), leaf(co, dtype=dt)
+            y = cplx.conv_transpose2d(C(xr, xi), C(wr, wi), C(br, bi), **c["kw"])
+            gr, gi = torch.randn_like(y.real), torch.randn_like(y.imag)
+            grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), [xr, xi, wr, wi, br, bi])
+            k = f"{tag}_{name}_"
+            for nm, t in dict(xr=xr, xi=xi, wr=wr, wi=wi, br=br, bi=bi, gr=gr, gi=gi, yr=y.real, yi=y.imag).items():
+                d[k + nm] = npy(t)
+            for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi"], grads):
+                d[k + nm] = npy(g)
+        torch.manual_seed(52)
+        xr, xi = leaf(2, 3, 9, dtype=dt), leaf(2, 3, 9, dtype=dt)
+        wr, wi = leaf(3, 4, 4, dtype=dt, scale=0.3), leaf(3, 4, 4, dtype=dt, scale=0.3)
+        y = cplx.conv_transpose1d(C(xr, xi), C(wr, wi), None, stride=2, padding=1, output_padding=1, groups=1)
+        for nm, t in dict(xr=xr, xi=xi, wr=wr, wi=wi, yr=y.real, yi=y.imag).items():
+            d[f"{tag}_1d_{nm}"] = npy(t)
+    save("conv_transpose", d)
+
+
 def gen_extras():
     """layout converters, modReLU (+ learnable thresholds), CplxDropout."""
     from cplxmodule.nn import CplxModReLU, CplxAdaptiveModReLU, CplxDropout  # noqa: F401
@@ -670,6 +699,6 @@ def gen_extras():
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reproducible summation order
     gens = dict(linear=gen_linear, lrt_linear=gen_lrt_linear, penalty=gen_penalty, conv=gen_conv,
-                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear, conv3d=gen_conv3d)
+                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear, conv3d=gen_conv3d, conv_transpose=gen_conv_transpose)
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

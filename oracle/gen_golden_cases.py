@@ -23,3 +23,12 @@ POOL3D_CASES = {
     "mixed": dict(kernel_size=(2, 3, 2), stride=(1, 2, 2), padding=(0, 1, 1), dilation=(2, 1, 1)),
     "ceil": dict(kernel_size=(2, 3, 2), stride=(2, 2, 3), ceil_mode=True),
 }
+
+CONVT_CASES = {
+    # name: x shape, w shape [Cin, Cout / groups, kh, kw], kwargs of cplx.conv_transpose2d
+    "base": dict(x=(2, 4, 5, 6), w=(4, 3, 3, 3), kw=dict(groups=1)),
+    "s2op1": dict(x=(2, 3, 6, 5), w=(3, 5, 3, 3), kw=dict(stride=2, padding=1, output_padding=1, groups=1)),
+    "mixed": dict(x=(1, 4, 7, 4), w=(4, 2, 2, 3), kw=dict(stride=(1, 3), padding=(0, 1), output_padding=(0, 2), groups=1)),
+    "dil": dict(x=(2, 2, 5, 5), w=(2, 3, 3, 2), kw=dict(dilation=(2, 3), padding=1, groups=1)),
+    "groups": dict(x=(2, 4, 4, 5), w=(4, 3, 3, 3), kw=dict(groups=2, stride=2, padding=1)),
+}

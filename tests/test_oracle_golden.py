@@ -412,3 +412,22 @@ def test_oracle_max_pool3d(golden, tag, name):
         for c in range(C):
             np.add.at(dzr[b, c], idx[b, c].reshape(-1), g[k + "gr"][b, c].reshape(-1))
     close(dzr.reshape(zr.shape), g[k + "dzr"], tag, 10)
+
+
+from oracle.gen_golden_cases import CONVT_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("case", list(CONVT_CASES))
+def test_conv_transpose2d(golden, tag, case):
+    g = golden("conv_transpose")
+    k = f"{tag}_{case}_"
+    kw = CONVT_CASES[case]["kw"]
+    a = [g[k + n] for n in ("xr", "xi", "wr", "wi")]
+    yr, yi = orc.cplx_conv_transpose2d(*a, g[k + "br"], g[k + "bi"], **kw)
+    assert yr.shape == g[k + "yr"].shape
+    close(yr, g[k + "yr"], tag, 100)
+    close(yi, g[k + "yi"], tag, 100)
+    bw = orc.cplx_conv_transpose2d_bwd(g[k + "gr"], g[k + "gi"], *a, **kw)
+    for n in ("dxr", "dxi", "dwr", "dwi", "dbr", "dbi"):
+        close(bw[n], g[k + n], tag, 300)
