@@ -29,7 +29,10 @@
 // one stage per tap 3.35 ms; kernel-row stages 2.34 ms; with weights staged through LDS at BK = 16
 // and a 3-stage ring 3.04 ms (32-B rows halve the LDS-DMA efficiency).  On the final structure
 // (1.65 ms): 128 x 32 wave tiles (half the weight-fragment loads) 1.68 ms; A fragments prefetched one
-// tap ahead 2.26 ms (32 spilled registers) -- neither is kept.
+// tap ahead 2.26 ms (32 spilled registers) -- neither is kept.  A single-stage variant with four
+// workgroups per CU (latency covered by occupancy instead of the 2-stage ring) does not exist for the
+// complex kernel: 128 accumulators + 126 other registers = 254 per lane, i.e. 2 waves per SIMD at most
+// (forcing 128 registers spills 750+).
 #include <stdlib.h>
 
 #include <type_traits>
