@@ -33,6 +33,10 @@
 // workgroups per CU (latency covered by occupancy instead of the 2-stage ring) does not exist for the
 // complex kernel: 128 accumulators + 126 other registers = 254 per lane, i.e. 2 waves per SIMD at most
 // (forcing 128 registers spills 750+).
+// Ablation of the final kernel (-DCONV_ABL=1 / 2 / 3, CPLXAMD_CONV_DBG=4; same box, cfg3 B=64 forward,
+// profiles/r01_conv_ablation.md): full 1.675 ms; without the epilogue stores 1.357; without LDS-DMA after
+// the prologue 1.397; without weight re-loads 1.506; with neither (MFMA + ds_read + barriers) 1.227, and
+// 0.856 ms when the stores are dropped too -- the MFMA floor is 0.59 ms at the power-limited clock.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -182,7 +186,10 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
               acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[ks][i], wi_, acc_i[i][j], 0, 0, 0);
             }
           }
-          if (STAGE) {
+#ifndef CONV_ABL
+#define CONV_ABL 0
+#endif
+          if (STAGE && !(CONV_ABL & 1)) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
               if (q < NPC) {
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
           }
         }
       __builtin_amdgcn_sched_barrier(0);
-      load_b(tn, kwn, ks, br[ks], bi[ks]);           // this sub-step's set, for the next tap
+      if (!(CONV_ABL & 2)) load_b(tn, kwn, ks, br[ks], bi[ks]);           // this sub-step's set, for the next tap
       __builtin_amdgcn_sched_barrier(0);
     }
   };
