@@ -11,8 +11,17 @@ import torch
 import torch.distributed as dist
 
 
+# Testing aid: run every collective even in a world of one (exercises the RCCL calls -- AVG,
+# async work handles, broadcast -- on a single-GPU box; tests/dp_gpu_check.py --rccl1).
+FORCE_COLLECTIVES = False
+
+
 def is_initialized():
     return dist.is_available() and dist.is_initialized()
+
+
+def _exchanging():
+    return is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def world():
@@ -49,7 +58,7 @@ class GradBucket:
     def adopt(self):
         """Make every .grad a view into the flat bucket: backward then writes (accumulates)
         straight into it and no gather / scatter copy is needed around the collective."""
-        if not (is_initialized() and dist.get_world_size() > 1):
+        if not _exchanging():
             for p in self.params:          # single process: nothing to exchange, let autograd
                 p.grad = None              # adopt the kernels' output buffers (no extra pass)
             return
@@ -59,7 +68,7 @@ class GradBucket:
 
     def all_reduce_mean(self, async_op=False):
         """In-place mean over ranks of the whole bucket (a no-op for a single process)."""
-        if not is_initialized() or dist.get_world_size() == 1:
+        if not _exchanging():
             return None
         for p, v in zip(self.params, self.views):     # tolerate grads that were re-pointed
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
@@ -97,7 +106,7 @@ def all_reduce_scalar_mean(value):
     """Mean over ranks of a 0-d tensor (the KL term / the loss, for logging and for the sharded
     KL option); returns a new tensor, leaves autograd alone."""
     out = value.detach().clone()
-    if is_initialized() and dist.get_world_size() > 1:
+    if _exchanging():
         dist.all_reduce(out, op=dist.ReduceOp.SUM)
         out /= dist.get_world_size()
     return out
@@ -114,7 +123,7 @@ class DataParallel(torch.nn.Module):
         self.module = module
         self.bucket = GradBucket(module)
         self.hook = None
-        if is_initialized() and dist.get_world_size() > 1:
+        if _exchanging():
             for p in module.parameters():              # replicate rank 0's parameters
                 dist.broadcast(p.data, src=0)
             for b in module.buffers():

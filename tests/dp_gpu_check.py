@@ -1,6 +1,12 @@
 """Functional check of the data-parallel overlap path on ONE GPU shared by 2 gloo ranks:
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/dp_gpu_check.py
-hook-averaged gradients == mean over ranks of the locally computed gradients."""
+hook-averaged gradients == mean over ranks of the locally computed gradients.
+
+    python tests/dp_gpu_check.py --rccl1
+runs the same check in a world of ONE rank on the RCCL backend with the collectives forced on: the
+values are trivially the local ones, but every RCCL call of the data-parallel path (communicator
+set-up bound to the device, ReduceOp.AVG, async work handles, broadcast, scalar all-reduce) is
+issued for real -- the multi-GPU bench launches exactly these calls."""
 import os
 import sys
 
@@ -14,9 +20,16 @@ from cplxmodule_amd.nn.relevance import noise
 
 
 def main():
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rccl1 = "--rccl1" in sys.argv
     torch.cuda.set_device(0)
+    if rccl1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dp.FORCE_COLLECTIVES = True
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     dev = "cuda"
     torch.manual_seed(0)
     layer = rel.CplxLinearVD(64, 96).to(dev)
@@ -63,8 +76,10 @@ def main():
     for n, p, r in zip(names, layer.parameters(), ref):
         err = float((p.grad - r).abs().max() / (r.abs().max() + 1e-12))
         assert err < 2e-3, (n, err)
+    kl_mean = dp.all_reduce_scalar_mean(sum(rel.penalties(layer)))
+    assert torch.isfinite(kl_mean)
     if rank == 0:
-        print(f"dp_gpu_check OK: world={world}, worst relative deviation {worst:.2e}")
+        print(f"dp_gpu_check OK: backend={dist.get_backend()} world={world}, worst relative deviation {worst:.2e}")
     dist.destroy_process_group()
 
 

@@ -79,3 +79,21 @@ def test_empty_batches_everywhere():
     assert cplx.from_interleaved_real(torch.randn(0, 8, device=DEV)).real.shape == (0, 4)
     assert cplx.max_pool2d(z(0, 3, 8, 8), 2).real.shape == (0, 3, 4, 4)
     assert cplx.dropout(z(0, 4), 0.5).imag.shape == (0, 4)
+
+
+def test_data_parallel_paths_on_gpu():
+    """tests/dp_gpu_check.py in subprocesses: two gloo ranks sharing the GPU (values: hook-averaged ==
+    hand-averaged gradients) and one RCCL rank with the collectives forced on (every RCCL call of the
+    multi-GPU bench path is issued for real)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "dp_gpu_check.py"), "--rccl1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "dp_gpu_check OK: backend=nccl" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(here, "dp_gpu_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "dp_gpu_check OK: backend=gloo world=2" in r.stdout, r.stdout + r.stderr
