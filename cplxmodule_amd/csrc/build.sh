@@ -9,7 +9,11 @@ mkdir -p build
 pids=()
 for f in *.hip; do
   o=build/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm.h -nt "$o" ] || [ ../../include/cplxamd.h -nt "$o" ]; then
+  stale=0
+  for h in "$f" *.h ../../include/cplxamd.h; do
+    if [ ! -f "$o" ] || [ "$h" -nt "$o" ]; then stale=1; fi
+  done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
