@@ -46,16 +46,27 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32, NT = 512, STAGES = 3;
+constexpr int BK = 32, STAGES = 3;
+// ablation bits are COMPILE-TIME (-DCPLXAMD_GEMM_DBG_BUILD=n): as run-time tests they put a branch
+// around every MFMA group and LDS-DMA piece, which splits the K loop into ~30 basic blocks and makes
+// the compiler's s_waitcnt placement conservative (it waited for the NEXT tile's fragments).
+// 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no barrier
+#ifndef CPLXAMD_GEMM_DBG_BUILD
+#define CPLXAMD_GEMM_DBG_BUILD 0
+#endif
+constexpr int kDbg = CPLXAMD_GEMM_DBG_BUILD;
 
 // complex: 256 x 128 tile, 4 x 2 waves of 64 x 64 (2 x 2 MFMA tiles x {re, im} = 128 accumulators);
 // real: 256 x 256 tile, 2 x 4 waves of 128 x 64 (4 x 2 MFMA tiles = 128 accumulators) -- with one
 // MFMA chain per staged byte instead of four, the real kernel needs the larger tile to keep the
 // LDS-DMA pieces and ds_reads per MFMA where the complex kernel has them.
-template <bool CPLX>
+// BIG (complex only, experiment): the same 256 x 128 tile on 4 waves of 128 x 64 (4 x 2 MFMA tiles x
+// {re, im} = 256 accumulators), one wave per SIMD -- 25 % fewer LDS reads per MFMA.
+template <bool CPLX, bool BIG = false>
 struct Cfg {
-  static constexpr int IB = CPLX ? 2 : 4;                       // 32-row MFMA blocks per wave
-  static constexpr int WM = CPLX ? 4 : 2, WN = CPLX ? 2 : 4;    // waves along M / N
+  static constexpr int NT = (CPLX && BIG) ? 256 : 512;
+  static constexpr int IB = CPLX ? (BIG ? 4 : 2) : 4;           // 32-row MFMA blocks per wave
+  static constexpr int WM = CPLX ? (BIG ? 2 : 4) : 2, WN = CPLX ? 2 : 4;    // waves along M / N
   static constexpr int BM = 32 * IB * WM, BN = 64 * WN;
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
@@ -73,7 +84,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // One LDS-DMA instruction: piece j (of ROWS*4/NT) of a plane tile.
 //  !T: chunk p = j*NT + tid holds (row = p >> 2, kc = (p & 3) ^ ((row >> 2) & 3)) of [rows][K]
 //   T: chunk p holds (k = p / (ROWS/8), c = (p % (ROWS/8)) ^ ((k & 3) << 2)) of [K][rows]
-template <int ROWS, bool T>
+template <int ROWS, bool T, int NT>
 __device__ __forceinline__ void stage_piece(const bf16_t* base, int64_t ld, int row0, int rows,
                                             int k0, char* lds_plane, int j) {
   const int tid = threadIdx.x;
@@ -130,10 +141,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL>
-__global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL, bool BIG = false>
+__global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using C = Cfg<CPLX>;
+  using C = Cfg<CPLX, BIG>;
+  constexpr int NT = C::NT;
 
   // ---- tile coordinates: split-K slice, XCD-contiguous grouped order ------------------------
   constexpr int BM = C::BM, BN = C::BN, IB = C::IB;
@@ -179,12 +191,12 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
   auto stage_q = [&](int buf, int k0, int q) {
     k0 += kbase;
     char* s = smem + buf * C::STAGE_BYTES;
-    if (q < C::PA) stage_piece<BM, TA>(Ar, lda, m0, g.M, k0, s, q);
-    else if (q < C::PA + C::PB) stage_piece<BN, TB>(Br, ldb, n0, g.N, k0, s + C::A_BYTES, q - C::PA);
+    if (q < C::PA) stage_piece<BM, TA, NT>(Ar, lda, m0, g.M, k0, s, q);
+    else if (q < C::PA + C::PB) stage_piece<BN, TB, NT>(Br, ldb, n0, g.N, k0, s + C::A_BYTES, q - C::PA);
     else if (q < 2 * C::PA + C::PB)
-      stage_piece<BM, TA>(Ai, lda, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES, q - C::PA - C::PB);
+      stage_piece<BM, TA, NT>(Ai, lda, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES, q - C::PA - C::PB);
     else
-      stage_piece<BN, TB>(Bi, ldb, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES, q - 2 * C::PA - C::PB);
+      stage_piece<BN, TB, NT>(Bi, ldb, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES, q - 2 * C::PA - C::PB);
   };
   auto stage_all = [&](int buf, int k0) {
 #pragma unroll
@@ -266,10 +278,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
       // own LDS-DMA of tile t landed (tile t+1 may stay in flight), then every wave's did
-      if ((g.dbg & 1) || t + 1 >= nt) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();
-      if (!(g.dbg & 4)) __builtin_amdgcn_s_barrier();        // ... and ring slot (t-1) % 3 is free for tile t+2
+      if ((kDbg & 1) || t + 1 >= nt) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();
+      if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();        // ... and ring slot (t-1) % 3 is free for tile t+2
       int nxt = cur + 2; nxt = nxt >= 3 ? nxt - 3 : nxt;
-      compute(cur, nxt, (t + 2) * BK, t + 2 < nt && !(g.dbg & 1), !(g.dbg & 2));
+      compute(cur, nxt, (t + 2) * BK, t + 2 < nt && !(kDbg & 1), !(kDbg & 2));
       cur = cur + 1 == 3 ? 0 : cur + 1;
     }
   } else {
@@ -304,12 +316,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
         for (int i = 0; i < IB; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
       }
       int q = q0;
-      const bool live = tile < nt && !(g.dbg & 1);
+      // tiles past the end re-load the last one into a free slot: no branch in the K loop
+      const int k0s = (tile < nt ? tile : nt - 1) * BK;
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (!(g.dbg & 2)) {
+          if (!(kDbg & 2)) {
             acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
             if (CPLX) {
               acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
           }
           if (q < q1) {
             __builtin_amdgcn_sched_barrier(0);
-            if (live) stage_q(slot, tile * BK, q);
+            if (!(kDbg & 1)) stage_q(slot, k0s, q);
             __builtin_amdgcn_sched_barrier(0);
             ++q;
           }
@@ -335,9 +348,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
     if (nt > 1) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     read_half(0, 0);
-    if (nt > 2 && !(g.dbg & 1)) {
+    if (!(kDbg & 1)) {
 #pragma unroll
-      for (int q = 0; q < H; ++q) stage_q(2, 2 * BK, q);
+      for (int q = 0; q < H; ++q) stage_q(2, (nt > 2 ? 2 : nt - 1) * BK, q);
     }
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
@@ -346,9 +359,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
       read_half(cur, 1);                                      // S1
       mfma_half(0, nx2, t + 2, H, C::LOADS);                  // S2
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // S3: this wave's F[1] is in registers
-      if ((g.dbg & 1) || t + 2 >= nt) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();
-      if (!(g.dbg & 4)) __builtin_amdgcn_s_barrier();
-      if (t + 1 < nt) read_half(nx1, 0);                      // S4
+      if (kDbg & 1) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();   // always LOADS younger pieces in flight
+      if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();
+      read_half(nx1, 0);                                      // S4 (past the end: a stale slot, unused)
       mfma_half(1, cur, t + 3, 0, H);                         // S5 (slot of tile t is free now)
       cur = nx1;
     }
@@ -466,6 +479,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g) {
     store_block(std::integral_constant<int, 2>{});
     store_block(std::integral_constant<int, 3>{});
   }
+  wait_vmcnt<0>();   // the branch-free K loop leaves (unused) LDS-DMA pieces in flight: land them before the LDS is released
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -475,24 +489,24 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL>
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL, bool BIG = false>
 static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
-  using C = Cfg<CPLX>;
+  using C = Cfg<CPLX, BIG>;
   // read-only tuning knobs, set once from the environment (A/B experiments only)
   static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 2),
                    dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
-  g.order = order; g.group_m = gm > 0 ? gm : 1; g.dbg = dbg;
+  g.order = order; g.group_m = gm > 0 ? gm : 1; (void)dbg;
   const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   if (tiles * g.splits > 0x7fffffff) return CPLXAMD_ESHAPE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB, ROLL>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB, ROLL, BIG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB, ROLL><<<dim3((unsigned)(tiles * g.splits)), NT, C::SMEM, st>>>(g);
+  gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB, ROLL, BIG><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -500,6 +514,10 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 static int launch_kernel(const GemmArgs& g, hipStream_t st) {
   static const int roll = env_int("CPLXAMD_GEMM_ROLL", 1);
+  if constexpr (CPLX) {
+    static const int big = env_int("CPLXAMD_GEMM_BIG", 0);
+    if (big) return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true, true>(g, st);
+  }
   return roll ? launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true>(g, st)
               : launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, false>(g, st);
 }
