@@ -56,6 +56,20 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const void* lds_wave
                : "memory");
 }
 
+// Same, with the LDS destination given as a wave-uniform BYTE OFFSET that the caller built from
+// scalar values (lds_offset_of() once per kernel + integer arithmetic on uniform values): the M0
+// set-up then stays on the scalar unit -- a generic LDS pointer costs two VALU ops and a
+// v_readfirstlane per transfer.
+__device__ __forceinline__ uint32_t lds_offset_of(const void* lds_ptr) {
+  return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_ptr);
+}
+__device__ __forceinline__ void lds_dma16_at(const void* gsrc, uint32_t lds_off_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :
+               : "s"(lds_off_uniform), "v"(gsrc)
+               : "memory");
+}
+
 // 4-wide vector access (16 B for float, 8 B for bf16)
 struct f4 { float v[4]; };
 // two f4 halves = 8 elements: one 16-B access for bf16, two for float (needs 16-B alignment of p)
