@@ -70,6 +70,24 @@ __device__ __forceinline__ void lds_dma16_at(const void* gsrc, uint32_t lds_off_
                : "memory");
 }
 
+// Scalar-base form: global address = sbase (wave-uniform, SGPR pair) + voff (32-bit per-lane byte
+// offset).  The per-lane part of a tile piece does not depend on the K position, so it is computed
+// once per kernel; advancing along K is scalar arithmetic on sbase -- no VALU work per transfer.
+__device__ __forceinline__ void lds_dma16_sv(const void* sbase_uniform, uint32_t voff,
+                                             uint32_t lds_off_uniform) {
+  // readfirstlane pins the base to scalar registers even where the compiler's divergence analysis
+  // gives up.  (The builtin returns a SIGNED int: widen through uint32_t, or the low half
+  // sign-extends into the high one -- that was a GPU memory fault in the first version.)
+  const uint64_t a = (uint64_t)(uintptr_t)sbase_uniform;
+  const uint64_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint64_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  const uint64_t sb = (hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_off_uniform), "v"(voff), "s"(sb)
+               : "memory");
+}
+
 // 4-wide vector access (16 B for float, 8 B for bf16)
 struct f4 { float v[4]; };
 // two f4 halves = 8 elements: one 16-B access for bf16, two for float (needs 16-B alignment of p)

@@ -77,35 +77,32 @@ struct Cfg {
   static constexpr int LOADS = (CPLX ? 2 : 1) * (PA + PB);      // ... per thread per K tile
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  lds_dma16(gsrc, lds_wave_base);     // common.h: inline asm, invisible to the compiler's waitcnt pass
-}
 
-// One LDS-DMA instruction: piece j (of ROWS*4/NT) of a plane tile.
+// One LDS-DMA instruction moves piece j (of ROWS*4/NT) of a plane tile.
 //  !T: chunk p = j*NT + tid holds (row = p >> 2, kc = (p & 3) ^ ((row >> 2) & 3)) of [rows][K]
 //   T: chunk p holds (k = p / (ROWS/8), c = (p % (ROWS/8)) ^ ((k & 3) << 2)) of [K][rows]
+// The address is split into a wave-uniform part (plane + tile origin + K position: piece_base, scalar)
+// and this lane's byte offset inside the tile (piece_voff: computed ONCE per kernel, 32 bits).
 template <int ROWS, bool T, int NT>
-__device__ __forceinline__ void stage_piece(const bf16_t* base, int64_t ld, int row0, int rows,
-                                            int k0, uint32_t lds_plane, int j) {
-  const int tid = threadIdx.x;
-  const int wave_chunk = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;   // scalar: feeds M0
-  const int p = j * NT + tid;
-  const bf16_t* src;
+__device__ __forceinline__ uint32_t piece_voff(int64_t ld, int row0, int rows, int j) {
+  const int p = j * NT + (int)threadIdx.x;
   if (!T) {
     const int row = p >> 2;
     const int kc = (p & 3) ^ ((row >> 2) & 3);
     int grow = row0 + row;
     grow = grow < rows ? grow : rows - 1;      // clamp: out-of-range rows are never stored
-    src = base + (int64_t)grow * ld + k0 + kc * 8;
-  } else {
-    constexpr int CPR = ROWS / 8;              // 16-B chunks per k row
-    const int k = p / CPR;
-    const int c = (p % CPR) ^ ((k & 3) << 2);
-    int col = row0 + c * 8;
-    col = col + 8 <= rows ? col : rows - 8;    // clamp (rows % 8 == 0 is required)
-    src = base + (int64_t)(k0 + k) * ld + col;
+    return (uint32_t)(((int64_t)(grow - row0) * ld + kc * 8) * 2);
   }
-  lds_dma16_at(src, lds_plane + (uint32_t)((j * NT + wave_chunk) * 16));
+  constexpr int CPR = ROWS / 8;                // 16-B chunks per k row
+  const int k = p / CPR;
+  const int c = (p % CPR) ^ ((k & 3) << 2);
+  int col = row0 + c * 8;
+  col = col + 8 <= rows ? col : rows - 8;      // clamp (rows % 8 == 0 is required)
+  return (uint32_t)(((int64_t)k * ld + (col - row0)) * 2);
+}
+template <bool T>
+__device__ __forceinline__ const bf16_t* piece_base(const bf16_t* plane, int64_t ld, int row0, int k0) {
+  return T ? plane + (int64_t)k0 * ld + row0 : plane + (int64_t)row0 * ld + k0;
 }
 
 // 8 consecutive k of matrix row `row` (k chunk kc of 4) from an "N" image
@@ -189,15 +186,27 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   const int kbase = split * g.kchunk;
   // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
   const uint32_t smem_off = lds_offset_of(smem);
+  const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024u;  // 64 lanes x 16 B
+  // this lane's byte offset of every piece (the two planes of an operand share it)
+  uint32_t voa[C::PA], vob[C::PB];
+#pragma unroll
+  for (int j = 0; j < C::PA; ++j) voa[j] = piece_voff<BM, TA, NT>(lda, m0, g.M, j);
+#pragma unroll
+  for (int j = 0; j < C::PB; ++j) vob[j] = piece_voff<BN, TB, NT>(ldb, n0, g.N, j);
+  // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
   auto stage_q = [&](int buf, int k0, int q) {
     k0 += kbase;
-    const uint32_t s = smem_off + (uint32_t)(buf * C::STAGE_BYTES);
-    if (q < C::PA) stage_piece<BM, TA, NT>(Ar, lda, m0, g.M, k0, s, q);
-    else if (q < C::PA + C::PB) stage_piece<BN, TB, NT>(Br, ldb, n0, g.N, k0, s + C::A_BYTES, q - C::PA);
+    const uint32_t s = smem_off + (uint32_t)(buf * C::STAGE_BYTES) + wave_lds;
+    if (q < C::PA)
+      lds_dma16_sv(piece_base<TA>(Ar, lda, m0, k0), voa[q], s + q * NT * 16);
+    else if (q < C::PA + C::PB)
+      lds_dma16_sv(piece_base<TB>(Br, ldb, n0, k0), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
     else if (q < 2 * C::PA + C::PB)
-      stage_piece<BM, TA, NT>(Ai, lda, m0, g.M, k0, s + C::A_BYTES + C::B_BYTES, q - C::PA - C::PB);
+      lds_dma16_sv(piece_base<TA>(Ai, lda, m0, k0), voa[q - C::PA - C::PB],
+                   s + C::A_BYTES + C::B_BYTES + (q - C::PA - C::PB) * NT * 16);
     else
-      stage_piece<BN, TB, NT>(Bi, ldb, n0, g.N, k0, s + 2 * C::A_BYTES + C::B_BYTES, q - 2 * C::PA - C::PB);
+      lds_dma16_sv(piece_base<TB>(Bi, ldb, n0, k0), vob[q - 2 * C::PA - C::PB],
+                   s + 2 * C::A_BYTES + C::B_BYTES + (q - 2 * C::PA - C::PB) * NT * 16);
   };
   auto stage_all = [&](int buf, int k0) {
 #pragma unroll
@@ -626,6 +635,7 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   if (g.K < BK || (g.K % BK) != 0) return CPLXAMD_ESHAPE;
   const int64_t lda = ta ? g.a_cs : g.a_rs, ldb = tb ? g.b_cs : g.b_rs;
   if ((lda % 8) != 0 || (ldb % 8) != 0) return CPLXAMD_ESHAPE;
+  if (lda >= (1 << 22) || ldb >= (1 << 22)) return CPLXAMD_ESHAPE;   // per-lane tile offsets are 32-bit
   if ((ta && ((g.M % 8) != 0 || g.M < 8)) || (tb && ((g.N % 8) != 0 || g.N < 8))) return CPLXAMD_ESHAPE;
   if (!aligned16(g.a_r) || !aligned16(g.b_r)) return CPLXAMD_ESHAPE;
   if (CPLX && (!aligned16(g.a_i) || !aligned16(g.b_i))) return CPLXAMD_ESHAPE;
