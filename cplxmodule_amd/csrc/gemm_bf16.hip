@@ -163,7 +163,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
     bm = first_m + in_grp % gm; bn = in_grp / gm;
   }
-  const int m0 = bm * BM, n0 = bn * BN;
+  const int m0 = __builtin_amdgcn_readfirstlane(bm * BM), n0 = __builtin_amdgcn_readfirstlane(bn * BN);
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = (wid / C::WN) * (32 * IB), wn = (wid % C::WN) * 64;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       if (CPLX) acc_i[i][j] = f32x16{0};
     }
 
-  const int kbase = split * g.kchunk;
+  const int kbase = __builtin_amdgcn_readfirstlane(split * g.kchunk);
   // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
   const uint32_t smem_off = lds_offset_of(smem);
   const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024u;  // 64 lanes x 16 B
@@ -281,7 +281,9 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   };
 
   const int klen = g.splits > 1 ? ((g.K - kbase) < g.kchunk ? (g.K - kbase) : g.kchunk) : g.K;
-  const int nt = klen / BK;
+  // pinned to a scalar register: in the real kernel the compiler otherwise carries the trip count (and
+  // with it the clamped K position of every LDS-DMA piece) in VGPRs
+  const int nt = __builtin_amdgcn_readfirstlane(klen / BK);
   if (!ROLL) {
     stage_all(0, 0);
     if (nt > 1) stage_all(1, BK);
