@@ -133,7 +133,7 @@ def _shift_rows(geom):
 
 def input_grid(xr, xi, geom):
     """Channels-last copy of the (padded) input: read by the forward and by the weight gradient."""
-    tail = 32 + _shift_rows(geom)
+    tail = 320 + _shift_rows(geom)       # the forward kernel stages 320-row windows without clamping
     return (nhwc_pad(xr, geom[9], geom[10], tail_rows=tail),
             None if xi is None else nhwc_pad(xi, geom[9], geom[10], tail_rows=tail))
 
@@ -142,7 +142,7 @@ def grad_grid(gr, gi, geom):
     """The output gradient laid top-left on the input's padded grid: read by the data gradient
     (backwards, hence the zero head rows) and by the weight gradient (zero tail up to 32 rows)."""
     Hp, Wp = _grid(geom)
-    head, tail = _shift_rows(geom), 32 + (-(geom[0] * Hp * Wp)) % 32
+    head, tail = _shift_rows(geom), 320 + (-(geom[0] * Hp * Wp)) % 32
     return (nhwc_pad(gr, 0, 0, Hp, Wp, head_rows=head, tail_rows=tail),
             None if gi is None else nhwc_pad(gi, 0, 0, Hp, Wp, head_rows=head, tail_rows=tail))
 

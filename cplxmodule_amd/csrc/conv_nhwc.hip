@@ -50,6 +50,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace cn {
 
 constexpr int BK = 32;
+#ifndef CONV_ABL
+#define CONV_ABL 0      // ablation builds: bit 1 no LDS-DMA after the prologue, bit 2 no weight re-loads
+#endif
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   lds_dma16(gsrc, lds_wave_base);     // common.h: inline asm, invisible to the compiler's waitcnt pass
@@ -71,7 +74,12 @@ template <typename TOUT, bool CPLX, bool CONJ>
 __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = CPLX ? 2 : 1;
-  constexpr int NPC = NP * (BM + MAX_EXTRA) * 4 / NT + 1;   // LDS-DMA pieces per stage (fixed: 9 / 5)
+  // every plane of a stage is PP whole LDS-DMA pieces (5 x 256 chunks = 320 rows >= BM + MAX_EXTRA), so a
+  // piece never straddles planes: its source is a SCALAR base (plane, tile row, kernel row, channel
+  // chunk) plus one per-lane offset that is the same for all pieces and all stages
+  constexpr int PP = ((BM + MAX_EXTRA) * 4 + NT - 1) / NT;
+  constexpr int NPC = NP * PP;                       // pieces per stage (10 / 5)
+  constexpr int PLANE = PP * NT * 16;                // bytes per staged plane (20 KiB)
   const int tiles_n = (g.Cout + BN - 1) / BN;
   const int bn = blockIdx.x % tiles_n;
   const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM;
@@ -82,10 +90,8 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
   const int wave_chunk = wid * 64;
   const int cpt = g.C / BK;                       // channel chunks per kernel row
   const int nk = g.KH * cpt;                      // stages: (kh, channel chunk)
-  const int nA = g.srows * 4;                     // 16-B chunks per plane
-  const int plane_bytes = nA * 16;
-  const int stage_bytes = g.npieces * NT * 16;    // [A_r | A_i] padded to whole pieces
-  char* const dump = smem + 2 * stage_bytes;      // where the (fixed-count) surplus pieces land
+  constexpr int plane_bytes = PLANE;
+  constexpr int stage_bytes = NP * PLANE;         // [A_r | A_i]
 
   f32x16 acc_r[2][2], acc_i[2][2];
 #pragma unroll
@@ -96,26 +102,19 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
       acc_i[i][j] = f32x16{0};
     }
 
-  // LDS-DMA piece q of stage kt into ring slot buf; every thread issues every piece (chunks past
-  // the image re-load chunk 0 into the padding)
+  // LDS-DMA piece q = (plane, 64-row group j) of stage kt into ring slot buf.  Rows past the end of the
+  // grid are NOT clamped: the caller allocates 320 + (KH-1)*dil_h*Wp + (KW-1)*dil_w readable rows
+  // behind it (cplxamd.h); they only feed outputs that are dropped at the store.
+  const uint32_t smem_off = lds_offset_of(smem);
+  const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * 1024u;
+  const uint32_t voff0 = (uint32_t)(((tid >> 2) * g.C + (((tid & 3) ^ ((tid >> 4) & 3)) << 3)) * 2);
   auto stage_q = [&](int buf, int kt, int q) {
     kt = kt < nk ? kt : nk - 1;
     const int kh = kt / cpt, c0 = (kt - kh * cpt) * BK;
-    // the per-piece source offsets are recomputed at every issue (a handful of VALU ops next to
-    // idle VALU slots) instead of living in 18 hoisted address registers: the opaque copy of tid
-    // keeps LICM away
-    int tid_ = tid;
-    asm volatile("" : "+v"(tid_));
-    int c = q * NT + tid_;
-    c = c < NP * nA ? c : 0;
-    const int plane = c >= nA;
-    c -= plane * nA;
-    const int row = c >> 2;
-    int64_t grow = m0 + row + g.row_bias + (int64_t)kh * g.dil_h * g.Wp;
-    grow = grow < g.rows ? grow : g.rows - 1;                    // rows past the end feed dropped outputs
-    const bf16_t* base = (const bf16_t*)(plane ? g.x_i : g.x_r);
-    glds16(base + grow * g.C + c0 + (((c & 3) ^ ((row >> 2) & 3)) << 3),
-           q < g.npieces ? smem + buf * stage_bytes + (q * NT + wave_chunk) * 16 : dump + wave_chunk * 16);
+    const int pl = q / PP, j = q - pl * PP;
+    const int64_t row = m0 + j * 64 + g.row_bias + (int64_t)kh * g.dil_h * g.Wp;
+    const bf16_t* base = (const bf16_t*)(pl ? g.x_i : g.x_r) + row * g.C + c0;
+    lds_dma16_sv(base, voff0, smem_off + (uint32_t)(buf * stage_bytes + pl * PLANE + j * (NT * 16)) + wave_lds);
   };
 
   // weight fragments of (stage kt, tap kw, K sub-step ks) straight from global memory
@@ -161,7 +160,15 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
         ar[ks][i] = frag(sA, r0 + i * 32, ks * 2 + lk);
         if (CPLX) ai[ks][i] = frag(sAi, r0 + i * 32, ks * 2 + lk);
       }
-    int q = 0;
+    if (STAGE && !(CONV_ABL & 1)) {
+      // the whole next stage goes out NOW, ahead of this tap's weight re-loads: vmcnt counts in order,
+      // so the first weight fragment consumed in the next tap forces everything older to have landed --
+      // issued here the pieces get a full tap, interleaved further down they got half of one
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) stage_q((t + 1) & 1, t + 1, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 na[2];
@@ -185,19 +192,6 @@ __global__ __launch_bounds__(NT, 2) void conv_nhwc_kernel(Args g) {
               acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na[i], wi_, acc_r[i][j], 0, 0, 0);
               acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[ks][i], wi_, acc_i[i][j], 0, 0, 0);
             }
-          }
-#ifndef CONV_ABL
-#define CONV_ABL 0
-#endif
-          if (STAGE && !(CONV_ABL & 1)) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-              if (q < NPC) {
-                __builtin_amdgcn_sched_barrier(0);
-                stage_q((t + 1) & 1, t + 1, q);
-                __builtin_amdgcn_sched_barrier(0);
-                ++q;
-              }
           }
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -279,8 +273,8 @@ static int launch_conj(const Args& g0, bool conj, hipStream_t st) {
   Args g = g0;
   static const int dbg = getenv("CPLXAMD_CONV_DBG") ? atoi(getenv("CPLXAMD_CONV_DBG")) : 0;
   g.dbg = dbg;
-  g.npieces = ((CPLX ? 2 : 1) * g.srows * 4 + NT - 1) / NT;
-  int smem = (2 * g.npieces + 1) * NT * 16;
+  g.npieces = 0;   // (field of the float32 kernel; the bf16 stage is 5 pieces per plane, always)
+  int smem = 2 * (CPLX ? 2 : 1) * 5 * NT * 16;
   const int out_img = (sizeof(TOUT) == 2 ? (CPLX ? 2 : 1) : 1) * BN * OUT_LD * (int)sizeof(TOUT);
   smem = smem > out_img ? smem : out_img;
   const int64_t tiles = ((g.rows + BM - 1) / BM) * ((g.Cout + BN - 1) / BN);

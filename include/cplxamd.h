@@ -256,7 +256,8 @@ int cplxamd_conv2d_bf16_wgrad(const void* gr, const void* gi, const void* xr, co
  *       xp_* channels-last bf16 grid [B, Hp, Wp, C], w_* bf16 [KH][KW][C/16][Cout][16] (C % 32 == 0,
  *       (KW-1)*dil_w <= 32), y_* planar NCHW [B, Cout, Hout, Wout] of out_dtype; xp_i == NULL: real
  *       convolution; conj_w: use conj(w).  row_bias <= 0; the buffer must hold -row_bias zero rows
- *       before the grid (rows past its end are never multiplied into a stored output).
+ *       before the grid and 320 + (KH-1)*dil_h*Wp + (KW-1)*dil_w READABLE rows behind it (the bf16
+ *       kernel does not clamp row indices; those rows only feed outputs that are not stored).
  * Forward (input padded by (ph, pw)): row_bias = oh = ow = 0, Hout = Hp-(KH-1)*dil_h,
  * w[kh][kw][c/16][co][c%16] = weight[co][c][kh][kw].  Data gradient: xp = the output gradient laid
  * top-left on the INPUT's padded grid (cplxamd_nhwc_pad(g, pad 0, Hp, Wp)), the roles of the two
