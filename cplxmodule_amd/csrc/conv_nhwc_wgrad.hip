@@ -32,6 +32,9 @@ constexpr int KR = 32;            // rows (GEMM k) per stage
 constexpr int TC = 64;            // channels per tile side
 constexpr int STAGES = 3;
 constexpr int MAXP = 8;           // LDS-DMA pieces per thread per stage at most
+#ifndef CW_ABL
+#define CW_ABL 0                  // ablation builds (bf16 kernel): bit 1 no LDS-DMA after the prologue, 2 no MFMA
+#endif
 
 struct Args {
   const bf16_t* g_r; const bf16_t* g_i;     // Gp [rows][Co]
@@ -151,18 +154,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_kernel(Args g) {
     xbits |= (uint32_t)isx << q;
   }
   const uint32_t step_g = KR * 2 * g.Co, step_x = KR * 2 * g.Ci;
+  // Every thread issues all MAXP pieces of every tile, tiles past the end re-load the last one, and
+  // pieces past npieces land in a dump slot behind the ring: the K loop has no run-time branch (one
+  // basic block), so the compiler's s_waitcnt placement is exact and the counted vmcnt is a constant.
+  const uint32_t smem_off = lds_offset_of(smem);
+  const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(kw) * 1024u;
+  const uint32_t dump_off = (uint32_t)(STAGES * stage_bytes);
   auto stage_q = [&](int buf, int trel, int q) {     // trel = t - t_begin; q is a compile-time index
+    trel = trel < nt ? trel : nt - 1;
     const uint32_t step = ((xbits >> q) & 1) ? step_x : step_g;
-    glds16(reinterpret_cast<const void*>(ptr0[q] + (uint64_t)trel * step),
-           smem + buf * stage_bytes + (q * NT + wave_chunk) * 16);
+    const uint32_t dst = q < g.npieces ? (uint32_t)(buf * stage_bytes + q * NT * 16) : dump_off;
+    lds_dma16_at(reinterpret_cast<const void*>(ptr0[q] + (uint64_t)trel * step), smem_off + dst + wave_lds);
   };
   auto stage_all = [&](int buf, int trel) {
 #pragma unroll
-    for (int q = 0; q < MAXP; ++q)
-      if (q < g.npieces) stage_q(buf, trel, q);
+    for (int q = 0; q < MAXP; ++q) stage_q(buf, trel, q);
   };
 
-  auto compute = [&](int buf, int nbuf, int tnext, bool do_stage) {
+  auto compute = [&](int buf, int nbuf, int tnext) {
     const char* sGr = smem + buf * stage_bytes;
     const char* sGi = sGr + nG * 16;
     const char* sXr = sGr + NP * nG * 16;
@@ -194,16 +203,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_kernel(Args g) {
         for (int j = 0; j < 2; ++j) {
           // X fragment first: the accumulator holds the tile transposed, row (co) = lane & 31,
           // 4 consecutive ci per register group.  G conj(X): re = gr xr + gi xi, im = gi xr - gr xi
-          if (!(g.dbg & 2))
+          if (!(CW_ABL & 2))
           acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
-          if (CPLX && !(g.dbg & 2)) {
+          if (CPLX && !(CW_ABL & 2)) {
             acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
             acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
             acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nar[i], acc_i[i][j], 0, 0, 0);
           }
           if (q < MAXP) {
             __builtin_amdgcn_sched_barrier(0);
-            if (do_stage && q < g.npieces) stage_q(nbuf, tnext, q);
+            if (!(CW_ABL & 1)) stage_q(nbuf, tnext, q);
             __builtin_amdgcn_sched_barrier(0);
             ++q;
           }
@@ -211,15 +220,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_kernel(Args g) {
     }
   };
 
-  if (nt > 0) stage_all(0, 0);
-  if (nt > 1) stage_all(1, 1);
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt && !(g.dbg & 1)) wait_vmcnt_rt(g.npieces); else wait_vmcnt_rt(0);
-    __builtin_amdgcn_s_barrier();
-    int nxt = cur + 2; nxt = nxt >= STAGES ? nxt - STAGES : nxt;
-    compute(cur, nxt, t + 2, t + 2 < nt && !(g.dbg & 1));
-    cur = cur + 1 == STAGES ? 0 : cur + 1;
+  if (nt > 0) {
+    stage_all(0, 0);
+    stage_all(1, 1);
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (CW_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXP) : "memory");   // tile t landed; tile t+1 may be in flight
+      __builtin_amdgcn_s_barrier();
+      int nxt = cur + 2; nxt = nxt >= STAGES ? nxt - STAGES : nxt;
+      compute(cur, nxt, t + 2);
+      cur = cur + 1 == STAGES ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads must land before the LDS is released
   }
 
   // slab [split][kh][kw][plane][tile_co][tile_ci][64][64]
@@ -491,7 +504,7 @@ int cplxamd_conv2d_nhwc_wgrad(const void* gp_r, const void* gp_i, const void* xp
   const int NT = 64 * KW;
   g.npieces = (NP * (cw::KR * 8 + g.xrows * 8) + NT - 1) / NT;
   if (g.npieces > cw::MAXP) return CPLXAMD_ESHAPE;
-  const int smem = cw::STAGES * g.npieces * NT * 16;
+  const int smem = (cw::STAGES * g.npieces + 1) * NT * 16;   // ring + one piece of dump
   dim3 grid(g.splits * KH, tco, tci);
   if (cplx)
     cw::conv_wgrad_nhwc_kernel<true><<<grid, NT, smem, st>>>(g);
