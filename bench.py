@@ -200,7 +200,7 @@ def main():
                          # shape (scripts/pmc_gemm.sh, profiles/r01_gemm_variants.md): FETCH_SIZE
                          # 528,699 KiB x 2 (gfx950 correction) + WRITE_SIZE 416,787 KiB (calibrated 1:1
                          # on a streaming write in the same run); algorithmic minimum 320 MB
-                         "traffic": 1.51e9 if B == BATCH else None, "flop_per_launch": flops,
+                         "traffic": 1.52e9 if B == BATCH else None, "flop_per_launch": flops,
                          "avg_launch_ms": round(gemm_ms, 4) if gemm_ms else None},
             "hbm_kernels_GBps": {
                 "kl_fwd(12B/elt)": round(12 * nw / (kl_f * 1e-3) / 1e9, 1) if kl_f else None,
