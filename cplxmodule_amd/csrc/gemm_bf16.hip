@@ -526,8 +526,8 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 static int launch_kernel(const GemmArgs& g, hipStream_t st) {
   static const int roll = env_int("CPLXAMD_GEMM_ROLL", 1);
-  // (Cfg<true, BIG>: 4 waves of 128 x 64 at one wave per SIMD was measured at 0.92 ms vs 0.88 ms on
-  //  the headline shape, also with the branch-free loop; it is not instantiated)
+  // (Cfg<true, BIG>: 4 waves of 128 x 64 at one wave per SIMD: 0.905 ms vs 0.86 ms on the headline shape
+  //  with the final loop, equal on the fp32-output wgrad shape; it is not instantiated)
   return roll ? launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true>(g, st)
               : launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, false>(g, st);
 }
