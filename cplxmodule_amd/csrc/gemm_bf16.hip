@@ -388,6 +388,68 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     cr = reinterpret_cast<TOUT*>(g.ws) + (int64_t)split * (CPLX ? 2 : 1) * slab;
     ci = cr + slab;
   }
+  // bf16 output without a fused elementwise operand: the wave's tile goes through LDS so that every
+  // global store instruction writes whole 128-B lines (8 rows x 64 columns); from the MFMA C layout a
+  // store instruction scatters 64 eight-byte pieces over 32 rows (measured: 6.5 % of the complex and
+  // 10 % of the real kernel, `profiles/r01_gemm_variants.md`).  One plane and 64 rows per round, each
+  // wave in its own 9 KiB of the (now idle) ring.
+  if constexpr (sizeof(TOUT) == 2) {
+    const bool lds_epi = g.setprio && !g.g1 && !g.emul && !g.accumulate && g.splits <= 1 && (g.ldc & 7) == 0 &&
+                         (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
+                         (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0);
+    if (lds_epi) {
+      constexpr int PITCH = 144;                       // bytes per staged row (64 bf16 + 16 B pad)
+      wait_vmcnt<0>();                                  // (the clamped LDS-DMA pieces of the loop tail)
+      __syncthreads();                                  // every wave is done with the ring
+      char* reg = smem + wid * (64 * PITCH);
+#pragma unroll
+      for (int pl = 0; pl < (CPLX ? 2 : 1); ++pl) {
+        TOUT* out = pl ? ci : cr;
+        const float* bias = pl ? g.bias_i : g.bias_r;
+#pragma unroll
+        for (int ih = 0; ih < IB / 2; ++ih) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int cl = j * 32 + 8 * q + 4 * lk;
+                const int col = n0 + wn + cl;
+                f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float b = (bias && col + e < g.N) ? bias[col + e] : 0.f;
+                  v.v[e] = (pl ? acc_i[CPLX ? ih * 2 + ii : 0][j][4 * q + e] : acc_r[ih * 2 + ii][j][4 * q + e]) + b;
+                }
+                st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
+              }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is in LDS (in-order LDS, own region)
+#pragma unroll
+          for (int pass = 0; pass < 8; ++pass) {
+            const int rl = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(reg + rl * PITCH + c8 * 2);
+            const int row = m0 + wm + ih * 64 + rl, col = n0 + wn + c8;
+            if (row < g.M && col < g.N) {
+              bf16_t* o = reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col;
+              if (col + 7 < g.N) {
+                *reinterpret_cast<uint4*>(o) = v;
+              } else {
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                  if (col + 2 * w < g.N) o[2 * w] = (bf16_t)(w4[w] & 0xffffu);
+                  if (col + 2 * w + 1 < g.N) o[2 * w + 1] = (bf16_t)(w4[w] >> 16);
+                }
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
+        }
+      }
+      return;
+    }
+  }
   const bool two_planes = CPLX || g.g1;
   const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
                       (!two_planes || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
@@ -508,6 +570,8 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
   static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 2),
                    dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
+  static const int ldsepi = env_int("CPLXAMD_GEMM_LDSEPI", 1);   // A/B switch of the LDS-staged epilogue
+  g.setprio = ldsepi;
   g.order = order; g.group_m = gm > 0 ? gm : 1; (void)dbg;
   const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   if (tiles * g.splits > 0x7fffffff) return CPLXAMD_ESHAPE;
