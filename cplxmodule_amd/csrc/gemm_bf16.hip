@@ -450,6 +450,77 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       return;
     }
   }
+  // float32 output: the same through LDS, 32 rows (one MFMA block row) per round -- a store instruction
+  // then writes 4 rows x 256 B instead of 32 rows x 32 B; the elementwise multiplier (LRT log_sigma2
+  // gradient) and the accumulate operand are read row-major at the same point.
+  if constexpr (sizeof(TOUT) == 4) {
+    const bool lds_epi = g.setprio && !g.g1 && g.splits <= 1 && (g.ldc & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
+                         (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
+                         (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
+    if (lds_epi) {
+      constexpr int PITCH = 272;                       // bytes per staged row (64 floats + 16 B pad)
+      wait_vmcnt<0>();
+      __syncthreads();
+      char* reg = smem + wid * (32 * PITCH);
+#pragma unroll
+      for (int pl = 0; pl < (CPLX ? 2 : 1); ++pl) {
+        float* out = reinterpret_cast<float*>(pl ? ci : cr);
+        const float* bias = pl ? g.bias_i : g.bias_r;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cl = j * 32 + 8 * q + 4 * lk;
+              const int col = n0 + wn + cl;
+              f4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float b = (bias && col + e < g.N) ? bias[col + e] : 0.f;
+                v.v[e] = (pl ? acc_i[CPLX ? i : 0][j][4 * q + e] : acc_r[i][j][4 * q + e]) + b;
+              }
+              st4(reinterpret_cast<float*>(reg + l31 * PITCH + cl * 4), v);
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int pass = 0; pass < 8; ++pass) {
+            const int rl = pass * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            f4 v = ld4(reinterpret_cast<const float*>(reg + rl * PITCH + c4 * 4));
+            const int row = m0 + wm + i * 32 + rl, col = n0 + wn + c4;
+            if (row < g.M && col < g.N) {
+              const int64_t o = (int64_t)row * g.ldc + col;
+              if (col + 3 < g.N) {
+                if (g.emul && !pl) {
+                  const f4 m = ld4(g.emul + o);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v.v[e] *= m.v[e];
+                }
+                if (g.accumulate) {
+                  const f4 p = ld4(out + o);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v.v[e] += p.v[e];
+                }
+                st4(out + o, v);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (col + e < g.N) {
+                    float x = v.v[e];
+                    if (g.emul && !pl) x *= g.emul[o + e];
+                    if (g.accumulate) x += out[o + e];
+                    out[o + e] = x;
+                  }
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      return;
+    }
+  }
   const bool two_planes = CPLX || g.g1;
   const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
                       (!two_planes || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
