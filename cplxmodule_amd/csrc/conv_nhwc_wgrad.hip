@@ -362,18 +362,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_f32_kernel(Args g) {
     xbits |= (uint32_t)isx << q;
   }
   const uint32_t step_g = KRF * 4 * g.Co, step_x = KRF * 4 * g.Ci;
+  // branch-free staging as in the bf16 kernel: all MAXP pieces always, tiles past the end re-load the
+  // last one, pieces past npieces go to a dump slot behind the two stages
+  const uint32_t smem_off = lds_offset_of(smem);
+  const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(kw) * 1024u;
+  const uint32_t dump_off = (uint32_t)(2 * stage_bytes);
   auto stage_q = [&](int buf, int trel, int q) {
+    trel = trel < nt ? trel : nt - 1;
     const uint32_t step = ((xbits >> q) & 1) ? step_x : step_g;
-    lds_dma16(reinterpret_cast<const void*>(ptr0[q] + (uint64_t)trel * step),
-              smem + buf * stage_bytes + (q * NT + wave_chunk) * 16);
+    const uint32_t dst = q < g.npieces ? (uint32_t)(buf * stage_bytes + q * NT * 16) : dump_off;
+    lds_dma16_at(reinterpret_cast<const void*>(ptr0[q] + (uint64_t)trel * step), smem_off + dst + wave_lds);
   };
   auto stage_all = [&](int buf, int trel) {
 #pragma unroll
-    for (int q = 0; q < MAXP; ++q)
-      if (q < g.npieces) stage_q(buf, trel, q);
+    for (int q = 0; q < MAXP; ++q) stage_q(buf, trel, q);
   };
 
-  auto compute = [&](int buf, int nbuf, int tnext, bool do_stage) {
+  auto compute = [&](int buf, int nbuf, int tnext) {
     const float* sGr = reinterpret_cast<const float*>(smem + buf * stage_bytes);
     const float* sGi = sGr + nG * 4;
     const float* sXr = sGr + NP * nG * 4;
@@ -408,18 +413,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nhwc_f32_kernel(Args g) {
         }
       if (q < MAXP) {
         __builtin_amdgcn_sched_barrier(0);
-        if (do_stage && q < g.npieces) stage_q(nbuf, tnext, q);
+        stage_q(nbuf, tnext, q);
         __builtin_amdgcn_sched_barrier(0);
         ++q;
       }
     }
   };
 
-  if (nt > 0) stage_all(0, 0);
-  for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    compute(t & 1, (t + 1) & 1, t + 1, t + 1 < nt);
+  if (nt > 0) {
+    stage_all(0, 0);
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(t & 1, (t + 1) & 1, t + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-load of the last tile
   }
 
   const int64_t tile = ((((int64_t)(split * g.KH + kh) * g.KW + kw) * NP) * gridDim.y + blockIdx.y) *
@@ -567,7 +575,7 @@ int cplxamd_conv2d_nhwc_wgrad_f32(const void* gp_r, const void* gp_i, const void
   g.npieces = (NP * (cw::KRF * 16 + g.xrows * 16) + NT - 1) / NT;
   if (g.npieces > cw::MAXP) return CPLXAMD_ESHAPE;
   g.dbg = 0;
-  const int smem = 2 * g.npieces * NT * 16;
+  const int smem = (2 * g.npieces + 1) * NT * 16;   // two stages + one piece of dump
   dim3 grid(g.splits * KH, tco, tci);
   if (cplx)
     cw::conv_wgrad_nhwc_f32_kernel<true><<<grid, NT, smem, st>>>(g);
