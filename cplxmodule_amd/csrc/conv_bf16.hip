@@ -2,7 +2,7 @@
 // (v_mfma_f32_32x32x16_bf16), implicit GEMM, im2col never materialised.
 //
 // Same three GEMM views as conv.hip (FWD / DGRAD / WGRAD) and the same 4-chain complex core as
-// gemm_bf16.hip, but the operand tiles are gathered through registers:
+// gemm_bf16_impl.h, but the operand tiles are gathered through registers:
 //   * index decode is hoisted: the (ci, kh, kw) -> (offset, dh, dw) map is a small table built on
 //     the host side (ktab), the pixel -> (b, oh, ow) decode happens once per thread per K tile;
 //   * "row-fast" operands (pixels along lanes): each thread fetches the 8 consecutive k of one

@@ -59,7 +59,7 @@ __device__ __forceinline__ int img_off(int k, int chunk) {           // chunk: 1
 }
 
 // 8 consecutive k (starting at kb) of channel block rb..rb+15 as an MFMA fragment:
-// two hardware-transposed 4 x 16 reads (lane m of a 16-lane group: see gemm_bf16.hip)
+// two hardware-transposed 4 x 16 reads (lane m of a 16-lane group: see gemm_bf16_impl.h)
 __device__ __forceinline__ bf16x8 frag_t(const char* img, int rb, int kb, int m) {
   const int r = rb + 4 * (m & 3);
   s16x4 v[2];

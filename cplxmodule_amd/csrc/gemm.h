@@ -11,7 +11,7 @@ struct GemmArgs {
   void* c_r; void* c_i; int64_t ldc;
   int M, N, K;
   int conj_b, accumulate;
-  int order = 1, group_m = 4, setprio = 0;   // bf16 kernel tuning knobs (gemm_bf16.hip)
+  int order = 1, group_m = 4, setprio = 0;   // bf16 kernel tuning knobs (gemm_bf16_impl.h)
   // split-K (bf16 kernel, fp32 output): block (split, tile) covers K range [split*kchunk, ...)
   // and writes slab `split` of the workspace; a second kernel reduces the slabs.
   int splits = 1; int kchunk = 0; void* ws = nullptr; int64_t ws_bytes = 0;
@@ -30,7 +30,7 @@ int launch_gemm_generic(const GemmArgs& g, int in_dtype, int out_dtype, hipStrea
 
 int64_t gemm_generic_ws_bytes(int M, int N, int K, bool cplx);   // split-K scratch (0: none)
 
-// bf16 MFMA fast path (gemm_bf16.hip); returns CPLXAMD_ESHAPE when the arguments do not
+// bf16 MFMA fast path (gemm_bf16_impl.h); returns CPLXAMD_ESHAPE when the arguments do not
 // qualify so that the caller can fall back to the generic kernel.
 template <bool CPLX>
 int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st);

@@ -2,7 +2,7 @@
 //   C[m,n] = sum_k A[m,k] * op(B[n,k]) (+ bias[n]),   any element strides, any M, N, K,
 //   float32 or bf16 inputs (bf16 is widened exactly), float32 accumulation.
 // This is the parity path (fp32 results == an fmaf chain in k order) and the fallback for
-// shapes / layouts the bf16 fast path (gemm_bf16.hip) does not take.
+// shapes / layouts the bf16 fast path (gemm_bf16_impl.h) does not take.
 //
 // Reference arithmetic: cplx.linear_naive cplx.py:634-648, Cplx.__matmul__ cplx.py:167-174,
 // F.linear in the LRT variance term nn/relevance/complex/base.py:50-54.
