@@ -11,7 +11,7 @@ struct GemmArgs {
   void* c_r; void* c_i; int64_t ldc;
   int M, N, K;
   int conj_b, accumulate;
-  int order = 1, group_m = 4, setprio = 0;   // bf16 kernel tuning knobs (gemm_bf16_impl.h)
+  int order = 1, group_m = 4, lds_epilogue = 1;   // bf16 kernel knobs (gemm_bf16_impl.h; env CPLXAMD_GEMM_*)
   // split-K (bf16 kernel, fp32 output): block (split, tile) covers K range [split*kchunk, ...)
   // and writes slab `split` of the workspace; a second kernel reduces the slabs.
   int splits = 1; int kchunk = 0; void* ws = nullptr; int64_t ws_bytes = 0;

@@ -394,7 +394,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   // 10 % of the real kernel, `profiles/r01_gemm_variants.md`).  One plane and 64 rows per round, each
   // wave in its own 9 KiB of the (now idle) ring.
   if constexpr (sizeof(TOUT) == 2) {
-    const bool lds_epi = g.setprio && !g.g1 && !g.emul && !g.accumulate && g.splits <= 1 && (g.ldc & 7) == 0 &&
+    const bool lds_epi = g.lds_epilogue && !g.g1 && !g.emul && !g.accumulate && g.splits <= 1 && (g.ldc & 7) == 0 &&
                          (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
                          (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0);
     if (lds_epi) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   // then writes 4 rows x 256 B instead of 32 rows x 32 B; the elementwise multiplier (LRT log_sigma2
   // gradient) and the accumulate operand are read row-major at the same point.
   if constexpr (sizeof(TOUT) == 4) {
-    const bool lds_epi = g.setprio && !g.g1 && g.splits <= 1 && (g.ldc & 3) == 0 &&
+    const bool lds_epi = g.lds_epilogue && !g.g1 && g.splits <= 1 && (g.ldc & 3) == 0 &&
                          (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
                          (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
                          (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
@@ -642,7 +642,7 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
                    dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
   static const int ldsepi = env_int("CPLXAMD_GEMM_LDSEPI", 1);   // A/B switch of the LDS-staged epilogue
-  g.setprio = ldsepi;
+  g.lds_epilogue = ldsepi;
   g.order = order; g.group_m = gm > 0 ? gm : 1; (void)dbg;
   const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   if (tiles * g.splits > 0x7fffffff) return CPLXAMD_ESHAPE;
