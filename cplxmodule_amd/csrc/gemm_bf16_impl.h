@@ -28,7 +28,7 @@
 //    panels) so the tiles resident on one XCD share A / B panels in that XCD's private L2.
 //  * accumulator tiles are kept transposed (B fragment as the first MFMA operand) so each lane
 //    owns 4 consecutive output columns: 8-byte (bf16) / 16-byte (fp32) stores.
-//  * rolling half-tile pipeline (default, CPLXAMD_GEMM_ROLL=0 selects the classic one): the
+//  * rolling half-tile pipeline (the classic per-tile one: build with -DCPLXAMD_GEMM_CLASSIC): the
 //    s_barrier sits in the middle of a tile, when the wave still holds the second K sub-step's
 //    fragments in registers, so the MFMA pipe runs across the barrier and across the LDS latency
 //    of the next tile's first fragments (+2-4 % on N(0,1) data, +6 % on zero-filled operands).
@@ -660,11 +660,15 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
 
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 static int launch_kernel(const GemmArgs& g, hipStream_t st) {
-  static const int roll = env_int("CPLXAMD_GEMM_ROLL", 1);
-  // (Cfg<true, BIG>: 4 waves of 128 x 64 at one wave per SIMD: 0.905 ms vs 0.86 ms on the headline shape
-  //  with the final loop, equal on the fp32-output wgrad shape; it is not instantiated)
-  return roll ? launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true>(g, st)
-              : launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, false>(g, st);
+  // Only the rolling pipeline is instantiated.  The classic per-tile pipeline (ROLL = false, kept in the
+  // kernel source: build with -DCPLXAMD_GEMM_CLASSIC to select it) and Cfg<true, BIG> (4 waves of
+  // 128 x 64 at one wave per SIMD: 0.905 ms vs 0.86 ms on the headline shape with the final loop) were
+  // measured slower; leaving them out halves the compile time.
+#ifdef CPLXAMD_GEMM_CLASSIC
+  return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, false>(g, st);
+#else
+  return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true>(g, st);
+#endif
 }
 
 template <typename TOUT, bool CPLX, bool CONJ>
