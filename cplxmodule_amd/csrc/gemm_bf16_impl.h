@@ -303,6 +303,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     //   S1 read F[1] <- (tile t, ks 1)           S2 16 MFMAs on F[0] + second half of tile t+2's pieces
     //   S3 lgkmcnt(0), vmcnt (tile t+1 landed), s_barrier   (slot of tile t is free: all in registers)
     //   S4 read F[0] <- (tile t+1, ks 0)         S5 16 MFMAs on F[1] + first half of tile t+3's pieces
+    // (S1 / S4 are not bursts: their ds_reads are dealt out behind the MFMA groups of S2 / S5)
     bf16x8 ar[2][IB], br[2][2], ai[2][IB], bi[2][2];         // [ks][block]
     auto read_half = [&](int buf, int ks) {
       const char* sA = smem + buf * C::STAGE_BYTES;
@@ -320,8 +321,33 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
         if (CPLX) bi[ks][j] = b_frag(sBi, j, ks);
       }
     };
+    // one fragment of (slot buf, sub-step ks), in the order the MFMA groups need them
+    constexpr int NFRAG = CPLX ? 2 * IB + 4 : IB + 2;
+    auto read_one = [&](int buf, int ks, int idx) {
+      const char* sA = smem + buf * C::STAGE_BYTES;
+      const char* sB = sA + C::A_BYTES;
+      const char* sAi = sB + C::B_BYTES;
+      const char* sBi = sAi + C::A_BYTES;
+      if (CPLX) {
+        // B0 Bi0 A0 Ai0 B1 Bi1 A1 Ai1 A2 Ai2 ...
+        if (idx == 0) br[ks][0] = b_frag(sB, 0, ks);
+        else if (idx == 1) bi[ks][0] = b_frag(sBi, 0, ks);
+        else if (idx == 2) ar[ks][0] = a_frag(sA, 0, ks);
+        else if (idx == 3) ai[ks][0] = a_frag(sAi, 0, ks);
+        else if (idx == 4) br[ks][1] = b_frag(sB, 1, ks);
+        else if (idx == 5) bi[ks][1] = b_frag(sBi, 1, ks);
+        else if ((idx & 1) == 0) ar[ks][(idx - 4) / 2] = a_frag(sA, (idx - 4) / 2, ks);
+        else ai[ks][(idx - 5) / 2] = a_frag(sAi, (idx - 5) / 2, ks);
+      } else {
+        // B0 A0 B1 A1 A2 A3
+        if (idx == 0) br[ks][0] = b_frag(sB, 0, ks);
+        else if (idx == 1) ar[ks][0] = a_frag(sA, 0, ks);
+        else if (idx == 2) br[ks][1] = b_frag(sB, 1, ks);
+        else ar[ks][idx - 2] = a_frag(sA, idx - 2, ks);
+      }
+    };
     constexpr int H = (C::LOADS + 1) / 2;                     // pieces issued in S5; the rest in S2
-    auto mfma_half = [&](int ks, int slot, int tile, int q0, int q1) {
+    auto mfma_half = [&](int ks, int slot, int tile, int q0, int q1, int rbuf, int rks) {
       bf16x8 nai[IB];
       if (CPLX) {
 #pragma unroll
@@ -347,6 +373,16 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
               }
             }
           }
+          {  // the other half's fragments: a few ds_reads behind every MFMA group instead of one burst of
+             // 8-16 (keeps the LDS command FIFO from filling: +1.5 % on the T-operand shapes, 0 elsewhere)
+            constexpr int PER = (NFRAG + IB * 2 - 1) / (IB * 2);
+            const int g0 = (i * 2 + j) * PER;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < PER; ++r)
+              if (g0 + r < NFRAG) read_one(rbuf, rks, g0 + r);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (q < q1) {
             __builtin_amdgcn_sched_barrier(0);
             if (!(kDbg & 1)) stage_q(slot, k0s, q);
@@ -368,13 +404,11 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     for (int t = 0; t < nt; ++t) {
       const int nx1 = cur + 1 == 3 ? 0 : cur + 1;
       const int nx2 = nx1 + 1 == 3 ? 0 : nx1 + 1;
-      read_half(cur, 1);                                      // S1
-      mfma_half(0, nx2, t + 2, H, C::LOADS);                  // S2
+      mfma_half(0, nx2, t + 2, H, C::LOADS, cur, 1);          // S1 + S2
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // S3: this wave's F[1] is in registers
       if (kDbg & 1) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();   // always LOADS younger pieces in flight
       if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();
-      read_half(nx1, 0);                                      // S4 (past the end: a stale slot, unused)
-      mfma_half(1, cur, t + 3, 0, H);                         // S5 (slot of tile t is free now)
+      mfma_half(1, cur, t + 3, 0, H, nx1, 0);                 // S4 + S5 (slot of tile t is free now; past the end the reads hit a stale slot, unused)
       cur = nx1;
     }
   }
