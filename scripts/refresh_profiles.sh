@@ -6,6 +6,8 @@ python scripts/bench_configs.py --cfg3-batch 64 > gpurun_out/r01/other_configs.j
 python scripts/bench_configs.py --only cfg3b --cfg3-batch 256 >> gpurun_out/r01/other_configs.jsonl 2>/dev/null
 python scripts/microbench.py > gpurun_out/r01/microbench.txt 2>&1
 python scripts/gemm_bench.py > gpurun_out/r01/gemm_bench.txt 2>&1
+python scripts/rgemm_bench.py >> gpurun_out/r01/gemm_bench.txt 2>&1
+python scripts/vendor_gemm.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r01/vendor_gemm.txt
 python scripts/conv_one.py > gpurun_out/r01/conv_one.txt 2>&1
 python scripts/conv_wgrad_one.py >> gpurun_out/r01/conv_one.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
