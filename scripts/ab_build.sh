@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B helper: build an alternative libcplxamd_<name>.so whose GEMM translation units are compiled with
-# extra flags (e.g. -DGEMM_DMA_BURST=1); select it at run time with CPLXAMD_LIB=<path>.
-#   scripts/ab_build.sh burst -DGEMM_DMA_BURST=1
+# extra flags (e.g. -DCPLXAMD_GEMM_CLASSIC); select it at run time with CPLXAMD_LIB=<path>.
+#   scripts/ab_build.sh classic -DCPLXAMD_GEMM_CLASSIC
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../cplxmodule_amd/csrc"
