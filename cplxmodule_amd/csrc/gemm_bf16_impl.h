@@ -64,10 +64,11 @@ constexpr int kDbg = CPLXAMD_GEMM_DBG_BUILD;
 // {re, im} = 256 accumulators), one wave per SIMD -- 25 % fewer LDS reads per MFMA.
 template <bool CPLX, bool BIG = false>
 struct Cfg {
-  static constexpr int NT = (CPLX && BIG) ? 256 : 512;
-  static constexpr int IB = CPLX ? (BIG ? 4 : 2) : 4;           // 32-row MFMA blocks per wave
-  static constexpr int WM = CPLX ? (BIG ? 2 : 4) : 2, WN = CPLX ? 2 : 4;    // waves along M / N
-  static constexpr int BM = 32 * IB * WM, BN = 64 * WN;
+  static constexpr int NT = BIG ? 256 : 512;
+  static constexpr int IB = BIG ? 4 : (CPLX ? 2 : 4);           // 32-row MFMA blocks per wave
+  static constexpr int JB = (!CPLX && BIG) ? 4 : 2;             // 32-column MFMA blocks per wave
+  static constexpr int WM = BIG ? 2 : (CPLX ? 4 : 2), WN = CPLX ? 2 : (BIG ? 2 : 4);    // waves along M / N
+  static constexpr int BM = 32 * IB * WM, BN = 32 * JB * WN;
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
   // (a fourth 32 KiB slot for the real tile fits in 160 KiB; a ring generalised to NS slots measured
@@ -145,7 +146,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   constexpr int NT = C::NT;
 
   // ---- tile coordinates: split-K slice, XCD-contiguous grouped order ------------------------
-  constexpr int BM = C::BM, BN = C::BN, IB = C::IB;
+  constexpr int BM = C::BM, BN = C::BN, IB = C::IB, JB = C::JB;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   int lin = blockIdx.x, split = 0;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   const int m0 = __builtin_amdgcn_readfirstlane(bm * BM), n0 = __builtin_amdgcn_readfirstlane(bn * BN);
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = (wid / C::WN) * (32 * IB), wn = (wid % C::WN) * 64;
+  const int wm = (wid / C::WN) * (32 * IB), wn = (wid % C::WN) * (32 * JB);
   const int l31 = lane & 31, lk = lane >> 5;
   const int l15 = lane & 15, lg = (lane >> 4) & 1;   // "T" reads: 16-lane group geometry
 
@@ -174,11 +175,11 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   const bf16_t* Br = (const bf16_t*)g.b_r; const bf16_t* Bi = (const bf16_t*)g.b_i;
   const int64_t lda = TA ? g.a_cs : g.a_rs, ldb = TB ? g.b_cs : g.b_rs;
 
-  f32x16 acc_r[IB][2], acc_i[CPLX ? IB : 1][2];
+  f32x16 acc_r[IB][JB], acc_i[CPLX ? IB : 1][JB];
 #pragma unroll
   for (int i = 0; i < IB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < JB; ++j) {
       acc_r[i][j] = f32x16{0};
       if (CPLX) acc_i[i][j] = f32x16{0};
     }
@@ -229,7 +230,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     const char* sB = sA + C::A_BYTES;
     const char* sAi = sB + C::B_BYTES;
     const char* sBi = sAi + C::A_BYTES;
-    bf16x8 ar[2][IB], br[2][2], ai[2][IB], bi[2][2];
+    bf16x8 ar[2][IB], br[2][JB], ai[2][IB], bi[2][JB];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -238,7 +239,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
         if (CPLX) ai[ks][i] = a_frag(sAi, i, ks);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < JB; ++j) {
         br[ks][j] = b_frag(sB, j, ks);
         if (CPLX) bi[ks][j] = b_frag(sBi, j, ks);
       }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JB; ++j) {
           if (do_mfma) {
             // B fragment first: the accumulator holds the TRANSPOSED 32x32 tile
             acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
@@ -304,7 +305,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     //   S3 lgkmcnt(0), vmcnt (tile t+1 landed), s_barrier   (slot of tile t is free: all in registers)
     //   S4 read F[0] <- (tile t+1, ks 0)         S5 16 MFMAs on F[1] + first half of tile t+3's pieces
     // (S1 / S4 are not bursts: their ds_reads are dealt out behind the MFMA groups of S2 / S5)
-    bf16x8 ar[2][IB], br[2][2], ai[2][IB], bi[2][2];         // [ks][block]
+    bf16x8 ar[2][IB], br[2][JB], ai[2][IB], bi[2][JB];       // [ks][block]
     auto read_half = [&](int buf, int ks) {
       const char* sA = smem + buf * C::STAGE_BYTES;
       const char* sB = sA + C::A_BYTES;
@@ -316,13 +317,13 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
         if (CPLX) ai[ks][i] = a_frag(sAi, i, ks);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < JB; ++j) {
         br[ks][j] = b_frag(sB, j, ks);
         if (CPLX) bi[ks][j] = b_frag(sBi, j, ks);
       }
     };
     // one fragment of (slot buf, sub-step ks), in the order the MFMA groups need them
-    constexpr int NFRAG = CPLX ? 2 * IB + 4 : IB + 2;
+    constexpr int NFRAG = CPLX ? 2 * IB + 4 : IB + JB;
     auto read_one = [&](int buf, int ks, int idx) {
       const char* sA = smem + buf * C::STAGE_BYTES;
       const char* sB = sA + C::A_BYTES;
@@ -339,11 +340,13 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
         else if ((idx & 1) == 0) ar[ks][(idx - 4) / 2] = a_frag(sA, (idx - 4) / 2, ks);
         else ai[ks][(idx - 5) / 2] = a_frag(sAi, (idx - 5) / 2, ks);
       } else {
-        // B0 A0 B1 A1 A2 A3
+        // B0 A0 B1 A1, then the remaining B blocks, then the remaining A blocks
         if (idx == 0) br[ks][0] = b_frag(sB, 0, ks);
         else if (idx == 1) ar[ks][0] = a_frag(sA, 0, ks);
         else if (idx == 2) br[ks][1] = b_frag(sB, 1, ks);
-        else ar[ks][idx - 2] = a_frag(sA, idx - 2, ks);
+        else if (idx == 3) ar[ks][1] = a_frag(sA, 1, ks);
+        else if (idx < 2 + JB) br[ks][idx - 2] = b_frag(sB, idx - 2, ks);
+        else ar[ks][idx - JB] = a_frag(sA, idx - JB, ks);
       }
     };
     constexpr int H = (C::LOADS + 1) / 2;                     // pieces issued in S5; the rest in S2
@@ -359,7 +362,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JB; ++j) {
           if (!(kDbg & 2)) {
             acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
             if (CPLX) {
@@ -375,8 +378,8 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
           }
           {  // the other half's fragments: a few ds_reads behind every MFMA group instead of one burst of
              // 8-16 (keeps the LDS command FIFO from filling: +1.5 % on the T-operand shapes, 0 elsewhere)
-            constexpr int PER = (NFRAG + IB * 2 - 1) / (IB * 2);
-            const int g0 = (i * 2 + j) * PER;
+            constexpr int PER = (NFRAG + IB * JB - 1) / (IB * JB);
+            const int g0 = (i * JB + j) * PER;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < PER; ++r)
@@ -428,7 +431,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   // 10 % of the real kernel, `profiles/r01_gemm_variants.md`).  One plane and 64 rows per round, each
   // wave in its own 9 KiB of the (now idle) ring.
   if constexpr (sizeof(TOUT) == 2) {
-    const bool lds_epi = g.lds_epilogue && !g.g1 && !g.emul && !g.accumulate && g.splits <= 1 && (g.ldc & 7) == 0 &&
+    const bool lds_epi = JB == 2 && g.lds_epilogue && !g.g1 && !g.emul && !g.accumulate && g.splits <= 1 && (g.ldc & 7) == 0 &&
                          (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
                          (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0);
     if (lds_epi) {
@@ -445,7 +448,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < JB; ++j)
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const int cl = j * 32 + 8 * q + 4 * lk;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   // then writes 4 rows x 256 B instead of 32 rows x 32 B; the elementwise multiplier (LRT log_sigma2
   // gradient) and the accumulate operand are read row-major at the same point.
   if constexpr (sizeof(TOUT) == 4) {
-    const bool lds_epi = g.lds_epilogue && !g.g1 && g.splits <= 1 && (g.ldc & 3) == 0 &&
+    const bool lds_epi = JB == 2 && g.lds_epilogue && !g.g1 && g.splits <= 1 && (g.ldc & 3) == 0 &&
                          (reinterpret_cast<uintptr_t>(cr) & 15) == 0 &&
                          (!CPLX || (reinterpret_cast<uintptr_t>(ci) & 15) == 0) &&
                          (!g.emul || (reinterpret_cast<uintptr_t>(g.emul) & 15) == 0);
@@ -504,7 +507,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < JB; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int cl = j * 32 + 8 * q + 4 * lk;
@@ -568,7 +571,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     const int row = m0 + wm + i * 32 + l31;
     if (row >= g.M) return;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < JB; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = n0 + wn + j * 32 + 8 * q + 4 * lk;
@@ -698,6 +701,10 @@ static int launch_kernel(const GemmArgs& g, hipStream_t st) {
   // kernel source: build with -DCPLXAMD_GEMM_CLASSIC to select it) and Cfg<true, BIG> (4 waves of
   // 128 x 64 at one wave per SIMD: 0.905 ms vs 0.86 ms on the headline shape with the final loop) were
   // measured slower; leaving them out halves the compile time.
+#ifdef GEMM_REAL_BIG      // experiment: real kernel as 4 waves of 128 x 128 (one wave per SIMD, the vendor's shape):
+                          // 0.296 / 0.314 / 0.247 ms vs 0.271 / 0.244 / 0.225 ms on the three variance GEMMs -- slower
+  if constexpr (!CPLX) return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true, true>(g, st);
+#endif
 #ifdef CPLXAMD_GEMM_CLASSIC
   return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, false>(g, st);
 #else
