@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -27,6 +27,10 @@ SIGNATURES = {
     "cplxamd_vd_kl_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P],
     "cplxamd_vd_kl_fwd_bwd": [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _L, _P],
     "cplxamd_vd_log_alpha": [_P, _P, _P, _P, _L, _P],
+    "cplxamd_vd_log_alpha_bwd": [_P, _P, _P, _P, _P, _L, _P],
+    "cplxamd_cplx_abs_fwd": [_P, _P, _P, _L, _I, _P],
+    "cplxamd_cplx_abs_bwd": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "cplxamd_mask_mul": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "cplxamd_vd_mask": [_P, _P, _P, _F, _P, _P, _P, _L, _P],
     "cplxamd_expi_fwd": [_P, _P, _L, _P],
     "cplxamd_expi_bwd": [_P, _P, _P, _L, _P],
@@ -36,6 +40,10 @@ SIGNATURES = {
     "cplxamd_philox_normal": [_P, _P, _U, _U, _L, _P],
     "cplxamd_cgemm": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,
                       _I, _I, _I, _P, _L, _P],
+    "cplxamd_cgemm_ex": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,
+                         _I, _I, _P, _I, _P, _L, _P],
+    "cplxamd_rgemm_ex": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P],
+    "cplxamd_vd_prep_kl": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "cplxamd_cgemm_batched": [_P, _P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],

@@ -245,9 +245,10 @@ class Cplx:
 
     def __abs__(self):
         """Modulus via one fused kernel (reference: stack + norm, cplxmodule/cplx.py:183-192)."""
-        if self._re.dtype == torch.float32 and not (self._re.requires_grad or self._im.requires_grad):
-            return ops.modulus(self._re, self._im)
-        return torch.sqrt(self._re * self._re + self._im * self._im)
+        if self._re.dtype in (torch.float32, torch.bfloat16) and self._im.dtype == self._re.dtype:
+            return ops.AbsFn.apply(self._re, self._im)
+        # other dtypes (float64 host-side utilities): the reference's own formulation
+        return torch.norm(torch.stack([self._re, self._im], dim=0), p=2, dim=0)
 
     @property
     def angle(self):

@@ -22,7 +22,14 @@ struct GemmArgs {
   const float* g1 = nullptr; const float* g2 = nullptr; float gsign = 1.0f;
   // batched (generic kernel only): blockIdx.z = batch entry, operands advance by these element strides
   int batch = 1; int64_t a_bs = 0, b_bs = 0, c_bs = 0;
+  // epilogue extensions (fused KL + LRT backward): with `accumulate`, C = result + (*beta) * C where beta
+  // is a float on the DEVICE (nullptr: 1); emul_exp: the multiplier is exp(emul[m,n]) (emul = log_sigma2)
+  const float* beta = nullptr; int emul_exp = 0;
+  int emul_both = 0;   // complex GEMM: the (real) multiplier applies to both planes (masked layers' dW * mask)
 };
+
+__device__ __forceinline__ float gemm_beta(const GemmArgs& g) { return (g.accumulate && g.beta) ? *g.beta : 1.0f; }
+__device__ __forceinline__ float gemm_emul(const GemmArgs& g, float m) { return g.emul_exp ? expf(m) : m; }
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)
 template <bool CPLX>

@@ -21,14 +21,24 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
                   const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
                   int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
                   int algo, void* ws, int64_t ws_bytes, void* stream) {
+  return cplxamd_cgemm_ex(a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, bias_r, bias_i, nullptr, c_r, c_i, ldc, M, N, K,
+                          conj_b, in_dtype, out_dtype, accumulate, nullptr, algo, ws, ws_bytes, stream);
+}
+
+int cplxamd_cgemm_ex(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
+                     const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
+                     const float* bias_r, const float* bias_i, const float* emul, void* c_r, void* c_i, int64_t ldc,
+                     int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
+                     const float* beta, int algo, void* ws, int64_t ws_bytes, void* stream) {
   if (!a_r || !a_i || !b_r || !b_i || !c_r || !c_i) return CPLXAMD_EINVAL;
   if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
   if ((bias_r == nullptr) != (bias_i == nullptr)) return CPLXAMD_EINVAL;
   if (accumulate && out_dtype != CPLXAMD_F32) return CPLXAMD_EINVAL;
   if (algo != CPLXAMD_ALGO_4M && algo != CPLXAMD_ALGO_3M) return CPLXAMD_EINVAL;
-  GemmArgs g{a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, bias_r, bias_i, nullptr,
+  if (emul && (out_dtype != CPLXAMD_F32 || algo != CPLXAMD_ALGO_4M)) return CPLXAMD_EINVAL;
+  GemmArgs g{a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, bias_r, bias_i, emul,
              c_r, c_i, ldc, M, N, K, conj_b ? 1 : 0, accumulate ? 1 : 0};
-  g.ws = ws; g.ws_bytes = ws_bytes;
+  g.ws = ws; g.ws_bytes = ws_bytes; g.beta = accumulate ? beta : nullptr; g.emul_both = emul ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (algo == CPLXAMD_ALGO_3M)     // Gauss: dense bf16 operands only, never a silent 4M fallback
     return in_dtype == CPLXAMD_BF16 ? launch_gemm_bf16_gauss(g, out_dtype, st) : CPLXAMD_ESHAPE;
@@ -56,12 +66,20 @@ int cplxamd_rgemm(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int6
                   int64_t b_cs, const float* bias, const float* emul, void* c, int64_t ldc,
                   int M, int N, int K, int in_dtype, int out_dtype, int accumulate,
                   void* ws, int64_t ws_bytes, void* stream) {
+  return cplxamd_rgemm_ex(a, a_rs, a_cs, b, b_rs, b_cs, bias, emul, 0, c, ldc, M, N, K, in_dtype, out_dtype,
+                          accumulate, nullptr, ws, ws_bytes, stream);
+}
+
+int cplxamd_rgemm_ex(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
+                     int64_t b_cs, const float* bias, const float* emul, int emul_exp, void* c, int64_t ldc,
+                     int M, int N, int K, int in_dtype, int out_dtype, int accumulate, const float* beta,
+                     void* ws, int64_t ws_bytes, void* stream) {
   if (!a || !b || !c) return CPLXAMD_EINVAL;
   if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
   if (accumulate && out_dtype != CPLXAMD_F32) return CPLXAMD_EINVAL;
   GemmArgs g{a, nullptr, a_rs, a_cs, b, nullptr, b_rs, b_cs, bias, nullptr, emul,
              c, nullptr, ldc, M, N, K, 0, accumulate ? 1 : 0};
-  g.ws = ws; g.ws_bytes = ws_bytes;
+  g.ws = ws; g.ws_bytes = ws_bytes; g.beta = accumulate ? beta : nullptr; g.emul_exp = (emul && emul_exp) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == CPLXAMD_BF16) {
     const int rc = launch_gemm_bf16<false>(g, out_dtype, st);

@@ -50,7 +50,10 @@ constexpr int BK = 32, STAGES = 3;
 // ablation bits are COMPILE-TIME (-DCPLXAMD_GEMM_DBG_BUILD=n): as run-time tests they put a branch
 // around every MFMA group and LDS-DMA piece, which splits the K loop into ~30 basic blocks and makes
 // the compiler's s_waitcnt placement conservative (it waited for the NEXT tile's fragments).
-// 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no barrier
+// 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no epilogue stores (accumulators kept live),
+// 16 no sign XOR (WRONG results: bounds what removing the XORs could buy), 32 every LDS-DMA piece re-reads K tile 0
+// (cache-hot source: separates the memory system's share of the staging cost from issue + LDS-write cost),
+// 64 never wait for the LDS-DMA (racy: the share of the counted vmcnt waits)
 #ifndef CPLXAMD_GEMM_DBG_BUILD
 #define CPLXAMD_GEMM_DBG_BUILD 0
 #endif
@@ -130,6 +133,7 @@ __device__ __forceinline__ bf16x8 frag_t(const char* lds_plane, int rb, int kb, 
 }
 
 __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
+  if (kDbg & 16) return v;
   uint4 u = __builtin_bit_cast(uint4, v);
   u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
   return __builtin_bit_cast(bf16x8, u);
@@ -358,7 +362,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       }
       int q = q0;
       // tiles past the end re-load the last one into a free slot: no branch in the K loop
-      const int k0s = (tile < nt ? tile : nt - 1) * BK;
+      const int k0s = (kDbg & 32) ? 0 : (tile < nt ? tile : nt - 1) * BK;
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
@@ -403,23 +407,60 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
       for (int q = 0; q < H; ++q) stage_q(2, (nt > 2 ? 2 : nt - 1) * BK, q);
     }
+#ifdef CPLXAMD_GEMM_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(1);              // static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
+    // one K tile in ring slot `cur`
+    auto tile_body = [&](int cur, int nx1, int nx2, int t) {
+      mfma_half(0, nx2, t + 2, H, C::LOADS, cur, 1);          // S1 + S2
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // S3: this wave's F[1] is in registers
+      if (kDbg & 1) wait_vmcnt<0>(); else if (!(kDbg & 64)) wait_vmcnt<C::LOADS>();   // always LOADS younger pieces in flight
+      if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();
+      mfma_half(1, cur, t + 3, 0, H, nx1, 0);                 // S4 + S5 (slot of tile t is free now; past the end the reads hit a stale slot, unused)
+    };
+#ifdef CPLXAMD_GEMM_UNROLL3
+    // ring position as a compile-time constant: the K loop is unrolled by the ring depth so that every
+    // LDS address is (per-lane base of the slot) + immediate and every M0 value one scalar add
+    int t = 0;
+    for (; t + 3 <= nt; t += 3) {
+      tile_body(0, 1, 2, t);
+      tile_body(1, 2, 0, t + 1);
+      tile_body(2, 0, 1, t + 2);
+    }
+    if (t < nt) tile_body(0, 1, 2, t);
+    if (t + 1 < nt) tile_body(1, 2, 0, t + 1);
+#else
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
       const int nx1 = cur + 1 == 3 ? 0 : cur + 1;
       const int nx2 = nx1 + 1 == 3 ? 0 : nx1 + 1;
-      mfma_half(0, nx2, t + 2, H, C::LOADS, cur, 1);          // S1 + S2
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // S3: this wave's F[1] is in registers
-      if (kDbg & 1) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();   // always LOADS younger pieces in flight
-      if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();
-      mfma_half(1, cur, t + 3, 0, H, nx1, 0);                 // S4 + S5 (slot of tile t is free now; past the end the reads hit a stale slot, unused)
+      tile_body(cur, nx1, nx2, t);
       cur = nx1;
     }
+#endif
+#ifdef CPLXAMD_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
 
+  if (kDbg & 8) {   // ablation: no stores; the accumulators stay live
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (a 512-bit "v" operand is not a valid constraint in the host pass)
+        asm volatile("" ::"v"(acc_r[i][j]));
+        if (CPLX) asm volatile("" ::"v"(acc_i[i][j]));
+#endif
+      }
+    wait_vmcnt<0>();
+    return;
+  }
   // ---- epilogue.  Transposed 32x32 C/D layout: output row = lane & 31, output columns
   // 8 q + 4 (lane >> 5) + {0..3} for register group q: one 8-B (bf16) / 16-B (fp32) store each.
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
   TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
+  const float beta = gemm_beta(g);
   if (g.splits > 1) {  // fp32 partial slabs [split][plane][M][ldc]; bias / emul applied by the reducer
     const int64_t slab = (int64_t)g.M * g.ldc;
     cr = reinterpret_cast<TOUT*>(g.ws) + (int64_t)split * (CPLX ? 2 : 1) * slab;
@@ -529,15 +570,15 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
             if (row < g.M && col < g.N) {
               const int64_t o = (int64_t)row * g.ldc + col;
               if (col + 3 < g.N) {
-                if (g.emul && !pl) {
+                if (g.emul && (!pl || g.emul_both)) {
                   const f4 m = ld4(g.emul + o);
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v.v[e] *= m.v[e];
+                  for (int e = 0; e < 4; ++e) v.v[e] *= gemm_emul(g, m.v[e]);
                 }
                 if (g.accumulate) {
                   const f4 p = ld4(out + o);
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v.v[e] += p.v[e];
+                  for (int e = 0; e < 4; ++e) v.v[e] += beta * p.v[e];
                 }
                 st4(out + o, v);
               } else {
@@ -545,8 +586,8 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
                 for (int e = 0; e < 4; ++e)
                   if (col + e < g.N) {
                     float x = v.v[e];
-                    if (g.emul && !pl) x *= g.emul[o + e];
-                    if (g.accumulate) x += out[o + e];
+                    if (g.emul && (!pl || g.emul_both)) x *= gemm_emul(g, g.emul[o + e]);
+                    if (g.accumulate) x += beta * out[o + e];
                     out[o + e] = x;
                   }
               }
@@ -623,16 +664,20 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
           if (g.emul) {
             const f4 m = ld4(g.emul + o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vr.v[e] *= m.v[e];
+            for (int e = 0; e < 4; ++e) vr.v[e] *= gemm_emul(g, m.v[e]);
+            if (CPLX && g.emul_both) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vi.v[e] *= gemm_emul(g, m.v[e]);
+            }
           }
           if (g.accumulate) {
             const f4 p = ld4(cr + o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vr.v[e] += p.v[e];
+            for (int e = 0; e < 4; ++e) vr.v[e] += beta * p.v[e];
             if (CPLX) {
               const f4 p2 = ld4(ci + o);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) vi.v[e] += p2.v[e];
+              for (int e = 0; e < 4; ++e) vi.v[e] += beta * p2.v[e];
             }
           }
           st4(cr + o, vr);
@@ -642,12 +687,13 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
           for (int e = 0; e < 4; ++e) {
             if (col + e >= g.N) break;
             float xr = vr.v[e] + (g.bias_r ? g.bias_r[col + e] : 0.f);
-            if (g.emul) xr *= g.emul[o + e];
-            if (g.accumulate) xr += io<TOUT>::ld(cr + o + e);
+            if (g.emul) xr *= gemm_emul(g, g.emul[o + e]);
+            if (g.accumulate) xr += beta * io<TOUT>::ld(cr + o + e);
             io<TOUT>::st(cr + o + e, xr);
             if (CPLX) {
               float xi = vi.v[e] + (g.bias_i ? g.bias_i[col + e] : 0.f);
-              if (g.accumulate) xi += io<TOUT>::ld(ci + o + e);
+              if (g.emul && g.emul_both) xi *= gemm_emul(g, g.emul[o + e]);
+              if (g.accumulate) xi += beta * io<TOUT>::ld(ci + o + e);
               io<TOUT>::st(ci + o + e, xi);
             }
           }
@@ -756,8 +802,9 @@ int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx) {
 static __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* slabs, int splits,
                                                                int64_t slab_stride, int M, int N,
                                                                int64_t ldc, const float* bias,
-                                                               const float* emul, int accumulate,
-                                                               float* out) {
+                                                               const float* emul, int emul_exp, int accumulate,
+                                                               const float* beta_p, float* out) {
+  const float beta = (accumulate && beta_p) ? *beta_p : 1.0f;
   const int64_t n4 = ((int64_t)M * ldc) >> 2;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -775,12 +822,12 @@ static __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const floa
     if (emul) {
       const f4 m = ld4(emul + 4 * i);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc.v[e] *= m.v[e];
+      for (int e = 0; e < 4; ++e) acc.v[e] *= emul_exp ? expf(m.v[e]) : m.v[e];
     }
     if (accumulate) {
       const f4 o = ld4(out + 4 * i);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc.v[e] += o.v[e];
+      for (int e = 0; e < 4; ++e) acc.v[e] += beta * o.v[e];
     }
     st4(out + 4 * i, acc);
   }
@@ -799,11 +846,11 @@ static int launch_splitk(const GemmArgs& g0, int splits, bool ta, bool tb, hipSt
   const int64_t slab = (int64_t)g.M * g.N, stride = (CPLX ? 2 : 1) * slab;
   const int grid = stream_grid(slab >> 2, 256);
   gemm_slab_reduce_kernel<<<grid, 256, 0, st>>>((const float*)g.ws, splits, stride, g.M, g.N, g.ldc,
-                                                g.bias_r, g.emul, g.accumulate, (float*)g.c_r);
+                                                g.bias_r, g.emul, g.emul_exp, g.accumulate, g.beta, (float*)g.c_r);
   CPLXAMD_CHECK_LAUNCH();
   if (CPLX) {
     gemm_slab_reduce_kernel<<<grid, 256, 0, st>>>((const float*)g.ws + slab, splits, stride, g.M, g.N,
-                                                  g.ldc, g.bias_i, nullptr, g.accumulate,
+                                                  g.ldc, g.bias_i, g.emul_both ? g.emul : nullptr, g.emul_exp, g.accumulate, g.beta,
                                                   (float*)g.c_i);
     CPLXAMD_CHECK_LAUNCH();
   }

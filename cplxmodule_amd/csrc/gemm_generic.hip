@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(GemmArgs g) {
   // C/D layout of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r) + bz * g.c_bs;
   TOUT* ci = reinterpret_cast<TOUT*>(g.c_i) + (CPLX ? bz * g.c_bs : 0);
+  const float beta = gemm_beta(g);
   float* slab = g.splits > 1 ? reinterpret_cast<float*>(g.ws) + (int64_t)blockIdx.z * (CPLX ? 2 : 1) * g.M * g.N
                              : nullptr;   // fp32 partial slabs [split][plane][M][N]; bias / emul / accumulate: the reducer
 #pragma unroll
@@ -174,12 +175,13 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(GemmArgs g) {
         }
         const int64_t o = (int64_t)row * g.ldc + col;
         float vr = acc_r[i][j][r] + b_r;
-        if (g.emul) vr *= g.emul[o];
-        if (g.accumulate) vr += io<TOUT>::ld(cr + o);
+        if (g.emul) vr *= gemm_emul(g, g.emul[o]);
+        if (g.accumulate) vr += beta * io<TOUT>::ld(cr + o);
         io<TOUT>::st(cr + o, vr);
         if (CPLX) {
           float vi = acc_i[i][j][r] + b_i;
-          if (g.accumulate) vi += io<TOUT>::ld(ci + o);
+          if (g.emul && g.emul_both) vi *= gemm_emul(g, g.emul[o]);
+          if (g.accumulate) vi += beta * io<TOUT>::ld(ci + o);
           io<TOUT>::st(ci + o, vi);
         }
       }
@@ -208,8 +210,9 @@ template <typename TOUT>
 __global__ __launch_bounds__(256) void generic_slab_reduce_kernel(const float* slabs, int splits,
                                                                   int64_t slab_stride, int M, int N,
                                                                   int64_t ldc, const float* bias,
-                                                                  const float* emul, int accumulate,
-                                                                  TOUT* out) {
+                                                                  const float* emul, int emul_exp, int accumulate,
+                                                                  const float* beta_p, TOUT* out) {
+  const float beta = (accumulate && beta_p) ? *beta_p : 1.0f;
   const int64_t n = (int64_t)M * N, stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     float acc = 0.f;
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(256) void generic_slab_reduce_kernel(const float* s
     const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
     const int64_t o = (int64_t)row * ldc + col;
     if (bias) acc += bias[col];
-    if (emul) acc *= emul[o];
-    if (accumulate) acc += io<TOUT>::ld(out + o);
+    if (emul) acc *= emul_exp ? expf(emul[o]) : emul[o];
+    if (accumulate) acc += beta * io<TOUT>::ld(out + o);
     io<TOUT>::st(out + o, acc);
   }
 }
@@ -261,10 +264,10 @@ int launch_gemm_generic(const GemmArgs& g0, int in_dtype, int out_dtype, hipStre
       void* out = pl ? g.c_i : g.c_r;
       if (out_dtype == CPLXAMD_F32)
         generic_slab_reduce_kernel<float><<<rgrid, 256, 0, st>>>(src, g.splits, stride, g.M, g.N, g.ldc, bias,
-                                                                pl ? nullptr : g.emul, g.accumulate, (float*)out);
+                                                                (pl && !g.emul_both) ? nullptr : g.emul, g.emul_exp, g.accumulate, g.beta, (float*)out);
       else
         generic_slab_reduce_kernel<bf16_t><<<rgrid, 256, 0, st>>>(src, g.splits, stride, g.M, g.N, g.ldc, bias,
-                                                                 pl ? nullptr : g.emul, g.accumulate, (bf16_t*)out);
+                                                                 (pl && !g.emul_both) ? nullptr : g.emul, g.emul_exp, g.accumulate, g.beta, (bf16_t*)out);
       CPLXAMD_CHECK_LAUNCH();
     }
   }

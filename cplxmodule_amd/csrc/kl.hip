@@ -139,7 +139,8 @@ __device__ __forceinline__ void weight_grad(float fp, float wr, float wi, float 
       gwr = c * wr;
       gwi = c * wi;
     } else {
-      gwr = copysignf(2.0f * fp / (theta + 1e-12f), wr);
+      // sign(w) * 2 fp / (|w| + 1e-12): fp carries the upstream gradient and may be negative
+      gwr = (wr < 0.0f ? -2.0f : 2.0f) * fp / (theta + 1e-12f);
       gwi = 0.0f;
     }
   } else {
@@ -161,6 +162,11 @@ struct KlArgs {
   float* g_wr;
   float* g_wi;
   int64_t n;
+  // fused per-step operand preparation of the bf16 LRT layers (all nullable; n % 4 == 0 required):
+  // bf16 copies of the weight planes and exp(log_sigma2) for the mean / variance GEMMs
+  bf16_t* wr_b = nullptr;
+  bf16_t* wi_b = nullptr;
+  bf16_t* s_b = nullptr;
 };
 
 template <int KIND, bool VALUE, bool GRAD>
@@ -205,6 +211,14 @@ __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
       if (a.g_ls2) st4(a.g_ls2 + 4 * i, d_ls);
       if (a.g_wr) st4(a.g_wr + 4 * i, d_wr);
       if (CPLX && a.g_wi) st4(a.g_wi + 4 * i, d_wi);
+    }
+    if (a.wr_b) st4(a.wr_b + 4 * i, wr);
+    if (CPLX && a.wi_b) st4(a.wi_b + 4 * i, wi);
+    if (a.s_b) {
+      f4 e;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e.v[j] = expf(ls.v[j]);
+      st4(a.s_b + 4 * i, e);
     }
   }
   // scalar tail (n % 4 elements), handled by block 0
@@ -278,6 +292,22 @@ static int launch_kl(int kind, const KlArgs& a, int grid, hipStream_t st) {
   return 0;
 }
 
+// operand preparation without the KL: bf16(wr), bf16(wi), bf16(exp(log_sigma2)) in one pass
+__global__ __launch_bounds__(kKlThreads) void prep_kernel(const float* wr, const float* wi, const float* ls2,
+                                                          bf16_t* wr_b, bf16_t* wi_b, bf16_t* s_b, int64_t n) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * kKlThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i < n4; i += stride) {
+    if (wr_b) st4(wr_b + 4 * i, ld4(wr + 4 * i));
+    if (wi_b) st4(wi_b + 4 * i, ld4(wi + 4 * i));
+    if (s_b) {
+      f4 e = ld4(ls2 + 4 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e.v[j] = expf(e.v[j]);
+      st4(s_b + 4 * i, e);
+    }
+  }
+}
+
 static bool kl_args_ok(const float* wr, const float* wi, const float* ls2, int kind, int64_t n) {
   if (!wr || !ls2 || n < 0 || kind < 0 || kind > CPLXAMD_KL_CPLX_VD_BOGUS) return false;
   const bool cplx = kind >= CPLXAMD_KL_CPLX_VD;
@@ -323,6 +353,22 @@ __global__ __launch_bounds__(kKlThreads) void log_alpha_kernel(const float* wr, 
   if (MASK && partial) {
     const double s = block_sum<double, kKlThreads>(cnt, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
+}
+
+// gradient of log_alpha wrt the weight: d/dw (ls2 - 2 log(|w| + 1e-12)) * g  (d/d ls2 = g itself)
+template <bool CPLX>
+__global__ __launch_bounds__(kKlThreads) void log_alpha_bwd_kernel(const float* g, const float* wr,
+                                                                   const float* wi, float* g_wr, float* g_wi,
+                                                                   int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kKlThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i < n; i += stride) {
+    const float a = wr[i], b = CPLX ? wi[i] : 0.0f;
+    const float theta = weight_abs<CPLX, true>(a, b);
+    float ga, gb;
+    weight_grad<CPLX>(-g[i], a, b, theta, ga, gb);
+    g_wr[i] = ga;
+    if (CPLX) g_wi[i] = gb;
   }
 }
 
@@ -449,6 +495,30 @@ int cplxamd_vd_kl_fwd_bwd(const float* wr, const float* wi, const float* log_sig
   return 0;
 }
 
+int cplxamd_vd_prep_kl(const float* wr, const float* wi, const float* log_sigma2, int kind, int with_kl,
+                       void* wr_bf16, void* wi_bf16, void* s_bf16, float* out_sum, float* g_log_sigma2,
+                       float* g_wr, float* g_wi, void* ws, int64_t n, void* stream) {
+  if (n < 0 || (n & 3)) return CPLXAMD_ESHAPE;
+  if ((wr_bf16 && !wr) || (wi_bf16 && !wi) || (s_bf16 && !log_sigma2)) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(n >> 2, kKlThreads);
+  if (!with_kl) {
+    prep_kernel<<<grid, kKlThreads, 0, st>>>(wr, wi, log_sigma2, (bf16_t*)wr_bf16, (bf16_t*)wi_bf16,
+                                             (bf16_t*)s_bf16, n);
+    CPLXAMD_CHECK_LAUNCH();
+    return 0;
+  }
+  if (!kl_args_ok(wr, wi, log_sigma2, kind, n) || !out_sum || !ws) return CPLXAMD_EINVAL;
+  KlArgs a{wr, wi, log_sigma2, nullptr, nullptr, 1.0f, nullptr, (double*)ws,
+           g_log_sigma2, g_wr, g_wi, n};
+  a.wr_b = (bf16_t*)wr_bf16; a.wi_b = (bf16_t*)wi_bf16; a.s_b = (bf16_t*)s_bf16;
+  int rc = launch_kl<true, true>(kind, a, grid, st);
+  if (rc) return rc;
+  kl_final_kernel<<<1, kKlThreads, 0, st>>>((const double*)ws, grid, out_sum);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
 int cplxamd_vd_log_alpha(const float* wr, const float* wi, const float* log_sigma2, float* out,
                          int64_t n, void* stream) {
   if (!wr || !log_sigma2 || !out || n < 0) return CPLXAMD_EINVAL;
@@ -460,6 +530,17 @@ int cplxamd_vd_log_alpha(const float* wr, const float* wi, const float* log_sigm
   else
     log_alpha_kernel<false, false><<<grid, kKlThreads, 0, st>>>(wr, wi, log_sigma2, 0.f, out,
                                                                 nullptr, n);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+int cplxamd_vd_log_alpha_bwd(const float* g, const float* wr, const float* wi, float* g_wr, float* g_wi,
+                             int64_t n, void* stream) {
+  if (!g || !wr || !g_wr || n < 0 || ((wi == nullptr) != (g_wi == nullptr))) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(n, kKlThreads);
+  if (wi) log_alpha_bwd_kernel<true><<<grid, kKlThreads, 0, st>>>(g, wr, wi, g_wr, g_wi, n);
+  else log_alpha_bwd_kernel<false><<<grid, kKlThreads, 0, st>>>(g, wr, wi, g_wr, g_wi, n);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }

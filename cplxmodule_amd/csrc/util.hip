@@ -177,11 +177,108 @@ __global__ __launch_bounds__(kUT) void dx_accum_kernel(T* dxr, T* dxi, const T* 
   }
 }
 
+// d|z| = g * z / |z|, 0 at z == 0 (the subgradient torch.norm uses, cplx.py:183-192; sqrt(re^2 + im^2)
+// differentiated by autograd gives inf * 0 = NaN there)
+template <typename T>
+__global__ __launch_bounds__(kUT) void abs_bwd_kernel(const T* g, const T* xr, const T* xi, T* dxr, T* dxi,
+                                                      int64_t n) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * kUT;
+  for (int64_t i = (int64_t)blockIdx.x * kUT + threadIdx.x; i < n4; i += stride) {
+    const f4 gg = ld4(g + 4 * i), a = ld4(xr + 4 * i), b = ld4(xi + 4 * i);
+    f4 da, db;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float r = rn_sqrt(fmaf(b.v[j], b.v[j], a.v[j] * a.v[j]));
+      const float s = r > 0.0f ? gg.v[j] / r : 0.0f;
+      da.v[j] = s * a.v[j];
+      db.v[j] = s * b.v[j];
+    }
+    st4(dxr + 4 * i, da);
+    st4(dxi + 4 * i, db);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      const float a = io<T>::ld(xr + e), b = io<T>::ld(xi + e);
+      const float r = rn_sqrt(fmaf(b, b, a * a));
+      const float s = r > 0.0f ? io<T>::ld(g + e) / r : 0.0f;
+      io<T>::st(dxr + e, s * a);
+      io<T>::st(dxi + e, s * b);
+    }
+  }
+}
+
+// out = in * mask for one or two planes (masked layers: the sparsified weight, and -- with the planes
+// being gradients -- the weight gradient; nn/masked/{real,complex}.py), float32 mask, any in/out dtype
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kUT) void mask_mul_kernel(const TI* ar, const TI* ai, const float* mask, TO* outr,
+                                                       TO* outi, int64_t n) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * kUT;
+  for (int64_t i = (int64_t)blockIdx.x * kUT + threadIdx.x; i < n4; i += stride) {
+    const f4 m = ld4(mask + 4 * i);
+    f4 a = ld4(ar + 4 * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.v[j] *= m.v[j];
+    st4(outr + 4 * i, a);
+    if (ai) {
+      f4 b = ld4(ai + 4 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b.v[j] *= m.v[j];
+      st4(outi + 4 * i, b);
+    }
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      io<TO>::st(outr + e, io<TI>::ld(ar + e) * mask[e]);
+      if (ai) io<TO>::st(outi + e, io<TI>::ld(ai + e) * mask[e]);
+    }
+  }
+}
+
 }  // namespace cplxamd
 
 using namespace cplxamd;
 
 extern "C" {
+
+int cplxamd_cplx_abs_fwd(const void* xr, const void* xi, void* out, int64_t n, int dtype, void* stream) {
+  if (!xr || !xi || !out || n < 0) return CPLXAMD_EINVAL;
+  return launch_ew<4>(xr, xi, out, n, dtype, dtype, (hipStream_t)stream);
+}
+
+int cplxamd_cplx_abs_bwd(const void* g, const void* xr, const void* xi, void* dxr, void* dxi, int64_t n,
+                         int dtype, void* stream) {
+  if (!g || !xr || !xi || !dxr || !dxi || n < 0) return CPLXAMD_EINVAL;
+  const int grid = stream_grid(n >> 2, kUT);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CPLXAMD_F32)
+    abs_bwd_kernel<float><<<grid, kUT, 0, st>>>((const float*)g, (const float*)xr, (const float*)xi,
+                                                (float*)dxr, (float*)dxi, n);
+  else if (dtype == CPLXAMD_BF16)
+    abs_bwd_kernel<bf16_t><<<grid, kUT, 0, st>>>((const bf16_t*)g, (const bf16_t*)xr, (const bf16_t*)xi,
+                                                 (bf16_t*)dxr, (bf16_t*)dxi, n);
+  else
+    return CPLXAMD_EINVAL;
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+int cplxamd_mask_mul(const void* in_r, const void* in_i, const float* mask, void* out_r, void* out_i,
+                     int64_t n, int in_dtype, int out_dtype, void* stream) {
+  if (!in_r || !mask || !out_r || n < 0 || ((in_i == nullptr) != (out_i == nullptr))) return CPLXAMD_EINVAL;
+  const int grid = stream_grid(n >> 2, kUT);
+  hipStream_t st = (hipStream_t)stream;
+#define MM(TI, TO) mask_mul_kernel<TI, TO><<<grid, kUT, 0, st>>>((const TI*)in_r, (const TI*)in_i, mask, (TO*)out_r, (TO*)out_i, n)
+  if (in_dtype == CPLXAMD_F32 && out_dtype == CPLXAMD_F32) MM(float, float);
+  else if (in_dtype == CPLXAMD_F32 && out_dtype == CPLXAMD_BF16) MM(float, bf16_t);
+  else if (in_dtype == CPLXAMD_BF16 && out_dtype == CPLXAMD_F32) MM(bf16_t, float);
+  else if (in_dtype == CPLXAMD_BF16 && out_dtype == CPLXAMD_BF16) MM(bf16_t, bf16_t);
+  else return CPLXAMD_EINVAL;
+#undef MM
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
 
 int cplxamd_abs2(const void* xr, const void* xi, void* out, int64_t n, int in_dtype,
                  int out_dtype, void* stream) {

@@ -65,7 +65,21 @@ class BaseMasked(torch.nn.Module):
         if not self.is_sparse:
             raise RuntimeError(f"`{type(self).__name__}` has no sparsity mask. Please, either set "
                                "a mask attribute, or call `deploy_masks()`.")
-        return self.weight * self.mask
+        w = self.weight
+        probe = w.real if isinstance(w, cplx.Cplx) else w
+        if not probe.is_cuda:
+            # host-side inspection of a module that has not been moved to the GPU yet (the layers'
+            # forward itself has no CPU path): the reference's expression, cplxmodule/nn/masked/base.py:137-147
+            return w * self.mask
+        if isinstance(w, cplx.Cplx):
+            return cplx.Cplx(*ops.MaskMulFn.apply(w.real, w.imag, self.mask))
+        return ops.MaskMulFn.apply(w, None, self.mask)
+
+    def _require_mask(self):
+        if not self.is_sparse:
+            raise RuntimeError(f"`{type(self).__name__}` has no sparsity mask. Please, either set "
+                               "a mask attribute, or call `deploy_masks()`.")
+        return self.mask
 
 
 class _MaskedStats(BaseMasked, SparsityStats):
@@ -80,7 +94,11 @@ class _MaskedStats(BaseMasked, SparsityStats):
 
 class CplxLinearMasked(CplxLinear, _MaskedStats):
     def forward(self, input):
-        return cplx.linear(input, self.weight_masked, self.bias)
+        # the mask rides in the GEMM operand preparation / weight-gradient epilogue (ops.CplxLinearFn)
+        w, b = self.weight, self.bias
+        br, bi = (None, None) if b is None else (b.real, b.imag)
+        yr, yi = ops.CplxLinearFn.apply(input.real, input.imag, w.real, w.imag, br, bi, 0, self._require_mask())
+        return cplx.Cplx(yr, yi)
 
     def sparsity(self, *, hard=True, **kwargs):
         w = self.weight
@@ -155,7 +173,7 @@ class Conv3dMasked(torch.nn.Conv3d, _RealMaskedStats):
 
 class LinearMasked(torch.nn.Linear, _MaskedStats):
     def forward(self, input):
-        return ops.RealLinearFn.apply(input, self.weight_masked, self.bias)
+        return ops.RealLinearFn.apply(input, self.weight, self.bias, self._require_mask())
 
     def sparsity(self, *, hard=True, **kwargs):
         return [(id(self.weight), self._n_dropped(self.weight.numel(), hard))]

@@ -7,7 +7,7 @@ run the fused log-alpha kernels, and the exponential integral is evaluated on th
 """
 import torch
 
-from .base import BaseARD
+from .base import BaseARD, KLFusion
 from .noise import noise
 from ..utils.sparsity import SparsityStats
 from ..modules.linear import CplxLinear, CplxBilinear
@@ -23,7 +23,7 @@ def torch_expi(x):
 ExpiFunction = ops.ExpiFn
 
 
-class _CplxGaussianMixin:
+class _CplxGaussianMixin(KLFusion):
     """log_sigma2 parameter (init -10), log_alpha, penalty, relevance for complex weights."""
 
     _kl_kind = "cplx_vd"
@@ -39,9 +39,7 @@ class _CplxGaussianMixin:
     @property
     def log_alpha(self):
         w = self.weight
-        if torch.is_grad_enabled() and (self.log_sigma2.requires_grad or w.real.requires_grad):
-            return self.log_sigma2 - 2 * torch.log(abs(w) + 1e-12)
-        return ops.log_alpha(w.real, w.imag, self.log_sigma2).view_as(self.log_sigma2)
+        return ops.LogAlphaFn.apply(self.log_sigma2, w.real, w.imag)
 
     @property
     def penalty(self):
@@ -50,7 +48,9 @@ class _CplxGaussianMixin:
 
     def _penalty_reduced(self, reduction):
         w = self.weight
-        total = ops.PenaltySumFn.apply(self._kl_kind, self.log_sigma2, w.real, w.imag)
+        total = self._kl_get((w.real, w.imag, self.log_sigma2))
+        if total is None:
+            total = ops.PenaltySumFn.apply(self._kl_kind, self.log_sigma2, w.real, w.imag)
         return total / self.log_sigma2.numel() if reduction == "mean" else total
 
     def relevance(self, *, threshold, **kwargs):
@@ -70,6 +70,9 @@ class _CplxGaussianMixin:
         if noise.mode == "torch":
             e = cplx.randn(*shape, dtype=like.dtype, device=like.device)
             return e.real, e.imag, 0, 0
+        if noise.mode == "tape":
+            e = noise.pop_tape(shape, like, True)
+            return e[0], e[1], 0, 0
         seed, offset = noise.next(like.device)
         return None, None, seed, offset
 
@@ -88,8 +91,11 @@ class CplxLinearGaussian(_CplxGaussianMixin, CplxLinear):
         else:
             er, ei, seed, offset = self._draw_noise((*input.shape[:-1], self.out_features), input)
         br, bi = (None, None) if b is None else (b.real, b.imag)
-        yr, yi = ops.CplxLinearLRTFn.apply(input.real, input.imag, w.real, w.imag, br, bi,
-                                           self.log_sigma2, er, ei, seed, offset)
+        kind = self._kl_kind_for_forward()
+        yr, yi, kl = ops.CplxLinearLRTFn.apply(input.real, input.imag, w.real, w.imag, br, bi,
+                                               self.log_sigma2, er, ei, seed, offset, kind)
+        if kind is not None:
+            self._kl_put(kl, (w.real, w.imag, self.log_sigma2))
         return cplx.Cplx(yr, yi)
 
 

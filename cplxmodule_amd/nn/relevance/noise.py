@@ -9,7 +9,12 @@ a training step captured in a hipGraph (torch.cuda.CUDAGraph) draws fresh noise 
 mode "torch": the layers draw the noise with torch.randn on the device in the reference's tape
 layout (one [2, B, O] draw / sqrt 2 for complex layers, cplxmodule/cplx.py:544-550) and hand it
 to the kernels -- bit-compatible with a recorded reference tape, 8-16 B/output more traffic.
+mode "tape": the layers consume a recorded tape (`noise.set_tape([...])`): one raw normal draw per
+stochastic forward, in call order -- [2, *shape] for complex layers (divided by sqrt 2 here exactly as
+cplx.randn does), [*shape] for real ones.  This is how a training trajectory captured from the
+reference is replayed step for step (tests/test_gpu_trajectory.py).
 """
+import math
 import torch
 
 
@@ -29,9 +34,23 @@ class _NoiseState:
         self._dev = {}
 
     def set_mode(self, mode):
-        if mode not in ("philox", "philox-device", "torch"):
-            raise ValueError("noise mode must be 'philox', 'philox-device' or 'torch'")
+        if mode not in ("philox", "philox-device", "torch", "tape"):
+            raise ValueError("noise mode must be 'philox', 'philox-device', 'torch' or 'tape'")
         self.mode = mode
+
+    def set_tape(self, tensors):
+        """Switch to "tape" mode with the given raw draws (consumed front to back)."""
+        self._tape = list(tensors)
+        self.mode = "tape"
+
+    def pop_tape(self, shape, like, complex_):
+        if not getattr(self, "_tape", None):
+            raise RuntimeError("noise tape exhausted")
+        t = self._tape.pop(0).to(device=like.device, dtype=like.dtype)
+        want = ((2, *shape) if complex_ else tuple(shape))
+        if tuple(t.shape) != tuple(want):
+            raise RuntimeError(f"noise tape entry has shape {tuple(t.shape)}, the layer needs {tuple(want)}")
+        return t / math.sqrt(2) if complex_ else t
 
     def next(self, device=None):
         """(seed, offset) for one stochastic forward pass; in "philox-device" mode a device

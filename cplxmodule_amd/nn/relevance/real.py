@@ -2,13 +2,13 @@
 on the real GEMM + fused LRT / KL kernels."""
 import torch
 
-from .base import BaseARD
+from .base import BaseARD, KLFusion
 from .noise import noise
 from ..utils.sparsity import SparsityStats
 from ... import ops
 
 
-class _RealGaussianMixin:
+class _RealGaussianMixin(KLFusion):
     _kl_kind = "real_vd"
     __sparsity_ignore__ = ("log_sigma2",)
 
@@ -21,16 +21,16 @@ class _RealGaussianMixin:
 
     @property
     def log_alpha(self):
-        if torch.is_grad_enabled() and (self.log_sigma2.requires_grad or self.weight.requires_grad):
-            return self.log_sigma2 - 2 * torch.log(abs(self.weight) + 1e-12)
-        return ops.log_alpha(self.weight, None, self.log_sigma2).view_as(self.log_sigma2)
+        return ops.LogAlphaFn.apply(self.log_sigma2, self.weight, None)
 
     @property
     def penalty(self):
         return ops.PenaltyFn.apply(self._kl_kind, self.log_sigma2, self.weight, None)
 
     def _penalty_reduced(self, reduction):
-        total = ops.PenaltySumFn.apply(self._kl_kind, self.log_sigma2, self.weight, None)
+        total = self._kl_get((self.weight, self.log_sigma2))
+        if total is None:
+            total = ops.PenaltySumFn.apply(self._kl_kind, self.log_sigma2, self.weight, None)
         return total / self.log_sigma2.numel() if reduction == "mean" else total
 
     def relevance(self, *, threshold, **kwargs):
@@ -45,6 +45,8 @@ class _RealGaussianMixin:
     def _draw_noise(self, shape, like):
         if noise.mode == "torch":
             return torch.randn(*shape, dtype=like.dtype, device=like.device), 0, 0
+        if noise.mode == "tape":
+            return noise.pop_tape(shape, like, False), 0, 0
         seed, offset = noise.next(like.device)
         return None, seed, offset
 
@@ -60,8 +62,12 @@ class LinearGaussian(_RealGaussianMixin, torch.nn.Linear):
         seed = offset = 0
         if eps is None:
             eps, seed, offset = self._draw_noise((*input.shape[:-1], self.out_features), input)
-        return ops.RealLinearLRTFn.apply(input, self.weight, self.bias, self.log_sigma2, eps,
-                                         seed, offset)
+        kind = self._kl_kind_for_forward()
+        y, kl = ops.RealLinearLRTFn.apply(input, self.weight, self.bias, self.log_sigma2, eps,
+                                          seed, offset, kind)
+        if kind is not None:
+            self._kl_put(kl, (self.weight, self.log_sigma2))
+        return y
 
 
 class LinearVD(LinearGaussian, SparsityStats, BaseARD):

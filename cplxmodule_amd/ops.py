@@ -65,6 +65,13 @@ def colsum(t):
     return out
 
 
+def colsum2(tr, ti, out=None):
+    """Column sums of two planes (the complex bias gradient) -> float32 ([C], [C])."""
+    o_r = colsum(tr) if out is None else out[0].copy_(colsum(tr))
+    o_i = colsum(ti) if out is None else out[1].copy_(colsum(ti))
+    return o_r, o_i
+
+
 def abs2(xr, xi=None, out_dtype=None):
     """xr^2 + xi^2 (or xr^2), cplxmodule/nn/relevance/complex/base.py:51."""
     require_device(xr, xi)
@@ -76,12 +83,24 @@ def abs2(xr, xi=None, out_dtype=None):
 
 
 def modulus(xr, xi):
-    """abs(Cplx), cplxmodule/cplx.py:183-192, float32 only."""
+    """abs(Cplx), cplxmodule/cplx.py:183-192 (float32 or bfloat16 planes)."""
     require_device(xr, xi)
-    xr, xi = _f32(_c(xr)), _f32(_c(xi))
+    xr, xi = _c(xr), _c(xi)
     out = torch.empty_like(xr)
-    call("cplxamd_modulus", ptr(xr), ptr(xi), ptr(out), xr.numel(), stream_ptr())
+    call("cplxamd_cplx_abs_fwd", ptr(xr), ptr(xi), ptr(out), xr.numel(), dtype_code(xr), stream_ptr())
     return out
+
+
+def mask_mul(tr, ti, mask, out_dtype=None):
+    """(tr * mask, ti * mask) in one pass, converted to `out_dtype`; ti may be None (real layers)."""
+    require_device(tr, ti, mask)
+    tr, ti, mask = _c(tr), _c(ti), _f32(_c(mask.expand_as(tr)))
+    odt = out_dtype or tr.dtype
+    our = torch.empty_like(tr, dtype=odt)
+    oui = None if ti is None else torch.empty_like(ti, dtype=odt)
+    call("cplxamd_mask_mul", ptr(tr), ptr(ti), ptr(mask), ptr(our), ptr(oui), tr.numel(), dtype_code(tr),
+         dtype_code(our), stream_ptr())
+    return our, oui
 
 
 def exp(x, out_dtype=torch.float32):
@@ -125,12 +144,22 @@ def gauss_ok(M, N, K):
     return K >= 32 and K % 32 == 0 and N % 4 == 0 and (M * K) % 8 == 0 and (N * K) % 8 == 0
 
 
+def _beta(beta):
+    """Device scalar for the scaled accumulate (None: plain +=)."""
+    if beta is None:
+        return None
+    require_device(beta)
+    return _f32(beta.reshape(()).contiguous()) if beta.dtype == torch.float32 else beta.reshape(()).float()
+
+
 def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False,
-          out_dtype=torch.float32, out=None, accumulate=False, algo=0):
+          out_dtype=torch.float32, out=None, accumulate=False, algo=0, beta=None, emul=None):
     """C[m,n] = sum_k A[m,k] op(B[n,k]) (+ bias[n]) on planar complex operands.
     `a_strides` / `b_strides` are (row, col) element strides into the given planes.
-    algo: 0 = 4M (one fused K loop), 1 = Gauss 3M (dense bf16 operands only)."""
-    require_device(ar, ai, br, bi)
+    algo: 0 = 4M (one fused K loop), 1 = Gauss 3M (dense bf16 operands only).
+    accumulate: C = result + beta * C with `beta` a 0-d DEVICE tensor (None: 1);
+    emul: float32 [M,N] multiplier of both result planes (float32 output only)."""
+    require_device(ar, ai, br, bi, emul)
     if out is None:
         cr = torch.empty(M, N, dtype=out_dtype, device=ar.device)
         ci = torch.empty(M, N, dtype=out_dtype, device=ar.device)
@@ -138,9 +167,10 @@ def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False
         cr, ci = out
     b_r, b_i = (None, None) if bias is None else bias
     ws = _gauss_ws(M, N, K, ar.device) if algo == 1 else _gemm_ws(M, N, K, True, ar, cr)
-    call("cplxamd_cgemm", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
-         b_strides[0], b_strides[1], ptr(b_r), ptr(b_i), ptr(cr), ptr(ci), N, M, N, K,
-         int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), int(algo), ptr(ws),
+    beta = _beta(beta) if accumulate else None
+    call("cplxamd_cgemm_ex", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
+         b_strides[0], b_strides[1], ptr(b_r), ptr(b_i), ptr(emul), ptr(cr), ptr(ci), N, M, N, K,
+         int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), ptr(beta), int(algo), ptr(ws),
          0 if ws is None else ws.numel(), stream_ptr())
     return cr, ci
 
@@ -157,13 +187,15 @@ def cgemm_batched(ar, ai, a_strides, br, bi, b_strides, batch, M, N, K, conj_b=F
 
 
 def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=torch.float32,
-          out=None):
+          out=None, emul_exp=False, accumulate=False, beta=None):
+    """C = (A B^T + bias) * emul (emul_exp: * exp(emul)); accumulate: C = that + beta * C."""
     require_device(a, b, bias, emul)
     c = torch.empty(M, N, dtype=out_dtype, device=a.device) if out is None else out
     ws = _gemm_ws(M, N, K, False, a, c)
-    call("cplxamd_rgemm", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
-         ptr(bias), ptr(emul), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c), 0, ptr(ws),
-         0 if ws is None else ws.numel(), stream_ptr())
+    beta = _beta(beta) if accumulate else None
+    call("cplxamd_rgemm_ex", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
+         ptr(bias), ptr(emul), int(emul_exp), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c),
+         int(accumulate), ptr(beta), ptr(ws), 0 if ws is None else ws.numel(), stream_ptr())
     return c
 
 
@@ -270,6 +302,44 @@ def kl_fwd_bwd(kind, wr, wi, ls2, gscale=1.0):
     return tot, g_ls2, g_wr, g_wi
 
 
+def prep_kl(kind, wr, wi, ls2, with_kl, grads=None):
+    """ONE pass over the float32 parameters of a bf16 VD / ARD layer: bf16 weight planes, bf16
+    exp(log_sigma2) and -- with_kl -- sum(penalty) with its unscaled gradients written to
+    `grads` = (g_ls2, g_wr, g_wi) (allocated here when None).  wi None: real layer.
+    -> (wr_bf16, wi_bf16, S_bf16, kl_total or None, grads or None)"""
+    require_device(wr, wi, ls2)
+    bf = torch.bfloat16
+    wb = torch.empty_like(wr, dtype=bf)
+    wib = None if wi is None else torch.empty_like(wi, dtype=bf)
+    sb = torch.empty_like(ls2, dtype=bf)
+    tot = None
+    if with_kl:
+        tot = torch.empty((), dtype=torch.float32, device=wr.device)
+        if grads is None:
+            grads = (torch.empty_like(ls2), torch.empty_like(wr), None if wi is None else torch.empty_like(wi))
+    g = grads if with_kl else (None, None, None)
+    call("cplxamd_vd_prep_kl", ptr(wr), ptr(wi), ptr(ls2), _lib.KL_KINDS.get(kind, 0), int(bool(with_kl)),
+         ptr(wb), ptr(wib), ptr(sb), ptr(tot), ptr(g[0]), ptr(g[1]), ptr(g[2]),
+         ptr(_ws(wr.device)) if with_kl else None, wr.numel(), stream_ptr())
+    return wb, wib, sb, tot, (grads if with_kl else None)
+
+
+def _prep_ok(x, *params):
+    """The fused preparation kernel takes dense float32 parameters, element count % 4 == 0, bf16 activations."""
+    return (x.dtype == torch.bfloat16 and params[0].numel() % 4 == 0 and
+            all(p is None or (p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0)
+                for p in params))
+
+
+def log_alpha_bwd(g, wr, wi):
+    require_device(g, wr, wi)
+    g, wr, wi = _f32(_c(g)), _f32(_c(wr)), _f32(_c(wi))
+    g_wr = torch.empty_like(wr)
+    g_wi = None if wi is None else torch.empty_like(wi)
+    call("cplxamd_vd_log_alpha_bwd", ptr(g), ptr(wr), ptr(wi), ptr(g_wr), ptr(g_wi), wr.numel(), stream_ptr())
+    return g_wr, g_wi
+
+
 def log_alpha(wr, wi, ls2):
     require_device(wr, wi, ls2)
     wr, wi, ls2 = _f32(_c(wr)), _f32(_c(wi)), _f32(_c(ls2))
@@ -317,13 +387,16 @@ def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype, algo=0):
                  algo=algo if gauss_ok(B, I, O) and I % 8 == 0 else 0)
 
 
-def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0):
+def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0, accumulate=False, beta=None, emul=None):
     """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]; both operands
-    are K-major as stored (the bf16 kernel reads them through ds_read_b64_tr_b16)."""
+    are K-major as stored (the bf16 kernel reads them through ds_read_b64_tr_b16).
+    accumulate: out = dW + beta * out (beta a device scalar, None = 1)."""
     B, O = g2r.shape
     I = x2r.shape[1]
+    plain = not accumulate and emul is None
     return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True, out=out,
-                 algo=algo if gauss_ok(O, I, B) and O % 8 == 0 and I % 8 == 0 else 0)
+                 accumulate=accumulate, beta=beta, emul=emul,
+                 algo=algo if plain and gauss_ok(O, I, B) and O % 8 == 0 and I % 8 == 0 else 0)
 
 
 def _real_linear_dx(g2, w, out_dtype):
@@ -334,12 +407,17 @@ def _real_linear_dx(g2, w, out_dtype):
     return rgemm(g2, (O, 1), w, (1, I), B, I, O, out_dtype=out_dtype)
 
 
-def _real_linear_dw(g2, x2, emul=None, out=None):
+def _real_linear_dw(g2, x2, emul=None, out=None, emul_exp=False, accumulate=False, beta=None):
     B, O = g2.shape
     I = x2.shape[1]
     if g2.dtype != x2.dtype:
         g2, x2 = cast(g2, torch.float32), cast(x2, torch.float32)
-    return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul, out=out)
+    return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul, out=out, emul_exp=emul_exp,
+                 accumulate=accumulate, beta=beta)
+
+
+def _scaled(beta, t):
+    return None if t is None else t * beta
 
 
 # Data-parallel hook (cplxmodule_amd.dp): when set, the linear layers' backward hands the
@@ -350,25 +428,33 @@ dp_hook = None
 
 
 class CplxLinearFn(torch.autograd.Function):
-    """cplx.linear (cplxmodule/cplx.py:634-648) + its backward."""
+    """cplx.linear (cplxmodule/cplx.py:634-648) + its backward.  `mask` (float32, weight
+    shape, not differentiated): the masked layers' `weight * mask` (nn/masked/complex.py:33-82) folded into
+    the operand preparation (one pass: multiply + conversion to the activation dtype) and, in backward,
+    into the epilogue of the weight-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, xr, xi, wr, wi, br, bi, algo=0):
-        require_device(xr, xi, wr, wi, br, bi)
+    def forward(ctx, xr, xi, wr, wi, br, bi, algo=0, mask=None):
+        require_device(xr, xi, wr, wi, br, bi, mask)
         I, O = wr.shape[1], wr.shape[0]
         x2r, x2i = xr.reshape(-1, I).contiguous(), xi.reshape(-1, I).contiguous()
         bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
         # Gauss 3M exists for the bf16 MFMA path only; float32 always runs the exact 4M kernel
         ctx.algo = algo = algo if _is_bf16(x2r) else 0
-        yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias, algo)
-        ctx.save_for_backward(x2r, x2i, wr, wi)
+        if mask is not None:
+            mask = _f32(_c(mask.expand_as(wr)))
+            wmr, wmi = mask_mul(wr, wi, mask, out_dtype=x2r.dtype)
+        else:
+            wmr, wmi = _c(wr), _c(wi)
+        yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, wmr, wmi, bias, algo)
+        ctx.save_for_backward(x2r, x2i, wr, wi, mask)
         ctx.has_bias = br is not None
         ctx.lead = xr.shape[:-1]
         return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O)
 
     @staticmethod
     def backward(ctx, gr, gi):
-        x2r, x2i, wr, wi = ctx.saved_tensors
+        x2r, x2i, wr, wi, mask = ctx.saved_tensors
         O, I = wr.shape
         g2r, g2i = gr.reshape(-1, O).contiguous(), gi.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
@@ -377,27 +463,51 @@ class CplxLinearFn(torch.autograd.Function):
             dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r.dtype, ctx.algo)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         if need[2] or need[3]:
-            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i, algo=ctx.algo)
+            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i, algo=ctx.algo, emul=mask)
         if ctx.has_bias and (need[4] or need[5]):
-            dbr, dbi = colsum(g2r), colsum(g2i)
-        return dxr, dxi, dwr, dwi, dbr, dbi, None
+            dbr, dbi = colsum2(g2r, g2i)
+        return dxr, dxi, dwr, dwi, dbr, dbi, None, None
 
 
 class CplxLinearLRTFn(torch.autograd.Function):
     """CplxLinearGaussian.forward in training mode (nn/relevance/complex/base.py:43-56):
-    mu GEMM + variance GEMM + noise injection, backward per SURVEY A.2."""
+    mu GEMM + variance GEMM + noise injection, backward per SURVEY A.2.
+
+    With `kl_kind` the KL term of the layer rides along (third output = sum(penalty), complex/vd.py:95-99
+    / ard.py:39): for bf16 activations ONE kernel reads the float32 parameters and writes the bf16 GEMM
+    operands, the KL total and the unscaled KL gradients; the backward then finishes
+    `dW = dW_data + g_kl * dW_kl` inside the epilogues of the weight-gradient GEMMs (device scalar
+    g_kl), so neither autograd's gradient accumulation passes nor separate cast / exp / KL passes run."""
 
     @staticmethod
-    def forward(ctx, xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i, seed, offset):
+    def forward(ctx, xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i, seed, offset, kl_kind=None):
         require_device(xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i)
+        ctx.set_materialize_grads(False)
         O, I = wr.shape
         x2r, x2i = xr.reshape(-1, I).contiguous(), xi.reshape(-1, I).contiguous()
         B = x2r.shape[0]
         bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
-        mur, mui, ctx.wc = _cplx_linear_fwd(x2r, x2i, _c(wr), _c(wi), bias)
+        wrc, wic, ls2c = _c(wr), _c(wi), _c(ls2)
+        kl = ctx.klg = ctx.flat = None
+        n_w = O * I
+        if kl_kind is not None:
+            # one flat buffer [dls2 | dwr | dwi | dbr | dbi]: the KL gradients land in it now, the data
+            # gradients are added in backward, and a data-parallel hook all-reduces it as one piece
+            ctx.flat = torch.empty(3 * n_w + (2 * O if br is not None else 0), dtype=torch.float32, device=x2r.device)
+            ctx.klg = tuple(ctx.flat[k * n_w:(k + 1) * n_w].view(O, I) for k in range(3))
+        if _prep_ok(x2r, wrc, wic, ls2c):
+            wcr, wci, S, kl, _ = prep_kl(kl_kind, wrc, wic, ls2c, kl_kind is not None, ctx.klg)
+        else:
+            wcr, wci = cast(wrc, x2r.dtype), cast(wic, x2r.dtype)
+            S = exp(ls2c, out_dtype=x2r.dtype)                # [O,I]
+            if kl_kind is not None:
+                kl = torch.empty((), dtype=torch.float32, device=x2r.device)
+                g = ctx.klg
+                call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wrc)), ptr(_f32(wic)), ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind],
+                     1.0, ptr(kl), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(_ws(x2r.device)), n_w, stream_ptr())
+        ctx.wc, ctx.S = (wcr, wci), S
+        mur, mui = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
         a = abs2(x2r, x2i)                                   # [B,I], activation dtype
-        S = exp(_c(ls2), out_dtype=x2r.dtype)                # [O,I]
-        ctx.S = S
         s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)            # float32 [B,O]
         eps = None
         if eps_r is not None:
@@ -407,40 +517,67 @@ class CplxLinearLRTFn(torch.autograd.Function):
         ctx.bias_ptrs = () if br is None else (br.data_ptr(), bi.data_ptr())
         ctx.has_bias = br is not None
         ctx.lead, ctx.seed, ctx.offset = xr.shape[:-1], seed, offset
-        return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O)
+        ctx.kl_kind, ctx.kl_used = kl_kind, False
+        return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O), kl
 
     @staticmethod
-    def backward(ctx, gr, gi):
+    def backward(ctx, gr, gi, gkl=None):
         x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i = ctx.saved_tensors
         O, I = wr.shape
         B = x2r.shape[0]
-        g2r, g2i = gr.reshape(B, O).contiguous(), gi.reshape(B, O).contiguous()
         need = ctx.needs_input_grad
+        dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
+        n_w = O * I
+        klg = ctx.klg if gkl is not None else None
+        if klg is not None and ctx.kl_used:
+            # second backward through a retained graph: the buffers now hold totals, redo the KL part
+            klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:]
+        if gr is None and gi is None:                       # only the KL term reached the loss
+            if klg is not None:
+                dls2, dwr, dwi = (_scaled(gkl, t) for t in klg)
+            return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
+        g2r = torch.zeros(B, O, dtype=x2r.dtype, device=x2r.device) if gr is None else gr.reshape(B, O).contiguous()
+        g2i = torch.zeros(B, O, dtype=x2r.dtype, device=x2r.device) if gi is None else gi.reshape(B, O).contiguous()
         eps = None if eps_r is None else (eps_r.reshape(B, O), eps_i.reshape(B, O))
         dt = x2r.dtype
         gs2 = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt)
-        dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
         # parameter gradients first: with a data-parallel hook their all-reduce overlaps dX
         handle = None
         want_w, want_b = need[2] or need[3], ctx.has_bias and (need[4] or need[5])
-        if dp_hook is not None and want_w and need[6]:
-            n_w = O * I
+        ls2c = _c(ls2)
+        fused_kl = klg is not None and klg is ctx.klg and want_w and need[6]
+        if fused_kl:
+            # dW = G^T conj(X) + g_kl * dW_kl and dls2 = (gs2^T |x|^2) exp(ls2) + g_kl * dls2_kl, in place
+            flat = ctx.flat
+            # FRESH views (autograd adopts a returned gradient without a copy only if nothing else holds it)
+            dls2, dwr, dwi = (flat[k * n_w:(k + 1) * n_w].view(O, I) for k in range(3))
+            _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), accumulate=True, beta=gkl)
+            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
+            ctx.kl_used = True
+        elif dp_hook is not None and want_w and need[6]:
             flat = torch.empty(3 * n_w + (2 * O if want_b else 0), dtype=torch.float32, device=x2r.device)
             dls2, dwr, dwi = (flat[k * n_w:(k + 1) * n_w].view(O, I) for k in range(3))
             _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi))
-            _real_linear_dw(gs2, a, emul=exp(_c(ls2)), out=dls2)
-            if want_b:
-                dbr, dbi = flat[3 * n_w:3 * n_w + O], flat[3 * n_w + O:]
-                dbr.copy_(colsum(g2r)); dbi.copy_(colsum(g2i))
-            handle = dp_hook.reduce(flat, (wr.data_ptr(), wi.data_ptr(), ls2.data_ptr()) +
-                                    (ctx.bias_ptrs if want_b else ()))
+            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
         else:
+            flat = None
             if want_w:
                 dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
-            if want_b:
-                dbr, dbi = colsum(g2r), colsum(g2i)
             if need[6]:
-                dls2 = _real_linear_dw(gs2, a, emul=exp(_c(ls2)))  # (gs2^T a) * exp(ls2)
+                dls2 = _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True)  # (gs2^T a) * exp(ls2)
+            if klg is not None:                              # KL requested, but not every gradient is wanted
+                dls2 = None if dls2 is None else dls2 + gkl * klg[0]
+                dwr = None if dwr is None else dwr + gkl * klg[1]
+                dwi = None if dwi is None else dwi + gkl * klg[2]
+        if want_b:
+            if flat is not None and flat.numel() == 3 * n_w + 2 * O:
+                dbr, dbi = flat[3 * n_w:3 * n_w + O], flat[3 * n_w + O:]
+                colsum2(g2r, g2i, out=(dbr, dbi))
+            else:
+                dbr, dbi = colsum2(g2r, g2i)
+        if dp_hook is not None and flat is not None:
+            handle = dp_hook.reduce(flat, (wr.data_ptr(), wi.data_ptr(), ls2.data_ptr()) +
+                                    (ctx.bias_ptrs if want_b and flat.numel() > 3 * n_w else ()))
         if need[0] or need[1]:
             dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], dt)
             ga = _real_linear_dx(gs2, ctx.S, dt)             # gs2 . S -> [B,I]
@@ -448,81 +585,163 @@ class CplxLinearLRTFn(torch.autograd.Function):
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         if handle is not None:
             dp_hook.finish(handle)
-        return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None
+        return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
 
 
 class RealLinearFn(torch.autograd.Function):
-    """F.linear on the real GEMM kernel (the mean of LinearGaussian, real/base.py:44)."""
+    """F.linear on the real GEMM kernel (the mean of LinearGaussian, real/base.py:44); `mask` as in
+    CplxLinearFn (LinearMasked, nn/masked/real.py:25-71)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        require_device(x, w, b)
+    def forward(ctx, x, w, b, mask=None):
+        require_device(x, w, b, mask)
         O, I = w.shape
         x2 = x.reshape(-1, I).contiguous()
-        y = rgemm(x2, (I, 1), cast(_c(w), x2.dtype), (I, 1), x2.shape[0], O, I, bias=_c(b),
-                  out_dtype=x2.dtype)
-        ctx.save_for_backward(x2, w)
+        if mask is not None:
+            mask = _f32(_c(mask.expand_as(w)))
+            wm, _ = mask_mul(w, None, mask, out_dtype=x2.dtype)
+        else:
+            wm = cast(_c(w), x2.dtype)
+        y = rgemm(x2, (I, 1), wm, (I, 1), x2.shape[0], O, I, bias=_c(b), out_dtype=x2.dtype)
+        ctx.wm = wm
+        ctx.save_for_backward(x2, w, mask)
         ctx.has_bias, ctx.lead = b is not None, x.shape[:-1]
         return y.view(*ctx.lead, O)
 
     @staticmethod
     def backward(ctx, g):
-        x2, w = ctx.saved_tensors
+        x2, w, mask = ctx.saved_tensors
         O, I = w.shape
         g2 = g.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
         dx = dw = db = None
         if need[0]:
-            dx = _real_linear_dx(g2, _c(w), x2.dtype).view(*ctx.lead, I)
+            dx = _real_linear_dx(g2, ctx.wm, x2.dtype).view(*ctx.lead, I)
         if need[1]:
-            dw = _real_linear_dw(g2, x2)
+            dw = _real_linear_dw(g2, x2, emul=mask)
         if ctx.has_bias and need[2]:
             db = colsum(g2)
-        return dx, dw, db
+        return dx, dw, db, None
+
+
+class MaskMulFn(torch.autograd.Function):
+    """(wr * mask, wi * mask) as one kernel (wi None: real weight); the conv / bilinear masked layers."""
+
+    @staticmethod
+    def forward(ctx, wr, wi, mask):
+        mask = _f32(_c(mask.expand_as(wr)))
+        ctx.save_for_backward(mask)
+        ctx.cplx = wi is not None
+        our, oui = mask_mul(wr, wi, mask)
+        return (our, oui) if ctx.cplx else our
+
+    @staticmethod
+    def backward(ctx, gr, gi=None):
+        (mask,) = ctx.saved_tensors
+        dr, di = mask_mul(gr, gi if ctx.cplx else None, mask)
+        return dr, di, None
 
 
 class RealLinearLRTFn(torch.autograd.Function):
-    """LinearGaussian.forward in training mode (nn/relevance/real/base.py:43-49)."""
+    """LinearGaussian.forward in training mode (nn/relevance/real/base.py:43-49); `kl_kind` as in
+    CplxLinearLRTFn (second output = sum(penalty), real/vd.py:54-76 / ard.py:39)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, ls2, eps, seed, offset):
+    def forward(ctx, x, w, b, ls2, eps, seed, offset, kl_kind=None):
         require_device(x, w, b, ls2, eps)
+        ctx.set_materialize_grads(False)
         O, I = w.shape
         x2 = x.reshape(-1, I).contiguous()
         B = x2.shape[0]
-        mu = rgemm(x2, (I, 1), cast(_c(w), x2.dtype), (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
+        wc_, ls2c = _c(w), _c(ls2)
+        n_w = O * I
+        kl = ctx.flat = None
+        if kl_kind is not None:
+            ctx.flat = torch.empty(2 * n_w + (O if b is not None else 0), dtype=torch.float32, device=x2.device)
+        klg = None if ctx.flat is None else (ctx.flat[:n_w].view(O, I), ctx.flat[n_w:2 * n_w].view(O, I), None)
+        if _prep_ok(x2, wc_, ls2c):
+            wb, _, S, kl, _ = prep_kl(kl_kind, wc_, None, ls2c, kl_kind is not None, klg)
+        else:
+            wb, S = cast(wc_, x2.dtype), exp(ls2c, out_dtype=x2.dtype)
+            if kl_kind is not None:
+                kl = torch.empty((), dtype=torch.float32, device=x2.device)
+                call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wc_)), None, ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind], 1.0,
+                     ptr(kl), ptr(klg[0]), ptr(klg[1]), None, ptr(_ws(x2.device)), n_w, stream_ptr())
+        ctx.wb, ctx.S = wb, S
+        mu = rgemm(x2, (I, 1), wb, (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
         a = abs2(x2)
-        S = exp(_c(ls2), out_dtype=x2.dtype)
         s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)
         e = None if eps is None else eps.reshape(B, O)
         y, _ = reparam_fwd(mu, None, s2, e, seed, offset, inplace=True)
         ctx.save_for_backward(x2, w, ls2, s2, a, eps)
         ctx.has_bias, ctx.lead, ctx.seed, ctx.offset = b is not None, x.shape[:-1], seed, offset
-        return y.view(*ctx.lead, O)
+        ctx.ptrs = (w.data_ptr(), ls2.data_ptr()) + (() if b is None else (b.data_ptr(),))
+        ctx.kl_kind, ctx.kl_used = kl_kind, False
+        return y.view(*ctx.lead, O), kl
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gkl=None):
         x2, w, ls2, s2, a, eps = ctx.saved_tensors
         O, I = w.shape
         B = x2.shape[0]
-        g2 = g.reshape(B, O).contiguous()
+        n_w = O * I
         need = ctx.needs_input_grad
+        dx = dw = db = dls2 = None
+        have_kl = ctx.flat is not None and gkl is not None
+        klg = None
+        if have_kl and ctx.kl_used:                          # second backward through a retained graph
+            r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
+            klg = (r[1], r[2])
+        elif have_kl:
+            klg = (ctx.flat[:n_w].view(O, I), ctx.flat[n_w:2 * n_w].view(O, I))
+        if g is None:                                        # only the KL term reached the loss
+            if klg is not None:
+                dls2, dw = _scaled(gkl, klg[0]), _scaled(gkl, klg[1])
+            return dx, dw, db, dls2, None, None, None, None
+        g2 = g.reshape(B, O).contiguous()
         dt = x2.dtype
         e = None if eps is None else eps.reshape(B, O)
         gs2 = reparam_bwd(g2, None, s2, e, ctx.seed, ctx.offset, out_dtype=dt)
-        dx = dw = db = dls2 = None
+        ls2c = _c(ls2)
+        want_b = ctx.has_bias and need[2]
+        fused_kl = have_kl and not ctx.kl_used and need[1] and need[3]
+        flat = None
+        if fused_kl:
+            flat = ctx.flat
+            dls2, dw = klg
+            _real_linear_dw(g2, x2, out=dw, accumulate=True, beta=gkl)
+            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
+            ctx.kl_used = True
+        elif dp_hook is not None and need[1] and need[3]:
+            flat = torch.empty(2 * n_w + (O if want_b else 0), dtype=torch.float32, device=x2.device)
+            dls2, dw = flat[:n_w].view(O, I), flat[n_w:2 * n_w].view(O, I)
+            _real_linear_dw(g2, x2, out=dw)
+            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
+        else:
+            if need[1]:
+                dw = _real_linear_dw(g2, x2)
+            if need[3]:
+                dls2 = _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True)
+            if klg is not None:
+                dls2 = None if dls2 is None else dls2 + gkl * klg[0]
+                dw = None if dw is None else dw + gkl * klg[1]
+        if want_b:
+            if flat is not None and flat.numel() == 2 * n_w + O:
+                db = flat[2 * n_w:]
+                db.copy_(colsum(g2))
+            else:
+                db = colsum(g2)
+        handle = None
+        if dp_hook is not None and flat is not None:
+            handle = dp_hook.reduce(flat, ctx.ptrs[:2] + (ctx.ptrs[2:] if want_b and flat.numel() > 2 * n_w else ()))
         if need[0]:
-            dx = _real_linear_dx(g2, _c(w), dt)
-            ga = _real_linear_dx(gs2, exp(_c(ls2), out_dtype=dt), dt)
+            dx = _real_linear_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), dt)
+            ga = _real_linear_dx(gs2, ctx.S, dt)
             lrt_dx_accum(dx, None, x2, None, ga)
             dx = dx.view(*ctx.lead, I)
-        if need[1]:
-            dw = _real_linear_dw(g2, x2)
-        if ctx.has_bias and need[2]:
-            db = colsum(g2)
-        if need[3]:
-            dls2 = _real_linear_dw(gs2, a, emul=exp(_c(ls2)))
-        return dx, dw, db, dls2, None, None, None
+        if handle is not None:
+            dp_hook.finish(handle)
+        return dx, dw, db, dls2, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------ #
@@ -694,6 +913,50 @@ class Abs2Fn(torch.autograd.Function):
         dxi = None if xi is None else torch.zeros_like(xi)
         lrt_dx_accum(dxr, dxi, xr, xi, _c(g))              # dx = 2 x g
         return dxr, dxi
+
+
+class AbsFn(torch.autograd.Function):
+    """abs(Cplx) (cplxmodule/cplx.py:183-192) with the subgradient 0 at z == 0 that the reference's
+    stack + norm has (autograd through sqrt(re^2 + im^2) gives NaN there)."""
+
+    @staticmethod
+    def forward(ctx, zr, zi):
+        require_device(zr, zi)
+        zr, zi = _c(zr), _c(zi)
+        ctx.save_for_backward(zr, zi)
+        return modulus(zr, zi)
+
+    @staticmethod
+    def backward(ctx, g):
+        zr, zi = ctx.saved_tensors
+        g = _c(g)
+        if g.dtype != zr.dtype:
+            g = cast(g, zr.dtype)
+        dzr, dzi = torch.empty_like(zr), torch.empty_like(zi)
+        call("cplxamd_cplx_abs_bwd", ptr(g), ptr(zr), ptr(zi), ptr(dzr), ptr(dzi), zr.numel(),
+             dtype_code(zr), stream_ptr())
+        return dzr, dzi
+
+
+class LogAlphaFn(torch.autograd.Function):
+    """log_alpha = log_sigma2 - 2 log(abs(w) + 1e-12) (complex/base.py:27-31, real/base.py:23-26) on the
+    exact-log kernel; backward: d log_sigma2 = g, d w = cplxamd_vd_log_alpha_bwd."""
+
+    @staticmethod
+    def forward(ctx, ls2, wr, wi):
+        ctx.save_for_backward(wr, wi)
+        return log_alpha(wr, wi, ls2).view_as(ls2)
+
+    @staticmethod
+    def backward(ctx, g):
+        wr, wi = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g_wr = g_wi = None
+        if need[1] or (wi is not None and need[2]):
+            g_wr, g_wi = log_alpha_bwd(g, wr, wi)
+            g_wr = g_wr.view_as(wr)
+            g_wi = None if g_wi is None else g_wi.view_as(wi)
+        return (g if need[0] else None), g_wr, g_wi
 
 
 class ExpFn(torch.autograd.Function):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 1
+#define CPLXAMD_ABI_VERSION 2
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -87,10 +87,25 @@ int cplxamd_vd_kl_fwd_bwd(const float* wr, const float* wi, const float* log_sig
                           float gscale, float* out_sum, float* g_log_sigma2, float* g_wr,
                           float* g_wi, void* ws, int64_t n, void* stream);
 
+/* Per-step operand preparation of a bf16 VD / ARD layer fused with its KL term, ONE pass over
+ * (wr, wi, log_sigma2): bf16 copies of the weight planes and of exp(log_sigma2) (the operands of the mean
+ * and variance GEMMs; replaces two casts + torch.exp, complex/base.py:50-52) and, with_kl != 0,
+ * out_sum = sum(penalty) plus its UNSCALED gradients (as cplxamd_vd_kl_fwd_bwd with gscale = 1).
+ * Every output is nullable; wi NULL = real layer; n % 4 == 0 (else CPLXAMD_ESHAPE).
+ * HBM: 12 B read + 6 B (bf16 operands) + 12 B (gradients) written per element. */
+int cplxamd_vd_prep_kl(const float* wr, const float* wi, const float* log_sigma2, int kind, int with_kl,
+                       void* wr_bf16, void* wi_bf16, void* s_bf16, float* out_sum, float* g_log_sigma2,
+                       float* g_wr, float* g_wi, void* ws, int64_t n, void* stream);
+
 /* out[n] = log_sigma2 - 2 log(|w| + 1e-12), evaluated so that it reproduces the reference's
  * float32 CPU result bit-for-bit wherever the libm log is correctly rounded. */
 int cplxamd_vd_log_alpha(const float* wr, const float* wi, const float* log_sigma2, float* out,
                          int64_t n, void* stream);
+
+/* g_w = g * d log_alpha / d w = -2 g w / (|w| (|w| + 1e-12)) (real: -2 g sign(w) / (|w| + 1e-12)), 0 at
+ * w == 0; the gradient wrt log_sigma2 is g itself.  Backward of the differentiable `.log_alpha` property. */
+int cplxamd_vd_log_alpha_bwd(const float* g, const float* wr, const float* wi, float* g_wr, float* g_wi,
+                             int64_t n, void* stream);
 
 /* mask[n] = (log_alpha <= threshold) ? 1.f : 0.f;  count[1] (nullable, int64) = #ones. */
 int cplxamd_vd_mask(const float* wr, const float* wi, const float* log_sigma2, float threshold,
@@ -158,6 +173,18 @@ int cplxamd_cgemm(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
                   int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
                   int algo, void* ws, int64_t ws_bytes, void* stream);
 
+/* Same, with (i) emul (nullable, float32 [M,N], leading dimension ldc, float32 C only): both planes of the
+ * result are multiplied by it -- the weight gradient of a masked layer, dW * mask, nn/masked/complex.py:33-82;
+ * (ii) a DEVICE-side scale on the accumulate operand: accumulate != 0 -> C = result + (*beta) * C
+ * (beta NULL: 1).  Lets the weight-gradient GEMM of a VD / ARD layer finish `dW = dW_data + g_kl * dW_kl`
+ * in its epilogue, g_kl being the upstream gradient of the KL term that autograd hands over as a device
+ * scalar (replaces autograd's separate accumulation pass over every parameter gradient). */
+int cplxamd_cgemm_ex(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
+                     const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
+                     const float* bias_r, const float* bias_i, const float* emul, void* c_r, void* c_i,
+                     int64_t ldc, int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
+                     const float* beta, int algo, void* ws, int64_t ws_bytes, void* stream);
+
 int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
 
 /* Optional scratch for split-K (few output tiles, long K -- e.g. the weight gradient at batch
@@ -179,6 +206,14 @@ int cplxamd_rgemm(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int6
                   int M, int N, int K, int in_dtype, int out_dtype, int accumulate, void* ws,
                   int64_t ws_bytes, void* stream);
 
+/* Same; emul_exp != 0: the multiplier is exp(emul[m,n]) (emul = log_sigma2: the LRT gradient
+ * d log_sigma2 = (g_s2^T |x|^2) * exp(log_sigma2), nn/relevance/complex/base.py:52, without a
+ * materialised exp); accumulate with the device-side scale *beta as in cplxamd_cgemm_ex. */
+int cplxamd_rgemm_ex(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
+                     int64_t b_cs, const float* bias, const float* emul, int emul_exp, void* c, int64_t ldc,
+                     int M, int N, int K, int in_dtype, int out_dtype, int accumulate, const float* beta,
+                     void* ws, int64_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * elementwise / layout helpers used by the layers (all HBM-bound streaming kernels)
  * ---------------------------------------------------------------------------------- */
@@ -188,6 +223,16 @@ int cplxamd_abs2(const void* xr, const void* xi, void* out, int64_t n, int in_dt
 /* out = |x| = sqrt(xr^2 + xi^2), float32, rounded exactly like torch's CPU 2-norm
  * (Cplx.__abs__, cplx.py:183-192) */
 int cplxamd_modulus(const float* xr, const float* xi, float* out, int64_t n, void* stream);
+/* abs(Cplx) for float32 / bf16 planes and its backward d x = g x / |x| with 0 at x == 0 (the
+ * subgradient of the reference's stack + norm, cplx.py:183-192) */
+int cplxamd_cplx_abs_fwd(const void* xr, const void* xi, void* out, int64_t n, int dtype, void* stream);
+int cplxamd_cplx_abs_bwd(const void* g, const void* xr, const void* xi, void* dxr, void* dxi, int64_t n,
+                         int dtype, void* stream);
+/* out = in * mask (float32 mask) for one (in_i = out_i = NULL) or two planes, with the dtype
+ * conversion of the bf16 path folded in: the sparsified weight of the masked layers
+ * (nn/masked/real.py:25-71, complex.py:33-82) and, applied to gradients, its backward. */
+int cplxamd_mask_mul(const void* in_r, const void* in_i, const float* mask, void* out_r, void* out_i,
+                     int64_t n, int in_dtype, int out_dtype, void* stream);
 /* out = exp(x), x float32                      nn/relevance/complex/base.py:52 */
 int cplxamd_exp(const float* x, void* out, int64_t n, int out_dtype, void* stream);
 /* dtype conversion */

@@ -455,6 +455,39 @@ def cplx_abs(wr, wi):
     return np.sqrt(wr * wr + wi * wi)
 
 
+def cplx_abs_bwd(g, zr, zi):
+    """Gradient of abs(Cplx) = norm(stack([re, im]), dim=0) (cplx.py:183-192): g z / |z|, and the 2-norm's
+    subgradient 0 at z == 0."""
+    r = np.sqrt(zr * zr + zi * zi)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.where(r > 0, g / r, 0.0)
+    return s * zr, s * zi
+
+
+def log_alpha_bwd(g, wr, wi=None):
+    """d/dw of log_sigma2 - 2 log(abs(w) + 1e-12) (complex/base.py:27-31, real/base.py:23-26) times g;
+    the gradient wrt log_sigma2 is g itself."""
+    if wi is None:
+        return -2.0 * g * np.sign(wr) / (np.abs(wr) + 1e-12), None
+    th = np.sqrt(wr * wr + wi * wi)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        c = np.where(th > 0, -2.0 * g / (th * (th + 1e-12)), 0.0)
+    return c * wr, c * wi
+
+
+def binarize_masks(state_dict, masks):
+    """nn/masked/base.py:232-264: weights times their (soft) mask with -0.0 cleaned up; masks -> 0/1."""
+    out = {}
+    for name, par in state_dict.items():
+        if "weight" in name:
+            key = name.rsplit("weight", 1)[0] + "mask"
+            if key in masks:
+                par = par * masks[key].astype(par.dtype)
+                par = np.where(np.abs(par) == 0, np.zeros_like(par), par)
+        out[name] = par
+    return out, {k: (m != 0).astype(m.dtype) for k, m in masks.items()}
+
+
 def log_alpha(log_sigma2, wr, wi=None):
     """GaussianMixin.log_alpha: complex cplxmodule/nn/relevance/complex/base.py:27-31,
     real cplxmodule/nn/relevance/real/base.py:23-26."""

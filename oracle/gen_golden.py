@@ -696,9 +696,255 @@ def gen_extras():
     save("extras", d)
 
 
+def gen_r02():
+    """Round-2 fixtures: abs(Cplx) and log_alpha as differentiable ops (exact zeros included), penalties
+    under a SIGNED cotangent, the masked layers (nn/masked) and the mask plumbing."""
+    from cplxmodule.nn import masked
+    d = {}
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        # --- abs(Cplx): value + gradient; zeros must give gradient 0 (cplx.py:183-192: stack + norm)
+        torch.manual_seed(41)
+        zr, zi = leaf(37, 29, dtype=dt), leaf(37, 29, dtype=dt)
+        with torch.no_grad():
+            zr.view(-1)[:5] = 0.0
+            zi.view(-1)[:5] = 0.0
+            zr.view(-1)[7] = 0.0
+            zi.view(-1)[9] = 0.0
+            zr.view(-1)[11], zi.view(-1)[11] = 1e-20, -1e-21
+        g = torch.randn(37, 29)
+        a = abs(C(zr, zi))
+        (a * g).sum().backward()
+        for nm, t in dict(zr=zr, zi=zi, g=g, abs=a, dzr=zr.grad, dzi=zi.grad).items():
+            d[f"{tag}_abs_{nm}"] = npy(t)
+        # --- log_alpha (differentiable) and penalties under a signed cotangent, all four kinds
+        O, I = 24, 20
+        torch.manual_seed(42)
+        wr, wi, ls2 = _mixed_vd_params(O, I, dt)
+        gs = torch.randn(O, I)                         # mixed signs
+        for nm, t in dict(wr=wr, wi=wi, ls2=ls2, g=gs).items():
+            d[f"{tag}_sg_{nm}"] = npy(t)
+        kinds = {"real_vd": rel.LinearVD, "real_ard": rel.LinearARD,
+                 "cplx_vd": rel.CplxLinearVD, "cplx_ard": rel.CplxLinearARD}
+        for kind, cls in kinds.items():
+            layer = cls(I, O, bias=False)
+            with torch.no_grad():
+                layer.log_sigma2.copy_(ls2)
+                if kind.startswith("cplx"):
+                    layer.weight.real.copy_(wr)
+                    layer.weight.imag.copy_(wi)
+                    wps = [layer.weight.real, layer.weight.imag]
+                else:
+                    layer.weight.copy_(wr)
+                    wps = [layer.weight]
+            k = f"{tag}_sg_{kind}_"
+            grads = torch.autograd.grad((layer.penalty * gs).sum(), [layer.log_sigma2] + wps)
+            for nm, t in zip(["dls2", "dwr", "dwi"], grads):
+                d[k + "pen_" + nm] = npy(t)
+            grads = torch.autograd.grad(-0.37 * layer.penalty.sum(), [layer.log_sigma2] + wps)
+            for nm, t in zip(["dls2", "dwr", "dwi"], grads):
+                d[k + "negsum_" + nm] = npy(t)
+            la = layer.log_alpha
+            grads = torch.autograd.grad((la * gs).sum(), [layer.log_sigma2] + wps)
+            d[k + "la"] = npy(la)
+            for nm, t in zip(["dls2", "dwr", "dwi"], grads):
+                d[k + "la_" + nm] = npy(t)
+        # --- masked layers: forward + gradients with a soft and a hard mask
+        torch.manual_seed(43)
+        B, I, O = 9, 16, 12
+        lay = masked.CplxLinearMasked(I, O, bias=True)
+        mask = (torch.rand(O, I) > 0.4).to(dt)
+        soft = torch.rand(O, I) * mask
+        x = cplx.randn(B, I)
+        xr, xi = x.real.clone().requires_grad_(True), x.imag.clone().requires_grad_(True)
+        gr, gi = torch.randn(B, O), torch.randn(B, O)
+        for mname, m in (("hard", mask), ("soft", soft)):
+            lay.mask = m
+            for t in (xr, xi, *lay.parameters()):
+                t.grad = None
+            y = lay(C(xr, xi))
+            torch.autograd.backward((y.real, y.imag), (gr, gi))
+            k = f"{tag}_mk_cl_{mname}_"
+            d[k + "mask"] = npy(m)
+            for nm, t in dict(yr=y.real, yi=y.imag, dxr=xr.grad, dxi=xi.grad, dwr=lay.weight.real.grad,
+                              dwi=lay.weight.imag.grad, dbr=lay.bias.real.grad, dbi=lay.bias.imag.grad).items():
+                d[k + nm] = npy(t)
+        for nm, t in dict(xr=xr, xi=xi, gr=gr, gi=gi, wr=lay.weight.real, wi=lay.weight.imag, br=lay.bias.real,
+                          bi=lay.bias.imag).items():
+            d[f"{tag}_mk_cl_{nm}"] = npy(t)
+        d[f"{tag}_mk_cl_state_keys"] = np.array(sorted(lay.state_dict().keys()))
+        d[f"{tag}_mk_cl_sparsity_hard"] = np.array([v for _, v in lay.sparsity(hard=True)])
+        d[f"{tag}_mk_cl_sparsity_soft"] = np.array([v for _, v in lay.sparsity(hard=False)])
+        rl = masked.LinearMasked(I, O, bias=True)
+        rl.mask = soft
+        xx = torch.randn(B, I).requires_grad_(True)
+        y = rl(xx)
+        y.backward(gr)
+        for nm, t in dict(x=xx, w=rl.weight, b=rl.bias, y=y, dx=xx.grad, dw=rl.weight.grad, db=rl.bias.grad).items():
+            d[f"{tag}_mk_rl_{nm}"] = npy(t)
+        # conv masked layers (complex + real), hard mask
+        torch.manual_seed(44)
+        cl = masked.CplxConv2dMasked(4, 6, 3, padding=1)
+        cm = (torch.rand(6, 4, 3, 3) > 0.5).to(dt)
+        cl.mask = cm
+        cx = cplx.randn(2, 4, 7, 8)
+        cxr, cxi = cx.real.clone().requires_grad_(True), cx.imag.clone().requires_grad_(True)
+        y = cl(C(cxr, cxi))
+        cgr, cgi = torch.randn_like(y.real), torch.randn_like(y.imag)
+        torch.autograd.backward((y.real, y.imag), (cgr, cgi))
+        for nm, t in dict(mask=cm, xr=cxr, xi=cxi, gr=cgr, gi=cgi, wr=cl.weight.real, wi=cl.weight.imag,
+                          br=cl.bias.real, bi=cl.bias.imag, yr=y.real, yi=y.imag, dxr=cxr.grad, dxi=cxi.grad,
+                          dwr=cl.weight.real.grad, dwi=cl.weight.imag.grad, dbr=cl.bias.real.grad,
+                          dbi=cl.bias.imag.grad).items():
+            d[f"{tag}_mk_cc_{nm}"] = npy(t)
+        rc = masked.Conv2dMasked(4, 6, 3, padding=1)
+        rc.mask = cm
+        rx = torch.randn(2, 4, 7, 8).requires_grad_(True)
+        y = rc(rx)
+        y.backward(cgr)
+        for nm, t in dict(x=rx, w=rc.weight, b=rc.bias, y=y, dx=rx.grad, dw=rc.weight.grad, db=rc.bias.grad).items():
+            d[f"{tag}_mk_rc_{nm}"] = npy(t)
+        # --- binarize_masks (incl. the -0.0 clean-up, base.py:257-258) and deploy_masks naming
+        torch.manual_seed(45)
+        src = torch.nn.Sequential()
+        src.add_module("a", rel.CplxLinearARD(6, 5))
+        src.add_module("b", rel.LinearARD(5, 4))
+        with torch.no_grad():
+            src.a.log_sigma2.uniform_(-6, 4)
+            src.b.log_sigma2.uniform_(-6, 4)
+            src.a.weight.real[0, :3] = -src.a.weight.real[0, :3].abs()   # negative weights under a zero mask -> -0.0
+        masks = rel.compute_ard_masks(src, hard=False, threshold=0.5)
+        sd, hard = masked.binarize_masks(src.state_dict(), masks)
+        d[f"{tag}_bz_mask_keys"] = np.array(sorted(masks.keys()))
+        for k_, v in src.state_dict().items():
+            d[f"{tag}_bz_in_{k_}"] = npy(v)
+        for k_, v in masks.items():
+            d[f"{tag}_bz_softmask_{k_}"] = npy(v)
+        for k_, v in sd.items():
+            d[f"{tag}_bz_out_{k_}"] = npy(v)
+            d[f"{tag}_bz_signbit_{k_}"] = np.signbit(npy(v))
+        for k_, v in hard.items():
+            d[f"{tag}_bz_hard_{k_}"] = npy(v)
+        dst = torch.nn.Sequential()
+        dst.add_module("a", masked.CplxLinearMasked(6, 5))
+        dst.add_module("b", masked.LinearMasked(5, 4))
+        missing = dst.load_state_dict(sd, strict=False)
+        d[f"{tag}_bz_missing"] = np.array(sorted(missing.missing_keys))
+        d[f"{tag}_bz_unexpected"] = np.array(sorted(missing.unexpected_keys))
+        masked.deploy_masks(dst, state_dict=hard)
+        d[f"{tag}_bz_deployed_keys"] = np.array(sorted(dst.state_dict().keys()))
+        d[f"{tag}_bz_named_masks"] = np.array([n for n, _ in masked.named_masks(dst)])
+    torch.set_default_dtype(torch.float32)
+    save("r02", d)
+
+
+def gen_trajectory():
+    """the reference's train -> sparsify -> fine-tune harness
+    (tests/test_relevance.py:52-84 train step, :216-229 phase hand-off) on a small 2-layer model, first
+    20 Adam steps of each phase: fixed init, fixed data, the noise tape of every stochastic forward,
+    and per step loss / mse / kl / sparsity@tau; the hand-off state dicts and masks; final masks."""
+    import torch.nn.functional as F
+    from collections import OrderedDict
+    from cplxmodule.nn import RealToCplx, CplxToReal, CplxModReLU
+    from cplxmodule.nn import masked
+    from cplxmodule.nn.utils.sparsity import sparsity
+    import warnings
+    warnings.simplefilter("ignore")
+    d = {}
+    N_STEPS, B, NF, NH, NO = 20, 32, 24, 10, 8      # real features 24 -> complex 12 -> 10 -> 4 -> real 8
+    tau = 0.73105
+    threshold = float(np.log(tau) - np.log(1 - tau))
+    d["threshold"] = np.array(threshold)
+
+    tape = []
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def rec_randn(*a, **k):
+        t = real_randn(*a, **k)
+        tape.append(npy(t))
+        return t
+
+    def rec_randn_like(x, **k):
+        t = real_randn_like(x, **k)
+        tape.append(npy(t))
+        return t
+
+    def build(kind, l1, l2):
+        if kind == "cplx":
+            return torch.nn.Sequential(OrderedDict([
+                ("cplx", RealToCplx()), ("l1", l1(NF // 2, NH, bias=True)), ("act", CplxModReLU(0.05)),
+                ("l2", l2(NH, NO // 2, bias=False)), ("real", CplxToReal())]))
+        return torch.nn.Sequential(OrderedDict([
+            ("l1", l1(NF, NH, bias=True)), ("act", torch.nn.LeakyReLU()), ("l2", l2(NH, NO, bias=False))]))
+
+    tracks = {
+        "cplx_ard": ("cplx", [CplxLinear, rel.CplxLinearARD, masked.CplxLinearMasked], [0.0, 1e-1, 0.0], "mean"),
+        "cplx_vd": ("cplx", [CplxLinear, rel.CplxLinearVD, masked.CplxLinearMasked], [0.0, 1e-1, 0.0], "mean"),
+        "real_vd": ("real", [torch.nn.Linear, rel.LinearVD, masked.LinearMasked], [0.0, 2e-2, 0.0], "sum"),
+    }
+    for tname, (kind, layers, klws, reduction) in tracks.items():
+        torch.manual_seed(1234)
+        X = torch.randn(B, NF)
+        y = -X[:, :NO].clone()
+        d[f"{tname}_X"], d[f"{tname}_y"] = npy(X), npy(y)
+        prev = None
+        for ph, (cls, klw) in enumerate(zip(layers, klws)):
+            torch.manual_seed(100 + ph)
+            model = build(kind, cls, cls)
+            k = f"{tname}_p{ph}_"
+            if prev is not None:
+                state_dict = prev.state_dict()
+                masks = rel.compute_ard_masks(prev, hard=False, threshold=threshold)
+                state_dict, masks = masked.binarize_masks(state_dict, masks)
+                model.load_state_dict(state_dict, strict=False)
+                model = masked.deploy_masks(model, state_dict=masks)
+                for kk, v in masks.items():
+                    d[k + "deploy_" + kk] = npy(v)
+            if ph == 1:
+                # start the sparsification phase from a spread of relevances so that masks are non-trivial
+                with torch.no_grad():
+                    for m in model.modules():
+                        if hasattr(m, "log_sigma2"):
+                            m.log_sigma2.uniform_(-8.0, 1.0)
+            for kk, v in model.state_dict().items():
+                d[k + "init_" + kk] = npy(v)
+            model.train()
+            optim = torch.optim.Adam(model.parameters())
+            rows = []
+            tape.clear()
+            torch.randn, torch.randn_like = rec_randn, rec_randn_like
+            try:
+                for _ in range(N_STEPS):
+                    optim.zero_grad()
+                    y_pred = model(X)
+                    mse = F.mse_loss(y_pred, y)
+                    kl_d = sum(rel.penalties(model, reduction=reduction))
+                    loss = mse + klw * kl_d
+                    loss.backward()
+                    optim.step()
+                    f_sp = sparsity(model, hard=True, threshold=threshold)
+                    rows.append([float(loss), float(mse), float(kl_d), float(f_sp)])
+            finally:
+                torch.randn, torch.randn_like = real_randn, real_randn_like
+            d[k + "traj"] = np.array(rows, dtype=np.float64)      # [step, (loss, mse, kl, sparsity)]
+            d[k + "klw"] = np.array(klw)
+            d[k + "n_tape"] = np.array(len(tape))
+            for j, t in enumerate(tape):
+                d[k + f"tape_{j:03d}"] = t
+            for kk, v in model.state_dict().items():
+                d[k + "final_" + kk] = npy(v)
+            fm = rel.compute_ard_masks(model, hard=False, threshold=threshold)
+            for kk, v in fm.items():
+                d[k + "finalmask_" + kk] = npy(v)
+            prev = model
+        d[f"{tname}_reduction"] = np.array(reduction)
+    save("trajectory", d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reproducible summation order
     gens = dict(linear=gen_linear, lrt_linear=gen_lrt_linear, penalty=gen_penalty, conv=gen_conv,
-                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear, conv3d=gen_conv3d, conv_transpose=gen_conv_transpose)
+                batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear, conv3d=gen_conv3d, conv_transpose=gen_conv_transpose,
+                r02=gen_r02, trajectory=gen_trajectory)
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

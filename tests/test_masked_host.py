@@ -56,3 +56,28 @@ def test_deploy_binarize_pipeline_names():
     masked.deploy_masks(fine, state_dict={}, reset=True)
     assert not masked.is_sparse(fine[0])
     assert nn.masked is masked
+
+
+def test_binarize_and_deploy_match_reference_fixture(golden):
+    """binarize_masks (incl. the -0.0 clean-up, nn/masked/base.py:257-258), the hand-off's missing /
+    unexpected keys and deploy_masks naming against what the reference produced (golden r02)."""
+    import numpy as np
+    g = golden("r02")
+    pre = "f32_bz_"
+    sd = {n[len(pre) + 3:]: torch.from_numpy(v) for n, v in g.items() if n.startswith(pre + "in_")}
+    masks = {n[len(pre) + 9:]: torch.from_numpy(v) for n, v in g.items() if n.startswith(pre + "softmask_")}
+    out, hard = masked.binarize_masks(sd, masks)
+    for n, v in out.items():
+        np.testing.assert_array_equal(v.numpy(), g[pre + "out_" + n])
+        np.testing.assert_array_equal(np.signbit(v.numpy()), g[pre + "signbit_" + n])
+    for n, v in hard.items():
+        np.testing.assert_array_equal(v.numpy(), g[pre + "hard_" + n])
+    dst = torch.nn.Sequential()
+    dst.add_module("a", masked.CplxLinearMasked(6, 5))
+    dst.add_module("b", masked.LinearMasked(5, 4))
+    res = dst.load_state_dict(out, strict=False)
+    assert sorted(res.missing_keys) == list(g[pre + "missing"])
+    assert sorted(res.unexpected_keys) == list(g[pre + "unexpected"])
+    masked.deploy_masks(dst, state_dict=hard)
+    assert sorted(dst.state_dict().keys()) == list(g[pre + "deployed_keys"])
+    assert [n for n, _ in masked.named_masks(dst)] == list(g[pre + "named_masks"])

@@ -431,3 +431,75 @@ def test_conv_transpose2d(golden, tag, case):
     bw = orc.cplx_conv_transpose2d_bwd(g[k + "gr"], g[k + "gi"], *a, **kw)
     for n in ("dxr", "dxi", "dwr", "dwi", "dbr", "dbi"):
         close(bw[n], g[k + n], tag, 300)
+
+
+# ---- round 2 fixtures (tests/golden/r02.npz) ----------------------------------------------------
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_abs_and_log_alpha_gradients(golden, tag):
+    g = golden("r02")
+    tol = TOL[tag]
+    zr, zi, up = g[f"{tag}_abs_zr"], g[f"{tag}_abs_zi"], g[f"{tag}_abs_g"]
+    np.testing.assert_allclose(orc.cplx_abs(zr, zi), g[f"{tag}_abs_abs"], **tol)
+    dzr, dzi = orc.cplx_abs_bwd(up, zr, zi)
+    np.testing.assert_allclose(dzr, g[f"{tag}_abs_dzr"], **tol)
+    np.testing.assert_allclose(dzi, g[f"{tag}_abs_dzi"], **tol)
+    assert np.all(g[f"{tag}_abs_dzr"][(zr == 0) & (zi == 0)] == 0)       # the reference's subgradient at 0
+    wr, wi, ls2, gs = (g[f"{tag}_sg_{k}"] for k in ("wr", "wi", "ls2", "g"))
+    for kind in orc.KINDS:
+        w_i = wi if kind.startswith("cplx") else None
+        k = f"{tag}_sg_{kind}_"
+        np.testing.assert_allclose(orc.log_alpha(ls2, wr, w_i), g[k + "la"], **tol)
+        np.testing.assert_array_equal(g[k + "la_dls2"], gs)
+        # the tiny-|w| entries amplify by 2/|w| ~ 1e20: compare relative to that scale
+        dwr, dwi = orc.log_alpha_bwd(gs, wr, w_i)
+        np.testing.assert_allclose(dwr, g[k + "la_dwr"], rtol=tol["rtol"] * 10, atol=tol["atol"])
+        if w_i is not None:
+            np.testing.assert_allclose(dwi, g[k + "la_dwi"], rtol=tol["rtol"] * 10, atol=tol["atol"])
+
+
+@pytest.mark.parametrize("tag", ["f64"])
+@pytest.mark.parametrize("kind", orc.KINDS)
+def test_penalty_gradients_signed_cotangent(golden, tag, kind):
+    """Negative / mixed-sign upstream gradients (the real kinds lost the sign)."""
+    g = golden("r02")
+    wr, wi, ls2, gs = (g[f"{tag}_sg_{k}"] for k in ("wr", "wi", "ls2", "g"))
+    w_i = wi if kind.startswith("cplx") else None
+    k = f"{tag}_sg_{kind}_"
+    for pre, up in (("pen_", gs), ("negsum_", np.full_like(gs, -0.37))):
+        o = orc.penalty_bwd(kind, up, ls2, wr, w_i)
+        fin = np.isfinite(g[k + pre + "dls2"])
+        np.testing.assert_allclose(o["dlog_sigma2"][fin], g[k + pre + "dls2"][fin], rtol=1e-7, atol=1e-9)
+        fin = np.isfinite(g[k + pre + "dwr"])
+        np.testing.assert_allclose(o["dwr"][fin], g[k + pre + "dwr"][fin], rtol=1e-6, atol=1e-9)
+        if w_i is not None:
+            fin = np.isfinite(g[k + pre + "dwi"])
+            np.testing.assert_allclose(o["dwi"][fin], g[k + pre + "dwi"][fin], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_masked_layers_and_binarize(golden, tag):
+    g = golden("r02")
+    tol = TOL[tag]
+    k = f"{tag}_mk_cl_"
+    for m in ("hard", "soft"):
+        mask = g[k + m + "_mask"]
+        yr, yi = orc.cplx_linear(g[k + "xr"], g[k + "xi"], g[k + "wr"] * mask, g[k + "wi"] * mask, g[k + "br"], g[k + "bi"])
+        np.testing.assert_allclose(yr, g[k + m + "_yr"], **tol)
+        np.testing.assert_allclose(yi, g[k + m + "_yi"], **tol)
+        bw = orc.cplx_linear_bwd(g[k + "gr"], g[k + "gi"], g[k + "xr"], g[k + "xi"], g[k + "wr"] * mask, g[k + "wi"] * mask)
+        np.testing.assert_allclose(bw["dwr"] * mask, g[k + m + "_dwr"], **tol)
+        np.testing.assert_allclose(bw["dwi"] * mask, g[k + m + "_dwi"], **tol)
+        np.testing.assert_allclose(bw["dxr"], g[k + m + "_dxr"], **tol)
+    assert list(g[k + "state_keys"]) == ["bias.imag", "bias.real", "mask", "weight.imag", "weight.real"]
+    # binarize_masks incl. the -0.0 clean-up
+    pre = f"{tag}_bz_"
+    sd = {n[len(pre) + 3:]: v for n, v in g.items() if n.startswith(pre + "in_")}
+    masks = {n[len(pre) + 9:]: v for n, v in g.items() if n.startswith(pre + "softmask_")}
+    out, hard = orc.binarize_masks(sd, masks)
+    for n, v in out.items():
+        np.testing.assert_array_equal(v, g[pre + "out_" + n])
+        np.testing.assert_array_equal(np.signbit(v), g[pre + "signbit_" + n])
+    for n, v in hard.items():
+        np.testing.assert_array_equal(v, g[pre + "hard_" + n])
+    assert list(g[pre + "mask_keys"]) == ["a.mask", "b.mask"]
+    assert list(g[pre + "named_masks"]) == ["a", "b"]
