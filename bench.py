@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for "
@@ -75,8 +75,10 @@ class KernelTimer:
 
 
 def cpu_baseline(sample_rows):
-    """The numpy oracle (a port of the reference's op sequence) on the host cores: forward +
-    backward + exact KL of CplxLinearVD(4096, 4096) on `sample_rows` rows, float32."""
+    """The numpy oracle (a port of the reference's op sequence) on the host cores, float32: the
+    batch-proportional part (LRT forward + backward) on `sample_rows` of the 8192 rows, the
+    batch-independent part (exact KL forward + backward over the 4096 x 4096 weights, scipy Ei) once;
+    one full step = rows_time * (BATCH / sample_rows) + kl_time."""
     import numpy as np
     from oracle import cplx_oracle as orc
     rs = np.random.RandomState(0)
@@ -90,14 +92,68 @@ def cpu_baseline(sample_rows):
     er, ei = (rs.randn(B, O) / np.sqrt(2)).astype(f), (rs.randn(B, O) / np.sqrt(2)).astype(f)
     t0 = time.perf_counter()
     yr, yi, _ = orc.lrt_cplx_linear(xr, xi, wr, wi, br, bi, ls2, er, ei)
-    kl = orc.penalty("cplx_vd", ls2, wr, wi).sum()
     orc.lrt_cplx_linear_bwd(2 * yr, 2 * yi, xr, xi, wr, wi, ls2, er, ei)
+    t_rows = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    kl = orc.penalty("cplx_vd", ls2, wr, wi).sum()
     orc.penalty_bwd("cplx_vd", np.full_like(ls2, KLW), ls2, wr, wi)
-    dt = time.perf_counter() - t0
+    t_kl = time.perf_counter() - t0
     assert np.isfinite(kl)
-    return {"value": round(B / dt, 2), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{B} of {BATCH} rows through the numpy oracle (fwd+bwd), plus the full "
-                      f"{O}x{I} exact KL fwd+bwd (scipy expi); {dt:.1f} s"}
+    step = t_rows * (BATCH / B) + t_kl
+    return {"value": round(BATCH / step, 2), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy oracle: LRT fwd+bwd on {B} of {BATCH} rows ({t_rows:.2f} s, scaled x{BATCH // B}) + the "
+                      f"full {O}x{I} exact KL fwd+bwd once ({t_kl:.2f} s, scipy expi) = {step:.1f} s per step of {BATCH} rows"}
+
+
+def gemm_traffic():
+    """HBM bytes per launch of the complex GEMM from the tracked PMC summary (separate rocprofv3 --pmc
+    passes of this kernel and shape, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE; scripts/r02/pmc_traffic.sh)."""
+    path = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return float(d["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def hbm_points(dev):
+    """The HBM-bound kernels at the sizes BASELINE.json quotes (rank 0, N = 1, outside the timed region):
+    LRT noise injection at batch 2^20 x 2048 outputs (bf16 I/O) and the fused KL forward + backward on a
+    16384 x 16384 complex weight; GB/s of ALGORITHMIC bytes, HIP events, median of 5."""
+    from cplxmodule_amd import ops
+    out = {}
+
+    def med(fn, n=5):
+        ts = []
+        for _ in range(n + 1):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); fn(); e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+        return sorted(ts[1:])[n // 2] * 1e-3
+
+    try:
+        n = (1 << 20) * 2048
+        mu_r = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        mu_i = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        s2 = torch.full((n,), 0.5, dtype=torch.float32, device=dev)
+        t = med(lambda: ops.reparam_fwd(mu_r, mu_i, s2, None, 1, 2, inplace=True))
+        out["reparam_fwd@2^20x2048(12B/out bf16)"] = round(12 * n / t / 1e9, 1)
+        t = med(lambda: ops.reparam_bwd(mu_r, mu_i, s2, None, 1, 2, out_dtype=torch.bfloat16))
+        out["reparam_bwd@2^20x2048(10B/out bf16)"] = round(10 * n / t / 1e9, 1)
+        del mu_r, mu_i, s2
+        m = 16384 * 16384
+        wr = torch.randn(m, device=dev) * 0.01
+        wi = torch.randn(m, device=dev) * 0.01
+        ls2 = torch.empty(m, device=dev).uniform_(-12, 4)
+        t = med(lambda: ops.kl_fwd("cplx_vd", wr, wi, ls2))
+        out["kl_fwd@16384^2(12B/elt)"] = round(12 * m / t / 1e9, 1)
+        t = med(lambda: ops.kl_fwd_bwd("cplx_vd", wr, wi, ls2))
+        out["kl_fwd_bwd@16384^2(24B/elt)"] = round(24 * m / t / 1e9, 1)
+    except Exception as e:  # pragma: no cover - out of memory on a shared box
+        out["error"] = str(e)[:100]
+    return out
 
 
 def main():
@@ -125,8 +181,7 @@ def main():
 
     timer = KernelTimer()
     timer.wrap(ops, "cgemm", lambda ar, *a, **k: "cgemm" if ar.dtype == torch.bfloat16 else None)
-    timer.wrap(ops, "kl_fwd", lambda *a, **k: "kl_fwd")
-    timer.wrap(ops, "kl_bwd", lambda *a, **k: "kl_bwd")
+    timer.wrap(ops, "prep_kl", lambda *a, **k: "prep_kl" if a[4] else None)
     timer.wrap(ops, "reparam_fwd", lambda *a, **k: "reparam_fwd")
     timer.wrap(ops, "reparam_bwd", lambda *a, **k: "reparam_bwd")
 
@@ -160,9 +215,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         kl = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,13 +239,16 @@ def main():
         flops = 8.0 * B * IN_F * OUT_F          # algorithmic flop of ONE 4M complex GEMM launch
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
         nw = IN_F * OUT_F
-        kl_f, kl_b = timer.mean_ms("kl_fwd"), timer.mean_ms("kl_bwd")
+        pk = timer.mean_ms("prep_kl")
         rp_f, rp_b = timer.mean_ms("reparam_fwd"), timer.mean_ms("reparam_bwd")
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         nout = B * OUT_F
         line = {
             "metric": "Cplx-samples/sec fwd+bwd (CplxLinear-4096 + VD)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "step_ms": {"min": round(per[0], 4), "median": round(per[len(per) // 2], 4), "max": round(per[-1], 4)},
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "CplxLinearVD 4096->4096, bf16 activations / fp32 master weights, "
                                    f"batch {B} per GPU, LRT fwd + KL + full bwd (BASELINE configs[1] + VD)",
@@ -196,21 +257,18 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM: fwd NN, dgrad NT, wgrad TT = 3 launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,
-                         # HBM bytes per launch from separate rocprofv3 --pmc passes of the same kernel /
-                         # shape (scripts/pmc_gemm.sh, profiles/r01_gemm_variants.md): FETCH_SIZE
-                         # 528,699 KiB x 2 (gfx950 correction) + WRITE_SIZE 416,787 KiB (calibrated 1:1
-                         # on a streaming write in the same run); algorithmic minimum 320 MB
-                         "traffic": 1.52e9 if B == BATCH else None, "flop_per_launch": flops,
+                         "traffic": gemm_traffic() if B == BATCH else None, "flop_per_launch": flops,
                          "avg_launch_ms": round(gemm_ms, 4) if gemm_ms else None},
             "hbm_kernels_GBps": {
-                "kl_fwd(12B/elt)": round(12 * nw / (kl_f * 1e-3) / 1e9, 1) if kl_f else None,
-                "kl_bwd(24B/elt)": round(24 * nw / (kl_b * 1e-3) / 1e9, 1) if kl_b else None,
+                # in-step: operand prep + KL sum + KL gradients in one pass (12 B read, 6 + 12 B written)
+                "prep_kl_fused(30B/elt)": round(30 * nw / (pk * 1e-3) / 1e9, 1) if pk else None,
                 "reparam_fwd(12B/out bf16)": round(12 * nout / (rp_f * 1e-3) / 1e9, 1) if rp_f else None,
                 "reparam_bwd(10B/out bf16)": round(10 * nout / (rp_b * 1e-3) / 1e9, 1) if rp_b else None,
                 "peak": HBM_PEAK_GBS},
             "kl": round(float(kl), 3),
         }
         if world == 1 and not args.no_cpu_baseline:
+            line["hbm_kernels_GBps"].update(hbm_points(dev))
             line["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(line), flush=True)
     if world > 1:

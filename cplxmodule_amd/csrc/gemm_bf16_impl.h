@@ -418,7 +418,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();
       mfma_half(1, cur, t + 3, 0, H, nx1, 0);                 // S4 + S5 (slot of tile t is free now; past the end the reads hit a stale slot, unused)
     };
-#ifdef CPLXAMD_GEMM_UNROLL3
+#ifndef CPLXAMD_GEMM_NO_UNROLL3   // (-2.0 % on the three bench launches, same-process A/B, profiles/r02_gemm_ablation.md)
     // ring position as a compile-time constant: the K loop is unrolled by the ring depth so that every
     // LDS address is (per-lane base of the slot) + immediate and every M0 value one scalar add
     int t = 0;

@@ -1,11 +1,30 @@
 """Data parallelism for the hot path: one process per GPU, batch rows sharded, parameters
-replicated, ONE flat gradient bucket all-reduced per step over RCCL/xGMI (torch.distributed
-backend "nccl"), plus the scalar KL term.
+replicated, gradients averaged over RCCL/xGMI (torch.distributed backend "nccl") in flat float32
+buckets, plus the scalar KL term.
 
 The reference has no distributed code; this is the exchange step of section 8(e).
-Bucket layout = the reference's parameter order (named_parameters(): log_sigma2, weight.imag,
-weight.real, bias.imag, bias.real per layer), so a bucket can be compared across implementations.
-The collective is the only cross-rank traffic: forward / backward kernels never communicate.
+
+Bucket layout.  The parameters in the reference's order (named_parameters(): per layer log_sigma2,
+weight.imag, weight.real, bias.imag, bias.real) are cut into buckets of about `bucket_mb` MiB, filled in
+REVERSE order (the backward pass produces the last layer's gradients first).  Each bucket is one flat
+float32 buffer; `GradBuckets.names` lists (bucket, offset, name) so that a bucket can be compared
+across implementations.
+
+Exchange.  Every parameter carries a post-accumulate-grad hook.  When its gradient exists the hook makes
+`.grad` a view of its bucket slice (no copy if the producing kernel already wrote there: the linear
+layers' backward asks `ops.grad_buffer(param)` for its output storage; one copy otherwise -- conv / BN
+parameters are small) and counts it ready; the bucket's `all_reduce(AVG)` is launched asynchronously as
+soon as its last parameter is ready, so it overlaps the rest of the backward pass (earlier layers).
+The LRT linear layers additionally announce their parameter gradients BEFORE their own input-gradient
+GEMMs (`ops.dp_hook.early_ready`), which gives the single-layer headline config its overlap.  Nothing
+waits inside backward: `sync_gradients()` waits for all buckets, reduces what never completed
+(parameters without a gradient contribute zeros) and hands out the averaged views.
+
+The collective is the only cross-rank traffic: forward / backward kernels never communicate.  The KL
+penalty is a function of the replicated weights only, so its gradient is identical on every rank and the
+mean leaves it unchanged; `all_reduce_scalar_mean` is the north star's "scalar KL term".
+Gradient accumulation over several backward passes per exchange and parameters shared between layers
+are not supported (call `zero_grad()` -- which sets every `.grad` to None -- before each step).
 """
 import torch
 import torch.distributed as dist
@@ -37,69 +56,153 @@ def shard_rows(n_rows, rank=None, world_size=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class GradBucket:
-    """Flat float32 bucket over the gradients of `module`'s parameters."""
+class _Bucket:
+    def __init__(self, index):
+        self.index = index
+        self.entries = []          # (name, param, offset, numel)
+        self.numel = 0
+        self.flat = None
+        self.reset()
 
-    def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        self.names = [n for n, p in module.named_parameters() if p.requires_grad]
-        self.sizes = [p.numel() for p in self.params]
-        total = sum(self.sizes)
-        ref = self.params[0]
-        self.flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
-        self.views, off = [], 0
-        for p, n in zip(self.params, self.sizes):
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+    def reset(self):
+        self.ready = set()         # data_ptr of the parameters whose gradient is in place
+        self.work = None           # async handle once launched
+        self.launched = False
+
+
+class GradBuckets:
+    """Flat float32 gradient buckets over the parameters of `module` (see the module docstring)."""
+
+    def __init__(self, module, bucket_mb=32.0):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
+        self.param_names = [n for n, _ in named]
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets, cur = [], _Bucket(0)
+        for n, p in reversed(named):
+            if cur.entries and cur.numel + p.numel() > cap:
+                self.buckets.append(cur)
+                cur = _Bucket(len(self.buckets))
+            cur.entries.append((n, p, cur.numel, p.numel()))
+            cur.numel += (p.numel() + 3) & ~3          # 16-byte aligned slices (the kernels move 16 B per lane)
+        if cur.entries:
+            self.buckets.append(cur)
+        self.where = {}
+        for b in self.buckets:
+            dev = b.entries[0][1].device
+            b.flat = torch.zeros(b.numel, dtype=torch.float32, device=dev)
+            for n, p, off, numel in b.entries:
+                self.where[p.data_ptr()] = (b, off, numel, tuple(p.shape))
+
+    @property
+    def names(self):
+        return [(b.index, off, n) for b in self.buckets for n, _, off, _ in b.entries]
 
     def nbytes(self):
-        return self.flat.numel() * 4
+        return sum(b.numel for b in self.buckets) * 4
 
-    def adopt(self):
-        """Make every .grad a view into the flat bucket: backward then writes (accumulates)
-        straight into it and no gather / scatter copy is needed around the collective."""
-        if not _exchanging():
-            for p in self.params:          # single process: nothing to exchange, let autograd
-                p.grad = None              # adopt the kernels' output buffers (no extra pass)
-            return
-        self.flat.zero_()
-        for p, v in zip(self.params, self.views):
-            p.grad = v
-
-    def all_reduce_mean(self, async_op=False):
-        """In-place mean over ranks of the whole bucket (a no-op for a single process)."""
-        if not _exchanging():
+    def view(self, data_ptr):
+        """A FRESH view of the bucket slice of the parameter at `data_ptr` (None: not registered)."""
+        e = self.where.get(data_ptr)
+        if e is None:
             return None
-        for p, v in zip(self.params, self.views):     # tolerate grads that were re-pointed
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-                p.grad = v
-        if dist.get_backend() == "nccl":
-            return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, async_op=async_op)
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)
-        self.flat.div_(dist.get_world_size())
-        return work
+        b, off, numel, shape = e
+        return b.flat[off:off + numel].view(shape)
 
 
-class OverlapHook:
-    """Installed as `ops.dp_hook` by DataParallel: averages a layer's data-term parameter
-    gradients across ranks asynchronously (RCCL stream) while the layer's backward continues
-    with the input-gradient GEMMs.  Parameters handled here are skipped by the bucket."""
+def _all_reduce(flat, async_op):
+    """In-place cross-rank SUM (gloo) or AVG (RCCL); returns (work or None, needs_division)."""
+    if dist.get_backend() == "nccl":
+        return dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=async_op), False
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op), True
 
-    def __init__(self):
-        self.done = set()
 
-    def reduce(self, flat, param_ptrs):
-        self.done.update(param_ptrs)
-        if dist.get_backend() == "nccl":
-            return (dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), None)
-        return (dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat)
+class BucketHook:
+    """Installed as `ops.dp_hook` by DataParallel."""
 
-    def finish(self, handle):
-        work, flat = handle
-        work.wait()
-        if flat is not None:
-            flat.div_(dist.get_world_size())
+    def __init__(self, buckets, overlap=True):
+        self.buckets = buckets
+        self.overlap = overlap
+        self.pending = []          # (bucket, work, needs_division)
+
+    # -- storage for gradients (zero-copy path of the linear layers) ---------------------------
+    def view_for(self, param):
+        return self.buckets.view(param.data_ptr())
+
+    # -- readiness ------------------------------------------------------------------------------
+    def _ready(self, data_ptr):
+        e = self.buckets.where.get(data_ptr)
+        if e is None:
+            return
+        b = e[0]
+        b.ready.add(data_ptr)
+        if self.overlap and not b.launched and len(b.ready) == len(b.entries):
+            self._launch(b, async_op=True)
+
+    def _launch(self, b, async_op):
+        b.launched = True
+        work, div = _all_reduce(b.flat, async_op)
+        self.pending.append((b, work if async_op else None, div))
+
+    def early_ready(self, *params):
+        """Called from inside a layer's backward: the gradients of `params` have been written into
+        their `view_for` storage; their bucket may start its all-reduce now, while the layer goes on
+        with its input-gradient GEMMs."""
+        for p in params:
+            if p is not None and self.buckets.view(p.data_ptr()) is not None:
+                self._ready(p.data_ptr())
+
+    def on_grad(self, param):
+        """post-accumulate-grad hook of every registered parameter."""
+        g = param.grad
+        if g is None:
+            return
+        e = self.buckets.where.get(param.data_ptr())
+        if e is None:
+            return
+        b, off, numel, shape = e
+        view = b.flat[off:off + numel].view(shape)
+        if g.data_ptr() != view.data_ptr():
+            if b.launched:
+                # announced early and autograd then cloned the (in-flight) storage: sync() re-points
+                return
+            view.copy_(g)
+            param.grad = view
+        self._ready(param.data_ptr())
+
+    # -- step boundary --------------------------------------------------------------------------
+    def reset(self):
+        self.pending = []
+        for b in self.buckets.buckets:
+            b.reset()
+
+    def sync(self):
+        bk = self.buckets
+        for b in bk.buckets:
+            if not b.launched:
+                # parameters that received no gradient contribute zeros; a gradient that was produced
+                # but never announced (hooks bypassed) is picked up from .grad
+                for n, p, off, numel in b.entries:
+                    if p.data_ptr() in b.ready:
+                        continue
+                    sl = b.flat[off:off + numel]
+                    if p.grad is None:
+                        sl.zero_()
+                    elif p.grad.data_ptr() != sl.data_ptr():
+                        sl.view_as(p).copy_(p.grad)
+                self._launch(b, async_op=False)
+        for b, work, div in self.pending:
+            if work is not None:
+                work.wait()
+            if div:
+                b.flat.div_(dist.get_world_size())
+        for b in bk.buckets:
+            for n, p, off, numel in b.entries:
+                if p.grad is not None or p.data_ptr() in b.ready:
+                    v = b.flat[off:off + numel].view_as(p)
+                    if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                        p.grad = v
+        self.pending = []
 
 
 def all_reduce_scalar_mean(value):
@@ -113,49 +216,52 @@ def all_reduce_scalar_mean(value):
 
 
 class DataParallel(torch.nn.Module):
-    """Thin wrapper: forward = module forward on the local shard; call `sync_gradients()` after
-    backward.  Gradients are the MEAN over ranks (torch DDP convention).  The KL penalty is a
-    function of the replicated weights only, so its gradient is identical on every rank and the
-    mean leaves it unchanged."""
+    """Thin wrapper: forward = module forward on the local shard; call `zero_grad()` before and
+    `sync_gradients()` after backward.  Gradients are the MEAN over ranks (torch DDP convention).
+    overlap=True: bucket all-reduces start during backward as buckets fill; overlap=False: every bucket is
+    reduced in `sync_gradients()` (A/B and debugging)."""
 
-    def __init__(self, module, overlap=True):
+    def __init__(self, module, overlap=True, bucket_mb=32.0):
         super().__init__()
         self.module = module
-        self.bucket = GradBucket(module)
+        self.buckets = GradBuckets(module, bucket_mb)
+        self.bucket = self.buckets                     # (round-1 attribute name)
         self.hook = None
+        self._handles = []
         if _exchanging():
+            from . import ops
+            from .nn.relevance.noise import noise
             for p in module.parameters():              # replicate rank 0's parameters
                 dist.broadcast(p.data, src=0)
             for b in module.buffers():
                 dist.broadcast(b.data, src=0)
-            if overlap:
-                from . import ops
-                self.hook = ops.dp_hook = OverlapHook()
+            self.hook = ops.dp_hook = BucketHook(self.buckets, overlap=overlap)
+            for p in self.buckets.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self.hook.on_grad))
+            # decorrelate the local-reparameterization / dropout noise of the ranks (same torch seed on
+            # every rank is the usual set-up): fold the rank into the Philox key
+            noise.fold_rank(dist.get_rank())
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=True):
+        for p in self.buckets.params:
+            p.grad = None
         if self.hook is not None:
-            self.hook.done.clear()
-            for p in self.bucket.params:               # gradients arrive already averaged (hook)
-                p.grad = None                          # or are averaged below
-            return
-        self.bucket.adopt()
+            self.hook.reset()
 
     def sync_gradients(self):
-        """Average whatever the overlap hook did not already average.  (The KL term is a function
-        of the replicated weights: its gradient is identical on every rank and needs no exchange.)"""
-        if self.hook is None:
-            return self.bucket.all_reduce_mean()
-        rest = [p for p in self.bucket.params if p.grad is not None and p.data_ptr() not in self.hook.done]
-        if rest:
-            flat = torch.cat([p.grad.reshape(-1) for p in rest])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(dist.get_world_size())
-            off = 0
-            for p in rest:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p))
-                off += n
-        return None
+        """Wait for / finish the gradient exchange; afterwards every `.grad` is the mean over ranks."""
+        if self.hook is not None:
+            self.hook.sync()
+
+    def remove(self):
+        """Detach the hooks (tests that wrap the same module more than once)."""
+        from . import ops
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        if ops.dp_hook is self.hook:
+            ops.dp_hook = None
+        self.hook = None

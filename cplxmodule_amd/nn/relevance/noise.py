@@ -27,7 +27,14 @@ class _NoiseState:
 
     @property
     def seed(self):
-        return torch.initial_seed() if self._seed is None else self._seed
+        base = torch.initial_seed() if self._seed is None else self._seed
+        # data-parallel ranks draw decorrelated noise from the same user seed (dp.DataParallel)
+        return (base + getattr(self, "_rank", 0) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+    def fold_rank(self, rank):
+        """Fold a data-parallel rank into the Philox key (rank 0 leaves the stream unchanged)."""
+        self._rank = int(rank)
+        self._dev = {}
 
     def manual_seed(self, seed):
         self._seed, self.counter = int(seed), 0

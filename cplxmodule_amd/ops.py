@@ -420,11 +420,25 @@ def _scaled(beta, t):
     return None if t is None else t * beta
 
 
-# Data-parallel hook (cplxmodule_amd.dp): when set, the linear layers' backward hands the
-# parameter gradients of the DATA term to `reduce(flat)` as soon as they exist -- one flat
-# float32 buffer [dls2 | dwr | dwi | dbr | dbi] -- so the RCCL all-reduce overlaps the dX GEMMs
-# that follow; `finish(handle)` is called right before the gradients are returned to autograd.
+# Data-parallel hook (cplxmodule_amd.dp.BucketHook): when set, the linear layers' backward writes the
+# parameter gradients straight into their all-reduce bucket (`grad_buffer`) and announces them
+# (`early_ready`) BEFORE its input-gradient GEMMs, so the RCCL all-reduce of a full bucket overlaps them.
 dp_hook = None
+
+
+def grad_buffer(param):
+    """float32 storage for the gradient of `param`: a fresh view of its data-parallel bucket slice when a
+    DataParallel wrapper is active (the all-reduce then needs no copy), a new tensor otherwise."""
+    if dp_hook is not None:
+        v = dp_hook.view_for(param)
+        if v is not None:
+            return v
+    return torch.empty(param.shape, dtype=torch.float32, device=param.device)
+
+
+def _announce(*params):
+    if dp_hook is not None:
+        dp_hook.early_ready(*params)
 
 
 class CplxLinearFn(torch.autograd.Function):
@@ -459,13 +473,16 @@ class CplxLinearFn(torch.autograd.Function):
         g2r, g2i = gr.reshape(-1, O).contiguous(), gi.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
+        # parameter gradients first (into their data-parallel bucket, announced before the dX GEMM)
+        if need[2] or need[3]:
+            dwr, dwi = grad_buffer(wr), grad_buffer(wi)
+            _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), algo=ctx.algo, emul=mask)
+            _announce(wr, wi)
+        if ctx.has_bias and (need[4] or need[5]):
+            dbr, dbi = colsum2(g2r, g2i)
         if need[0] or need[1]:
             dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r.dtype, ctx.algo)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
-        if need[2] or need[3]:
-            dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i, algo=ctx.algo, emul=mask)
-        if ctx.has_bias and (need[4] or need[5]):
-            dbr, dbi = colsum2(g2r, g2i)
         return dxr, dxi, dwr, dwi, dbr, dbi, None, None
 
 
@@ -488,13 +505,11 @@ class CplxLinearLRTFn(torch.autograd.Function):
         B = x2r.shape[0]
         bias = None if br is None else (_f32(_c(br)), _f32(_c(bi)))
         wrc, wic, ls2c = _c(wr), _c(wi), _c(ls2)
-        kl = ctx.klg = ctx.flat = None
-        n_w = O * I
+        kl = ctx.klg = None
         if kl_kind is not None:
-            # one flat buffer [dls2 | dwr | dwi | dbr | dbi]: the KL gradients land in it now, the data
-            # gradients are added in backward, and a data-parallel hook all-reduces it as one piece
-            ctx.flat = torch.empty(3 * n_w + (2 * O if br is not None else 0), dtype=torch.float32, device=x2r.device)
-            ctx.klg = tuple(ctx.flat[k * n_w:(k + 1) * n_w].view(O, I) for k in range(3))
+            # the (unscaled) KL gradients are written now -- into the parameters' data-parallel bucket
+            # slices when there is one -- and the data gradients are added to them in backward
+            ctx.klg = (grad_buffer(ls2), grad_buffer(wr), grad_buffer(wi))
         if _prep_ok(x2r, wrc, wic, ls2c):
             wcr, wci, S, kl, _ = prep_kl(kl_kind, wrc, wic, ls2c, kl_kind is not None, ctx.klg)
         else:
@@ -504,7 +519,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
                 kl = torch.empty((), dtype=torch.float32, device=x2r.device)
                 g = ctx.klg
                 call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wrc)), ptr(_f32(wic)), ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind],
-                     1.0, ptr(kl), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(_ws(x2r.device)), n_w, stream_ptr())
+                     1.0, ptr(kl), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(_ws(x2r.device)), O * I, stream_ptr())
         ctx.wc, ctx.S = (wcr, wci), S
         mur, mui = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
         a = abs2(x2r, x2i)                                   # [B,I], activation dtype
@@ -513,8 +528,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
         if eps_r is not None:
             eps = (eps_r.reshape(B, O), eps_i.reshape(B, O))
         yr, yi = reparam_fwd(mur, mui, s2, eps, seed, offset, inplace=True)
-        ctx.save_for_backward(x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i)
-        ctx.bias_ptrs = () if br is None else (br.data_ptr(), bi.data_ptr())
+        ctx.save_for_backward(x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi)
         ctx.has_bias = br is not None
         ctx.lead, ctx.seed, ctx.offset = xr.shape[:-1], seed, offset
         ctx.kl_kind, ctx.kl_used = kl_kind, False
@@ -522,16 +536,15 @@ class CplxLinearLRTFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gr, gi, gkl=None):
-        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i = ctx.saved_tensors
+        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi = ctx.saved_tensors
         O, I = wr.shape
         B = x2r.shape[0]
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
-        n_w = O * I
-        klg = ctx.klg if gkl is not None else None
-        if klg is not None and ctx.kl_used:
-            # second backward through a retained graph: the buffers now hold totals, redo the KL part
-            klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:]
+        klg = None
+        if gkl is not None and ctx.kl_kind is not None:
+            # (a second backward through a retained graph: the buffers hold totals by then, redo the KL part)
+            klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:] if ctx.kl_used else ctx.klg
         if gr is None and gi is None:                       # only the KL term reached the loss
             if klg is not None:
                 dls2, dwr, dwi = (_scaled(gkl, t) for t in klg)
@@ -541,50 +554,39 @@ class CplxLinearLRTFn(torch.autograd.Function):
         eps = None if eps_r is None else (eps_r.reshape(B, O), eps_i.reshape(B, O))
         dt = x2r.dtype
         gs2 = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt)
-        # parameter gradients first: with a data-parallel hook their all-reduce overlaps dX
-        handle = None
+        # parameter gradients first: under data parallelism their bucket's all-reduce overlaps dX
         want_w, want_b = need[2] or need[3], ctx.has_bias and (need[4] or need[5])
         ls2c = _c(ls2)
-        fused_kl = klg is not None and klg is ctx.klg and want_w and need[6]
-        if fused_kl:
-            # dW = G^T conj(X) + g_kl * dW_kl and dls2 = (gs2^T |x|^2) exp(ls2) + g_kl * dls2_kl, in place
-            flat = ctx.flat
-            # FRESH views (autograd adopts a returned gradient without a copy only if nothing else holds it)
-            dls2, dwr, dwi = (flat[k * n_w:(k + 1) * n_w].view(O, I) for k in range(3))
+        if klg is not None and klg is ctx.klg and want_w and need[6]:
+            # dW = G^T conj(X) + g_kl * dW_kl and dls2 = (gs2^T |x|^2) exp(ls2) + g_kl * dls2_kl, in place.
+            # (ctx.klg are views nobody else holds once ctx dies, so autograd adopts them without a copy)
+            dls2, dwr, dwi = klg
+            ctx.klg = None
             _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), accumulate=True, beta=gkl)
             _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
             ctx.kl_used = True
-        elif dp_hook is not None and want_w and need[6]:
-            flat = torch.empty(3 * n_w + (2 * O if want_b else 0), dtype=torch.float32, device=x2r.device)
-            dls2, dwr, dwi = (flat[k * n_w:(k + 1) * n_w].view(O, I) for k in range(3))
-            _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi))
-            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
         else:
-            flat = None
             if want_w:
-                dwr, dwi = _cplx_linear_dw(g2r, g2i, x2r, x2i)
+                dwr, dwi = grad_buffer(wr), grad_buffer(wi)
+                _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi))
             if need[6]:
-                dls2 = _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True)  # (gs2^T a) * exp(ls2)
+                dls2 = grad_buffer(ls2)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)  # (gs2^T a) * exp(ls2)
             if klg is not None:                              # KL requested, but not every gradient is wanted
-                dls2 = None if dls2 is None else dls2 + gkl * klg[0]
-                dwr = None if dwr is None else dwr + gkl * klg[1]
-                dwi = None if dwi is None else dwi + gkl * klg[2]
+                if dls2 is not None:
+                    dls2.add_(klg[0] * gkl)
+                if dwr is not None:
+                    dwr.add_(klg[1] * gkl)
+                    dwi.add_(klg[2] * gkl)
         if want_b:
-            if flat is not None and flat.numel() == 3 * n_w + 2 * O:
-                dbr, dbi = flat[3 * n_w:3 * n_w + O], flat[3 * n_w + O:]
-                colsum2(g2r, g2i, out=(dbr, dbi))
-            else:
-                dbr, dbi = colsum2(g2r, g2i)
-        if dp_hook is not None and flat is not None:
-            handle = dp_hook.reduce(flat, (wr.data_ptr(), wi.data_ptr(), ls2.data_ptr()) +
-                                    (ctx.bias_ptrs if want_b and flat.numel() > 3 * n_w else ()))
+            dbr, dbi = colsum2(g2r, g2i, out=(grad_buffer(br), grad_buffer(bi)))
+        _announce(ls2 if dls2 is not None else None, wr if dwr is not None else None,
+                  wi if dwi is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
         if need[0] or need[1]:
             dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], dt)
             ga = _real_linear_dx(gs2, ctx.S, dt)             # gs2 . S -> [B,I]
             lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
-        if handle is not None:
-            dp_hook.finish(handle)
         return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
 
 
@@ -615,12 +617,14 @@ class RealLinearFn(torch.autograd.Function):
         g2 = g.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
         dx = dw = db = None
-        if need[0]:
-            dx = _real_linear_dx(g2, ctx.wm, x2.dtype).view(*ctx.lead, I)
         if need[1]:
-            dw = _real_linear_dw(g2, x2, emul=mask)
+            dw = grad_buffer(w)
+            _real_linear_dw(g2, x2, emul=mask, out=dw)
+            _announce(w)
         if ctx.has_bias and need[2]:
             db = colsum(g2)
+        if need[0]:
+            dx = _real_linear_dx(g2, ctx.wm, x2.dtype).view(*ctx.lead, I)
         return dx, dw, db, None
 
 
@@ -654,46 +658,43 @@ class RealLinearLRTFn(torch.autograd.Function):
         x2 = x.reshape(-1, I).contiguous()
         B = x2.shape[0]
         wc_, ls2c = _c(w), _c(ls2)
-        n_w = O * I
-        kl = ctx.flat = None
+        kl = ctx.klg = None
         if kl_kind is not None:
-            ctx.flat = torch.empty(2 * n_w + (O if b is not None else 0), dtype=torch.float32, device=x2.device)
-        klg = None if ctx.flat is None else (ctx.flat[:n_w].view(O, I), ctx.flat[n_w:2 * n_w].view(O, I), None)
+            ctx.klg = (grad_buffer(ls2), grad_buffer(w))
         if _prep_ok(x2, wc_, ls2c):
-            wb, _, S, kl, _ = prep_kl(kl_kind, wc_, None, ls2c, kl_kind is not None, klg)
+            wb, _, S, kl, _ = prep_kl(kl_kind, wc_, None, ls2c, kl_kind is not None,
+                                      None if ctx.klg is None else (*ctx.klg, None))
         else:
             wb, S = cast(wc_, x2.dtype), exp(ls2c, out_dtype=x2.dtype)
             if kl_kind is not None:
                 kl = torch.empty((), dtype=torch.float32, device=x2.device)
                 call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wc_)), None, ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind], 1.0,
-                     ptr(kl), ptr(klg[0]), ptr(klg[1]), None, ptr(_ws(x2.device)), n_w, stream_ptr())
+                     ptr(kl), ptr(ctx.klg[0]), ptr(ctx.klg[1]), None, ptr(_ws(x2.device)), O * I, stream_ptr())
         ctx.wb, ctx.S = wb, S
         mu = rgemm(x2, (I, 1), wb, (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
         a = abs2(x2)
         s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)
         e = None if eps is None else eps.reshape(B, O)
         y, _ = reparam_fwd(mu, None, s2, e, seed, offset, inplace=True)
-        ctx.save_for_backward(x2, w, ls2, s2, a, eps)
+        ctx.save_for_backward(x2, w, ls2, s2, a, eps, b)
         ctx.has_bias, ctx.lead, ctx.seed, ctx.offset = b is not None, x.shape[:-1], seed, offset
-        ctx.ptrs = (w.data_ptr(), ls2.data_ptr()) + (() if b is None else (b.data_ptr(),))
         ctx.kl_kind, ctx.kl_used = kl_kind, False
         return y.view(*ctx.lead, O), kl
 
     @staticmethod
     def backward(ctx, g, gkl=None):
-        x2, w, ls2, s2, a, eps = ctx.saved_tensors
+        x2, w, ls2, s2, a, eps, b = ctx.saved_tensors
         O, I = w.shape
         B = x2.shape[0]
-        n_w = O * I
         need = ctx.needs_input_grad
         dx = dw = db = dls2 = None
-        have_kl = ctx.flat is not None and gkl is not None
         klg = None
-        if have_kl and ctx.kl_used:                          # second backward through a retained graph
-            r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
-            klg = (r[1], r[2])
-        elif have_kl:
-            klg = (ctx.flat[:n_w].view(O, I), ctx.flat[n_w:2 * n_w].view(O, I))
+        if gkl is not None and ctx.kl_kind is not None:
+            if ctx.kl_used:                                  # second backward through a retained graph
+                r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
+                klg = (r[1], r[2])
+            else:
+                klg = ctx.klg
         if g is None:                                        # only the KL term reached the loss
             if klg is not None:
                 dls2, dw = _scaled(gkl, klg[0]), _scaled(gkl, klg[1])
@@ -703,44 +704,33 @@ class RealLinearLRTFn(torch.autograd.Function):
         e = None if eps is None else eps.reshape(B, O)
         gs2 = reparam_bwd(g2, None, s2, e, ctx.seed, ctx.offset, out_dtype=dt)
         ls2c = _c(ls2)
-        want_b = ctx.has_bias and need[2]
-        fused_kl = have_kl and not ctx.kl_used and need[1] and need[3]
-        flat = None
-        if fused_kl:
-            flat = ctx.flat
+        if klg is not None and klg is ctx.klg and need[1] and need[3]:
             dls2, dw = klg
+            ctx.klg = None
             _real_linear_dw(g2, x2, out=dw, accumulate=True, beta=gkl)
             _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
             ctx.kl_used = True
-        elif dp_hook is not None and need[1] and need[3]:
-            flat = torch.empty(2 * n_w + (O if want_b else 0), dtype=torch.float32, device=x2.device)
-            dls2, dw = flat[:n_w].view(O, I), flat[n_w:2 * n_w].view(O, I)
-            _real_linear_dw(g2, x2, out=dw)
-            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
         else:
             if need[1]:
-                dw = _real_linear_dw(g2, x2)
+                dw = grad_buffer(w)
+                _real_linear_dw(g2, x2, out=dw)
             if need[3]:
-                dls2 = _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True)
+                dls2 = grad_buffer(ls2)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
             if klg is not None:
-                dls2 = None if dls2 is None else dls2 + gkl * klg[0]
-                dw = None if dw is None else dw + gkl * klg[1]
-        if want_b:
-            if flat is not None and flat.numel() == 2 * n_w + O:
-                db = flat[2 * n_w:]
-                db.copy_(colsum(g2))
-            else:
-                db = colsum(g2)
-        handle = None
-        if dp_hook is not None and flat is not None:
-            handle = dp_hook.reduce(flat, ctx.ptrs[:2] + (ctx.ptrs[2:] if want_b and flat.numel() > 2 * n_w else ()))
+                if dls2 is not None:
+                    dls2.add_(klg[0] * gkl)
+                if dw is not None:
+                    dw.add_(klg[1] * gkl)
+        if ctx.has_bias and need[2]:
+            db = grad_buffer(b)
+            db.copy_(colsum(g2))
+        _announce(ls2 if dls2 is not None else None, w if dw is not None else None, b if db is not None else None)
         if need[0]:
             dx = _real_linear_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), dt)
             ga = _real_linear_dx(gs2, ctx.S, dt)
             lrt_dx_accum(dx, None, x2, None, ga)
             dx = dx.view(*ctx.lead, I)
-        if handle is not None:
-            dp_hook.finish(handle)
         return dx, dw, db, dls2, None, None, None, None
 
 

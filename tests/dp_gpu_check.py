@@ -31,6 +31,7 @@ def main():
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = "cuda"
+    noise.fold_rank(rank)      # what DataParallel does: set it up front so that every pass below draws the same noise
     torch.manual_seed(0)
     layer = rel.CplxLinearVD(64, 96).to(dev)
     with torch.no_grad():
@@ -46,36 +47,79 @@ def main():
         (y.real.float().square().sum() + y.imag.float().square().sum() + klw * kl).backward()
 
     layer.train()
-    # reference: plain local gradients, averaged by hand
-    ops.dp_hook = None
-    layer.zero_grad(set_to_none=True)
-    run()
-    names = [n for n, _ in layer.named_parameters()]
-    local = [p.grad.detach().clone() for p in layer.parameters()]
-    ref = []
-    for g in local:
-        t = g.clone()
-        dist.all_reduce(t)
-        ref.append(t / world)
-    # overlap path
-    model = dp.DataParallel(layer, overlap=True)
-    model.zero_grad()
-    run()
-    model.sync_gradients()
-    worst = 0.0
-    for n, p, r in zip(names, layer.parameters(), ref):
-        err = float((p.grad - r).abs().max() / (r.abs().max() + 1e-12))
-        worst = max(worst, err)
-        assert err < 2e-3, (n, err)          # KL part is replicated, data part bf16 GEMMs
-    # and without overlap (flat bucket through .grad views)
-    ops.dp_hook = None
-    model2 = dp.DataParallel(layer, overlap=False)
-    model2.zero_grad()
-    run()
-    model2.sync_gradients()
-    for n, p, r in zip(names, layer.parameters(), ref):
-        err = float((p.grad - r).abs().max() / (r.abs().max() + 1e-12))
-        assert err < 2e-3, (n, err)
+
+    def hand_average(module, run_fn):
+        """plain local gradients (no wrapper), averaged with explicit all-reduces"""
+        ops.dp_hook = None
+        module.zero_grad(set_to_none=True)
+        run_fn()
+        out = {}
+        for n, p in module.named_parameters():
+            if p.grad is None:
+                continue
+            t = p.grad.detach().clone()
+            dist.all_reduce(t)
+            out[n] = t / world
+        module.zero_grad(set_to_none=True)
+        return out
+
+    def check(module, run_fn, ref, tol, **kw):
+        model = dp.DataParallel(module, **kw)
+        worst = 0.0
+        for _ in range(2):                                   # two steps: the buckets are reused
+            model.zero_grad()
+            run_fn()
+            model.sync_gradients()
+            for n, p in module.named_parameters():
+                if n not in ref:
+                    assert p.grad is None, n
+                    continue
+                err = float((p.grad - ref[n]).abs().max() / (ref[n].abs().max() + 1e-12))
+                worst = max(worst, err)
+                assert err < tol, (n, err, kw)
+                assert p.grad.data_ptr() == model.buckets.view(p.data_ptr()).data_ptr(), n
+        launched = sum(1 for b in model.buckets.buckets if b.launched)
+        model.remove()
+        return worst, launched
+
+    run()                                                    # arms the fused KL: every later step is alike
+    ref = hand_average(layer, run)
+    worst, _ = check(layer, run, ref, 2e-3, overlap=True)    # KL part replicated, data part bf16 GEMMs
+    check(layer, run, ref, 2e-3, overlap=False)
+    check(layer, run, ref, 2e-3, overlap=True, bucket_mb=0.01)
+
+    # cfg5-shaped model: 6 x (CplxConv2d + CplxBatchNorm2d + split-ReLU) + CplxLinearARD head, several
+    # buckets; every parameter's averaged gradient == the hand-averaged one
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "train_sparsify", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                                       "train_sparsify.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    torch.manual_seed(0)
+    net = ts.Net(rel.CplxLinearARD, width=4).to(dev)
+    xs, ys = ts.synthetic_complex_mnist(32, dev, seed=3 + rank)
+
+    def run_net():
+        noise.manual_seed(5)
+        loss = torch.nn.functional.cross_entropy(net(xs), ys)
+        kl = sum(rel.penalties(net), torch.zeros((), device=dev))
+        (loss + 1e-3 * kl).backward()
+
+    net.train()
+    run_net()
+    net.zero_grad(set_to_none=True)
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+
+    def run_net_same_stats():
+        net.load_state_dict(bn_state, strict=False)          # identical running statistics for every pass
+        run_net()
+
+    ref5 = hand_average(net, run_net_same_stats)
+    w5, nb = check(net, run_net_same_stats, ref5, 5e-4, overlap=True, bucket_mb=0.05)
+    assert nb >= 3, nb
+    check(net, run_net_same_stats, ref5, 5e-4, overlap=False)
+    worst = max(worst, w5)
     kl_mean = dp.all_reduce_scalar_mean(sum(rel.penalties(layer)))
     assert torch.isfinite(kl_mean)
     if rank == 0:

@@ -19,41 +19,80 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from cplxmodule_amd import dp
+    from cplxmodule_amd import dp, ops
     from cplxmodule_amd.nn import relevance as rel
+    from cplxmodule_amd.nn.relevance.noise import noise
     torch.manual_seed(100 + rank)              # different init per rank: broadcast must fix it
-    model = torch.nn.Sequential(rel.CplxLinearVD(6, 5), rel.LinearARD(5, 3))
-    wrapped = dp.DataParallel(model, overlap=False)
-    names = wrapped.bucket.names
-    first = model[0].weight.real.detach().clone()
+    # our VD layers (parameters only: their kernels need the GPU) next to plain torch layers that DO run here
+    model = torch.nn.Sequential()
+    model.add_module("vd", rel.CplxLinearVD(6, 5))
+    model.add_module("ard", rel.LinearARD(5, 3))
+    model.add_module("fc1", torch.nn.Linear(7, 9))
+    model.add_module("fc2", torch.nn.Linear(9, 4))
+    wrapped = dp.DataParallel(model, overlap=True, bucket_mb=200 * 4 / (1 << 20))    # ~200 floats per bucket
+    layout = wrapped.buckets.names
+    first = model.vd.weight.real.detach().clone()
+    assert ops.dp_hook is wrapped.hook and noise._rank == rank
+    seeds = noise.seed
+
+    def step(w):
+        w.zero_grad()
+        assert all(p.grad is None for p in model.parameters())
+        torch.manual_seed(7 + rank)            # rank-dependent data
+        x = torch.randn(11, 7)
+        y = model.fc2(torch.tanh(model.fc1(x)))
+        (y ** 2).sum().backward()
+        local = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        w.sync_gradients()
+        return local
+
+    local = step(wrapped)
+    # hand-averaged reference
+    ok = True
+    for n, p in model.named_parameters():
+        if n.startswith("fc"):
+            ref = local[n].clone()
+            dist.all_reduce(ref)
+            ref /= world
+            ok &= bool(torch.allclose(p.grad, ref, rtol=1e-6, atol=1e-7))
+            ok &= p.grad.data_ptr() == wrapped.buckets.view(p.data_ptr()).data_ptr()      # .grad IS the bucket slice
+        else:
+            ok &= p.grad is None                                                           # no gradient -> stays None
+    launched_async = sum(1 for b in wrapped.buckets.buckets if b.launched)
+    # a second step reuses the buckets
+    step(wrapped)
+    # the linear layers' zero-copy path: write into grad_buffer, announce early, autograd-style adoption
     wrapped.zero_grad()
-    # emulate a backward: rank-dependent gradients written through .grad (views of the bucket)
-    for i, p in enumerate(model.parameters()):
-        p.grad.add_(float(rank + 1) * (i + 1))
+    w = model.vd.log_sigma2
+    buf = ops.grad_buffer(w)
+    assert buf.data_ptr() == wrapped.buckets.view(w.data_ptr()).data_ptr()
+    buf.fill_(float(rank + 1))
+    ops._announce(w)
+    w.grad = buf
+    wrapped.hook.on_grad(w)                                          # what the post-accumulate hook does
     wrapped.sync_gradients()
-    grads = [float(p.grad.mean()) for p in model.parameters()]
+    early = float(w.grad.mean())                                     # mean of (1, 2) = 1.5
+    others_none = all(p.grad is None or n.startswith("fc") or n == "vd.log_sigma2"
+                      for n, p in model.named_parameters())
+    wrapped.remove()
+    # overlap=False: nothing is launched before sync_gradients
+    plain = dp.DataParallel(model, overlap=False, bucket_mb=1.0)
+    plain.zero_grad()
+    torch.manual_seed(7 + rank)
+    (model.fc2(torch.tanh(model.fc1(torch.randn(11, 7)))) ** 2).sum().backward()
+    none_launched = not any(b.launched for b in plain.buckets.buckets)
+    plain.sync_gradients()
+    ok2 = True
+    for n, p in model.named_parameters():
+        if n.startswith("fc"):
+            ref = local[n].clone()
+            dist.all_reduce(ref)
+            ok2 &= bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+    plain.remove()
     lo, hi = dp.shard_rows(11)
     kl = dp.all_reduce_scalar_mean(torch.tensor(float(rank)))
-    alias = (model[0].weight.real.grad.data_ptr() ==
-             wrapped.bucket.views[names.index("0.weight.real")].data_ptr())
-    # overlap path: the hook averages a layer's flat gradient buffer asynchronously, the wrapper
-    # then averages only what the hook has not handled
-    over = dp.DataParallel(model, overlap=True)
-    over.zero_grad()
-    assert all(p.grad is None for p in model.parameters())
-    flat = torch.full((7,), float(rank + 1))
-    h = over.hook.reduce(flat, (model[0].log_sigma2.data_ptr(),))
-    over.hook.finish(h)
-    assert torch.allclose(flat, torch.full((7,), 1.5))
-    model[0].log_sigma2.grad = torch.full_like(model[0].log_sigma2, 9.0 + rank)   # "already averaged"
-    model[1].weight.grad = torch.full_like(model[1].weight, float(rank))          # left to the wrapper
-    over.sync_gradients()
-    assert float(model[0].log_sigma2.grad.mean()) == 9.0 + rank                    # untouched
-    assert abs(float(model[1].weight.grad.mean()) - 0.5) < 1e-6                    # averaged
-    from cplxmodule_amd import ops
-    ops.dp_hook = None
-    out.put((rank, names, grads, first.numpy(), (lo, hi), float(kl),
-             wrapped.bucket.flat.numel(), alias))
+    out.put((rank, layout, ok, ok2, first.numpy(), (lo, hi), float(kl), launched_async, early, others_none,
+             none_launched, seeds, ops.dp_hook is None))
     dist.destroy_process_group()
 
 
@@ -69,16 +108,22 @@ def test_dp_bucket_allreduce_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, names0, g0, w0, s0, kl0, n0, alias0), (r1, names1, g1, w1, s1, kl1, n1, alias1) = res
-    assert names0 == names1 == ["0.log_sigma2", "0.weight.imag", "0.weight.real", "0.bias.imag",
-                                "0.bias.real", "1.weight", "1.bias", "1.log_sigma2"]
-    np.testing.assert_array_equal(w0, w1)                    # broadcast from rank 0
-    want = [1.5 * (i + 1) for i in range(len(g0))]           # mean of (1, 2) * (i + 1)
-    np.testing.assert_allclose(g0, want)
-    np.testing.assert_allclose(g1, want)
-    assert s0 == (0, 6) and s1 == (6, 11)
-    assert kl0 == kl1 == 0.5
-    assert n0 == 30 + 30 + 30 + 5 + 5 + 15 + 3 + 15 and alias0 and alias1
+    r0, r1 = res
+    # bucket layout: reference parameter order (named_parameters()) walked BACKWARDS in ~200-float buckets
+    assert r0[1] == r1[1]
+    names = [n for _, _, n in r0[1]]
+    assert names == ["fc2.bias", "fc2.weight", "fc1.bias", "fc1.weight", "ard.log_sigma2", "ard.bias", "ard.weight",
+                     "vd.bias.real", "vd.bias.imag", "vd.weight.real", "vd.weight.imag", "vd.log_sigma2"]
+    assert [b for b, _, _ in r0[1]] == [0] * 10 + [1, 1]
+    assert len({b for b, _, _ in r0[1]}) >= 2 and all(off % 4 == 0 for _, off, _ in r0[1])
+    for r in (r0, r1):
+        assert r[2] and r[3], "averaged gradients == hand-averaged gradients (overlap and plain)"
+        assert r[7] >= 1, "at least one bucket was all-reduced asynchronously during backward"
+        assert abs(r[8] - 1.5) < 1e-6 and r[9] and r[10] and r[12]
+    np.testing.assert_array_equal(r0[4], r1[4])                    # broadcast from rank 0
+    assert r0[5] == (0, 6) and r1[5] == (6, 11)
+    assert r0[6] == r1[6] == 0.5
+    assert r0[11] != r1[11]                                        # the ranks' noise keys differ
 
 
 def test_shard_rows_cover_everything():
