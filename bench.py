@@ -253,7 +253,7 @@ def main():
             "config": {"workload": "CplxLinearVD 4096->4096, bf16 activations / fp32 master weights, "
                                    f"batch {B} per GPU, LRT fwd + KL + full bwd (BASELINE configs[1] + VD)",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "kl_weight": KLW, "noise": "in-kernel Philox4x32-10"},
+                       "kl_weight": KLW, "noise": "in-kernel Philox4x32-7"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM: fwd NN, dgrad NT, wgrad TT = 3 launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,

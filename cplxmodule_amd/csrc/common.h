@@ -15,18 +15,34 @@ namespace cplxamd {
 
 constexpr int kWave = 64;
 
+// Rounds of the Philox4x32 counter-based generator behind the in-kernel noise (reparam.hip, layout.hip;
+// numpy statement + Random123 known answers: oracle/philox.py).  7 is the smallest round count for which
+// Philox4x32 passes BigCrush (Salmon et al., SC'11, "Parallel random numbers: as easy as 1, 2, 3", table 2);
+// 10 is Random123's default safety margin.  The bf16 noise-injection kernels are bound by the generator's
+// quarter-rate 32x32->64 multiplies, not by HBM, so the margin costs throughput directly
+// (profiles/r02_reparam_rounds.txt).
+#ifndef CPLXAMD_PHILOX_ROUNDS
+#define CPLXAMD_PHILOX_ROUNDS 7
+#endif
+constexpr int kPhiloxRounds = CPLXAMD_PHILOX_ROUNDS;
+
 typedef uint16_t bf16_t;  // raw bf16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
 
-// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
+// round-to-nearest-even, NaN stays NaN (same rule as torch's float -> bfloat16): the gfx950 hardware
+// conversion v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer emulation it replaces was ~5 VALU ops
+// per value, which showed in the VALU-bound bf16 noise-injection kernels)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2_hw v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+}
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
 template <typename T> struct io;
@@ -106,8 +122,8 @@ __device__ __forceinline__ f4 ld4(const bf16_t* p) {
 }
 __device__ __forceinline__ void st4(bf16_t* p, const f4& a) {
   uint2 t;
-  t.x = (uint32_t)f32_to_bf16(a.v[0]) | ((uint32_t)f32_to_bf16(a.v[1]) << 16);
-  t.y = (uint32_t)f32_to_bf16(a.v[2]) | ((uint32_t)f32_to_bf16(a.v[3]) << 16);
+  t.x = pack_bf16(a.v[0], a.v[1]);
+  t.y = pack_bf16(a.v[2], a.v[3]);
   *reinterpret_cast<uint2*>(p) = t;
 }
 __device__ __forceinline__ f8 ld8(const float* p) { return f8{{ld4(p), ld4(p + 4)}}; }
@@ -127,8 +143,7 @@ __device__ __forceinline__ void st8(bf16_t* p, const f8& a) {
   uint32_t w[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    w[e] = (uint32_t)f32_to_bf16(a.h[e >> 1].v[(e & 1) * 2]) |
-           ((uint32_t)f32_to_bf16(a.h[e >> 1].v[(e & 1) * 2 + 1]) << 16);
+    w[e] = pack_bf16(a.h[e >> 1].v[(e & 1) * 2], a.h[e >> 1].v[(e & 1) * 2 + 1]);
   *reinterpret_cast<uint4*>(p) = uint4{w[0], w[1], w[2], w[3]};
 }
 

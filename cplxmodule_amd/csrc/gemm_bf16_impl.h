@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void gauss_sum_kernel(const bf16_t* r, const b
     for (int e = 0; e < 4; ++e) {
       const float lo = __uint_as_float(aw[e] << 16) + sign * __uint_as_float(bw[e] << 16);
       const float hi = __uint_as_float(aw[e] & 0xffff0000u) + sign * __uint_as_float(bw[e] & 0xffff0000u);
-      ow[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+      ow[e] = pack_bf16(lo, hi);
     }
     *reinterpret_cast<uint4*>(out + 8 * c) = uint4{ow[0], ow[1], ow[2], ow[3]};
   }

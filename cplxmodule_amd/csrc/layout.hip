@@ -125,14 +125,14 @@ __global__ __launch_bounds__(kLT) void modrelu_bwd_kernel(const T* zr, const T* 
   }
 }
 
-// Philox4x32-10, counter (group_lo, group_hi, offset_lo, offset_hi), key seed: 4 uniform words per
+// Philox4x32-7 (common.h: kPhiloxRounds), counter (group_lo, group_hi, offset_lo, offset_hi), key seed: 4 uniform words per
 // group of 4 complex elements; element e is kept iff word (e & 3) of group e >> 2 is >= p * 2^32.
 __device__ __forceinline__ void philox4(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key, uint32_t (&o)[4]) {
   uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
   uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < kPhiloxRounds; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
     const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);

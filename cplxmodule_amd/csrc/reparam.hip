@@ -1,6 +1,6 @@
 // K5: local-reparameterization noise injection  y = mu + eps * sqrt(max(s2, 1e-8))  and its
 // backward, with the noise either supplied (parity mode) or generated in-kernel from a
-// counter-based Philox4x32-10 stream (so the backward regenerates it instead of storing it).
+// counter-based Philox4x32-7 (common.h: kPhiloxRounds) stream (so the backward regenerates it instead of storing it).
 //
 // Reference arithmetic (file:line under /root/reference/cplxmodule):
 //   nn/relevance/complex/base.py:56, nn/relevance/real/base.py:49, cplx.py:544-562 (randn).
@@ -28,12 +28,12 @@ constexpr int kRpThreads = 256;
 
 struct u32x4 { uint32_t v[4]; };
 
-__device__ __forceinline__ u32x4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+__device__ __forceinline__ u32x4 philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
   uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
   uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < kPhiloxRounds; ++r) {
     // one 32x32->64 product each (v_mad_u64_u32) instead of a mul_lo + mul_hi pair
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t lo0 = (uint32_t)p0, hi0 = (uint32_t)(p0 >> 32);
@@ -64,7 +64,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float scale, 
 
 __device__ __forceinline__ f4 philox_normals(uint64_t group, uint64_t seed, uint64_t offset,
                                              float scale) {
-  const u32x4 x = philox4x32_10(group, offset, seed);
+  const u32x4 x = philox4x32(group, offset, seed);
   f4 z;
   box_muller(x.v[0], x.v[1], scale, z.v[0], z.v[1]);
   box_muller(x.v[2], x.v[3], scale, z.v[2], z.v[3]);

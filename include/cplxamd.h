@@ -122,7 +122,7 @@ int cplxamd_expi_bwd(const float* g, const float* x, float* gx, int64_t n, void*
  *           cplx.randn / randn_like              cplx.py:544-562
  *   y = mu + eps * sqrt(max(s2, 1e-8))
  * mu_i / y_i / eps_i NULL  => real layer (eps ~ N(0,1)); else eps_r, eps_i ~ N(0,1/2).
- * eps_r NULL => noise from the counter-based Philox4x32-10 stream (seed, offset) defined in
+ * eps_r NULL => noise from the counter-based Philox4x32-7 stream (seed, offset) defined in
  * DESIGN.md ("noise stream"); the backward regenerates it from the same (seed, offset).
  * `state` (nullable): device uint64[2] = {seed, offset}; when given it overrides the two host
  * scalars, so a hipGraph that captured the launch draws fresh noise on every replay
@@ -382,7 +382,7 @@ int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* x
  *       bwd writes dz and, if dtau != NULL, the elementwise d/dtau (float32 [n]; the caller
  *       sums it down to the parameter's shape).
  *   cplxamd_cplx_dropout : y = x * keep / (1 - p), ONE Bernoulli(1 - p) draw per complex element
- *       (nn/modules/extra.py:7-25); keep comes from the Philox4x32-10 stream (seed, offset) or
+ *       (nn/modules/extra.py:7-25); keep comes from the Philox4x32-7 stream (seed, offset) or
  *       the device pair `state`; applying it to the gradient is the backward.
  * All planes contiguous, 16-byte aligned, n = number of complex elements.
  * ---------------------------------------------------------------------------------- */

@@ -904,10 +904,10 @@ def modrelu_bwd(gr, gi, zr, zi, tau):
 
 def cplx_dropout_mask(n, p, seed, offset):
     """Keep mask of the package's complex dropout (csrc/layout.hip): element e is kept iff word
-    (e & 3) of Philox4x32-10(counter = (e >> 2, offset), key = seed) >= floor(p * 2^32)."""
-    from .philox import philox4x32_10
+    (e & 3) of Philox4x32-7(counter = (e >> 2, offset), key = seed) >= floor(p * 2^32)."""
+    from .philox import philox4x32
     groups = (n + 3) // 4
-    words = philox4x32_10(np.arange(groups, dtype=np.uint64), int(offset), int(seed))
+    words = philox4x32(np.arange(groups, dtype=np.uint64), int(offset), int(seed))
     t = p * 4294967296.0
     thresh = np.uint32(0xFFFFFFFF) if t >= 4294967295.0 else np.uint32(int(t))
     return (words.reshape(-1)[:n] >= thresh)

@@ -1,21 +1,25 @@
 """numpy statement of the noise stream the kernels generate in-register ("noise
-stream"): Philox4x32-10 + Box-Muller.  TEST INFRASTRUCTURE ONLY (checks reparam.hip)."""
+stream"): Philox4x32-R + Box-Muller, R = ROUNDS = 7 (the round count of csrc/common.h: kPhiloxRounds).
+TEST INFRASTRUCTURE ONLY (checks reparam.hip / layout.hip).  Pinned by the Random123 known-answer vectors for
+philox4x32 with 7 and with 10 rounds (tests/test_oracle_golden.py::test_philox_known_answers)."""
 import numpy as np
 
 M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
 MASK = np.uint64(0xFFFFFFFF)
+ROUNDS = 7
 
 
-def philox4x32_10(group, offset, seed):
-    """group: uint64 array; returns uint32 array [len(group), 4]."""
+def philox4x32(group, offset, seed, rounds=ROUNDS):
+    """group: uint64 array; returns uint32 array [len(group), 4].  Counter = (group_lo, group_hi, offset_lo,
+    offset_hi), key = (seed_lo, seed_hi)."""
     g = np.asarray(group, dtype=np.uint64)
     c0, c1 = (g & MASK).astype(np.uint32), (g >> np.uint64(32)).astype(np.uint32)
     c2 = np.full_like(c0, np.uint32(offset & 0xFFFFFFFF))
     c3 = np.full_like(c0, np.uint32((offset >> 32) & 0xFFFFFFFF))
     k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = M0 * c0.astype(np.uint64)
             p1 = M1 * c2.astype(np.uint64)
             lo0, hi0 = (p0 & MASK).astype(np.uint32), (p0 >> np.uint64(32)).astype(np.uint32)
@@ -31,7 +35,7 @@ def _u01(x):
 
 def normals(n_groups, seed, offset, scale=1.0):
     """[n_groups, 4] standard normals (times `scale`) in stream order z0..z3."""
-    x = philox4x32_10(np.arange(n_groups, dtype=np.uint64), offset, seed)
+    x = philox4x32(np.arange(n_groups, dtype=np.uint64), offset, seed)
     u = _u01(x)
     r0, r1 = np.sqrt(-2 * np.log(u[:, 0])), np.sqrt(-2 * np.log(u[:, 2]))
     a0, a1 = 2 * np.pi * u[:, 1], 2 * np.pi * u[:, 3]

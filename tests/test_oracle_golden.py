@@ -503,3 +503,28 @@ def test_masked_layers_and_binarize(golden, tag):
         np.testing.assert_array_equal(v, g[pre + "hard_" + n])
     assert list(g[pre + "mask_keys"]) == ["a.mask", "b.mask"]
     assert list(g[pre + "named_masks"]) == ["a", "b"]
+
+
+def test_philox_known_answers():
+    """Random123's known-answer vectors for philox4x32 (kat_vectors: counter c0..c3, key k0 k1 -> output), with
+    7 rounds (the kernels' stream, csrc/common.h kPhiloxRounds) and with 10 (Random123's default)."""
+    from oracle import philox
+
+    def run(ctr, key, rounds):
+        group = np.array([ctr[0] | (ctr[1] << 32)], dtype=np.uint64)
+        offset = ctr[2] | (ctr[3] << 32)
+        seed = key[0] | (key[1] << 32)
+        return [int(v) for v in philox.philox4x32(group, offset, seed, rounds)[0]]
+
+    ones = [0xFFFFFFFF] * 4
+    pi_c, pi_k = [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]
+    assert run([0] * 4, [0, 0], 7) == [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]
+    assert run(ones, [0xFFFFFFFF] * 2, 7) == [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]
+    assert run(pi_c, pi_k, 7) == [0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A]
+    assert run([0] * 4, [0, 0], 10) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert run(ones, [0xFFFFFFFF] * 2, 10) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert run(pi_c, pi_k, 10) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    assert philox.ROUNDS == 7
+    # the normal stream built on it: moments of 2^18 draws
+    z = philox.real_noise(1 << 18, 12345, 3)
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1) < 0.01
