@@ -98,9 +98,11 @@ __device__ __forceinline__ void lds_dma16_sv(const void* sbase_uniform, uint32_t
   const uint64_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
   const uint64_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
   const uint64_t sb = (hi << 32) | lo;
+  // (readfirstlane: a no-op for a value that already lives in an SGPR; a loop-carried ring position may not)
+  const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_off_uniform);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                :
-               : "s"(lds_off_uniform), "v"(voff), "s"(sb)
+               : "s"(m0v), "v"(voff), "s"(sb)
                : "memory");
 }
 

@@ -188,6 +188,46 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       if (CPLX) acc_i[i][j] = f32x16{0};
     }
 
+  // The bias rides in the accumulators (acc starts at bias[n] instead of 0): its 16-B loads are issued here,
+  // ahead of the prologue's LDS-DMA, and land while the first K tiles are fetched.  In the epilogue the same
+  // values cost 128 dependent 4-byte loads per wave with nothing to overlap (18 us of the 52 us the bf16
+  // forward epilogue took, profiles/r02_gemm_ablation.md).
+  const bool bias_in_acc = g.bias_r != nullptr && g.g1 == nullptr && g.splits <= 1;
+  f4 bias_v[CPLX ? 2 : 1][JB][4];
+  if (bias_in_acc) {
+    const bool vec = (g.N & 3) == 0 && (reinterpret_cast<uintptr_t>(g.bias_r) & 15) == 0 &&
+                     (!CPLX || (reinterpret_cast<uintptr_t>(g.bias_i) & 15) == 0);
+#pragma unroll
+    for (int pl = 0; pl < (CPLX ? 2 : 1); ++pl) {
+      const float* bias = pl ? g.bias_i : g.bias_r;
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = n0 + wn + j * 32 + 8 * q + 4 * lk;
+          if (vec && col + 3 < g.N) {
+            bias_v[pl][j][q] = ld4(bias + col);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_v[pl][j][q].v[e] = col + e < g.N ? bias[col + e] : 0.f;
+          }
+        }
+    }
+  }
+  auto apply_bias = [&]() {
+    if (!bias_in_acc) return;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc_r[i][j][4 * q + e] = bias_v[0][j][q].v[e];
+            if (CPLX) acc_i[i][j][4 * q + e] = bias_v[CPLX ? 1 : 0][j][q].v[e];
+          }
+  };
   const int kbase = __builtin_amdgcn_readfirstlane(split * g.kchunk);
   // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
   const uint32_t smem_off = lds_offset_of(smem);
@@ -292,6 +332,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   if (!ROLL) {
     stage_all(0, 0);
     if (nt > 1) stage_all(1, BK);
+    apply_bias();
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
       // own LDS-DMA of tile t landed (tile t+1 may stay in flight), then every wave's did
@@ -400,6 +441,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     };
     stage_all(0, 0);
     if (nt > 1) stage_all(1, BK);
+    apply_bias();      // (the compiler waits for the bias loads here; they are older than the LDS-DMA above)
     if (nt > 1) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     read_half(0, 0);
@@ -497,7 +539,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
                 f4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  const float b = (bias && col + e < g.N) ? bias[col + e] : 0.f;
+                  const float b = (bias && !bias_in_acc && col + e < g.N) ? bias[col + e] : 0.f;
                   v.v[e] = (pl ? acc_i[CPLX ? ih * 2 + ii : 0][j][4 * q + e] : acc_r[ih * 2 + ii][j][4 * q + e]) + b;
                 }
                 st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
@@ -556,7 +598,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
               f4 v;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float b = (bias && col + e < g.N) ? bias[col + e] : 0.f;
+                const float b = (bias && !bias_in_acc && col + e < g.N) ? bias[col + e] : 0.f;
                 v.v[e] = (pl ? acc_i[CPLX ? i : 0][j][4 * q + e] : acc_r[i][j][4 * q + e]) + b;
               }
               st4(reinterpret_cast<float*>(reg + l31 * PITCH + cl * 4), v);
@@ -651,7 +693,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
           continue;
         }
         if (vec_ok && col + 3 < g.N) {
-          if (g.bias_r) {
+          if (g.bias_r && !bias_in_acc) {
             const f4 b = ld4(g.bias_r + col);
 #pragma unroll
             for (int e = 0; e < 4; ++e) vr.v[e] += b.v[e];
@@ -686,12 +728,12 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (col + e >= g.N) break;
-            float xr = vr.v[e] + (g.bias_r ? g.bias_r[col + e] : 0.f);
+            float xr = vr.v[e] + ((g.bias_r && !bias_in_acc) ? g.bias_r[col + e] : 0.f);
             if (g.emul) xr *= gemm_emul(g, g.emul[o + e]);
             if (g.accumulate) xr += beta * io<TOUT>::ld(cr + o + e);
             io<TOUT>::st(cr + o + e, xr);
             if (CPLX) {
-              float xi = vi.v[e] + (g.bias_i ? g.bias_i[col + e] : 0.f);
+              float xi = vi.v[e] + ((g.bias_i && !bias_in_acc) ? g.bias_i[col + e] : 0.f);
               if (g.emul && g.emul_both) xi *= gemm_emul(g, g.emul[o + e]);
               if (g.accumulate) xi += beta * io<TOUT>::ld(ci + o + e);
               io<TOUT>::st(ci + o + e, xi);
@@ -741,8 +783,74 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
   return 0;
 }
 
+}  // namespace cplxamd
+#include "gemm_bf16_persist.h"
+namespace cplxamd {
+
+// persistent form (gemm_bf16_persist.h): more than one round of full tiles, plain (bias-only) epilogue
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
+  using C = Cfg<CPLX, false>;
+  taken = false;
+#ifdef CPLXAMD_GEMM_NO_PERSIST       // (A/B builds; at run time: CPLXAMD_GEMM_PERSIST=0)
+  static const int enabled = 0;
+#else
+  static const int enabled = env_int("CPLXAMD_GEMM_PERSIST", 1);
+#endif
+  static int ncu = 0;
+  if (!enabled) return 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
+    ncu = n & ~7;
+  }
+  const GemmArgs& g = g0;
+  if (g.splits > 1 || g.g1 || g.emul || g.accumulate || (g.M % C::BM) || (g.N % C::BN) || g.K / BK < 12) return 0;
+  // instantiated for the layouts the layers launch with a plain epilogue: forward (N,N), input gradient (N,T)
+  // -- the weight gradients carry the fused KL accumulate and stay on the one-tile kernel
+  constexpr bool kBf16Out = sizeof(TOUT) == 2;
+  constexpr bool kInstantiated = !TA && (CPLX ? (CONJ == TB && kBf16Out) : (TB == kBf16Out));
+  if (!kInstantiated) return 0;
+  const int64_t tiles = (int64_t)(g.M / C::BM) * (g.N / C::BN);
+  if (tiles <= ncu || tiles > 0x7fffffff) return 0;
+  const int align = sizeof(TOUT) == 2 ? 7 : 3;
+  if ((g.ldc & align) || !aligned16(g.c_r) || (CPLX && !aligned16(g.c_i))) return 0;
+  if (g.bias_r && (!aligned16(g.bias_r) || (CPLX && !aligned16(g.bias_i)))) return 0;
+  constexpr int smem = 3 * C::STAGE_BYTES + 16384;
+  GemmArgs a = g;
+  static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 2);
+  a.group_m = gm > 0 ? gm : 1;
+  if constexpr (kInstantiated) {
+    auto go = [&](auto RR) -> int {
+      constexpr int R = decltype(RR)::value;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+      }
+      gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R><<<dim3((unsigned)ncu), C::NT, smem, st>>>(a);
+      CPLXAMD_CHECK_LAUNCH();
+      return 0;
+    };
+    const int r = (g.K / BK) % 3;
+    const int rc = r == 0 ? go(std::integral_constant<int, 0>{}) : r == 1 ? go(std::integral_constant<int, 1>{})
+                                                                          : go(std::integral_constant<int, 2>{});
+    if (rc) return rc;
+    taken = true;
+  }
+  return 0;
+}
+
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 static int launch_kernel(const GemmArgs& g, hipStream_t st) {
+  {
+    bool taken = false;
+    const int rc = launch_persist<TOUT, CPLX, CONJ, TA, TB>(g, st, taken);
+    if (rc || taken) return rc;
+  }
   // Only the rolling pipeline is instantiated.  The classic per-tile pipeline (ROLL = false, kept in the
   // kernel source: build with -DCPLXAMD_GEMM_CLASSIC to select it) and Cfg<true, BIG> (4 waves of
   // 128 x 64 at one wave per SIMD: 0.905 ms vs 0.86 ms on the headline shape with the final loop) were
