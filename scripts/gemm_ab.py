@@ -24,7 +24,7 @@ ONLY = os.environ.get("ONLY", "")          # comma list of shape names
 
 def load(path):
     lib = ctypes.CDLL(os.path.abspath(path))
-    for name in ("cplxamd_cgemm", "cplxamd_rgemm"):
+    for name in ("cplxamd_cgemm", "cplxamd_rgemm", "cplxamd_cgemm_ex", "cplxamd_rgemm_ex"):
         fn = getattr(lib, name)
         fn.argtypes = L.SIGNATURES[name]
         fn.restype = c_int
@@ -63,6 +63,19 @@ def main():
                                p(out), N, M, N, K, L.BF16, odt, 0, None, 0, st)
         assert rc == 0, rc
 
+    beta = torch.tensor(1e-3, device=dev)
+    ls2 = torch.empty(O, I, device=dev).uniform_(-12, 4)
+
+    def cg_kl(lib):      # the weight gradient as the fused-KL layer launches it: dW = G^T conj(X) + beta * dW_kl
+        rc = lib.cplxamd_cgemm_ex(p(gr), p(gi), 1, O, p(xr), p(xi), 1, I, None, None, None, p(dw_f[0]), p(dw_f[1]), I,
+                                  O, I, B, 1, L.BF16, L.F32, 1, p(beta), 0, None, 0, st)
+        assert rc == 0, rc
+
+    def rg_kl(lib):      # dls2 = (gs2^T |x|^2) * exp(ls2) + beta * dls2_kl
+        rc = lib.cplxamd_rgemm_ex(p(gs2), 1, O, p(a2), 1, I, None, p(ls2), 1, p(dw_f[0]), I, O, I, B, L.BF16, L.F32,
+                                  1, p(beta), None, 0, st)
+        assert rc == 0, rc
+
     shapes = {
         "c_fwd": (lambda lib: cg(lib, xr, xi, (I, 1), wr, wi, (I, 1), (br, bi), y_bf, B, O, I, False, L.BF16), 8.0),
         "c_dgrad": (lambda lib: cg(lib, gr, gi, (O, 1), wr, wi, (1, I), None, dx_bf, B, I, O, True, L.BF16), 8.0),
@@ -70,6 +83,8 @@ def main():
         "r_fwd": (lambda lib: rg(lib, a2, (I, 1), S, (I, 1), None, s2_f, B, O, I, L.F32), 2.0),
         "r_dgrad": (lambda lib: rg(lib, gs2, (O, 1), S, (1, I), None, dx_bf[0], B, I, O, L.BF16), 2.0),
         "r_wgrad": (lambda lib: rg(lib, gs2, (1, O), a2, (1, I), emul, dw_f[0], O, I, B, L.F32), 2.0),
+        "c_wgrad_kl": (cg_kl, 8.0),
+        "r_wgrad_kl": (rg_kl, 2.0),
     }
     if ONLY:
         shapes = {k: v for k, v in shapes.items() if k in ONLY.split(",")}
@@ -99,7 +114,7 @@ def main():
         for s, (_, mult) in shapes.items():
             med, mn = statistics.median(times[(n, s)]), min(times[(n, s)])
             row += f"{med:.4f} ({mn:.4f}) [{mult * flop / med / 1e9:6.0f}]".rjust(30)
-            if s.startswith("c_"):
+            if s in ("c_fwd", "c_dgrad", "c_wgrad"):
                 tot += med
         print(row + f"{tot:10.4f}")
 

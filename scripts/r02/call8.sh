@@ -1,0 +1,7 @@
+#!/bin/bash
+cd /root/repo
+mkdir -p gpurun_out/r02
+L=cplxmodule_amd
+ONLY=c_wgrad,c_wgrad_kl,r_wgrad,r_wgrad_kl timeout 300 python scripts/gemm_ab.py nopersist=$L/libcplxamd_nopersist.so new=$L/libcplxamd.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02/gemm_ab4.txt
+timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -3
+timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tee gpurun_out/r02/bench_f.json
