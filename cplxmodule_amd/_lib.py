@@ -176,6 +176,15 @@ def stream_ptr():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def scratch_key(device):
+    """Key of the per-(device, stream) scratch caches (split-K slabs, BN / KL partial sums, conv slabs): kernels
+    launched on two streams must not share a workspace.  During hipGraph capture the capturing stream's key is
+    used like any other, so a cache grown inside a capture belongs to that capture's pool only."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return (dev.type, idx, torch.cuda.current_stream(idx).cuda_stream if dev.type == "cuda" else 0)
+
+
 def dtype_code(t):
     if t.dtype == torch.float32:
         return F32

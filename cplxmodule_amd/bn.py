@@ -2,14 +2,20 @@
 import torch
 
 from . import _lib
-from ._lib import call, dtype_code, ptr, require_device, stream_ptr
+from ._lib import call, dtype_code, ptr, require_device, stream_ptr, scratch_key
 
 _ws_cache = {}
 
 
+def _al16(t):
+    """The vectorised reduce / apply kernels issue 16-byte accesses: re-home the rare contiguous view that
+    does not start on a 16-byte boundary."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _ws(device, F):
     need = int(_lib.load().cplxamd_bn_ws_bytes(F))
-    key = (device.type, device.index)
+    key = scratch_key(device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = _ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=device)
@@ -32,7 +38,7 @@ class CplxBatchNormFn(torch.autograd.Function):
         require_device(xr, xi, weight, bias, running_mean, running_var)
         if not training and running_mean is None:
             raise ValueError("evaluation mode requires running statistics")
-        xr, xi = xr.contiguous(), xi.contiguous()
+        xr, xi = _al16(xr.contiguous()), _al16(xi.contiguous())
         B, F, S = _geom(xr)
         yr, yi = torch.empty_like(xr), torch.empty_like(xi)
         saved = torch.empty(8, F, dtype=torch.float32, device=xr.device)
@@ -49,7 +55,7 @@ class CplxBatchNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gr, gi):
         xr, xi, w, saved = ctx.saved_tensors
-        gr, gi = gr.contiguous(), gi.contiguous()
+        gr, gi = _al16(gr.contiguous()), _al16(gi.contiguous())
         B, F, S = _geom(xr)
         dxr, dxi = torch.empty_like(xr), torch.empty_like(xi)
         dw = db = None

@@ -33,7 +33,7 @@ def _geom(x_shape, w_shape, stride, padding, dilation, groups):
 
 
 def _scratch(device, nbytes):
-    key = (device.type, device.index)
+    key = _lib.scratch_key(device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _ws_cache[key] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)

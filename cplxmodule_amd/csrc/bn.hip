@@ -367,7 +367,9 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
   if (S > 1) {
     const int64_t planes = B * F;
     if (planes > 0x7fffffff / 1) return CPLXAMD_ESHAPE;
-    // gridDim.y is limited to 65535: fold planes over several launches
+    // gridDim.y is limited to 65535: fold planes over several launches of a whole number of batch entries
+    // (F > 65535 features with spatial dims would make that step 0: not a shape this kernel serves)
+    if (F > 65535) return CPLXAMD_ESHAPE;
     const unsigned gx = (unsigned)((S + 4 * kBnT - 1) / (4 * kBnT));
     for (int64_t p0 = 0; p0 < planes; p0 += 65535 - (65535 % F)) {
       int64_t np = planes - p0;

@@ -7,13 +7,13 @@ complex tensors are (real, imag) pairs of equal-shaped planes (cplxmodule/cplx.p
 import torch
 
 from . import _lib
-from ._lib import call, dtype_code, ptr, require_device, stream_ptr
+from ._lib import call, dtype_code, ptr, require_device, scratch_key, stream_ptr
 
 _ws_cache = {}
 
 
 def _ws(device):
-    key = (device.type, device.index)
+    key = scratch_key(device)
     if key not in _ws_cache:
         nbytes = int(_lib.load().cplxamd_vd_kl_ws_bytes())
         _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -119,7 +119,7 @@ def _gemm_ws(M, N, K, cplx, a, c):
     need = int(_lib.load().cplxamd_gemm_ws_bytes(M, N, K, int(cplx), dtype_code(a), dtype_code(c)))
     if need == 0:
         return None
-    key = (a.device.type, a.device.index)
+    key = scratch_key(a.device)
     buf = _gemm_ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = _gemm_ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=a.device)
@@ -131,7 +131,7 @@ _gauss_ws_cache = {}
 
 def _gauss_ws(M, N, K, device):
     need = int(_lib.load().cplxamd_cgemm3m_ws_bytes(M, N, K))
-    key = (device.type, device.index)
+    key = scratch_key(device)
     buf = _gauss_ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = _gauss_ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=device)

@@ -37,7 +37,7 @@ def test_batchnorm_layer_golden(golden, name, cls):
         bn.zero_grad()
         ((y.real * T(g[s + "gr"])).sum() + (y.imag * T(g[s + "gi"])).sum()).backward()
         for n, t in dict(dxr=xr.grad, dxi=xi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
-            np.testing.assert_allclose(N(t), g[s + n], **_tol(g[s + n], 1e-4), err_msg=f"{n} step {step}")
+            np.testing.assert_allclose(N(t), g[s + n], **_tol(g[s + n], 2e-5), err_msg=f"{n} step {step}")   # achieved: 7e-7 of max|ref| (profiles/r02_parity_report.txt)
     bn.eval()
     bn.zero_grad()
     xr, xi = xr.detach().requires_grad_(True), xi.detach().requires_grad_(True)
