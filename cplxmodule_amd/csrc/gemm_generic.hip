@@ -192,9 +192,13 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(GemmArgs g) {
 // batch, heads with few outputs) would leave most CUs idle and expose the load latency serially
 int gemm_generic_splits(int M, int N, int K) {
   const int64_t tiles = (int64_t)((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
-  if (tiles >= 128 || K < 16 * GBK) return 1;
+  // a layer that is ONE or a few tiles (cfg1: 64 x 128 x 128) runs its whole K loop of 64-cycle f32 MFMAs on one
+  // CU -- 24 us (real) / 52 us (complex) per launch, which IS the launch-bound config's step time: such shapes
+  // split already from K = 64 with >= 2 K tiles per split
+  const bool tiny = tiles <= 8;
+  if (tiles >= 128 || K < (tiny ? 4 : 16) * GBK) return 1;
   int64_t s = 512 / tiles;
-  const int64_t maxs = K / (4 * GBK);                 // >= 4 K tiles per split
+  const int64_t maxs = K / ((tiny ? 2 : 4) * GBK);     // >= 4 (tiny: 2) K tiles per split
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
   return s < 2 ? 1 : (int)s;
