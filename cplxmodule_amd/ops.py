@@ -54,22 +54,23 @@ def transpose2d(t):
     return out
 
 
-def colsum(t):
-    """sum over dim 0 of a [R, C] matrix -> float32 [C]."""
+def colsum(t, out=None):
+    """sum over dim 0 of a [R, C] matrix -> float32 [C] (written into `out` when given)."""
     require_device(t)
     t = t.contiguous()
     R, C = t.shape
-    out = torch.empty(C, dtype=torch.float32, device=t.device)
+    if out is None or not (out.is_contiguous() and out.dtype == torch.float32 and out.numel() == C):
+        dst, out = out, torch.empty(C, dtype=torch.float32, device=t.device)
+    else:
+        dst = None
     ws = torch.empty(int(_lib.load().cplxamd_colsum_ws_bytes(C)), dtype=torch.uint8, device=t.device)
     call("cplxamd_colsum", ptr(t), C, ptr(out), R, C, dtype_code(t), ptr(ws), stream_ptr())
-    return out
+    return out if dst is None else dst.copy_(out)
 
 
 def colsum2(tr, ti, out=None):
     """Column sums of two planes (the complex bias gradient) -> float32 ([C], [C])."""
-    o_r = colsum(tr) if out is None else out[0].copy_(colsum(tr))
-    o_i = colsum(ti) if out is None else out[1].copy_(colsum(ti))
-    return o_r, o_i
+    return colsum(tr, None if out is None else out[0]), colsum(ti, None if out is None else out[1])
 
 
 def abs2(xr, xi=None, out_dtype=None):
@@ -723,8 +724,7 @@ class RealLinearLRTFn(torch.autograd.Function):
                 if dw is not None:
                     dw.add_(klg[1] * gkl)
         if ctx.has_bias and need[2]:
-            db = grad_buffer(b)
-            db.copy_(colsum(g2))
+            db = colsum(g2, out=grad_buffer(b))
         _announce(ls2 if dls2 is not None else None, w if dw is not None else None, b if db is not None else None)
         if need[0]:
             dx = _real_linear_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), dt)
