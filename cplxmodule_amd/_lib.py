@@ -64,6 +64,10 @@ SIGNATURES = {
     "cplxamd_conv2d_nhwc_wgrad_f32": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
     "cplxamd_conv2d_nhwc_wgrad": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
     "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_L] + [_I] * 5 + [_P],
+    "cplxamd_conv2d_cl_pack_bytes": [_I, _I, _I, _I],
+    "cplxamd_conv2d_cl_ws_bytes": [_I],
+    "cplxamd_conv2d_cl_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cplxamd_conv2d_cl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
     "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],
     "cplxamd_abs2": [_P, _P, _P, _L, _I, _I, _P],
     "cplxamd_modulus": [_P, _P, _P, _L, _P],
@@ -94,7 +98,8 @@ _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,
              "cplxamd_cgemm3m_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,
-             "cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes": c_int64}
+             "cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes": c_int64,
+             "cplxamd_conv2d_cl_pack_bytes": c_int64, "cplxamd_conv2d_cl_ws_bytes": c_int64}
 
 _lib = None
 

@@ -147,6 +147,66 @@ def grad_grid(gr, gi, geom):
             None if gi is None else nhwc_pad(gi, 0, 0, Hp, Wp, head_rows=head, tail_rows=tail))
 
 
+# ---- channels-last end to end (csrc/conv_cl.hip): 3 x 3-style "same" convolutions, stride 1, groups 1 -------- #
+_CL_FORCE = False            # tests: take the kernels on tiny shapes too
+_CL_ENABLED = True
+_CL_MIN_FLOP = 4e9
+
+
+def _cl_ok(geom, dgrad=False):
+    """Can the persistent channels-last kernel run this convolution (forward) / its data gradient?  `same` zero padding,
+    KW = 3, contraction channels a multiple of 16 with KH * C/16 a multiple of 6 (the ring is unrolled over 3 slots
+    x 2 fragment register sets), output channels a multiple of 64, one activation plane below 4 GiB."""
+    B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups = (geom[i] for i in range(14))
+    C, N = (Co, Ci) if dgrad else (Ci, Co)
+    if not _CL_ENABLED or sh != 1 or sw != 1 or groups != 1 or KW != 3 or KH > 8:
+        return False
+    if 2 * ph != dh * (KH - 1) or 2 * pw != dw * (KW - 1) or (KW - 1) * dw > 64:
+        return False
+    if C % 16 or N % 64 or (KH * (C // 16)) % 6:
+        return False
+    P = B * H * W
+    if P == 0 or P >= 2 ** 31 - 512 or P * C * 2 + 4 * (ph * W + pw + 512) * C >= 2 ** 32:
+        return False
+    return _CL_FORCE or 8.0 * P * Ci * Co * KH * KW >= _CL_MIN_FLOP
+
+
+def to_channels_last(t):
+    """[B, C, H, W] -> the same logical tensor stored [B, H, W, C] (torch.channels_last); no copy if it already is."""
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return t
+    B, C, H, W = t.shape
+    if t.is_contiguous() and t.dtype == torch.bfloat16 and C % 8 == 0 and B * (-(-C // 32)) <= 65535 and H <= 65535 \
+            and t.data_ptr() % 16 == 0:
+        return nhwc_pad(t, 0, 0).permute(0, 3, 1, 2)
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _cl_pack(wr, wi, dgrad):
+    """bf16 weight planes [Co, Ci, KH, KW] -> the per-stage LDS images of conv_cl.hip."""
+    Co, Ci, KH, KW = wr.shape
+    N, C = (Ci, Co) if dgrad else (Co, Ci)
+    nbytes = int(_lib.load().cplxamd_conv2d_cl_pack_bytes(N, C, KH, KW))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=wr.device)
+    call("cplxamd_conv2d_cl_pack", ptr(wr), ptr(wi), ptr(out), Co, Ci, KH, KW, int(dgrad), stream_ptr())
+    return out
+
+
+def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False):
+    """Forward (or, with dgrad, the data gradient read as a convolution of the output gradient with the flipped,
+    conjugated, channel-swapped kernel) on channels-last planes; returns channels-last [B, N, H, W] tensors."""
+    B, Ci, Co, H, W, KH, KW = (geom[i] for i in range(7))
+    C, N = (Co, Ci) if dgrad else (Ci, Co)
+    xr, xi = to_channels_last(xr), to_channels_last(xi)
+    wp = _cl_pack(wr, wi, dgrad)
+    yr = torch.empty((B, N, H, W), dtype=xr.dtype, device=xr.device, memory_format=torch.channels_last)
+    yi = torch.empty_like(yr)
+    ws = _scratch(xr.device, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(N)))
+    call("cplxamd_conv2d_cl", ptr(xr), ptr(xi), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, N, KH, KW,
+         geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr())
+    return yr, yi
+
+
 def _pack_rows(w, swap):
     """[Co, Ci, KH, KW] -> [KH][KW][C/v][N][v] for the shifted-row kernels (v = 16 bf16 or 4 float32 =
     one MFMA operand load): (C, N) = (Ci, Co) for the forward, (Co, Ci) with both spatial dims
@@ -315,16 +375,44 @@ def chansum(g):
     return out
 
 
+def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
+    """Backward of the channels-last forward: xr / xi are the saved channels-last inputs."""
+    need = ctx.needs_input_grad
+    geom = ctx.geom
+    dxr = dxi = dwr = dwi = dbr = dbi = None
+    gr, gi = to_channels_last(gr), to_channels_last(gi)
+    if need[0] or need[1]:
+        if _cl_ok(geom, dgrad=True):
+            dxr, dxi = cl_conv(gr, gi, wcr, wci, None, None, geom, dgrad=True)
+        else:
+            dxr, dxi = conv_dgrad(gr.contiguous(), gi.contiguous(), wcr, wci, geom, ctx.xshape)
+    if need[2] or need[3]:
+        dwr, dwi = conv_wgrad(gr.contiguous(), gi.contiguous(), xr.contiguous(), xi.contiguous(), geom, ctx.wshape)
+    if ctx.has_bias and (need[4] or need[5]):
+        B, Co, H, W = gr.shape
+        dbr = ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+        dbi = ops.colsum(gi.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+    return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
+
+
 class CplxConv2dFn(torch.autograd.Function):
     """Zero-padded complex conv (A.1 algebra with cross-correlation)."""
 
     @staticmethod
     def forward(ctx, xr, xi, wr, wi, br, bi, stride, padding, dilation, groups):
         require_device(xr, xi, wr, wi, br, bi)
-        xr, xi = xr.contiguous(), xi.contiguous()
-        wcr, wci = ops.cast(wr.contiguous(), xr.dtype), ops.cast(wi.contiguous(), xr.dtype)
         geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
+        ctx.cl = xr.dtype == torch.bfloat16 and xi.dtype == torch.bfloat16 and _cl_ok(geom)
+        if ctx.cl:                       # channels-last in, channels-last out: no layout copies between such layers
+            xr, xi = to_channels_last(xr), to_channels_last(xi)
+            wcr, wci = ops.cast(wr.contiguous(), xr.dtype), ops.cast(wi.contiguous(), xr.dtype)
+            yr, yi = cl_conv(xr, xi, wcr, wci, b[0], b[1], geom)
+            ctx.save_for_backward(xr, xi, wcr, wci)
+            ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, br is not None, wr.shape, xr.shape
+            return yr, yi
+        xr, xi = xr.contiguous(), xi.contiguous()
+        wcr, wci = ops.cast(wr.contiguous(), xr.dtype), ops.cast(wi.contiguous(), xr.dtype)
         yr, yi, xp = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape, keep_grid=True)
         # keep the channels-last input for the weight gradient instead of the planar one
         ctx.grid = xp is not None and _rows_wgrad_ok(geom, True, xr.dtype)
@@ -335,9 +423,11 @@ class CplxConv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gr, gi):
         xr, xi, wcr, wci = ctx.saved_tensors
-        gr, gi = gr.contiguous(), gi.contiguous()
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
+        if ctx.cl:
+            return _cl_backward(ctx, gr, gi, xr, xi, wcr, wci)
+        gr, gi = gr.contiguous(), gi.contiguous()
         gp = _shared_grad_grid(gr, gi, ctx.geom, need[0] or need[1], need[2] or need[3])
         if need[0] or need[1]:
             dxr, dxi = conv_dgrad(gr, gi, wcr, wci, ctx.geom, ctx.xshape, gp=gp)

@@ -1,0 +1,69 @@
+"""Time the channels-last conv kernel (csrc/conv_cl.hip) on the cfg3 layer: CplxConv2d(64, 64, 3) on 256 x 256,
+forward and data gradient, against the round-1 path (pad passes + conv_nhwc.hip).   B from argv (default 64)."""
+import os
+import sys
+import statistics
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from cplxmodule_amd import conv  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+C = Co = 64
+H = W = 256
+dev = "cuda"
+torch.manual_seed(0)
+bf = torch.bfloat16
+xr, xi = (torch.randn(B, C, H, W, device=dev).to(bf) for _ in range(2))
+wr, wi = (torch.randn(Co, C, 3, 3, device=dev).mul(0.05).to(bf) for _ in range(2))
+br, bi = torch.randn(Co, device=dev), torch.randn(Co, device=dev)
+geom, oshape = conv._geom(xr.shape, wr.shape, 1, 1, 1, 1)
+xr_cl, xi_cl = conv.to_channels_last(xr), conv.to_channels_last(xi)
+flop = 8.0 * B * H * W * C * Co * 9
+
+
+def timeit(fn, n=10, rounds=5):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / n)
+    return statistics.median(ts), min(ts)
+
+
+wp = conv._cl_pack(wr, wi, False)
+wpd = conv._cl_pack(wr, wi, True)
+from cplxmodule_amd._lib import call, ptr, stream_ptr  # noqa: E402
+from cplxmodule_amd import _lib  # noqa: E402
+yr = torch.empty((B, Co, H, W), dtype=bf, device=dev, memory_format=torch.channels_last)
+yi = torch.empty_like(yr)
+ws = torch.empty(int(_lib.load().cplxamd_conv2d_cl_ws_bytes(Co)), dtype=torch.uint8, device=dev)
+
+
+def k_fwd():
+    call("cplxamd_conv2d_cl", ptr(xr_cl), ptr(xi_cl), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, Co, 3, 3,
+         1, 1, 1, 1, ptr(ws), ws.numel(), stream_ptr())
+
+
+def k_dgrad():
+    call("cplxamd_conv2d_cl", ptr(xr_cl), ptr(xi_cl), ptr(wpd), None, None, ptr(yr), ptr(yi), B, H, W, Co, C, 3, 3,
+         1, 1, 1, 1, ptr(ws), ws.numel(), stream_ptr())
+
+
+rows = [("cl kernel fwd (+bias)", k_fwd), ("cl kernel dgrad", k_dgrad),
+        ("cl fwd incl. weight pack", lambda: conv.cl_conv(xr_cl, xi_cl, wr, wi, br, bi, geom)),
+        ("r01 fwd (2 pads + conv_nhwc)", lambda: conv.conv_fwd(xr, xi, wr, wi, br, bi, geom, oshape)),
+        ("NCHW -> channels-last copy x2", lambda: (conv.to_channels_last(xr), conv.to_channels_last(xi)))]
+if os.environ.get("ONLY"):
+    rows = [r for r in rows if r[0].startswith(os.environ["ONLY"])]
+print(f"# B={B} C={C} Co={Co} {H}x{W} 3x3: {flop / 1e12:.3f} TFLOP per launch; median ms (min) [TF/s, frac of 2.5 PF/s]")
+for name, fn in rows:
+    med, mn = timeit(fn)
+    print(f"{name:34s} {med:8.4f} ({mn:.4f})  [{flop / med / 1e9:7.1f}  {flop / med / 1e9 / 2500:.3f}]")

@@ -1,0 +1,97 @@
+"""The persistent channels-last convolution kernel (csrc/conv_cl.hip: forward and data gradient on unpadded
+[B H W][C] planes, borders by masked fragment addresses, out-of-tensor rows by the buffer range check) against the
+float64 numpy oracle on the bf16-rounded operands, through the public operator (cplx.conv2d + autograd)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cplx_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def force_cl():
+    from cplxmodule_amd import conv
+    old = conv._CL_FORCE
+    conv._CL_FORCE = True
+    yield
+    conv._CL_FORCE = old
+
+
+CASES = {
+    "two_tiles": dict(B=2, Ci=32, Co=64, H=18, W=21, k=3, padding=1, dilation=1),
+    "dil2_two_column_tiles": dict(B=1, Ci=64, Co=128, H=16, W=16, k=3, padding=2, dilation=2),
+    "nine_tiles_18_stages": dict(B=3, Ci=96, Co=64, H=40, W=37, k=3, padding=1, dilation=1),
+    "one_by_three": dict(B=2, Ci=96, Co=64, H=9, W=30, k=(1, 3), padding=(0, 1), dilation=1),
+    "tiny_image": dict(B=5, Ci=32, Co=64, H=3, W=2, k=3, padding=1, dilation=1),
+    "five_by_three_dil": dict(B=2, Ci=96, Co=64, H=14, W=15, k=(5, 3), padding=(4, 3), dilation=(2, 3)),
+}
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+@pytest.mark.parametrize("case", list(CASES))
+def test_cl_conv_vs_oracle(case, layout):
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import Cplx, cplx, conv
+    cfg = CASES[case]
+    rs = np.random.RandomState(len(case))
+    B, Ci, Co, H, W = cfg["B"], cfg["Ci"], cfg["Co"], cfg["H"], cfg["W"]
+    kh, kw = (cfg["k"], cfg["k"]) if isinstance(cfg["k"], int) else cfg["k"]
+    xr, xi = bf16_round(rs.randn(B, Ci, H, W)), bf16_round(rs.randn(B, Ci, H, W) + 0.2)
+    wr, wi = bf16_round(rs.randn(Co, Ci, kh, kw) * 0.1), bf16_round(rs.randn(Co, Ci, kh, kw) * 0.1)
+    br, bi = rs.randn(Co).astype(np.float32), rs.randn(Co).astype(np.float32)
+    q = lambda a: T(a, torch.bfloat16)  # noqa: E731
+    txr, txi = q(xr), q(xi)
+    if layout == "channels_last":
+        txr, txi = txr.contiguous(memory_format=torch.channels_last), txi.contiguous(memory_format=torch.channels_last)
+    txr, txi = txr.requires_grad_(True), txi.requires_grad_(True)
+    twr, twi = T(wr).requires_grad_(True), T(wi).requires_grad_(True)
+    tbr, tbi = T(br).requires_grad_(True), T(bi).requires_grad_(True)
+    kw_ = dict(stride=1, padding=cfg["padding"], dilation=cfg["dilation"], groups=1)
+    geom, _ = conv._geom(txr.shape, twr.shape, 1, cfg["padding"], cfg["dilation"], 1)
+    assert conv._cl_ok(geom) and conv._cl_ok(geom, dgrad=True) == (Ci % 64 == 0 and (kh * (Co // 16)) % 6 == 0)
+    y = cplx.conv2d(Cplx(txr, txi), Cplx(twr, twi), Cplx(tbr, tbi), **kw_)
+    assert y.real.is_contiguous(memory_format=torch.channels_last)          # the channels-last kernel ran
+    f = np.float64
+    yr, yi = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), br.astype(f), bi.astype(f), **kw_)
+    assert tuple(y.shape) == yr.shape
+    np.testing.assert_allclose(N(y.real), yr, rtol=1e-2, atol=1e-2 * np.abs(yr).max())
+    np.testing.assert_allclose(N(y.imag), yi, rtol=1e-2, atol=1e-2 * np.abs(yi).max())
+    gr, gi = bf16_round(rs.randn(*yr.shape)), bf16_round(rs.randn(*yr.shape))
+    ((y.real * q(gr)).sum() + (y.imag * q(gi)).sum()).backward()
+    bw = orc.cplx_conv2d_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), **kw_)
+    got = dict(dxr=txr.grad, dxi=txi.grad, dwr=twr.grad, dwi=twi.grad, dbr=tbr.grad, dbi=tbi.grad)
+    for n, t in got.items():
+        np.testing.assert_allclose(N(t), bw[n], rtol=2e-2, atol=2e-2 * np.abs(bw[n]).max(), err_msg=n)
+
+
+def test_cl_conv_many_tiles_per_workgroup():
+    """More tiles than CUs (the ring runs through tile boundaries, bias by LDS-DMA, dump rows): against aten's float32
+    convolution of the same bf16 operands -- a checker only -- and exactly linear in the input."""
+    from cplxmodule_amd import Cplx, cplx
+    dev = "cuda"
+    torch.manual_seed(5)
+    B, C, H, W = 3, 64, 250, 251                # P = 188250 -> 370 tiles of 510 rows
+    xr, xi = torch.randn(B, C, H, W, device=dev).bfloat16(), torch.randn(B, C, H, W, device=dev).bfloat16()
+    wr, wi = (torch.randn(64, C, 3, 3, device=dev) * 0.05).bfloat16().float(), (torch.randn(64, C, 3, 3, device=dev) * 0.05).bfloat16().float()
+    br, bi = torch.randn(64, device=dev), torch.randn(64, device=dev)
+    xr.requires_grad_(True); xi.requires_grad_(True)
+    y = cplx.conv2d(Cplx(xr, xi), Cplx(wr, wi), Cplx(br, bi), padding=1)
+    assert y.real.is_contiguous(memory_format=torch.channels_last)
+    F = torch.nn.functional
+    a, b = xr.detach().float(), xi.detach().float()
+    ref_r = F.conv2d(a, wr, padding=1) - F.conv2d(b, wi, padding=1) + br.view(1, -1, 1, 1)
+    ref_i = F.conv2d(a, wi, padding=1) + F.conv2d(b, wr, padding=1) + bi.view(1, -1, 1, 1)
+    for got, ref in ((y.real, ref_r), (y.imag, ref_i)):
+        err = (got.float() - ref).abs().max().item()
+        assert err <= 1e-2 * ref.abs().max().item(), err
+    gr, gi = torch.randn_like(ref_r).bfloat16(), torch.randn_like(ref_r).bfloat16()
+    torch.autograd.backward((y.real, y.imag), (gr, gi))
+    g1, g2 = gr.float(), gi.float()
+    # dX = conv_transpose(G, conj(W)): real part Gr*Wr + Gi*Wi, imaginary part Gi*Wr - Gr*Wi
+    dref_r = F.conv_transpose2d(g1, wr, padding=1) + F.conv_transpose2d(g2, wi, padding=1)
+    dref_i = F.conv_transpose2d(g2, wr, padding=1) - F.conv_transpose2d(g1, wi, padding=1)
+    for got, ref in ((xr.grad, dref_r), (xi.grad, dref_i)):
+        err = (got.float() - ref).abs().max().item()
+        assert err <= 1e-2 * ref.abs().max().item(), err
