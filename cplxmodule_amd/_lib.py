@@ -68,6 +68,8 @@ SIGNATURES = {
     "cplxamd_conv2d_cl_ws_bytes": [_I],
     "cplxamd_conv2d_cl_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cplxamd_conv2d_cl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
+    "cplxamd_conv2d_cl_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
+    "cplxamd_conv2d_cl_wgrad": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
     "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],
     "cplxamd_abs2": [_P, _P, _P, _L, _I, _I, _P],
     "cplxamd_modulus": [_P, _P, _P, _L, _P],
@@ -99,7 +101,8 @@ _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_cgemm3m_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes": c_int64,
-             "cplxamd_conv2d_cl_pack_bytes": c_int64, "cplxamd_conv2d_cl_ws_bytes": c_int64}
+             "cplxamd_conv2d_cl_pack_bytes": c_int64, "cplxamd_conv2d_cl_ws_bytes": c_int64,
+             "cplxamd_conv2d_cl_wgrad_ws_bytes": c_int64}
 
 _lib = None
 

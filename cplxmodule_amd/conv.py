@@ -171,6 +171,29 @@ def _cl_ok(geom, dgrad=False):
     return _CL_FORCE or 8.0 * P * Ci * Co * KH * KW >= _CL_MIN_FLOP
 
 
+def _cl_wgrad_ok(geom):
+    """3 x 3 `same` convolution, image width a multiple of the 32-pixel stage, channel counts multiples of 64."""
+    B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups = (geom[i] for i in range(14))
+    if not _CL_ENABLED or sh != 1 or sw != 1 or groups != 1 or KH != 3 or KW != 3 or ph != dh or pw != dw or pw > 3:
+        return False
+    P = B * H * W
+    if W % 32 or Ci % 64 or Co % 64 or P == 0 or P >= 2 ** 31 or (P + ph * W + 64) * max(Ci, Co) * 2 >= 2 ** 32 - 64:
+        return False
+    return _CL_FORCE or 8.0 * P * Ci * Co * 9 >= _CL_MIN_FLOP
+
+
+def cl_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
+    """dW (float32, [Co, Ci, 3, 3] planes) from channels-last gradient / input planes (csrc/conv_cl_wgrad.hip)."""
+    B, Ci, Co, H, W = (geom[i] for i in range(5))
+    gr, gi, xr, xi = (to_channels_last(t) for t in (gr, gi, xr, xi))
+    ws = _scratch(gr.device, int(_lib.load().cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, Ci, Co)))
+    dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)
+    dwi = torch.empty_like(dwr)
+    call("cplxamd_conv2d_cl_wgrad", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul), ptr(dwr), ptr(dwi), B, H, W, Ci, Co,
+         geom[5], geom[6], geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr())
+    return dwr, dwi
+
+
 def to_channels_last(t):
     """[B, C, H, W] -> the same logical tensor stored [B, H, W, C] (torch.channels_last); no copy if it already is."""
     if t.is_contiguous(memory_format=torch.channels_last):
@@ -387,7 +410,10 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
         else:
             dxr, dxi = conv_dgrad(gr.contiguous(), gi.contiguous(), wcr, wci, geom, ctx.xshape)
     if need[2] or need[3]:
-        dwr, dwi = conv_wgrad(gr.contiguous(), gi.contiguous(), xr.contiguous(), xi.contiguous(), geom, ctx.wshape)
+        if _cl_wgrad_ok(geom):
+            dwr, dwi = cl_wgrad(gr, gi, xr, xi, geom, ctx.wshape)
+        else:
+            dwr, dwi = conv_wgrad(gr.contiguous(), gi.contiguous(), xr.contiguous(), xi.contiguous(), geom, ctx.wshape)
     if ctx.has_bias and (need[4] or need[5]):
         B, Co, H, W = gr.shape
         dbr = ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))

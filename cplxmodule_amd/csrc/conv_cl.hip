@@ -23,6 +23,8 @@
 //    stages later.
 //  * weights are pre-packed per (output-channel tile, stage) as the LDS image itself (csrc: pack_kernel), with
 //    the conjugate / flip / channel swap of the data gradient folded into the packing, so the kernel has one form.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -37,7 +39,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = 512, TM = 512, BN = 64;
 constexpr int A_PLANE = TM * 32 + 64;        // 512 rows x 16 channels, then the zero row (row 512)
 constexpr int ZROW = TM * 32;                // plane-relative byte address of the zero row
-constexpr int NST = 16;                      // global stores per wave in the epilogue (2 planes x 2 blocks x 4 rounds)
+// ablation builds (-DCPLXAMD_CL_DBG=n, timing only): 1 no global stores, 2 every store goes to the dump rows
+// (L2-resident), 4 no epilogue at all, 8 no LDS-DMA after the prologue, 16 no start stagger
+#ifndef CPLXAMD_CL_DBG
+#define CPLXAMD_CL_DBG 0
+#endif
+constexpr int kClDbg = CPLXAMD_CL_DBG;
+constexpr int NST = (kClDbg & 5) ? 0 : 16;   // global stores per wave in the epilogue (2 planes x 2 blocks x 4 rounds)
 
 template <int KW> struct Geo {
   static constexpr int W_PLANE = KW * 64 * 32;                 // [kw][64 co][16 ch] bf16
@@ -45,8 +53,9 @@ template <int KW> struct Geo {
   static constexpr int STAGE = 2 * A_PLANE + W_BYTES;
   static constexpr int PWN = (W_BYTES + 8191) / 8192;          // LDS-DMA pieces (8 KiB per workgroup) of the weights
   static constexpr int L = 4 + PWN;                            // pieces per stage and wave
-  static constexpr int EPI = 3 * STAGE;                        // 8 x 2 KiB: epilogue rows + bias of each wave
-  static constexpr int DUMP = EPI + 8 * 2048;                  // where the surplus half of a weight piece goes
+  static constexpr int EPI = 3 * STAGE;                        // per wave: 16 epilogue rows of 144 B, then 512 B of bias
+  static constexpr int EPI_WAVE = 16 * 144 + 512;
+  static constexpr int DUMP = EPI + 8 * EPI_WAVE;              // where the surplus half of a weight piece goes
   static constexpr int SMEM = DUMP + 4096;
 };
 
@@ -63,6 +72,7 @@ struct Args {
   int H, W, C, Cout, KH, dil_h, dil_w, pad_h, pad_w;
   int C16, NS, tm_out, tiles_m, tiles_n;
   FastDiv div_w, div_h;
+  int stagger, stagger_from;                 // start delay: (blockIdx - stagger_from) * stagger clocks (0 below stagger_from)
 };
 
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv d) {
@@ -201,7 +211,9 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
   };
   const uint32_t soff[3] = {smem_off, smem_off + (uint32_t)STAGE, smem_off + 2u * (uint32_t)STAGE};
   // piece q of the stage at the pointer -> slot
+  bool dma_on = true;
   auto dma_piece = [&](int q, uint32_t slot_off) __attribute__((always_inline)) {
+    if ((kClDbg & 8) && !dma_on) return;
     if (q < 2) buf_lds16(rs_xr, voa[q] + d_aoff, 0u, slot_off + (uint32_t)(q * 8192) + wave_lds);
     else if (q < 4) buf_lds16(rs_xi, voa[q - 2] + d_aoff, 0u, slot_off + (uint32_t)(A_PLANE + (q - 2) * 8192) + wave_lds);
     else {
@@ -262,13 +274,12 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
   auto mfma_sub = [&](int st, const char* rsl, int rkw, int rkh, bool do_read, uint32_t ds, int q0, int q1)
       __attribute__((always_inline)) {
     bf16x8 nai[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) nai[i] = neg_frag(ai[st][i]);
     int q = q0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if (j == 0) nai[i] = neg_frag(ai[st][i]);          // (not earlier: block 1's fragments were read last)
         acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ar[st][i], acc_r[i][j], 0, 0, 0);
         acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ai[st][i], acc_i[i][j], 0, 0, 0);
         acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[st][j], nai[i], acc_r[i][j], 0, 0, 0);
@@ -338,12 +349,21 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
   // ---- epilogue: 8 rows x 128 bytes per round through this wave's 2 KiB; NST unpredicated stores per wave (rows a
   // tile does not own -- the overlap with the next tile, rows past the tensor -- go to the dump buffer)
   auto epilogue = [&](int nt_) __attribute__((always_inline)) {
+    if (kClDbg & 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc_r[i][j]), "v"(acc_i[i][j]));
+#endif
+      return;
+    }
     const int t = opaque_tid();
     const int ln = t & 63, w_ = t >> 6, q31 = ln & 31, qk = ln >> 5;
     const int wm_ = w_ * 64;
-    char* reg = smem + G::EPI + w_ * 2048;
+    char* reg = smem + G::EPI + w_ * G::EPI_WAVE;
     constexpr int PITCH = 144;
-    const int r8 = q31 >> 3, rr = q31 & 7;
+    const int r16 = q31 >> 4, rr = q31 & 15;
     const int64_t ldc = g.Cout;
     int64_t own = g.P - r0;
     if (own > g.tm_out) own = g.tm_out;
@@ -353,8 +373,8 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int round = 0; round < 4; ++round) {
-          if (r8 == round) {
+        for (int half = 0; half < 2; ++half) {
+          if (r16 == half) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -366,19 +386,28 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
               }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const uint4 val = *reinterpret_cast<const uint4*>(reg + (ln >> 3) * PITCH + (ln & 7) * 16);
-          const int m = wm_ + i * 32 + round * 8 + (ln >> 3);
-          const int col = nt_ * BN + (ln & 7) * 8;
-          bf16_t* dst = m < own ? out + ((int64_t)r0 + m) * ldc + col
-                                : reinterpret_cast<bf16_t*>(g.dump) + (int64_t)m * ldc + col;
-          *reinterpret_cast<uint4*>(dst) = val;
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const uint4 val = *reinterpret_cast<const uint4*>(reg + (sub * 8 + (ln >> 3)) * PITCH + (ln & 7) * 16);
+            if (kClDbg & 1) continue;
+            const int m = wm_ + i * 32 + half * 16 + sub * 8 + (ln >> 3);
+            const int col = nt_ * BN + (ln & 7) * 8;
+            bf16_t* dst = (m < own && !(kClDbg & 2)) ? out + ((int64_t)r0 + m) * ldc + col
+                                                     : reinterpret_cast<bf16_t*>(g.dump) + (int64_t)m * ldc + col;
+#ifndef CPLXAMD_CL_NO_NT          // streaming stores: the output is read by a later kernel, not by this one (-1.4 %)
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4_t{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4_t*>(dst));
+#else
+            *reinterpret_cast<uint4*>(dst) = val;
+#endif
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
   };
 
   // bias of column tile nt_ -> this wave's 512 bytes behind its epilogue rows (lanes 0-15 real, 16-31 imaginary)
-  const uint32_t bias_lds = smem_off + (uint32_t)G::EPI + wid_u * 2048u + 1152u;
+  const uint32_t bias_lds = smem_off + (uint32_t)G::EPI + wid_u * (uint32_t)G::EPI_WAVE + 2304u;
   auto bias_dma = [&](int nt_) __attribute__((always_inline)) {
     const int t = opaque_tid();
     const int ln = t & 63;
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
   auto init_acc = [&]() __attribute__((always_inline)) {
     const int t = opaque_tid();
     const int w_ = t >> 6, qk = (t & 63) >> 5;
-    const char* breg = smem + G::EPI + w_ * 2048 + 1152;
+    const char* breg = smem + G::EPI + w_ * G::EPI_WAVE + 2304;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -414,6 +443,12 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
     for (int idx = 0; idx < 8; ++idx) read_one(0, sbase[0], 0, 0, idx);
   };
 
+  // start stagger: tiles take the same time on every CU, so without it all 256 CUs reach their epilogues together
+  // and the 128 KiB per CU of stores arrive at the L2s / HBM as one burst per tile
+  if (!(kClDbg & 16)) {
+    const int n = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - g.stagger_from) * g.stagger);
+    for (int i = 0; i < n; i += 32 * 64) __builtin_amdgcn_s_sleep(32);
+  }
   // ---- prologue of the first tile: stages 0, 1, 2 whole (the state every later tile starts from) -------------
   __syncthreads();                                         // zero rows written
   bias_dma(nt0);
@@ -425,6 +460,7 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
   }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
+  dma_on = false;
   init_acc();
   tile_masks();
   first_frags();
@@ -553,6 +589,7 @@ int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, co
   g.tiles_m = (int)((P + g.tm_out - 1) / g.tm_out);
   g.tiles_n = N / 64;
   g.div_w = cl::make_div((uint32_t)W); g.div_h = cl::make_div((uint32_t)H);
+  static const int stagger_pct = [] { const char* e = getenv("CPLXAMD_CL_STAGGER"); return e ? atoi(e) : 100; }();
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0, n = 0;
@@ -563,6 +600,14 @@ int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, co
   const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n;
   if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
   int grid = ntiles < ncu ? (int)ntiles : ncu;
+  // Start stagger.  A tile takes ~ NS stages x 2 waves per SIMD x 48 MFMAs x 32 clocks / 0.5; the workgroups that get
+  // one tile less than the longest ones (ntiles % grid != 0) have that much slack: their starts are spread over it.
+  g.stagger = 0; g.stagger_from = 0;
+  if (ntiles > 2 * grid && ntiles % grid) {
+    const int64_t tile_clk = (int64_t)g.NS * 2 * 48 * 32 * 2;
+    g.stagger_from = (int)(ntiles % grid);
+    g.stagger = (int)(tile_clk * stagger_pct / 100 / (grid - g.stagger_from));
+  }
   using G3 = cl::Geo<3>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -24,6 +24,9 @@ CASES = {
     "dil2_two_column_tiles": dict(B=1, Ci=64, Co=128, H=16, W=16, k=3, padding=2, dilation=2),
     "nine_tiles_18_stages": dict(B=3, Ci=96, Co=64, H=40, W=37, k=3, padding=1, dilation=1),
     "one_by_three": dict(B=2, Ci=96, Co=64, H=9, W=30, k=(1, 3), padding=(0, 1), dilation=1),
+    "wgrad_cl_w32": dict(B=2, Ci=64, Co=64, H=8, W=32, k=3, padding=1, dilation=1),
+    "wgrad_cl_dil2_tiles": dict(B=3, Ci=128, Co=64, H=5, W=64, k=3, padding=2, dilation=2),
+    "wgrad_cl_one_row_images": dict(B=7, Ci=64, Co=128, H=1, W=96, k=3, padding=1, dilation=1),
     "tiny_image": dict(B=5, Ci=32, Co=64, H=3, W=2, k=3, padding=1, dilation=1),
     "five_by_three_dil": dict(B=2, Ci=96, Co=64, H=14, W=15, k=(5, 3), padding=(4, 3), dilation=(2, 3)),
 }
@@ -72,17 +75,18 @@ def test_cl_conv_many_tiles_per_workgroup():
     from cplxmodule_amd import Cplx, cplx
     dev = "cuda"
     torch.manual_seed(5)
-    B, C, H, W = 3, 64, 250, 251                # P = 188250 -> 370 tiles of 510 rows
+    B, C, H, W = 3, 64, 250, 256                # P = 192000 -> 377 tiles of 510 rows; 6000 wgrad stages
     xr, xi = torch.randn(B, C, H, W, device=dev).bfloat16(), torch.randn(B, C, H, W, device=dev).bfloat16()
     wr, wi = (torch.randn(64, C, 3, 3, device=dev) * 0.05).bfloat16().float(), (torch.randn(64, C, 3, 3, device=dev) * 0.05).bfloat16().float()
     br, bi = torch.randn(64, device=dev), torch.randn(64, device=dev)
-    xr.requires_grad_(True); xi.requires_grad_(True)
+    xr.requires_grad_(True); xi.requires_grad_(True); wr.requires_grad_(True); wi.requires_grad_(True)
     y = cplx.conv2d(Cplx(xr, xi), Cplx(wr, wi), Cplx(br, bi), padding=1)
     assert y.real.is_contiguous(memory_format=torch.channels_last)
     F = torch.nn.functional
     a, b = xr.detach().float(), xi.detach().float()
-    ref_r = F.conv2d(a, wr, padding=1) - F.conv2d(b, wi, padding=1) + br.view(1, -1, 1, 1)
-    ref_i = F.conv2d(a, wi, padding=1) + F.conv2d(b, wr, padding=1) + bi.view(1, -1, 1, 1)
+    wr_, wi_ = wr.detach(), wi.detach()
+    ref_r = F.conv2d(a, wr_, padding=1) - F.conv2d(b, wi_, padding=1) + br.view(1, -1, 1, 1)
+    ref_i = F.conv2d(a, wi_, padding=1) + F.conv2d(b, wr_, padding=1) + bi.view(1, -1, 1, 1)
     for got, ref in ((y.real, ref_r), (y.imag, ref_i)):
         err = (got.float() - ref).abs().max().item()
         assert err <= 1e-2 * ref.abs().max().item(), err
@@ -90,8 +94,15 @@ def test_cl_conv_many_tiles_per_workgroup():
     torch.autograd.backward((y.real, y.imag), (gr, gi))
     g1, g2 = gr.float(), gi.float()
     # dX = conv_transpose(G, conj(W)): real part Gr*Wr + Gi*Wi, imaginary part Gi*Wr - Gr*Wi
-    dref_r = F.conv_transpose2d(g1, wr, padding=1) + F.conv_transpose2d(g2, wi, padding=1)
-    dref_i = F.conv_transpose2d(g2, wr, padding=1) - F.conv_transpose2d(g1, wi, padding=1)
+    dref_r = F.conv_transpose2d(g1, wr_, padding=1) + F.conv_transpose2d(g2, wi_, padding=1)
+    dref_i = F.conv_transpose2d(g2, wr_, padding=1) - F.conv_transpose2d(g1, wi_, padding=1)
     for got, ref in ((xr.grad, dref_r), (xi.grad, dref_i)):
         err = (got.float() - ref).abs().max().item()
         assert err <= 1e-2 * ref.abs().max().item(), err
+    # dW = G^H-correlation with X: real part cw(Gr, Xr) + cw(Gi, Xi), imaginary part cw(Gi, Xr) - cw(Gr, Xi)
+    cw = lambda gg, xx: torch.nn.grad.conv2d_weight(xx, wr_.shape, gg, padding=1)  # noqa: E731
+    wref_r = cw(g1, a) + cw(g2, b)
+    wref_i = cw(g2, a) - cw(g1, b)
+    for got, ref in ((wr.grad, wref_r), (wi.grad, wref_i)):
+        err = (got.float() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item(), err
