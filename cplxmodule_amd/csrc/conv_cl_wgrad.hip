@@ -199,30 +199,43 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   // ---- one stage: 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity) ---------------
   auto compute = [&](uint32_t cur_off, uint32_t nxt_off) __attribute__((always_inline)) {
     const char* st = smem + cur_off;
-    int q = 0;
+    // fragments one block ahead of the MFMAs (two register sets); LDS-DMA pieces at fixed places of the schedule
+    bf16x8 xr[2], xi[2], gr[2], gi[2];
+    gr[0] = frag_at(st, ga, 0); gi[0] = frag_at(st + KR * 128, ga, 0);
+    xr[0] = frag_at(st, xa[0], 0); xi[0] = frag_at(st + XW_BYTES, xa[0], 0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 gr = frag_at(st, ga, ks), gi = frag_at(st + KR * 128, ga, ks);
-      const bf16x8 ngr = neg(gr);
+      const bf16x8 ngr = neg(gr[ks]);
 #pragma unroll
-      for (int n = 0; n < 5; ++n) {
-        if (n == 4 && ks != hpar) continue;
-        const bf16x8 xr = frag_at(st, xa[n], ks), xi = frag_at(st + XW_BYTES, xa[n], ks);
+      for (int n = 0; n < 4; ++n) {
+        const int cur = n & 1;
+        // next block's X fragments: block n + 1 of this sub-step, or block 0 of the next one
+        if (n < 3) {
+          xr[cur ^ 1] = frag_at(st, xa[n + 1], ks); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[n + 1], ks);
+        } else if (ks == 0) {
+          gr[1] = frag_at(st, ga, 1); gi[1] = frag_at(st + KR * 128, ga, 1);
+          xr[cur ^ 1] = frag_at(st, xa[0], 1); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[0], 1);
+        }
         // G conj(X): re = gr xr + gi xi, im = gi xr - gr xi; X first: accumulator rows = co, 4 consecutive ci per group
-        acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr, gr, acc_r[n], 0, 0, 0);
-        acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr, gi, acc_i[n], 0, 0, 0);
-        acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi, gi, acc_r[n], 0, 0, 0);
-        acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi, ngr, acc_i[n], 0, 0, 0);
-        if (q < L && (n & 1) == 0) {
+        acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[cur], gr[ks], acc_r[n], 0, 0, 0);
+        acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[cur], gi[ks], acc_i[n], 0, 0, 0);
+        acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi[cur], gi[ks], acc_r[n], 0, 0, 0);
+        acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi[cur], ngr, acc_i[n], 0, 0, 0);
+        const int piece = ks == 0 ? (n == 0 ? 0 : (n == 2 ? 1 : (n == 3 ? 2 : -1))) : (n == 0 ? 3 : (n == 2 ? 4 : -1));
+        if (piece >= 0) {
           __builtin_amdgcn_sched_barrier(0);
-          issue_piece(q, nxt_off);
+          issue_piece(piece, nxt_off);
           __builtin_amdgcn_sched_barrier(0);
-          ++q;
         }
       }
+      if (ks == hpar) {                                // the shared block: this wave's half of its pixels
+        const bf16x8 hr = frag_at(st, xa[4], ks), hi = frag_at(st + XW_BYTES, xa[4], ks);
+        acc_r[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hr, gr[ks], acc_r[4], 0, 0, 0);
+        acc_i[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hr, gi[ks], acc_i[4], 0, 0, 0);
+        acc_r[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, gi[ks], acc_r[4], 0, 0, 0);
+        acc_i[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, ngr, acc_i[4], 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (; q < L; ++q) issue_piece(q, nxt_off);
   };
 
   if (nt > 0) {

@@ -57,7 +57,10 @@ def k_dgrad():
          1, 1, 1, 1, ptr(ws), ws.numel(), stream_ptr())
 
 
-rows = [("cl kernel fwd (+bias)", k_fwd), ("cl kernel dgrad", k_dgrad),
+gr_cl, gi_cl = conv.to_channels_last(torch.randn(B, Co, H, W, device=dev).to(bf)), conv.to_channels_last(torch.randn(B, Co, H, W, device=dev).to(bf))
+gr_n, gi_n = gr_cl.contiguous(), gi_cl.contiguous()
+rows = [("cl kernel fwd (+bias)", k_fwd), ("cl wgrad (+ slab reduce)", lambda: conv.cl_wgrad(gr_cl, gi_cl, xr_cl, xi_cl, geom, wr.shape)),
+        ("r01 wgrad (2+2 pads + kernel)", lambda: conv.conv_wgrad(gr_n, gi_n, xr, xi, geom, wr.shape)), ("cl kernel dgrad", k_dgrad),
         ("cl fwd incl. weight pack", lambda: conv.cl_conv(xr_cl, xi_cl, wr, wi, br, bi, geom)),
         ("r01 fwd (2 pads + conv_nhwc)", lambda: conv.conv_fwd(xr, xi, wr, wi, br, bi, geom, oshape)),
         ("NCHW -> channels-last copy x2", lambda: (conv.to_channels_last(xr), conv.to_channels_last(xi)))]
