@@ -30,6 +30,21 @@ def _geom(x):
     return B, F, S
 
 
+def _is_cl(x):
+    """4-d, stored channels-last (and not at the same time plain contiguous: C == 1 or H * W == 1)."""
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
+def _prep(xr, xi):
+    """-> (xr, xi, (B, F, S), channels_last): channels-last 4-d inputs are normalised as [B H W, F] rows (the output keeps
+    the layout, so a channels-last convolution on either side needs no copy); anything else as [B, F, S] planes."""
+    if _is_cl(xr) and _is_cl(xi):
+        B, F, H, W = xr.shape
+        return _al16(xr), _al16(xi), (B * H * W, F, 1), True
+    xr, xi = _al16(xr.contiguous()), _al16(xi.contiguous())
+    return xr, xi, _geom(xr), False
+
+
 class CplxBatchNormFn(torch.autograd.Function):
     """cplx_batch_norm (cplxmodule/nn/modules/batchnorm.py:189-278) incl. whiten2x2 (:62-123)."""
 
@@ -38,9 +53,8 @@ class CplxBatchNormFn(torch.autograd.Function):
         require_device(xr, xi, weight, bias, running_mean, running_var)
         if not training and running_mean is None:
             raise ValueError("evaluation mode requires running statistics")
-        xr, xi = _al16(xr.contiguous()), _al16(xi.contiguous())
-        B, F, S = _geom(xr)
-        yr, yi = torch.empty_like(xr), torch.empty_like(xi)
+        xr, xi, (B, F, S), ctx.cl = _prep(xr, xi)
+        yr, yi = torch.empty_like(xr), torch.empty_like(xi)      # (preserve_format: channels-last stays channels-last)
         saved = torch.empty(8, F, dtype=torch.float32, device=xr.device)
         ws = _ws(xr.device, F)
         w = None if weight is None else weight.detach().contiguous()
@@ -55,8 +69,13 @@ class CplxBatchNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gr, gi):
         xr, xi, w, saved = ctx.saved_tensors
-        gr, gi = _al16(gr.contiguous()), _al16(gi.contiguous())
-        B, F, S = _geom(xr)
+        if ctx.cl:
+            fmt = torch.channels_last
+            gr, gi = _al16(gr.contiguous(memory_format=fmt)), _al16(gi.contiguous(memory_format=fmt))
+            B, F, S = xr.shape[0] * xr.shape[2] * xr.shape[3], xr.shape[1], 1
+        else:
+            gr, gi = _al16(gr.contiguous()), _al16(gi.contiguous())
+            B, F, S = _geom(xr)
         dxr, dxi = torch.empty_like(xr), torch.empty_like(xi)
         dw = db = None
         if ctx.affine:

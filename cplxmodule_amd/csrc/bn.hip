@@ -142,6 +142,96 @@ __global__ __launch_bounds__(kBnT) void bn_reduce_cols(const T* xr, const T* xi,
   }
 }
 
+// S == 1 with many rows and F % 8 == 0 (channels-last activations [B H W][F]): a thread owns 8 consecutive channels
+// (16-byte accesses for bf16), kBnT / (F / 8) row lanes per block, two rows in flight per thread.
+constexpr int kBnRowChunks = 1024;
+template <typename T, int NS, bool BWD>
+__global__ __launch_bounds__(kBnT) void bn_reduce_rows(const T* xr, const T* xi, const T* gr, const T* gi,
+                                                       const float* saved, int64_t R, int F, double* partial) {
+  __shared__ double red[kBnT * 8];
+  const int CG = F >> 3, RL = kBnT / CG;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  Acc<NS> a[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) a[c].v[j] = 0.0;
+  float mu[8], mv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    mu[c] = (BWD && rl < RL) ? saved[cg * 8 + c] : 0.f;
+    mv[c] = (BWD && rl < RL) ? saved[F + cg * 8 + c] : 0.f;
+  }
+  if (rl < RL) {
+    const int64_t step = (int64_t)gridDim.x * RL;
+    for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < R; r += 2 * step) {
+      const int64_t o0 = r * F + cg * 8;
+      const bool two = r + step < R;
+      const int64_t o1 = two ? o0 + step * F : o0;
+      const f8 u0 = ld8(xr + o0), v0 = ld8(xi + o0), u1 = ld8(xr + o1), v1 = ld8(xi + o1);
+      f8 p0 = u0, q0 = v0, p1 = u1, q1 = v1;
+      if (BWD) { p0 = ld8(gr + o0); q0 = ld8(gi + o0); p1 = ld8(gr + o1); q1 = ld8(gi + o1); }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        accum<NS, BWD>(a[c], u0.h[c >> 2].v[c & 3], v0.h[c >> 2].v[c & 3], p0.h[c >> 2].v[c & 3], q0.h[c >> 2].v[c & 3], mu[c], mv[c]);
+      if (two) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          accum<NS, BWD>(a[c], u1.h[c >> 2].v[c & 3], v1.h[c >> 2].v[c & 3], p1.h[c >> 2].v[c & 3], q1.h[c >> 2].v[c & 3], mu[c], mv[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    if (rl < RL) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[rl * F + cg * 8 + c] = a[c].v[j];
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += kBnT) {
+      double t = 0.0;
+      for (int l = 0; l < RL; ++l) t += red[l * F + f];
+      partial[((int64_t)blockIdx.x * F + f) * NS + j] = t;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, const T* gr, const T* gi, T* yr, T* yi,
+                                                      const float* coef, int64_t R, int F) {
+  const int CG = F >> 3, RL = kBnT / CG;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  if (rl >= RL) return;
+  constexpr int NC = BWD ? kBwdCoef : kFwdCoef;
+  float k[8][BWD ? 11 : 8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int j = 0; j < (BWD ? 11 : 8); ++j) k[c][j] = coef[(int64_t)(cg * 8 + c) * NC + j];
+  const int64_t step = (int64_t)gridDim.x * RL;
+  for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < R; r += step) {
+    const int64_t o = r * F + cg * 8;
+    const f8 u = ld8(xr + o), v = ld8(xi + o);
+    f8 p = u, q = v, ou, ov;
+    if (BWD) { p = ld8(gr + o); q = ld8(gi + o); }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float cu = u.h[c >> 2].v[c & 3] - k[c][0], cv = v.h[c >> 2].v[c & 3] - k[c][1];
+      if (!BWD) {
+        ou.h[c >> 2].v[c & 3] = fmaf(k[c][2], cu, fmaf(k[c][3], cv, k[c][6]));
+        ov.h[c >> 2].v[c & 3] = fmaf(k[c][4], cu, fmaf(k[c][5], cv, k[c][7]));
+      } else {
+        const float pp = p.h[c >> 2].v[c & 3], qq = q.h[c >> 2].v[c & 3];
+        ou.h[c >> 2].v[c & 3] = k[c][2] * pp + k[c][3] * qq + k[c][6] * cu + k[c][7] * cv - k[c][9];
+        ov.h[c >> 2].v[c & 3] = k[c][4] * pp + k[c][5] * qq + k[c][8] * cv + k[c][7] * cu - k[c][10];
+      }
+    }
+    st8(yr + o, ou);
+    st8(yi + o, ov);
+  }
+}
+
 struct Whiten { double p, q, w; };
 
 __device__ __forceinline__ Whiten inv_sqrt_2x2(double a, double b, double d) {
@@ -329,8 +419,10 @@ __global__ __launch_bounds__(kBnT) void bn_apply_cols(const T* xr, const T* xi, 
   }
 }
 
+static bool bn_rows_ok(int64_t B, int F, int64_t S) { return S == 1 && F % 8 == 0 && F <= 1024 && B >= 4096; }
+static int bn_max_chunks(int F) { return (F % 8 == 0 && F <= 1024) ? kBnRowChunks : kBnMaxChunks; }
 static int64_t bn_ws_bytes(int F) {
-  return (int64_t)kBnMaxChunks * F * 6 * sizeof(double) + (int64_t)F * kBwdCoef * sizeof(float);
+  return (int64_t)bn_max_chunks(F) * F * 6 * sizeof(double) + (int64_t)F * kBwdCoef * sizeof(float);
 }
 
 template <typename T, bool BWD>
@@ -341,11 +433,21 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
                   hipStream_t st) {
   const BnGeom g = bn_geom(B, F, S);
   double* partial = (double*)ws;
-  float* coef = (float*)((char*)ws + (int64_t)kBnMaxChunks * F * 6 * sizeof(double));
+  float* coef = (float*)((char*)ws + (int64_t)bn_max_chunks(F) * F * 6 * sizeof(double));
+  const bool rows = bn_rows_ok(B, F, S);
+  int chunks = g.chunks;
+  if (rows) {
+    const int RL = kBnT / (F / 8);
+    const int64_t want = (B + 2 * RL - 1) / (2 * RL);
+    chunks = (int)(want < kBnRowChunks ? want : kBnRowChunks);
+  }
   constexpr int NS = BWD ? 6 : 5;
   const bool need_reduce = BWD ? true : (training != 0);
   if (need_reduce) {
-    if (S > 1) {
+    if (rows) {
+      bn_reduce_rows<T, NS, BWD><<<chunks, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi,
+                                                         saved, B, F, partial);
+    } else if (S > 1) {
       dim3 grid(F, g.chunks);
       bn_reduce_planes<T, NS, BWD><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr,
                                                           (const T*)gi, saved, g, partial);
@@ -358,13 +460,18 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
   }
   const double count = (double)B * (double)S;
   if (!BWD)
-    bn_fwd_finalize<<<F, 64, 0, st>>>(partial, g.chunks, F, count, weight, bias, running_mean,
+    bn_fwd_finalize<<<F, 64, 0, st>>>(partial, chunks, F, count, weight, bias, running_mean,
                                         running_var, training, momentum, eps, saved, coef);
   else
-    bn_bwd_finalize<<<F, 64, 0, st>>>(partial, g.chunks, F, count, weight, saved, training,
+    bn_bwd_finalize<<<F, 64, 0, st>>>(partial, chunks, F, count, weight, saved, training,
                                         dweight, dbias, coef);
   CPLXAMD_CHECK_LAUNCH();
-  if (S > 1) {
+  if (rows) {
+    const int RL = kBnT / (F / 8);
+    bn_apply_rows<T, BWD><<<stream_grid((B + RL - 1) / RL * kBnT, kBnT), kBnT, 0, st>>>(
+        (const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr, (T*)yi, coef, B, F);
+    CPLXAMD_CHECK_LAUNCH();
+  } else if (S > 1) {
     const int64_t planes = B * F;
     if (planes > 0x7fffffff / 1) return CPLXAMD_ESHAPE;
     // gridDim.y is limited to 65535: fold planes over several launches of a whole number of batch entries

@@ -110,3 +110,49 @@ def test_batchnorm_vs_oracle_shapes(shape):
     np.testing.assert_allclose((zr * zr).mean(ax), 1, atol=2e-3)
     np.testing.assert_allclose((zi * zi).mean(ax), 1, atol=2e-3)
     assert np.abs((zr * zi).mean(ax)).max() < 2e-3
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 64, 64, 40), "f32"), ((3, 24, 48, 32), "f32"), ((2, 64, 64, 64), "bf16"),
+                                         ((1, 8, 70, 64), "f32")])
+def test_batchnorm_channels_last_rows_kernels(shape, dtype):
+    """Channels-last 4-d inputs take the row kernels (a thread owns 8 channels of [B H W, F] rows) and keep their
+    layout: same oracle as the planar path, forward, backward, eval mode."""
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import Cplx, nn
+    rs = np.random.RandomState(sum(shape))
+    base = rs.randn(*shape)
+    xr = (1.5 * base + 0.4 * rs.randn(*shape) + 0.7).astype(np.float32)
+    xi = (0.8 * base - 0.5 * rs.randn(*shape) - 0.2).astype(np.float32)
+    gr, gi = rs.randn(*shape).astype(np.float32), rs.randn(*shape).astype(np.float32)
+    td = torch.float32
+    if dtype == "bf16":
+        xr, xi, gr, gi = (bf16_round(a) for a in (xr, xi, gr, gi))
+        td = torch.bfloat16
+    F_ = shape[1]
+    W = (np.eye(2)[:, :, None] + 0.2 * rs.randn(2, 2, F_)).astype(np.float32)
+    b = (0.3 * rs.randn(2, F_)).astype(np.float32)
+    bn = nn.CplxBatchNorm2d(F_).to("cuda")
+    with torch.no_grad():
+        bn.weight.copy_(T(W)); bn.bias.copy_(T(b))
+    cl = lambda a: T(a, td).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    txr, txi = cl(xr).requires_grad_(True), cl(xi).requires_grad_(True)
+    y = bn(Cplx(txr, txi))
+    assert y.real.is_contiguous(memory_format=torch.channels_last) and not y.real.is_contiguous()
+    f = np.float64
+    rm, rv = np.zeros((2, F_)), np.stack([np.ones(F_), np.zeros(F_), np.zeros(F_), np.ones(F_)]).reshape(2, 2, F_)
+    yr, yi = orc.cplx_batch_norm(xr.astype(f), xi.astype(f), rm, rv, W.astype(f), b.astype(f), True, 0.1, 1e-5)
+    tol = _tol(yr) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(np.abs(yr).max()))
+    np.testing.assert_allclose(N(y.real), yr, **tol)
+    np.testing.assert_allclose(N(y.imag), yi, **tol)
+    np.testing.assert_allclose(N(bn.running_var), rv, rtol=1e-5, atol=1e-6)
+    torch.autograd.backward((y.real, y.imag), (cl(gr), cl(gi)))
+    bw = orc.cplx_batch_norm_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), None, None, W.astype(f), True, 1e-5)
+    for n, t in dict(dxr=txr.grad, dxi=txi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
+        r = 1e-4 if dtype == "f32" else (2e-2 if n[1] == "x" else 1e-3)
+        np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], r), err_msg=n)
+    bn.eval()
+    z = bn(Cplx(cl(xr), cl(xi)))
+    zr, zi = orc.cplx_batch_norm(xr.astype(f), xi.astype(f), rm, rv, W.astype(f), b.astype(f), False, 0.1, 1e-5)
+    tol = _tol(zr) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(np.abs(zr).max()))
+    np.testing.assert_allclose(N(z.real), zr, **tol)
+    np.testing.assert_allclose(N(z.imag), zi, **tol)
