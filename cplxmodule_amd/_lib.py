@@ -67,7 +67,7 @@ SIGNATURES = {
     "cplxamd_conv2d_cl_pack_bytes": [_I, _I, _I, _I],
     "cplxamd_conv2d_cl_ws_bytes": [_I],
     "cplxamd_conv2d_cl_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "cplxamd_conv2d_cl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
+    "cplxamd_conv2d_cl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _P],
     "cplxamd_conv2d_cl_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
     "cplxamd_conv2d_cl_wgrad": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
     "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],

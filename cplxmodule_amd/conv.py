@@ -154,19 +154,19 @@ _CL_MIN_FLOP = 4e9
 
 
 def _cl_ok(geom, dgrad=False):
-    """Can the persistent channels-last kernel run this convolution (forward) / its data gradient?  `same` zero padding,
-    KW = 3, contraction channels a multiple of 16 with KH * C/16 a multiple of 6 (the ring is unrolled over 3 slots
-    x 2 fragment register sets), output channels a multiple of 64, one activation plane below 4 GiB."""
+    """Can the persistent channels-last kernel run this convolution (forward) / its data gradient?  Zero padding up to
+    `same`, KW = 3, contraction channels a multiple of 16 with KH * C/16 a multiple of 6 (the ring is unrolled over
+    3 slots x 2 fragment register sets), output channels a multiple of 64, one activation plane below ~3.7 GiB."""
     B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups = (geom[i] for i in range(14))
     C, N = (Co, Ci) if dgrad else (Ci, Co)
     if not _CL_ENABLED or sh != 1 or sw != 1 or groups != 1 or KW != 3 or KH > 8:
         return False
-    if 2 * ph != dh * (KH - 1) or 2 * pw != dw * (KW - 1) or (KW - 1) * dw > 64:
+    if 2 * ph > dh * (KH - 1) or 2 * pw > dw * (KW - 1) or (KW - 1) * dw > 64:
         return False
     if C % 16 or N % 64 or (KH * (C // 16)) % 6:
         return False
     P = B * H * W
-    if P == 0 or P >= 2 ** 31 - 512 or P * C * 2 + 4 * (ph * W + pw + 512) * C >= 2 ** 32:
+    if P == 0 or P >= 2 ** 31 - 512 or P * C * 2 + 4 * (dh * (KH - 1) * W + dw * (KW - 1) + 512) * C >= 0xF0000000:
         return False
     return _CL_FORCE or 8.0 * P * Ci * Co * KH * KW >= _CL_MIN_FLOP
 
@@ -174,7 +174,9 @@ def _cl_ok(geom, dgrad=False):
 def _cl_wgrad_ok(geom):
     """3 x 3 `same` convolution, image width a multiple of the 32-pixel stage, channel counts multiples of 64."""
     B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups = (geom[i] for i in range(14))
-    if not _CL_ENABLED or sh != 1 or sw != 1 or groups != 1 or KH != 3 or KW != 3 or ph != dh or pw != dw or pw > 3:
+    if not _CL_ENABLED or sh != 1 or sw != 1 or groups != 1 or KH != 3 or KW != 3 or ph > dh or pw > dw or dw > 4:
+        return False
+    if H + 2 * ph - 2 * dh <= 0 or W + 2 * pw - 2 * dw <= 0:
         return False
     P = B * H * W
     if W % 32 or Ci % 64 or Co % 64 or P == 0 or P >= 2 ** 31 or (P + ph * W + 64) * max(Ci, Co) * 2 >= 2 ** 32 - 64:
@@ -222,11 +224,14 @@ def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False):
     C, N = (Co, Ci) if dgrad else (Ci, Co)
     xr, xi = to_channels_last(xr), to_channels_last(xi)
     wp = _cl_pack(wr, wi, dgrad)
-    yr = torch.empty((B, N, H, W), dtype=xr.dtype, device=xr.device, memory_format=torch.channels_last)
+    Ho = H + 2 * geom[9] - geom[11] * (KH - 1)
+    Wo = W + 2 * geom[10] - geom[12] * (KW - 1)
+    oshape = (B, N, H, W) if dgrad else (B, N, Ho, Wo)
+    yr = torch.empty(oshape, dtype=xr.dtype, device=xr.device, memory_format=torch.channels_last)
     yi = torch.empty_like(yr)
     ws = _scratch(xr.device, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(N)))
     call("cplxamd_conv2d_cl", ptr(xr), ptr(xi), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, N, KH, KW,
-         geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr())
+         geom[11], geom[12], geom[9], geom[10], int(dgrad), ptr(ws), ws.numel(), stream_ptr())
     return yr, yi
 
 

@@ -69,7 +69,8 @@ struct Args {
   void* dump;                                // 512 x Cout bf16: where the rows a tile does not own are stored
   int64_t P;
   uint32_t x_bytes, w_bytes;                 // bytes of one activation plane / of the packed weights
-  int H, W, C, Cout, KH, dil_h, dil_w, pad_h, pad_w;
+  int H, W, C, Cout, KH, dil_h, dil_w, pad_h, pad_w;   // H x W: the grid the tiles walk (the larger of the two images)
+  int Hi, Wi, Ho, Wo;                        // extent of the input / output image, both top-left aligned on that grid
   int C16, NS, tm_out, tiles_m, tiles_n;
   FastDiv div_w, div_h;
   int stagger, stagger_from;                 // start delay: (blockIdx - stagger_from) * stagger clocks (0 below stagger_from)
@@ -166,6 +167,30 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
     vow[j] = (uint32_t)p * 16u;
   }
 
+  // An input image smaller than the grid (the data gradient of a convolution with less than `same` padding reads the
+  // (Ho, Wo) output gradient on the (H, W) grid of the input): a window row is a grid pixel, its source the pixel of the
+  // same coordinates in the dense input -- no longer window start + row, so the lane offsets are rebuilt per tile
+  // (two divisions per piece).  Pixels outside the input alias others or fall out of range; the fragment masks skip them.
+  const bool in_dense = g.Hi == g.H && g.Wi == g.W;
+  uint32_t voa_c[2], voa_n[2];                     // offsets of the tile the LDS-DMA pointer is in / of the one after it
+  auto lane_offsets = [&](int rr, uint32_t (&out)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (in_dense) { out[j] = voa[j]; continue; }
+      const int pr = j * NT + tid0, row = pr >> 1, c = (pr & 1) ^ ((row >> 3) & 1);
+      // (the kernel-row part of the shift stays in the scalar offset: it may turn a row that starts above the image,
+      //  i.e. at a wrapped "negative" offset, into a valid one two kernel rows later)
+      const int64_t pix = (int64_t)rr - g.pad_w + row;
+      uint32_t o = 0xF8000000u;
+      if (pix >= 0 && pix < g.P) {
+        const uint32_t q = (uint32_t)pix, qh = fast_div(q, g.div_w), w = q - qh * (uint32_t)g.W;
+        const uint32_t b = fast_div(qh, g.div_h), h = qh - b * (uint32_t)g.H;
+        o = ((b * (uint32_t)g.Hi + h) * (uint32_t)g.Wi + w) * rowbytes + (uint32_t)c * 16u;
+      }
+      out[j] = o;
+    }
+  };
+
   // fragment addresses relative to the slot.  x: row = wm + i*32 + l31 + kw*dil_w; w: co = j*32 + l31.
   uint32_t a_rel[2][KW], w_rel[2];
 #pragma unroll
@@ -192,11 +217,13 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
   origin(has_next ? v + nwg : v, r0n, ntn);
 
   // ---- the LDS-DMA stage pointer: runs three stages ahead of the MFMAs, through the tile boundaries ----------
-  const uint32_t kh_step = (uint32_t)(g.dil_h * g.W) * rowbytes - (uint32_t)(g.C16 - 1) * 32u;
+  const uint32_t kh_step = (uint32_t)(g.dil_h * g.Wi) * rowbytes - (uint32_t)(g.C16 - 1) * 32u;
   auto a_origin = [&](int rr) __attribute__((always_inline)) -> uint32_t {
     // window of kernel row 0 starts pad_h image rows and pad_w pixels before the tile (wraps below zero: out of range)
-    return (uint32_t)(rr - g.pad_w - g.pad_h * g.W) * rowbytes;
+    return in_dense ? (uint32_t)(rr - g.pad_w - g.pad_h * g.W) * rowbytes : (uint32_t)(-g.pad_h * g.Wi) * rowbytes;
   };
+  lane_offsets(r0, voa_c);
+  lane_offsets(r0n, voa_n);
   uint32_t d_aoff = a_origin(r0), d_woff = (uint32_t)(nt0 * g.NS) * (uint32_t)G::W_BYTES;
   int d_cs = 0, d_u = 0;
   auto dma_advance = [&]() __attribute__((always_inline)) {
@@ -207,6 +234,7 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
       d_u = 0; d_cs = 0;
       d_aoff = a_origin(r0n);
       d_woff = (uint32_t)(ntn * g.NS) * (uint32_t)G::W_BYTES;
+      voa_c[0] = voa_n[0]; voa_c[1] = voa_n[1];
     }
   };
   const uint32_t soff[3] = {smem_off, smem_off + (uint32_t)STAGE, smem_off + 2u * (uint32_t)STAGE};
@@ -214,8 +242,8 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
   bool dma_on = true;
   auto dma_piece = [&](int q, uint32_t slot_off) __attribute__((always_inline)) {
     if ((kClDbg & 8) && !dma_on) return;
-    if (q < 2) buf_lds16(rs_xr, voa[q] + d_aoff, 0u, slot_off + (uint32_t)(q * 8192) + wave_lds);
-    else if (q < 4) buf_lds16(rs_xi, voa[q - 2] + d_aoff, 0u, slot_off + (uint32_t)(A_PLANE + (q - 2) * 8192) + wave_lds);
+    if (q < 2) buf_lds16(rs_xr, voa_c[q] + d_aoff, 0u, slot_off + (uint32_t)(q * 8192) + wave_lds);
+    else if (q < 4) buf_lds16(rs_xi, voa_c[q - 2] + d_aoff, 0u, slot_off + (uint32_t)(A_PLANE + (q - 2) * 8192) + wave_lds);
     else {
       const int j = q - 4;
       constexpr int FULLW = G::W_BYTES / 1024;             // waves of weight data in total
@@ -238,11 +266,11 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
 #pragma unroll
       for (int kw = 0; kw < KW; ++kw) {
         const int ww = (int)w + kw * g.dil_w - g.pad_w;
-        m |= (ww >= 0 && ww < g.W) ? (1u << kw) : 0u;
+        m |= (ww >= 0 && ww < g.Wi) ? (1u << kw) : 0u;
       }
       for (int kh = 0; kh < g.KH; ++kh) {
         const int hh = (int)h + kh * g.dil_h - g.pad_h;
-        m |= (hh >= 0 && hh < g.H) ? (0x100u << kh) : 0u;
+        m |= (hh >= 0 && hh < g.Hi) ? (0x100u << kh) : 0u;
       }
       vmask[i] = m;
     }
@@ -365,6 +393,7 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
     constexpr int PITCH = 144;
     const int r16 = q31 >> 4, rr = q31 & 15;
     const int64_t ldc = g.Cout;
+    const bool out_dense = g.Ho == g.H && g.Wo == g.W;
     int64_t own = g.P - r0;
     if (own > g.tm_out) own = g.tm_out;
 #pragma unroll
@@ -392,8 +421,15 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
             if (kClDbg & 1) continue;
             const int m = wm_ + i * 32 + half * 16 + sub * 8 + (ln >> 3);
             const int col = nt_ * BN + (ln & 7) * 8;
-            bf16_t* dst = (m < own && !(kClDbg & 2)) ? out + ((int64_t)r0 + m) * ldc + col
-                                                     : reinterpret_cast<bf16_t*>(g.dump) + (int64_t)m * ldc + col;
+            int64_t orow = (int64_t)r0 + m;
+            bool ok = m < own && !(kClDbg & 2);
+            if (!out_dense) {                       // output image smaller than the grid: its own dense row index
+              const uint32_t q = (uint32_t)orow, qh = fast_div(q, g.div_w), w = q - qh * (uint32_t)g.W;
+              const uint32_t b = fast_div(qh, g.div_h), h = qh - b * (uint32_t)g.H;
+              ok = ok && h < (uint32_t)g.Ho && w < (uint32_t)g.Wo;
+              orow = ((int64_t)b * g.Ho + h) * g.Wo + w;
+            }
+            bf16_t* dst = ok ? out + orow * ldc + col : reinterpret_cast<bf16_t*>(g.dump) + (int64_t)m * ldc + col;
 #ifndef CPLXAMD_CL_NO_NT          // streaming stores: the output is read by a later kernel, not by this one (-1.4 %)
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(u32x4_t{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4_t*>(dst));
@@ -486,6 +522,7 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
     r0 = r0n; nt0 = ntn;
     has_next = v + nwg < ntiles;
     origin(has_next ? v + nwg : v, r0n, ntn);
+    lane_offsets(r0n, voa_n);
     init_acc();
     tile_masks();
     first_frags();
@@ -558,22 +595,26 @@ int cplxamd_conv2d_cl_pack(const void* w_r, const void* w_i, void* out, int Co, 
   return 0;
 }
 
-// y[p, n] = bias[n] + sum_{kh, kw, c} x[p + (kh dil_h - pad_h) W + (kw dil_w - pad_w), c] w[n, c, kh, kw] over the taps
-// that stay inside the image of pixel p; x, y channels-last planes [B H W][C] / [B H W][N], w packed by
-// cplxamd_conv2d_cl_pack.  ESHAPE for what the kernel is not built for (the caller falls back to conv_nhwc / conv_bf16).
+// Forward (mode 0):  y[b, ho, wo, n] = bias[n] + sum_{kh, kw, c} x[b, ho + kh dil_h - pad_h, wo + kw dil_w - pad_w, c] w[n, c, kh, kw]
+// over the taps inside the H x W image; x: [B][H][W][C], y: [B][Ho][Wo][N] with Ho = H + 2 pad_h - dil_h (KH - 1) <= H
+// (likewise Wo): any zero padding up to `same`.  Data gradient (mode 1) OF THAT convolution: x is the output gradient
+// [B][Ho][Wo][C = Cout], y the input gradient [B][H][W][N = Cin], w packed with dgrad = 1; H, W, pad_* are still the
+// forward's.  ESHAPE for what the kernel is not built for (the caller falls back to conv_nhwc / conv_bf16).
 int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
                       void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
-                      int pad_h, int pad_w, void* ws, int64_t ws_bytes, void* stream) {
+                      int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream) {
   if (!x_r || !x_i || !w_packed || !y_r || !y_i || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || KH <= 0 ||
-      KW <= 0 || dil_h <= 0 || dil_w <= 0 || pad_h < 0 || pad_w < 0 || (bias_r == nullptr) != (bias_i == nullptr))
+      KW <= 0 || dil_h <= 0 || dil_w <= 0 || pad_h < 0 || pad_w < 0 || (bias_r == nullptr) != (bias_i == nullptr) ||
+      (mode != 0 && mode != 1))
     return CPLXAMD_EINVAL;
-  if (KW != 3 || C % 16 || N % 64 || (KH * (C / 16)) % 6 || 2 * pad_h != dil_h * (KH - 1) || 2 * pad_w != dil_w * (KW - 1) ||
+  const int Hs = H + 2 * pad_h - dil_h * (KH - 1), Ws = W + 2 * pad_w - dil_w * (KW - 1);   // the smaller image
+  if (KW != 3 || C % 16 || N % 64 || (KH * (C / 16)) % 6 || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W ||
       (KW - 1) * dil_w > 64 || KH > 8)
     return CPLXAMD_ESHAPE;
   const int64_t P = B * H * W;
   if (P == 0) return 0;
-  const int64_t halo = ((int64_t)pad_h * W + pad_w + cl::TM) * C * 2;
-  if (P >= ((int64_t)1 << 31) - cl::TM || P * C * 2 + 2 * halo >= ((int64_t)1 << 32)) return CPLXAMD_ESHAPE;
+  const int64_t halo = ((int64_t)dil_h * (KH - 1) * W + dil_w * (KW - 1) + cl::TM) * C * 2;
+  if (P >= ((int64_t)1 << 31) - cl::TM || P * C * 2 + 2 * halo >= (int64_t)0xF0000000) return CPLXAMD_ESHAPE;
   auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (!a16(x_r) || !a16(x_i) || !a16(w_packed) || !a16(y_r) || !a16(y_i) || !a16(ws) || (bias_r && (!a16(bias_r) || !a16(bias_i))))
     return CPLXAMD_EALIGN;
@@ -581,7 +622,9 @@ int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, co
   cl::Args g{};
   g.x_r = x_r; g.x_i = x_i; g.w = w_packed; g.bias_r = bias_r; g.bias_i = bias_i; g.y_r = y_r; g.y_i = y_i; g.dump = ws;
   g.P = P;
-  g.x_bytes = (uint32_t)(P * C * 2);
+  g.Hi = mode ? Hs : H; g.Wi = mode ? Ws : W; g.Ho = mode ? H : Hs; g.Wo = mode ? W : Ws;
+  g.x_bytes = (uint32_t)(B * g.Hi * g.Wi * C * 2);
+  if (mode) { pad_h = dil_h * (KH - 1) - pad_h; pad_w = dil_w * (KW - 1) - pad_w; }
   g.w_bytes = (uint32_t)cplxamd_conv2d_cl_pack_bytes(N, C, KH, KW);
   g.H = H; g.W = W; g.C = C; g.Cout = N; g.KH = KH; g.dil_h = dil_h; g.dil_w = dil_w; g.pad_h = pad_h; g.pad_w = pad_w;
   g.C16 = C / 16; g.NS = KH * g.C16;

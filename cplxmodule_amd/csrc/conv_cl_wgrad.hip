@@ -52,7 +52,8 @@ struct Args {
   float* ws;
   int64_t P;
   uint32_t g_bytes, x_bytes;
-  int H, W, Co, Ci, dil_h, dil_w, pad_h, pad_w;
+  int H, W, Co, Ci, dil_h, dil_w, pad_h, pad_w;      // H x W: the input image = the grid the pixel loop walks
+  int Ho, Wo;                                        // the output image (<= H x W, top-left aligned on the grid)
   int nstages, per_split, splits, tiles_ci;
 };
 
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   {                                                  // bit1 top rows, bit2 bottom rows, bit3 set for every lane
     const int c = (int)(wid_u & 3) * 64 + lane, k = c >> 3, ch = (c & 7) ^ (((k >> 1) & 1) << 2);
     vo[0] = (uint32_t)k * rb_g + (uint32_t)(co0 + ch * 8) * 2u;
-    vflag[0] = 8u;
+    vflag[0] = (uint32_t)k;                          // (piece 0: the pixel of this lane inside the stage)
   }
   int kh_of[L];
 #pragma unroll
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
     kh_of[j] = kh_ < 3 ? kh_ : 0;
     vo[j] = (uint32_t)r * rb_x + (uint32_t)(ci0 + ch * 8) * 2u;
     uint32_t f = 8u;
-    if (u >= 15 || r >= KR + 2 * g.pad_w) f |= 1u;
+    if (u >= 15 || r >= KR + 2 * g.dil_w) f |= 1u;
     if (r < g.pad_w) f |= 2u;
     if (r >= KR + g.pad_w) f |= 4u;
     vflag[j] = f;
@@ -171,16 +172,20 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   nt = __builtin_amdgcn_readfirstlane(nt);
   int d_t = 0;                                       // stages issued so far
   uint32_t d_q0 = (uint32_t)t0 * KR;                 // first pixel of the stage at the pointer
-  int d_w0, d_h;
+  int d_w0, d_h, d_b;
   {
     const uint32_t row = d_q0 / (uint32_t)g.W;
     d_w0 = (int)(d_q0 - row * (uint32_t)g.W);
-    d_h = (int)(row % (uint32_t)g.H);
+    d_b = (int)(row / (uint32_t)g.H);
+    d_h = (int)(row - (uint32_t)d_b * (uint32_t)g.H);
   }
   auto issue_piece = [&](int j, uint32_t slot_off) __attribute__((always_inline)) {
     const bool live = d_t < nt;                      // stages past the end: everything out of range (zeros)
     if (j == 0) {
-      const uint32_t v = live ? vo[0] + d_q0 * rb_g : OOB;
+      // G lives on the (Ho, Wo) image: grid pixel (b, h, w0 + k) -> its dense row, nothing beyond row Ho / column Wo
+      const uint32_t goff = (((uint32_t)d_b * (uint32_t)g.Ho + (uint32_t)d_h) * (uint32_t)g.Wo + (uint32_t)d_w0) * rb_g;
+      const int lim = (live && d_h < g.Ho) ? g.Wo - d_w0 : 0;
+      const uint32_t v = (int)vflag[0] < lim ? vo[0] + goff : OOB;
       buf_lds16(rs_g, v, slot_off + dst[0]);
     } else {
       const int kh = kh_of[j];
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   };
   auto advance = [&]() __attribute__((always_inline)) {
     ++d_t; d_q0 += KR; d_w0 += KR;
-    if (d_w0 == g.W) { d_w0 = 0; if (++d_h == g.H) d_h = 0; }
+    if (d_w0 == g.W) { d_w0 = 0; if (++d_h == g.H) { d_h = 0; ++d_b; } }
   };
 
   // ---- one stage: 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity) ---------------
@@ -333,8 +338,8 @@ extern "C" {
 
 static int clw_shape_ok(int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
                         int pad_w) {
-  if (KH != 3 || KW != 3 || W % clw::KR || Ci % 64 || Co % 64 || 2 * pad_h != dil_h * 2 || 2 * pad_w != dil_w * 2 ||
-      pad_w > 3)
+  if (KH != 3 || KW != 3 || W % clw::KR || Ci % 64 || Co % 64 || pad_h < 0 || pad_w < 0 || pad_h > dil_h ||
+      pad_w > dil_w || dil_w > 4 || H + 2 * pad_h - 2 * dil_h <= 0 || W + 2 * pad_w - 2 * dil_w <= 0)
     return 0;
   const int64_t P = B * H * W;
   const int64_t cmax = Ci > Co ? Ci : Co;
@@ -350,7 +355,8 @@ int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co
   return (int64_t)splits * tiles * clw::NBLK * 2048 * 4;
 }
 
-// dw_r / dw_i: float32 [Co][Ci][3][3]; g: [B H W][Co], x: [B H W][Ci] channels-last bf16 planes.
+// dw_r / dw_i: float32 [Co][Ci][3][3]; x: [B][H][W][Ci], g: [B][Ho][Wo][Co] channels-last bf16 planes, Ho = H + 2 pad_h -
+// 2 dil_h <= H (any zero padding up to `same`).
 int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                             float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
                             int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, void* stream) {
@@ -368,7 +374,8 @@ int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, c
   if (!ws || ws_bytes < cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, Ci, Co)) return CPLXAMD_EINVAL;
   clw::Args g{};
   g.g_r = g_r; g.g_i = g_i; g.x_r = x_r; g.x_i = x_i; g.ws = (float*)ws; g.P = P;
-  g.g_bytes = (uint32_t)(P * Co * 2); g.x_bytes = (uint32_t)(P * Ci * 2);
+  g.Ho = H + 2 * pad_h - 2 * dil_h; g.Wo = W + 2 * pad_w - 2 * dil_w;
+  g.g_bytes = (uint32_t)(B * g.Ho * g.Wo * Co * 2); g.x_bytes = (uint32_t)(P * Ci * 2);
   g.H = H; g.W = W; g.Co = Co; g.Ci = Ci; g.dil_h = dil_h; g.dil_w = dil_w; g.pad_h = pad_h; g.pad_w = pad_w;
   g.nstages = (int)(P / clw::KR);
   g.tiles_ci = Ci / 64;

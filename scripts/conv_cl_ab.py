@@ -44,7 +44,7 @@ def main():
     ws = torch.empty(int(l0.cplxamd_conv2d_cl_ws_bytes(Co)), dtype=torch.uint8, device=dev)
 
     def run(lib):
-        rc = lib.cplxamd_conv2d_cl(p(xr), p(xi), p(wp), p(br), p(bi), p(yr), p(yi), B, H, W, C, Co, 3, 3, 1, 1, 1, 1,
+        rc = lib.cplxamd_conv2d_cl(p(xr), p(xi), p(wp), p(br), p(bi), p(yr), p(yi), B, H, W, C, Co, 3, 3, 1, 1, 1, 1, 0,
                                    p(ws), ws.numel(), st)
         assert rc == 0, rc
 

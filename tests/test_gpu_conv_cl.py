@@ -27,6 +27,9 @@ CASES = {
     "wgrad_cl_w32": dict(B=2, Ci=64, Co=64, H=8, W=32, k=3, padding=1, dilation=1),
     "wgrad_cl_dil2_tiles": dict(B=3, Ci=128, Co=64, H=5, W=64, k=3, padding=2, dilation=2),
     "wgrad_cl_one_row_images": dict(B=7, Ci=64, Co=128, H=1, W=96, k=3, padding=1, dilation=1),
+    "valid_padding": dict(B=2, Ci=64, Co=64, H=9, W=32, k=3, padding=0, dilation=1),
+    "half_padding_dil2": dict(B=2, Ci=64, Co=64, H=11, W=64, k=3, padding=(1, 0), dilation=(2, 1)),
+    "valid_one_row_out": dict(B=3, Ci=32, Co=64, H=3, W=40, k=3, padding=0, dilation=1),
     "tiny_image": dict(B=5, Ci=32, Co=64, H=3, W=2, k=3, padding=1, dilation=1),
     "five_by_three_dil": dict(B=2, Ci=96, Co=64, H=14, W=15, k=(5, 3), padding=(4, 3), dilation=(2, 3)),
 }
@@ -54,6 +57,8 @@ def test_cl_conv_vs_oracle(case, layout):
     kw_ = dict(stride=1, padding=cfg["padding"], dilation=cfg["dilation"], groups=1)
     geom, _ = conv._geom(txr.shape, twr.shape, 1, cfg["padding"], cfg["dilation"], 1)
     assert conv._cl_ok(geom) and conv._cl_ok(geom, dgrad=True) == (Ci % 64 == 0 and (kh * (Co // 16)) % 6 == 0)
+    if case.startswith(("wgrad_cl", "valid_padding", "half_padding")):
+        assert conv._cl_wgrad_ok(geom)
     y = cplx.conv2d(Cplx(txr, txi), Cplx(twr, twi), Cplx(tbr, tbi), **kw_)
     assert y.real.is_contiguous(memory_format=torch.channels_last)          # the channels-last kernel ran
     f = np.float64
