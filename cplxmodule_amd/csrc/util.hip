@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int64_t ld_
 
 // out[c] = sum_r in[r, c].  Stage 1: block = 64 column-quads x 4 row lanes over one row chunk,
 // 8-16 B loads per lane, partial[chunk][c]; stage 2 sums the chunks.  (cols % 4 != 0: scalar path.)
-constexpr int kColChunks = 256;
+constexpr int kColChunks = 1024;
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* in, int64_t ld, float* partial,
@@ -123,13 +123,58 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* in, int64_
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int chunks, int cols,
-                                                           float* out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+// 64 columns per block, 16 chunk lanes (fixed summation order: deterministic)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* partial, int chunks, int cols,
+                                                            float* out) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float acc = 0.f;
-  for (int j = 0; j < chunks; ++j) acc += partial[(int64_t)j * cols + c];
-  out[c] = acc;
+  if (c < cols)
+    for (int j = ty; j < chunks; j += 16) acc += partial[(int64_t)j * cols + c];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][tx];
+    out[c] = t;
+  }
+}
+
+// tall and narrow ([B H W][C] activations: the bias gradient of a channels-last convolution): a thread owns 8
+// consecutive columns (one 16-byte load for bf16), 256 / (cols / 8) row lanes per block, 4 rows in flight per thread
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* in, float* partial, int64_t rows, int cols) {
+  __shared__ float red[256 * 8];
+  const int CG = cols >> 3, RL = 256 / CG;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    const int64_t step = (int64_t)gridDim.x * RL;
+    int64_t r = (int64_t)blockIdx.x * RL + rl;
+    for (; r + 3 * step < rows; r += 4 * step) {
+      f8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ld8(in + (r + u * step) * cols + cg * 8);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        acc[c] += (v[0].h[c >> 2].v[c & 3] + v[1].h[c >> 2].v[c & 3]) + (v[2].h[c >> 2].v[c & 3] + v[3].h[c >> 2].v[c & 3]);
+    }
+    for (; r < rows; r += step) {
+      const f8 v = ld8(in + r * cols + cg * 8);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] += v.h[c >> 2].v[c & 3];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[rl * cols + cg * 8 + c] = acc[c];
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < cols; f += 256) {
+    float t = 0.f;
+    for (int l = 0; l < RL; ++l) t += red[l * cols + f];
+    partial[(int64_t)blockIdx.x * cols + f] = t;
+  }
 }
 
 template <typename T>
@@ -328,6 +373,21 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
   hipStream_t st = (hipStream_t)stream;
   const bool vec = ws && (cols % 4 == 0) && (ld % 4 == 0) && rows >= 64 &&
                    ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  if (vec && cols % 8 == 0 && cols <= 512 && ld == cols && rows >= 8192) {
+    const int RL = 256 / (cols / 8);
+    int64_t chunks = ((int64_t)rows + 4 * RL - 1) / (4 * RL);
+    if (chunks > kColChunks) chunks = kColChunks;
+    if (dtype == CPLXAMD_F32)
+      colsum_rows_kernel<float><<<(unsigned)chunks, 256, 0, st>>>((const float*)in, (float*)ws, rows, cols);
+    else if (dtype == CPLXAMD_BF16)
+      colsum_rows_kernel<bf16_t><<<(unsigned)chunks, 256, 0, st>>>((const bf16_t*)in, (float*)ws, rows, cols);
+    else
+      return CPLXAMD_EINVAL;
+    CPLXAMD_CHECK_LAUNCH();
+    colsum_final_kernel<<<(cols + 63) / 64, 1024, 0, st>>>((const float*)ws, (int)chunks, cols, out);
+    CPLXAMD_CHECK_LAUNCH();
+    return 0;
+  }
   if (vec) {
     const int gx = (cols / 4 + 63) / 64;
     int chunks = (2048 + gx - 1) / gx;            // ~8 blocks per CU
@@ -342,7 +402,7 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
     else
       return CPLXAMD_EINVAL;
     CPLXAMD_CHECK_LAUNCH();
-    colsum_final_kernel<<<(cols + 255) / 256, 256, 0, st>>>((const float*)ws, chunks, cols, out);
+    colsum_final_kernel<<<(cols + 63) / 64, 1024, 0, st>>>((const float*)ws, chunks, cols, out);
     CPLXAMD_CHECK_LAUNCH();
     return 0;
   }

@@ -69,11 +69,15 @@ def cfg1_graph():
             "ms": t * 1e3, "samples_per_s": 64 / t, "reference_cpu_samples_per_s": 33400}
 
 
-def cfg3(batch, dtype):
+def cfg3(batch, dtype, layout="channels_last"):
+    """layout: how the input images are stored.  channels_last (torch.channels_last, [B, H, W, C] in memory) is what the
+    bf16 kernels work on end to end; with a plain contiguous (NCHW) input the layer converts on entry and autograd
+    converts the input gradient back, two extra passes each way that a layer inside a network does not pay."""
     dev = "cuda"
     conv, bn = nn.CplxConv2d(64, 64, 3).to(dev), nn.CplxBatchNorm2d(64).to(dev)
-    x = Cplx(torch.randn(batch, 64, 256, 256, device=dev).to(dtype).requires_grad_(True),
-             torch.randn(batch, 64, 256, 256, device=dev).to(dtype).requires_grad_(True))
+    fmt = torch.channels_last if layout == "channels_last" else torch.contiguous_format
+    mk = lambda: torch.randn(batch, 64, 256, 256, device=dev).to(dtype).contiguous(memory_format=fmt).requires_grad_(True)  # noqa: E731
+    x = Cplx(mk(), mk())
     times = {}
 
     def step():
@@ -87,7 +91,7 @@ def cfg3(batch, dtype):
         y = conv(x)
         tb = timed(lambda: bn(y), 5, 2)
     nelem = batch * 64 * 254 * 254
-    return {"config": f"cfg3 CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, B={batch} {dtype} fwd+bwd",
+    return {"config": f"cfg3 CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, B={batch} {dtype} fwd+bwd, input {layout}",
             "ms": t * 1e3, "images_per_s": batch / t, "conv_TFLOPs_algorithmic": flop / 1e12,
             "achieved_TFLOP_s_incl_bn": flop / t / 1e12, "bn_fwd_ms": tb * 1e3,
             "bn_fwd_GBps(24B/elt fp32, 12 bf16)": (24 if dtype == torch.float32 else 12) * nelem / tb / 1e9,
@@ -120,11 +124,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg3-batch", type=int, default=32)
     ap.add_argument("--cfg4-batch", type=int, default=1 << 20)
+    ap.add_argument("--cfg3-layout", default="channels_last", choices=["channels_last", "nchw"])
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
-    jobs = [("cfg1", cfg1), ("cfg1g", cfg1_graph), ("cfg3f", lambda: cfg3(a.cfg3_batch, torch.float32)),
-            ("cfg3b", lambda: cfg3(a.cfg3_batch, torch.bfloat16)),
+    jobs = [("cfg1", cfg1), ("cfg1g", cfg1_graph), ("cfg3f", lambda: cfg3(a.cfg3_batch, torch.float32, a.cfg3_layout)),
+            ("cfg3b", lambda: cfg3(a.cfg3_batch, torch.bfloat16, a.cfg3_layout)),
             ("cfg4b", lambda: cfg4(a.cfg4_batch, torch.bfloat16)),
             ("cfg4f", lambda: cfg4(a.cfg4_batch // 4, torch.float32))]
     for name, fn in jobs:

@@ -346,3 +346,20 @@ def test_fused_kl_only_and_retain_graph():
     y = layer(x)
     gd = torch.autograd.grad(y.real.float().square().sum() + y.imag.float().square().sum(), [layer.log_sigma2])
     assert torch.isfinite(gd[0]).all()
+
+
+@pytest.mark.parametrize("rows,cols,dtype", [(20000, 64, torch.bfloat16), (9000, 24, torch.float32), (8192, 512, torch.bfloat16),
+                                             (70000, 8, torch.float32), (300, 64, torch.bfloat16), (5000, 4096, torch.bfloat16),
+                                             (1000, 20, torch.float32)])
+def test_colsum_all_paths(rows, cols, dtype):
+    """ops.colsum (bias gradients): the tall-and-narrow row kernel (channels-last activations), the wide partial kernel
+    and the scalar fallback against a float64 sum of the same values."""
+    from cplxmodule_amd import ops
+    torch.manual_seed(rows + cols)
+    x = torch.randn(rows, cols, device="cuda").to(dtype)
+    got = ops.colsum(x).double().cpu().numpy()
+    ref = x.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * float(np.abs(x.double().cpu().numpy()).sum(0).max()))
+    out = torch.empty(cols, device="cuda")
+    assert ops.colsum(x, out=out) is out
+    np.testing.assert_array_equal(out.double().cpu().numpy(), got)
