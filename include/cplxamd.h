@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 2
+#define CPLXAMD_ABI_VERSION 3
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -348,6 +348,32 @@ int cplxamd_conv2d_nhwc_wgrad_f32(const void* gp_r, const void* gp_i, const void
                                   const float* emul, float* dw_r, float* dw_i, int B, int Hp, int Wp,
                                   int Ci, int Co, int KH, int KW, int dil_h, int dil_w, void* ws,
                                   int64_t ws_bytes, void* stream);
+/* ---- complex convolution on UNPADDED channels-last planes (csrc/conv_cl.hip, conv_cl_wgrad.hip), bf16 in, fp32
+ * accumulation: stride 1, groups 1, kernel width 3, zero padding 0 <= 2 pad <= dil (K - 1) per dimension (up to `same`).
+ * Activations x: [B][H][W][C], y: [B][Ho][Wo][N] (Ho = H + 2 pad_h - dil_h (KH - 1), likewise Wo) -- the storage of
+ * torch.channels_last tensors; no padded copies, no layout passes between layers that stay channels-last.
+ * Replaces cplx.conv2d -> convnd and its autograd (cplxmodule/cplx.py:717-838) for these shapes; everything else:
+ * CPLXAMD_ESHAPE, and the caller takes cplxamd_conv2d_nhwc / _bf16 / _fwd.
+ *   cplxamd_conv2d_cl_pack: bf16 weight planes [Co][Ci][KH][KW] -> the kernel's per-stage LDS images (bytes:
+ *       cplxamd_conv2d_cl_pack_bytes(N, C, KH, KW) with (N, C) = (Co, Ci) forward, (Ci, Co) data gradient); dgrad = 1
+ *       folds the flip, the channel swap and the conjugate of the data gradient into the packing.
+ *   cplxamd_conv2d_cl: mode 0 forward (C = Ci, N = Co, bias optional), mode 1 the data gradient OF that forward
+ *       (x = output gradient [B][Ho][Wo][C = Co], y = input gradient [B][H][W][N = Ci]; H, W, pad_* still the forward's).
+ *       Needs C % 16 == 0, N % 64 == 0, (KH * C / 16) % 6 == 0; ws >= cplxamd_conv2d_cl_ws_bytes(N).
+ *   cplxamd_conv2d_cl_wgrad: dW[Co][Ci][3][3] (float32 planes, optionally times emul) from x [B][H][W][Ci] and
+ *       g [B][Ho][Wo][Co]; needs KH = KW = 3, W % 32 == 0, Ci % 64 == Co % 64 == 0;
+ *       ws >= cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, Ci, Co).  Deterministic (fixed-order slab reduction). */
+int64_t cplxamd_conv2d_cl_pack_bytes(int N, int C, int KH, int KW);
+int64_t cplxamd_conv2d_cl_ws_bytes(int N);
+int cplxamd_conv2d_cl_pack(const void* w_r, const void* w_i, void* out, int Co, int Ci, int KH, int KW, int dgrad,
+                           void* stream);
+int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                      void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                      int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream);
+int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co);
+int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
+                            float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
+                            int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, void* stream);
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);
