@@ -64,6 +64,7 @@ SIGNATURES = {
     "cplxamd_conv2d_nhwc_wgrad_f32": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
     "cplxamd_conv2d_nhwc_wgrad": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
     "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_L] + [_I] * 5 + [_P],
+    "cplxamd_cl_to_nchw": [_P, _P, _L, _I, _L, _P],
     "cplxamd_conv2d_cl_pack_bytes": [_I, _I, _I, _I],
     "cplxamd_conv2d_cl_ws_bytes": [_I],
     "cplxamd_conv2d_cl_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

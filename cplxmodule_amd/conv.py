@@ -207,6 +207,19 @@ def to_channels_last(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
+def from_channels_last(t):
+    """A channels-last [B, C, H, W] tensor -> plain contiguous (NCHW) storage, by the LDS-tile transpose when it can."""
+    if t.is_contiguous():
+        return t
+    B, C, H, W = t.shape
+    if (t.is_contiguous(memory_format=torch.channels_last) and t.dtype == torch.bfloat16 and C % 8 == 0 and (H * W) % 8 == 0
+            and B * (-(-C // 64)) <= 65535 and t.data_ptr() % 16 == 0):
+        out = torch.empty((B, C, H, W), dtype=t.dtype, device=t.device)
+        call("cplxamd_cl_to_nchw", ptr(t), ptr(out), B, C, H * W, stream_ptr())
+        return out
+    return t.contiguous()
+
+
 def _cl_pack(wr, wi, dgrad):
     """bf16 weight planes [Co, Ci, KH, KW] -> the per-stage LDS images of conv_cl.hip."""
     Co, Ci, KH, KW = wr.shape
@@ -412,6 +425,8 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
     if need[0] or need[1]:
         if _cl_ok(geom, dgrad=True):
             dxr, dxi = cl_conv(gr, gi, wcr, wci, None, None, geom, dgrad=True)
+            if ctx.x_planar:             # the input was a plain contiguous tensor: hand its gradient back in that layout
+                dxr, dxi = from_channels_last(dxr), from_channels_last(dxi)   # (autograd would do it with a slow copy)
         else:
             dxr, dxi = conv_dgrad(gr.contiguous(), gi.contiguous(), wcr, wci, geom, ctx.xshape)
     if need[2] or need[3]:
@@ -436,6 +451,7 @@ class CplxConv2dFn(torch.autograd.Function):
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
         ctx.cl = xr.dtype == torch.bfloat16 and xi.dtype == torch.bfloat16 and _cl_ok(geom)
         if ctx.cl:                       # channels-last in, channels-last out: no layout copies between such layers
+            ctx.x_planar = xr.is_contiguous() and not xr.is_contiguous(memory_format=torch.channels_last)
             xr, xi = to_channels_last(xr), to_channels_last(xi)
             wcr, wci = ops.cast(wr.contiguous(), xr.dtype), ops.cast(wi.contiguous(), xr.dtype)
             yr, yi = cl_conv(xr, xi, wcr, wci, b[0], b[1], geom)

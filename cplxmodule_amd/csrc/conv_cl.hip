@@ -96,7 +96,10 @@ __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
 // [0, num_records) (voff wraps in 32 bits, so a "negative" row is out of range too); destination M0 + lane * 16.
 __device__ __forceinline__ void buf_lds16(i32x4 rsrc, uint32_t voff, uint32_t soff_uniform, uint32_t lds_off_uniform) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+#ifndef CPLXAMD_CL_DMA_MOD
+#define CPLXAMD_CL_DMA_MOD ""
+#endif
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen " CPLXAMD_CL_DMA_MOD " lds"
                :
                : "v"(voff), "s"(rsrc), "s"(lds_off_uniform), "s"(soff_uniform)
                : "memory");
@@ -562,6 +565,35 @@ __global__ void pack_kernel(const bf16_t* w_r, const bf16_t* w_i, bf16_t* out, i
   }
 }
 
+// channels-last [B][S][C] -> planar [B][C][S] (bf16), 64 pixels x 64 channels per block through LDS: the way back for
+// a caller that holds plain contiguous tensors (a gradient for an NCHW leaf); 16-byte accesses on both sides.
+__global__ __launch_bounds__(256) void cl_to_nchw_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int C,
+                                                         int64_t S) {
+  __shared__ bf16_t tile[64][64 + 8];                        // [pixel][channel]
+  const int ctiles = (C + 63) / 64;
+  const int64_t b = blockIdx.y / ctiles;
+  const int c0 = (int)(blockIdx.y - b * ctiles) * 64;
+  const int64_t s0 = (int64_t)blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int idx = r * 256 + tid, p = idx >> 3, c8 = (idx & 7) * 8;
+    uint4 v = uint4{0, 0, 0, 0};
+    if (s0 + p < S && c0 + c8 < C) v = *reinterpret_cast<const uint4*>(x + ((int64_t)b * S + s0 + p) * C + c0 + c8);
+    *reinterpret_cast<uint4*>(&tile[p][c8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int idx = r * 256 + tid, c = idx >> 3, p8 = (idx & 7) * 8;
+    if (c0 + c >= C || s0 + p8 >= S) continue;
+    bf16_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[p8 + e][c];
+    *reinterpret_cast<uint4*>(out + ((int64_t)b * C + c0 + c) * S + s0 + p8) = *reinterpret_cast<const uint4*>(v);
+  }
+}
+
 static FastDiv make_div(uint32_t d) {
   if (d <= 1) return FastDiv{0u, -1};
   int s = 0;
@@ -576,6 +608,17 @@ static FastDiv make_div(uint32_t d) {
 using namespace cplxamd;
 
 extern "C" {
+
+int cplxamd_cl_to_nchw(const void* x_cl, void* out, int64_t B, int C, int64_t S, void* stream) {
+  if (!x_cl || !out || B < 0 || C <= 0 || S <= 0) return CPLXAMD_EINVAL;
+  if (C % 8 || S % 8 || B * ((C + 63) / 64) > 65535) return CPLXAMD_ESHAPE;
+  if ((reinterpret_cast<uintptr_t>(x_cl) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return CPLXAMD_EALIGN;
+  if (B == 0) return 0;
+  dim3 grid((unsigned)((S + 63) / 64), (unsigned)(B * ((C + 63) / 64)));
+  cl::cl_to_nchw_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x_cl, (bf16_t*)out, C, S);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
 
 int64_t cplxamd_conv2d_cl_pack_bytes(int N, int C, int KH, int KW) {
   if (N <= 0 || C <= 0 || KH <= 0 || KW <= 0 || C % 16) return 0;

@@ -111,3 +111,16 @@ def test_cl_conv_many_tiles_per_workgroup():
     for got, ref in ((wr.grad, wref_r), (wi.grad, wref_i)):
         err = (got.float() - ref).abs().max().item()
         assert err <= 2e-3 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 8, 32), (3, 40, 5, 24), (1, 136, 16, 16)])
+def test_layout_round_trip_exact(B, C, H, W):
+    """to_channels_last / from_channels_last are pure data movement (the LDS-tile transposes): bit-identical to aten's."""
+    from cplxmodule_amd import conv
+    torch.manual_seed(B + C)
+    x = torch.randn(B, C, H, W, device="cuda").bfloat16()
+    cl = conv.to_channels_last(x)
+    assert cl.is_contiguous(memory_format=torch.channels_last) and torch.equal(cl, x)
+    assert torch.equal(cl.permute(0, 2, 3, 1).contiguous(), x.permute(0, 2, 3, 1).contiguous())
+    back = conv.from_channels_last(cl)
+    assert back.is_contiguous() and torch.equal(back, x)
