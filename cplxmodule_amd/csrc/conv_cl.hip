@@ -40,7 +40,7 @@ constexpr int NT = 512, TM = 512, BN = 64;
 constexpr int A_PLANE = TM * 32 + 64;        // 512 rows x 16 channels, then the zero row (row 512)
 constexpr int ZROW = TM * 32;                // plane-relative byte address of the zero row
 // ablation builds (-DCPLXAMD_CL_DBG=n, timing only): 1 no global stores, 2 every store goes to the dump rows
-// (L2-resident), 4 no epilogue at all, 8 no LDS-DMA after the prologue, 16 no start stagger
+// (L2-resident), 4 no epilogue at all, 8 no LDS-DMA after the prologue, 16 no start stagger, 32 contiguous A source
 #ifndef CPLXAMD_CL_DBG
 #define CPLXAMD_CL_DBG 0
 #endif
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
 
   const i32x4 rs_xr = make_rsrc(g.x_r, g.x_bytes), rs_xi = make_rsrc(g.x_i, g.x_bytes);
   const i32x4 rs_w = make_rsrc(g.w, g.w_bytes);
-  const uint32_t rowbytes = (uint32_t)g.C * 2u;
+  // (ablation bit 32: rows of the source read as if they were 32 bytes apart -- every LDS-DMA piece one contiguous KiB)
+  const uint32_t rowbytes = (kClDbg & 32) ? 32u : (uint32_t)g.C * 2u;
 
   const uint32_t smem_off = lds_offset_of(smem);
   const uint32_t wid_u = (uint32_t)__builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -396,7 +397,12 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
     constexpr int PITCH = 144;
     const int r16 = q31 >> 4, rr = q31 & 15;
     const int64_t ldc = g.Cout;
-    const bool out_dense = g.Ho == g.H && g.Wo == g.W;
+    const bool out_dense = g.Ho == g.H && g.Wo == g.W, wide = g.W >= 64;
+    uint32_t w_first = 0, h_first = 0, b_first = 0;       // grid coordinates of this lane's first row (r0 + wm + lane / 8)
+    if (!out_dense) {
+      const uint32_t q = (uint32_t)(r0 + wm_ + (ln >> 3)), qh = fast_div(q, g.div_w);
+      w_first = q - qh * (uint32_t)g.W; b_first = fast_div(qh, g.div_h); h_first = qh - b_first * (uint32_t)g.H;
+    }
     int64_t own = g.P - r0;
     if (own > g.tm_out) own = g.tm_out;
 #pragma unroll
@@ -427,8 +433,13 @@ __global__ __launch_bounds__(NT) void conv_cl_kernel(Args g) {
             int64_t orow = (int64_t)r0 + m;
             bool ok = m < own && !(kClDbg & 2);
             if (!out_dense) {                       // output image smaller than the grid: its own dense row index
-              const uint32_t q = (uint32_t)orow, qh = fast_div(q, g.div_w), w = q - qh * (uint32_t)g.W;
-              const uint32_t b = fast_div(qh, g.div_h), h = qh - b * (uint32_t)g.H;
+              uint32_t w = w_first + (uint32_t)(i * 32 + half * 16 + sub * 8), h = h_first, b = b_first;
+              if (wide) {                           // (W >= 64: one carry at most for the 64 rows of a wave)
+                if (w >= (uint32_t)g.W) { w -= (uint32_t)g.W; if (++h == (uint32_t)g.H) { h = 0; ++b; } }
+              } else {
+                const uint32_t q = (uint32_t)orow, qh = fast_div(q, g.div_w);
+                w = q - qh * (uint32_t)g.W; b = fast_div(qh, g.div_h); h = qh - b * (uint32_t)g.H;
+              }
               ok = ok && h < (uint32_t)g.Ho && w < (uint32_t)g.Wo;
               orow = ((int64_t)b * g.Ho + h) * g.Wo + w;
             }
