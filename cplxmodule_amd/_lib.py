@@ -96,6 +96,8 @@ SIGNATURES = {
     "cplxamd_bn_ws_bytes": [_I],
     "cplxamd_bn_fwd": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P],
     "cplxamd_bn_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _L, _P],
+    "cplxamd_bn_bwd_sums": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _P, _L, _P],
+    "cplxamd_bn_rows_path": [_L, _I, _L],
 }
 _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,

@@ -1,7 +1,7 @@
 """Complex batch-norm autograd Function over the 2-pass moment / apply kernels (csrc/bn.hip)."""
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import call, dtype_code, ptr, require_device, stream_ptr, scratch_key
 
 _ws_cache = {}
@@ -82,7 +82,15 @@ class CplxBatchNormFn(torch.autograd.Function):
             dw = torch.empty(2, 2, F, dtype=torch.float32, device=xr.device)
             db = torch.empty(2, F, dtype=torch.float32, device=xr.device)
         ws = _ws(xr.device, F)
-        call("cplxamd_bn_bwd", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S,
-             ptr(w), ptr(saved), ptr(dw), ptr(db), int(ctx.training), dtype_code(xr), ptr(ws),
+        # channels-last rows: the apply pass also sums dX per channel -- the bias gradient of the convolution that
+        # produced x, which finds it on the gradient tensors (ops.colsum_hint) instead of reading them once more
+        sums = None
+        if ctx.cl and _lib.load().cplxamd_bn_rows_path(B, F, S):
+            sums = torch.empty(2, F, dtype=torch.float32, device=xr.device)
+        call("cplxamd_bn_bwd_sums", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S,
+             ptr(w), ptr(saved), ptr(dw), ptr(db), int(ctx.training), dtype_code(xr), ptr(sums), ptr(ws),
              ws.numel(), stream_ptr())
+        if sums is not None:
+            ops.attach_colsum(dxr, sums[0])
+            ops.attach_colsum(dxi, sums[1])
         return dxr, dxi, dw, db, None, None, None, None, None

@@ -421,6 +421,7 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
     need = ctx.needs_input_grad
     geom = ctx.geom
     dxr = dxi = dwr = dwi = dbr = dbi = None
+    hint_r, hint_i = ops.colsum_hint(gr), ops.colsum_hint(gi)
     gr, gi = to_channels_last(gr), to_channels_last(gi)
     if need[0] or need[1]:
         if _cl_ok(geom, dgrad=True):
@@ -436,8 +437,8 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
             dwr, dwi = conv_wgrad(gr.contiguous(), gi.contiguous(), xr.contiguous(), xi.contiguous(), geom, ctx.wshape)
     if ctx.has_bias and (need[4] or need[5]):
         B, Co, H, W = gr.shape
-        dbr = ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))
-        dbi = ops.colsum(gi.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+        dbr = hint_r if hint_r is not None else ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+        dbi = hint_i if hint_i is not None else ops.colsum(gi.permute(0, 2, 3, 1).reshape(B * H * W, Co))
     return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
 
 

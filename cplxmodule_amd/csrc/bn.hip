@@ -197,12 +197,17 @@ __global__ __launch_bounds__(kBnT) void bn_reduce_rows(const T* xr, const T* xi,
   }
 }
 
-template <typename T, bool BWD>
+// SUMS: also the per-channel sums of the two OUTPUT planes (as stored, i.e. after rounding to T) -> sums_partial[block]
+// [2][F]: the bias gradient of the layer that produced this layer's input is exactly that column sum of dX, and this
+// pass already holds every dX value in registers.
+template <typename T, bool BWD, bool SUMS>
 __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, const T* gr, const T* gi, T* yr, T* yi,
-                                                      const float* coef, int64_t R, int F) {
+                                                      const float* coef, int64_t R, int F, float* sums_partial) {
+  __shared__ float sred[SUMS ? kBnT * 16 : 1];
   const int CG = F >> 3, RL = kBnT / CG;
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
-  if (rl >= RL) return;
+  float su[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
   constexpr int NC = BWD ? kBwdCoef : kFwdCoef;
   float k[8][BWD ? 11 : 8];
 #pragma unroll
@@ -229,6 +234,48 @@ __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, 
     }
     st8(yr + o, ou);
     st8(yi + o, ov);
+    if (SUMS) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a = ou.h[c >> 2].v[c & 3], b = ov.h[c >> 2].v[c & 3];
+        if (sizeof(T) == 2) { a = bf16_to_f32(f32_to_bf16(a)); b = bf16_to_f32(f32_to_bf16(b)); }
+        su[c] += a; sv[c] += b;
+      }
+    }
+  }
+  }
+  if (SUMS) {
+    if (rl < RL) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        sred[rl * 2 * F + cg * 8 + c] = su[c];
+        sred[rl * 2 * F + F + cg * 8 + c] = sv[c];
+      }
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < 2 * F; f += kBnT) {
+      float t = 0.f;
+      for (int l = 0; l < RL; ++l) t += sred[l * 2 * F + f];
+      sums_partial[(int64_t)blockIdx.x * 2 * F + f] = t;
+    }
+  }
+}
+
+// out[n] = sum over chunks of partial[chunk][n] (fixed order), 64 columns per block x 16 chunk lanes
+__global__ __launch_bounds__(1024) void bn_sums_final(const float* partial, int chunks, int n, float* out) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (c < n)
+    for (int j = ty; j < chunks; j += 16) acc += partial[(int64_t)j * n + c];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][tx];
+    out[c] = t;
   }
 }
 
@@ -421,8 +468,11 @@ __global__ __launch_bounds__(kBnT) void bn_apply_cols(const T* xr, const T* xi, 
 
 static bool bn_rows_ok(int64_t B, int F, int64_t S) { return S == 1 && F % 8 == 0 && F <= 1024 && B >= 4096; }
 static int bn_max_chunks(int F) { return (F % 8 == 0 && F <= 1024) ? kBnRowChunks : kBnMaxChunks; }
+static int64_t bn_coef_off(int F) { return (int64_t)bn_max_chunks(F) * F * 6 * sizeof(double); }
+static int64_t bn_sums_off(int F) { return (bn_coef_off(F) + (int64_t)F * kBwdCoef * sizeof(float) + 255) / 256 * 256; }
 static int64_t bn_ws_bytes(int F) {
-  return (int64_t)bn_max_chunks(F) * F * 6 * sizeof(double) + (int64_t)F * kBwdCoef * sizeof(float);
+  // [moment partials][coefficients][2048 x 2F partial sums of the row-kernel backward's dX (only F % 8 == 0, F <= 1024)]
+  return bn_sums_off(F) + ((F % 8 == 0 && F <= 1024) ? (int64_t)2048 * 2 * F * sizeof(float) : 0);
 }
 
 template <typename T, bool BWD>
@@ -430,10 +480,10 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
                   void* yi, int64_t B, int F, int64_t S, const float* weight, const float* bias,
                   float* running_mean, float* running_var, float* saved, float* dweight,
                   float* dbias, int training, float momentum, float eps, void* ws,
-                  hipStream_t st) {
+                  hipStream_t st, float* dx_sums = nullptr) {
   const BnGeom g = bn_geom(B, F, S);
   double* partial = (double*)ws;
-  float* coef = (float*)((char*)ws + (int64_t)bn_max_chunks(F) * F * 6 * sizeof(double));
+  float* coef = (float*)((char*)ws + bn_coef_off(F));
   const bool rows = bn_rows_ok(B, F, S);
   int chunks = g.chunks;
   if (rows) {
@@ -468,8 +518,17 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
   CPLXAMD_CHECK_LAUNCH();
   if (rows) {
     const int RL = kBnT / (F / 8);
-    bn_apply_rows<T, BWD><<<stream_grid((B + RL - 1) / RL * kBnT, kBnT), kBnT, 0, st>>>(
-        (const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr, (T*)yi, coef, B, F);
+    const int grid = stream_grid((B + RL - 1) / RL * kBnT, kBnT);
+    if (BWD && dx_sums) {
+      float* sp = (float*)((char*)ws + bn_sums_off(F));
+      bn_apply_rows<T, BWD, true><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr,
+                                                        (T*)yi, coef, B, F, sp);
+      CPLXAMD_CHECK_LAUNCH();
+      bn_sums_final<<<(2 * F + 63) / 64, 1024, 0, st>>>(sp, grid, 2 * F, dx_sums);
+    } else {
+      bn_apply_rows<T, BWD, false><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr,
+                                                         (T*)yi, coef, B, F, nullptr);
+    }
     CPLXAMD_CHECK_LAUNCH();
   } else if (S > 1) {
     const int64_t planes = B * F;
@@ -527,10 +586,26 @@ int cplxamd_bn_fwd(const void* xr, const void* xi, void* yr, void* yi, int64_t B
   return CPLXAMD_EINVAL;
 }
 
+int cplxamd_bn_rows_path(int64_t B, int F, int64_t S) { return bn_rows_ok(B, F, S) ? 1 : 0; }
+
+int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr,
+                        void* dxi, int64_t B, int F, int64_t S, const float* weight,
+                        const float* saved, float* dweight, float* dbias, int training, int dtype,
+                        float* dx_sums, void* ws, int64_t ws_bytes, void* stream);
+
 int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr,
                    void* dxi, int64_t B, int F, int64_t S, const float* weight,
                    const float* saved, float* dweight, float* dbias, int training, int dtype,
                    void* ws, int64_t ws_bytes, void* stream) {
+  return cplxamd_bn_bwd_sums(gr, gi, xr, xi, dxr, dxi, B, F, S, weight, saved, dweight, dbias, training, dtype, nullptr,
+                             ws, ws_bytes, stream);
+}
+
+int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr,
+                        void* dxi, int64_t B, int F, int64_t S, const float* weight,
+                        const float* saved, float* dweight, float* dbias, int training, int dtype,
+                        float* dx_sums, void* ws, int64_t ws_bytes, void* stream) {
+  if (dx_sums && !bn_rows_ok(B, F, S)) return CPLXAMD_ESHAPE;
   if (!gr || !gi || !xr || !xi || !dxr || !dxi || !saved || !ws || B <= 0 || F <= 0 || S <= 0)
     return CPLXAMD_EINVAL;
   if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
@@ -538,11 +613,11 @@ int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* x
   if (dtype == CPLXAMD_F32)
     return bn_run<float, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr,
                                nullptr, const_cast<float*>(saved), dweight, dbias, training, 0.f,
-                               0.f, ws, st);
+                               0.f, ws, st, dx_sums);
   if (dtype == CPLXAMD_BF16)
     return bn_run<bf16_t, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr,
                                 nullptr, const_cast<float*>(saved), dweight, dbias, training, 0.f,
-                                0.f, ws, st);
+                                0.f, ws, st, dx_sums);
   return CPLXAMD_EINVAL;
 }
 

@@ -202,44 +202,67 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   };
 
   // ---- one stage: 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity) ---------------
-  auto compute = [&](uint32_t cur_off, uint32_t nxt_off) __attribute__((always_inline)) {
+  // One stage = 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity).  Fragments are read one
+  // block ahead of the MFMAs.  The barrier sits in front of the LAST block of the stage, when every read of this slot
+  // has been issued and completed: the first fragments of the next stage are then read under that block's MFMAs
+  // instead of right behind a barrier at which all eight waves (both of every SIMD) would wait for the LDS together.
+  bf16x8 xr[2], xi[2], gr[2], gi[2], hr, hi;
+  auto mfma_block = [&](int n, bf16x8 ar, bf16x8 ai, bf16x8 pr, bf16x8 pi, bf16x8 npr) __attribute__((always_inline)) {
+    // G conj(X): re = gr xr + gi xi, im = gi xr - gr xi; X first: accumulator rows = co, 4 consecutive ci per group
+    acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, pr, acc_r[n], 0, 0, 0);
+    acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, pi, acc_i[n], 0, 0, 0);
+    acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, pi, acc_r[n], 0, 0, 0);
+    acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, npr, acc_i[n], 0, 0, 0);
+  };
+  auto stage = [&](uint32_t cur_off, uint32_t nxt_off, uint32_t next_cur_off) __attribute__((always_inline)) {
     const char* st = smem + cur_off;
-    // fragments one block ahead of the MFMAs (two register sets); LDS-DMA pieces at fixed places of the schedule
-    bf16x8 xr[2], xi[2], gr[2], gi[2];
-    gr[0] = frag_at(st, ga, 0); gi[0] = frag_at(st + KR * 128, ga, 0);
-    xr[0] = frag_at(st, xa[0], 0); xi[0] = frag_at(st + XW_BYTES, xa[0], 0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 ngr = neg(gr[ks]);
+    const char* sn = smem + next_cur_off;
+    // ---- sub-step 0 (entry: gr[0], gi[0], xr[0], xi[0] hold block 0 of this stage)
+    {
+      const bf16x8 ngr = neg(gr[0]);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const int cur = n & 1;
-        // next block's X fragments: block n + 1 of this sub-step, or block 0 of the next one
         if (n < 3) {
-          xr[cur ^ 1] = frag_at(st, xa[n + 1], ks); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[n + 1], ks);
-        } else if (ks == 0) {
+          xr[cur ^ 1] = frag_at(st, xa[n + 1], 0); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[n + 1], 0);
+        } else {
           gr[1] = frag_at(st, ga, 1); gi[1] = frag_at(st + KR * 128, ga, 1);
           xr[cur ^ 1] = frag_at(st, xa[0], 1); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[0], 1);
+          if (hpar == 0) { hr = frag_at(st, xa[4], 0); hi = frag_at(st + XW_BYTES, xa[4], 0); }
         }
-        // G conj(X): re = gr xr + gi xi, im = gi xr - gr xi; X first: accumulator rows = co, 4 consecutive ci per group
-        acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[cur], gr[ks], acc_r[n], 0, 0, 0);
-        acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[cur], gi[ks], acc_i[n], 0, 0, 0);
-        acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi[cur], gi[ks], acc_r[n], 0, 0, 0);
-        acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xi[cur], ngr, acc_i[n], 0, 0, 0);
-        const int piece = ks == 0 ? (n == 0 ? 0 : (n == 2 ? 1 : (n == 3 ? 2 : -1))) : (n == 0 ? 3 : (n == 2 ? 4 : -1));
+        mfma_block(n, xr[cur], xi[cur], gr[0], gi[0], ngr);
+        const int piece = n == 0 ? 0 : (n == 2 ? 1 : (n == 3 ? 2 : -1));
         if (piece >= 0) {
           __builtin_amdgcn_sched_barrier(0);
           issue_piece(piece, nxt_off);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (ks == hpar) {                                // the shared block: this wave's half of its pixels
-        const bf16x8 hr = frag_at(st, xa[4], ks), hi = frag_at(st + XW_BYTES, xa[4], ks);
-        acc_r[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hr, gr[ks], acc_r[4], 0, 0, 0);
-        acc_i[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hr, gi[ks], acc_i[4], 0, 0, 0);
-        acc_r[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, gi[ks], acc_r[4], 0, 0, 0);
-        acc_i[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, ngr, acc_i[4], 0, 0, 0);
+      if (hpar == 0) mfma_block(4, hr, hi, gr[0], gi[0], ngr);
+    }
+    // ---- sub-step 1 (xr[0], xi[0] hold its block 0)
+    {
+      const bf16x8 ngr = neg(gr[1]);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const int cur = n & 1;
+        xr[cur ^ 1] = frag_at(st, xa[n + 1], 1); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[n + 1], 1);
+        if (n == 2 && hpar == 1) { hr = frag_at(st, xa[4], 1); hi = frag_at(st + XW_BYTES, xa[4], 1); }
+        mfma_block(n, xr[cur], xi[cur], gr[1], gi[1], ngr);
+        const int piece = n == 0 ? 3 : (n == 2 ? 4 : -1);
+        if (piece >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(piece, nxt_off);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // every read of this slot has completed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");       // the next stage has landed (this wave's pieces)
+      __builtin_amdgcn_s_barrier();
+      gr[0] = frag_at(sn, ga, 0); gi[0] = frag_at(sn + KR * 128, ga, 0);
+      xr[0] = frag_at(sn, xa[0], 0); xi[0] = frag_at(sn + XW_BYTES, xa[0], 0);
+      mfma_block(3, xr[1], xi[1], gr[1], gi[1], ngr);
+      if (hpar == 1) mfma_block(4, hr, hi, gr[1], gi[1], ngr);
     }
   };
 
@@ -250,14 +273,15 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
       for (int j = 0; j < L; ++j) issue_piece(j, smem_off + (uint32_t)(s * STAGE));
       advance();
     }
-    uint32_t cur = 0, nxt = 2u * STAGE;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");         // stage 0 landed; stage 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+    gr[0] = frag_at(smem, ga, 0); gi[0] = frag_at(smem + KR * 128, ga, 0);
+    xr[0] = frag_at(smem, xa[0], 0); xi[0] = frag_at(smem + XW_BYTES, xa[0], 0);
+    uint32_t cur = 0, nx1 = STAGE, nx2 = 2u * STAGE;
     for (int t = 0; t < nt; ++t) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");       // stage t landed; t + 1 may be in flight
-      __builtin_amdgcn_s_barrier();
-      compute(cur, smem_off + nxt);
+      stage(cur, smem_off + nx2, nx1);
       advance();
-      cur = cur + STAGE == 3u * STAGE ? 0u : cur + STAGE;
-      nxt = nxt + STAGE == 3u * STAGE ? 0u : nxt + STAGE;
+      const uint32_t c = cur; cur = nx1; nx1 = nx2; nx2 = c;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the zero re-loads land before the LDS is released
   }

@@ -139,6 +139,24 @@ __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
+// streaming (nontemporal) 16-byte stores for epilogue outputs that a LATER kernel reads (-DCPLXAMD_GEMM_NT to enable)
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(void* p, uint4 v) {
+#ifdef CPLXAMD_GEMM_NT
+  __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(p));
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void nt_store16(float* p, const f4& a) {
+#ifdef CPLXAMD_GEMM_NT
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f32x4_nt{a.v[0], a.v[1], a.v[2], a.v[3]}, reinterpret_cast<f32x4_nt*>(p));
+#else
+  st4(p, a);
+#endif
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -553,7 +571,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
             if (row < g.M && col < g.N) {
               bf16_t* o = reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col;
               if (col + 7 < g.N) {
-                *reinterpret_cast<uint4*>(o) = v;
+                nt_store16(o, v);
               } else {
                 const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -622,7 +640,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
                   for (int e = 0; e < 4; ++e) v.v[e] += beta * p.v[e];
                 }
-                st4(out + o, v);
+                nt_store16(out + o, v);
               } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)

@@ -267,7 +267,7 @@ __global__ __launch_bounds__((Cfg<CPLX, false>::NT)) void gemm_bf16_persist_kern
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const uint4 val = *reinterpret_cast<const uint4*>(reg + (lane >> 3) * PITCH + (lane & 7) * 16);
             const int row = m0 + wm + i * 32 + round * 8 + (lane >> 3), col = n0 + wn + (lane & 7) * 8;
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col) = val;
+            nt_store16(reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col, val);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
         } else {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__((Cfg<CPLX, false>::NT)) void gemm_bf16_persist_kern
               const int row = m0 + wm + i * 32 + round * 8 + (lane >> 3), col = n0 + wn + j * 32 + (lane & 7) * 4;
               const int64_t o = (int64_t)row * g.ldc + col;
               float* of = reinterpret_cast<float*>(out);
-              st4(of + o, x);
+              nt_store16(of + o, x);
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }

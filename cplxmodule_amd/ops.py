@@ -68,6 +68,21 @@ def colsum(t, out=None):
     return out if dst is None else dst.copy_(out)
 
 
+def attach_colsum(t, sums):
+    """Remember on the tensor object that `sums` (float32 [C]) holds its per-channel sums over every other dimension:
+    a producer that had all values in registers anyway (the batch-norm backward) leaves them for the consumer's bias
+    gradient.  Validated on use against the storage address and the version counter."""
+    t._cplxamd_colsum = (sums, t.data_ptr(), t._version, tuple(t.shape))
+
+
+def colsum_hint(t):
+    """The sums attach_colsum left on exactly this tensor (same storage, unmodified since), or None."""
+    h = getattr(t, "_cplxamd_colsum", None)
+    if h is not None and h[1] == t.data_ptr() and h[2] == t._version and h[3] == tuple(t.shape) and h[0].numel() == t.shape[1]:
+        return h[0]
+    return None
+
+
 def colsum2(tr, ti, out=None):
     """Column sums of two planes (the complex bias gradient) -> float32 ([C], [C])."""
     return colsum(tr, None if out is None else out[0]), colsum(ti, None if out is None else out[1])

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 3
+#define CPLXAMD_ABI_VERSION 4
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -400,6 +400,15 @@ int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* x
                    void* dxi, int64_t B, int F, int64_t S, const float* weight,
                    const float* saved, float* dweight, float* dbias, int training, int dtype,
                    void* ws, int64_t ws_bytes, void* stream);
+/* The same, plus (dx_sums != NULL) the per-feature sums over all rows of the two dX planes as stored, float32 [2][F] --
+ * the bias gradient of a convolution / linear layer whose output this batch-norm normalised, for free: the apply pass
+ * already holds every dX value.  Only on the row-kernel path (cplxamd_bn_rows_path(B, F, S) == 1: S == 1, F % 8 == 0,
+ * F <= 1024, B >= 4096), else CPLXAMD_ESHAPE. */
+int cplxamd_bn_rows_path(int64_t B, int F, int64_t S);
+int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr,
+                        void* dxi, int64_t B, int F, int64_t S, const float* weight,
+                        const float* saved, float* dweight, float* dbias, int training, int dtype,
+                        float* dx_sums, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * layout converters and the non-GEMM layers either side of the path.

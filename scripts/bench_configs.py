@@ -85,7 +85,7 @@ def cfg3(batch, dtype, layout="channels_last"):
         x.real.grad = x.imag.grad = None
         y = bn(conv(x))
         torch.autograd.backward((y.real, y.imag), (y.real.detach(), y.imag.detach()))
-    t = timed(step, 3, 1)
+    t = timed(step, 10, 2)
     flop = 8.0 * batch * 64 * 254 * 254 * 64 * 9 * 3
     with torch.no_grad():
         y = conv(x)

@@ -124,3 +124,37 @@ def test_layout_round_trip_exact(B, C, H, W):
     assert torch.equal(cl.permute(0, 2, 3, 1).contiguous(), x.permute(0, 2, 3, 1).contiguous())
     back = conv.from_channels_last(cl)
     assert back.is_contiguous() and torch.equal(back, x)
+
+
+def test_bias_gradient_from_batchnorm_backward_sums(monkeypatch):
+    """conv -> batch-norm, both channels-last: the convolution's bias gradient is the column sum of the gradient the
+    batch-norm backward writes; its apply pass leaves those sums on the gradient tensors (ops.attach_colsum) and the
+    convolution picks them up instead of a separate pass.  Same numbers as the separate pass."""
+    from cplxmodule_amd import Cplx, nn, ops
+    torch.manual_seed(3)
+    dev = "cuda"
+    conv_, bn = nn.CplxConv2d(64, 64, 3, padding=1).to(dev), nn.CplxBatchNorm2d(64).to(dev)
+    mk = lambda: torch.randn(2, 64, 32, 64, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x = Cplx(mk().requires_grad_(True), mk().requires_grad_(True))
+    g = (mk(), mk())
+    used = []
+    real_hint = ops.colsum_hint
+
+    def run(hint):
+        monkeypatch.setattr(ops, "colsum_hint", hint)
+        conv_.zero_grad(set_to_none=True)
+        y = bn(conv_(x))
+        torch.autograd.backward((y.real, y.imag), g)
+        return conv_.bias.real.grad.clone(), conv_.bias.imag.grad.clone()
+
+    def spy(t):
+        h = real_hint(t)
+        used.append(h is not None)
+        return h
+
+    with_r, with_i = run(spy)
+    assert used == [True, True]
+    sep_r, sep_i = run(lambda t: None)
+    for a, b in ((with_r, sep_r), (with_i, sep_i)):
+        # (4096 terms of magnitude ~1 summed in float32 in two different orders)
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 5e-5
