@@ -429,12 +429,13 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
             if ctx.x_planar:             # the input was a plain contiguous tensor: hand its gradient back in that layout
                 dxr, dxi = from_channels_last(dxr), from_channels_last(dxi)   # (autograd would do it with a slow copy)
         else:
-            dxr, dxi = conv_dgrad(gr.contiguous(), gi.contiguous(), wcr, wci, geom, ctx.xshape)
+            dxr, dxi = conv_dgrad(from_channels_last(gr), from_channels_last(gi), wcr, wci, geom, ctx.xshape)
     if need[2] or need[3]:
         if _cl_wgrad_ok(geom):
             dwr, dwi = cl_wgrad(gr, gi, xr, xi, geom, ctx.wshape)
         else:
-            dwr, dwi = conv_wgrad(gr.contiguous(), gi.contiguous(), xr.contiguous(), xi.contiguous(), geom, ctx.wshape)
+            dwr, dwi = conv_wgrad(from_channels_last(gr), from_channels_last(gi), from_channels_last(xr),
+                                  from_channels_last(xi), geom, ctx.wshape)
     if ctx.has_bias and (need[4] or need[5]):
         B, Co, H, W = gr.shape
         dbr = hint_r if hint_r is not None else ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))
@@ -450,7 +451,10 @@ class CplxConv2dFn(torch.autograd.Function):
         require_device(xr, xi, wr, wi, br, bi)
         geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
-        ctx.cl = xr.dtype == torch.bfloat16 and xi.dtype == torch.bfloat16 and _cl_ok(geom)
+        # (a layer whose weight gradient cannot run channels-last -- image width not a multiple of 32 -- stays on the
+        #  planar path as a whole: converting both operands back for it costs more than the forward saves)
+        ctx.cl = xr.dtype == torch.bfloat16 and xi.dtype == torch.bfloat16 and _cl_ok(geom) and (
+            _cl_wgrad_ok(geom) or not (wr.requires_grad or wi.requires_grad))
         if ctx.cl:                       # channels-last in, channels-last out: no layout copies between such layers
             ctx.x_planar = xr.is_contiguous() and not xr.is_contiguous(memory_format=torch.channels_last)
             xr, xi = to_channels_last(xr), to_channels_last(xi)

@@ -60,7 +60,21 @@ def test_cl_conv_vs_oracle(case, layout):
     if case.startswith(("wgrad_cl", "valid_padding", "half_padding")):
         assert conv._cl_wgrad_ok(geom)
     y = cplx.conv2d(Cplx(txr, txi), Cplx(twr, twi), Cplx(tbr, tbi), **kw_)
-    assert y.real.is_contiguous(memory_format=torch.channels_last)          # the channels-last kernel ran
+    if not conv._cl_wgrad_ok(geom):                  # such a layer stays planar as a whole; the kernel itself is
+        assert not y.real.is_contiguous(memory_format=torch.channels_last) or y.real.is_contiguous()   # checked below
+        y0 = conv.cl_conv(txr.detach(), txi.detach(), q(wr), q(wi), tbr.detach(), tbi.detach(), geom)
+        f = np.float64
+        yr0, yi0 = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), br.astype(f), bi.astype(f), **kw_)
+        np.testing.assert_allclose(N(y0[0]), yr0, rtol=1e-2, atol=1e-2 * np.abs(yr0).max())
+        np.testing.assert_allclose(N(y0[1]), yi0, rtol=1e-2, atol=1e-2 * np.abs(yi0).max())
+        if conv._cl_ok(geom, dgrad=True):
+            g0r, g0i = bf16_round(rs.randn(*yr0.shape)), bf16_round(rs.randn(*yr0.shape))
+            d0 = conv.cl_conv(q(g0r), q(g0i), q(wr), q(wi), None, None, geom, dgrad=True)
+            bw0 = orc.cplx_conv2d_bwd(g0r.astype(f), g0i.astype(f), xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), **kw_)
+            np.testing.assert_allclose(N(d0[0]), bw0["dxr"], rtol=2e-2, atol=2e-2 * np.abs(bw0["dxr"]).max())
+            np.testing.assert_allclose(N(d0[1]), bw0["dxi"], rtol=2e-2, atol=2e-2 * np.abs(bw0["dxi"]).max())
+    else:
+        assert y.real.is_contiguous(memory_format=torch.channels_last)      # the channels-last kernels ran
     f = np.float64
     yr, yi = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), br.astype(f), bi.astype(f), **kw_)
     assert tuple(y.shape) == yr.shape
