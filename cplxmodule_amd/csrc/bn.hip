@@ -261,20 +261,21 @@ __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, 
   }
 }
 
-// out[n] = sum over chunks of partial[chunk][n] (fixed order), 64 columns per block x 16 chunk lanes
+// out[n] = sum over chunks of partial[chunk][n] (fixed order): 16 columns per block x 64 chunk lanes, so that a couple
+// of thousand partial rows are a few dozen loads per thread, not a serial walk
 __global__ __launch_bounds__(1024) void bn_sums_final(const float* partial, int chunks, int n, float* out) {
-  __shared__ float red[16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  __shared__ float red[64][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
   float acc = 0.f;
   if (c < n)
-    for (int j = ty; j < chunks; j += 16) acc += partial[(int64_t)j * n + c];
+    for (int j = ty; j < chunks; j += 64) acc += partial[(int64_t)j * n + c];
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && c < n) {
     float t = 0.f;
-#pragma unroll
-    for (int l = 0; l < 16; ++l) t += red[l][tx];
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) t += red[l][tx];
     out[c] = t;
   }
 }
@@ -524,7 +525,7 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
       bn_apply_rows<T, BWD, true><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr,
                                                         (T*)yi, coef, B, F, sp);
       CPLXAMD_CHECK_LAUNCH();
-      bn_sums_final<<<(2 * F + 63) / 64, 1024, 0, st>>>(sp, grid, 2 * F, dx_sums);
+      bn_sums_final<<<(2 * F + 15) / 16, 1024, 0, st>>>(sp, grid, 2 * F, dx_sums);
     } else {
       bn_apply_rows<T, BWD, false><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr,
                                                          (T*)yi, coef, B, F, nullptr);

@@ -307,34 +307,39 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
 }
 
 // dW[co][ci][kh][kw] (plane) = sum over splits of the block that holds it (+ the second half of a shared block), times
-// emul if given.  One thread per SLAB element of the 36 first-half blocks (consecutive threads read consecutive
-// addresses of every split; the 4-byte writes into dW are scattered but few), fixed summation order.
+// emul if given.  64 consecutive SLAB elements x 4 split lanes per block (consecutive threads read consecutive
+// addresses of a split; lane s sums splits s, s + 4, ... in a fixed order, then the four are added in order): the
+// 4-byte writes into dW are scattered but few.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int splits, int tiles, int tiles_ci, int Co,
                                                            int Ci, const float* emul, float* dw_r, float* dw_i) {
+  __shared__ float red[4][64];
   const int tile = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;            // [36 blocks][plane][32 co][32 ci]
-  if (e >= 36 * 2048) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + tx;                      // [36 blocks][plane][32 co][32 ci]
   const int id = e >> 11, in_blk = e & 2047, pl = in_blk >> 10, col = (in_blk >> 5) & 31, cil = in_blk & 31;
   const int coh = id / 18, b = id - coh * 18, tap = b >> 1, cih = b & 1;
   const int64_t per_split = (int64_t)tiles * NBLK * 2048;
   const float* p = ws + (int64_t)tile * NBLK * 2048 + e;
   const int64_t o2 = (b == 4 || b == 13) ? (int64_t)(36 + coh * 2 + (b == 13 ? 1 : 0) - id) * 2048 : 0;
-  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int s = 0;
-  for (; s + 8 <= splits; s += 8) {
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  int s = ty;
+  for (; s + 12 < splits; s += 16) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float v = p[(int64_t)(s + u) * per_split];
-      if (o2) v += p[(int64_t)(s + u) * per_split + o2];
-      a8[u] += v;
+    for (int u = 0; u < 4; ++u) {
+      float v = p[(int64_t)(s + 4 * u) * per_split];
+      if (o2) v += p[(int64_t)(s + 4 * u) * per_split + o2];
+      a4[u] += v;
     }
   }
-  for (; s < splits; ++s) {
+  for (; s < splits; s += 4) {
     float v = p[(int64_t)s * per_split];
     if (o2) v += p[(int64_t)s * per_split + o2];
-    a8[s & 7] += v;
+    a4[0] += v;
   }
-  const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  red[ty][tx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  __syncthreads();
+  if (ty != 0) return;
+  const float acc = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
   const int co = (tile / tiles_ci) * TC + coh * 32 + col, ci = (tile % tiles_ci) * TC + cih * 32 + cil;
   const int64_t i = ((int64_t)co * Ci + ci) * 9 + tap;
   float* dw = pl ? dw_i : dw_r;
@@ -418,7 +423,7 @@ int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, c
   }
   clw::conv_cl_wgrad_kernel<<<dim3((unsigned)g.splits, (unsigned)tiles), clw::NT, smem, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
-  clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 256, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, Co, Ci,
+  clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, Co, Ci,
                                                                                    emul, dw_r, dw_i);
   CPLXAMD_CHECK_LAUNCH();
   return 0;

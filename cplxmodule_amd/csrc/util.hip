@@ -123,21 +123,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* in, int64_
   }
 }
 
-// 64 columns per block, 16 chunk lanes (fixed summation order: deterministic)
+// 16 columns per block, 64 chunk lanes (fixed summation order: deterministic)
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* partial, int chunks, int cols,
                                                             float* out) {
-  __shared__ float red[16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  __shared__ float red[64][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
   float acc = 0.f;
   if (c < cols)
-    for (int j = ty; j < chunks; j += 16) acc += partial[(int64_t)j * cols + c];
+    for (int j = ty; j < chunks; j += 64) acc += partial[(int64_t)j * cols + c];
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && c < cols) {
     float t = 0.f;
-#pragma unroll
-    for (int l = 0; l < 16; ++l) t += red[l][tx];
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) t += red[l][tx];
     out[c] = t;
   }
 }
@@ -384,7 +384,7 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
     else
       return CPLXAMD_EINVAL;
     CPLXAMD_CHECK_LAUNCH();
-    colsum_final_kernel<<<(cols + 63) / 64, 1024, 0, st>>>((const float*)ws, (int)chunks, cols, out);
+    colsum_final_kernel<<<(cols + 15) / 16, 1024, 0, st>>>((const float*)ws, (int)chunks, cols, out);
     CPLXAMD_CHECK_LAUNCH();
     return 0;
   }
@@ -402,7 +402,7 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
     else
       return CPLXAMD_EINVAL;
     CPLXAMD_CHECK_LAUNCH();
-    colsum_final_kernel<<<(cols + 63) / 64, 1024, 0, st>>>((const float*)ws, chunks, cols, out);
+    colsum_final_kernel<<<(cols + 15) / 16, 1024, 0, st>>>((const float*)ws, chunks, cols, out);
     CPLXAMD_CHECK_LAUNCH();
     return 0;
   }
