@@ -24,6 +24,20 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+def _layout_of(t):
+    """The dense layout the elementwise kernels should keep for `t`: torch.channels_last when a 4-d tensor is stored
+    so (and is not plain contiguous as well), else torch.contiguous_format.  The kernels walk the storage linearly, so
+    any ONE dense layout shared by all operands and outputs is as good as another -- and converting a channels-last
+    activation to NCHW here would break a conv -> batch-norm -> activation -> conv chain that needs no copy at all."""
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
+        return torch.channels_last
+    return torch.contiguous_format
+
+
+def _cf(t, fmt):
+    return None if t is None else t.contiguous(memory_format=fmt)
+
+
 def _f32(t):
     if t is not None and t.dtype != torch.float32:
         raise _lib.CplxAmdError(f"expected a float32 tensor, got {t.dtype}")
@@ -101,7 +115,8 @@ def abs2(xr, xi=None, out_dtype=None):
 def modulus(xr, xi):
     """abs(Cplx), cplxmodule/cplx.py:183-192 (float32 or bfloat16 planes)."""
     require_device(xr, xi)
-    xr, xi = _c(xr), _c(xi)
+    fmt = _layout_of(xr)
+    xr, xi = _cf(xr, fmt), _cf(xi, fmt)
     out = torch.empty_like(xr)
     call("cplxamd_cplx_abs_fwd", ptr(xr), ptr(xi), ptr(out), xr.numel(), dtype_code(xr), stream_ptr())
     return out
@@ -927,14 +942,15 @@ class AbsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, zr, zi):
         require_device(zr, zi)
-        zr, zi = _c(zr), _c(zi)
+        ctx.fmt = fmt = _layout_of(zr)
+        zr, zi = _cf(zr, fmt), _cf(zi, fmt)
         ctx.save_for_backward(zr, zi)
         return modulus(zr, zi)
 
     @staticmethod
     def backward(ctx, g):
         zr, zi = ctx.saved_tensors
-        g = _c(g)
+        g = _cf(g, ctx.fmt)
         if g.dtype != zr.dtype:
             g = cast(g, zr.dtype)
         dzr, dzi = torch.empty_like(zr), torch.empty_like(zi)
@@ -1092,15 +1108,15 @@ class InterleaveFn(torch.autograd.Function):
         return DeinterleaveFn.apply(g)
 
 
-def _tau_args(tau, like):
+def _tau_args(tau, like, fmt=torch.contiguous_format):
     """(device pointer, value, numel) of a modReLU threshold: python float -> by value; 1-element
-    tensor -> read on the device; anything else -> broadcast to the activation's shape."""
+    tensor -> read on the device; anything else -> broadcast to the activation's shape (and storage layout)."""
     if not isinstance(tau, torch.Tensor):
         return None, float(tau), 0, None
     t = _f32(tau)
     if t.numel() == 1:
         return t, 0.0, 1, t
-    t = _al16(t.expand(like.shape).contiguous())
+    t = _al16(t.expand(like.shape).contiguous(memory_format=fmt))
     return t, 0.0, t.numel(), t
 
 
@@ -1110,8 +1126,9 @@ class ModReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, zr, zi, tau):
         require_device(zr, zi)
-        zr, zi = _al16(_c(zr)), _al16(_c(zi))
-        tp, tv, tn, keep = _tau_args(tau, zr)
+        ctx.fmt = fmt = _layout_of(zr)
+        zr, zi = _al16(_cf(zr, fmt)), _al16(_cf(zi, fmt))
+        tp, tv, tn, keep = _tau_args(tau, zr, fmt)
         yr, yi = torch.empty_like(zr), torch.empty_like(zi)
         call("cplxamd_modrelu_fwd", ptr(zr), ptr(zi), ptr(tp), tv, tn, ptr(yr), ptr(yi), zr.numel(),
              dtype_code(zr), stream_ptr())
@@ -1124,10 +1141,10 @@ class ModReluFn(torch.autograd.Function):
         zr, zi, *rest = ctx.saved_tensors
         tv, tn, tshape = ctx.tau
         tp = rest[0] if rest else None
-        gr, gi = _al16(_c(gr)), _al16(_c(gi))
+        gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
         dzr, dzi = torch.empty_like(zr), torch.empty_like(zi)
         want_tau = tshape is not None and ctx.needs_input_grad[2]
-        dtau = torch.empty(zr.shape, dtype=torch.float32, device=zr.device) if want_tau else None
+        dtau = torch.empty(zr.shape, dtype=torch.float32, device=zr.device, memory_format=ctx.fmt) if want_tau else None
         call("cplxamd_modrelu_bwd", ptr(zr), ptr(zi), ptr(tp), tv, tn, ptr(gr), ptr(gi), ptr(dzr),
              ptr(dzi), ptr(dtau), zr.numel(), dtype_code(zr), stream_ptr())
         if want_tau:
@@ -1142,7 +1159,8 @@ class CplxDropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xr, xi, p, seed, offset):
         require_device(xr, xi)
-        xr, xi = _al16(_c(xr)), _al16(_c(xi))
+        ctx.fmt = fmt = _layout_of(xr)       # (the mask is a function of the position in STORAGE order: same layout in backward)
+        xr, xi = _al16(_cf(xr, fmt)), _al16(_cf(xi, fmt))
         ctx.p, ctx.seed, ctx.offset = p, seed, offset
         return CplxDropoutFn._run(xr, xi, p, seed, offset)
 
@@ -1156,7 +1174,7 @@ class CplxDropoutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gr, gi):
-        dr, di = CplxDropoutFn._run(_al16(_c(gr)), _al16(_c(gi)), ctx.p, ctx.seed, ctx.offset)
+        dr, di = CplxDropoutFn._run(_al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt)), ctx.p, ctx.seed, ctx.offset)
         return dr, di, None, None, None
 
 

@@ -172,3 +172,37 @@ def test_bias_gradient_from_batchnorm_backward_sums(monkeypatch):
     for a, b in ((with_r, sep_r), (with_i, sep_i)):
         # (4096 terms of magnitude ~1 summed in float32 in two different orders)
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 5e-5
+
+
+def test_activations_keep_channels_last():
+    """modReLU (scalar, 1-element and per-channel thresholds, with gradients), abs and dropout are elementwise: on
+    channels-last inputs they keep the layout (no NCHW round trip inside a conv -> bn -> activation -> conv chain) and
+    give the same numbers as on plain contiguous copies of the same tensors."""
+    from cplxmodule_amd import Cplx, cplx, ops
+    torch.manual_seed(11)
+    dev = "cuda"
+    for dtype in (torch.float32, torch.bfloat16):
+        a, b = torch.randn(2, 16, 6, 10, device=dev).to(dtype), torch.randn(2, 16, 6, 10, device=dev).to(dtype)
+        g1, g2 = torch.randn_like(a), torch.randn_like(a)
+        for tau in (0.3, torch.tensor(0.3, device=dev), (0.5 * torch.rand(1, 16, 1, 1, device=dev))):
+            outs = []
+            for fmt in (torch.contiguous_format, torch.channels_last):
+                zr, zi = (t.contiguous(memory_format=fmt).clone().requires_grad_(True) for t in (a, b))
+                th = tau.clone().requires_grad_(True) if isinstance(tau, torch.Tensor) else tau
+                y = cplx.modrelu(Cplx(zr, zi), th)
+                if fmt == torch.channels_last:
+                    assert y.real.is_contiguous(memory_format=fmt) and not y.real.is_contiguous()
+                torch.autograd.backward((y.real, y.imag), (g1.contiguous(memory_format=fmt), g2.contiguous(memory_format=fmt)))
+                outs.append([y.real, y.imag, zr.grad, zi.grad] + ([th.grad] if isinstance(th, torch.Tensor) else []))
+                if fmt == torch.channels_last:
+                    assert zr.grad.is_contiguous(memory_format=fmt)
+            for p, q in zip(*outs):
+                tol = 0 if p.shape == a.shape else 1e-5 * float(q.abs().max()) + 1e-6     # (dtau: a sum, order differs)
+                assert float((p.detach().float() - q.detach().float()).abs().max()) <= tol
+        zr, zi = (t.contiguous(memory_format=torch.channels_last).clone().requires_grad_(True) for t in (a, b))
+        m = abs(Cplx(zr, zi))
+        assert m.is_contiguous(memory_format=torch.channels_last) and torch.equal(m, ops.modulus(a, b))
+        m.backward(g1.contiguous(memory_format=torch.channels_last))
+        zr2, zi2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        abs(Cplx(zr2, zi2)).backward(g1)
+        assert torch.equal(zr.grad, zr2.grad) and torch.equal(zi.grad, zi2.grad)
