@@ -156,6 +156,48 @@ def hbm_points(dev):
     return out
 
 
+def conv_point(dev, batch=64):
+    """BASELINE configs[2] beside the headline (rank 0, N = 1, outside the timed region): CplxConv2d(64, 64, 3) on
+    256 x 256 bf16 images + CplxBatchNorm2d, forward + backward, channels-last input, `batch` images per step;
+    images/s over 10 steps and the three convolution kernels' share of the dense bf16 MFMA peak (HIP events around
+    the C-ABI calls: algorithmic 8 B Co Ho Wo Ci 9 flop per launch)."""
+    try:
+        from cplxmodule_amd import Cplx, nn, conv as cv
+        timer = KernelTimer()
+        timer.wrap(cv, "cl_conv", lambda *a, **k: "dgrad" if k.get("dgrad") else "fwd")
+        timer.wrap(cv, "cl_wgrad", lambda *a, **k: "wgrad")
+        torch.manual_seed(0)
+        layer, bn = nn.CplxConv2d(64, 64, 3).to(dev), nn.CplxBatchNorm2d(64).to(dev)
+        mk = lambda: (torch.randn(batch, 64, 256, 256, device=dev).bfloat16()  # noqa: E731
+                      .contiguous(memory_format=torch.channels_last).requires_grad_(True))
+        x = Cplx(mk(), mk())
+
+        def step():
+            layer.zero_grad(set_to_none=True); bn.zero_grad(set_to_none=True)
+            x.real.grad = x.imag.grad = None
+            y = bn(layer(x))
+            torch.autograd.backward((y.real, y.imag), (y.real.detach(), y.imag.detach()))
+        for _ in range(3):
+            step()
+        timer.enabled = True
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        flop = 8.0 * batch * 64 * 254 * 254 * 64 * 9
+        out = {"workload": f"CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, bf16, batch {batch}, fwd+bwd, channels-last",
+               "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flop_per_launch": flop}
+        for k in ("fwd", "dgrad", "wgrad"):
+            ms = timer.mean_ms(k)
+            out[f"{k}_ms"] = round(ms, 4) if ms else None
+            out[f"{k}_frac_of_mfma_peak"] = round(flop / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4) if ms else None
+        return out
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)[:200]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -269,6 +311,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["hbm_kernels_GBps"].update(hbm_points(dev))
+            line["conv_cfg3"] = conv_point(dev)
             line["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(line), flush=True)
     if world > 1:
