@@ -252,3 +252,44 @@ def test_three_block_chain_matches_planar_path():
     for p, q in zip(*res):
         assert p.shape == q.shape
         assert float((p - q).abs().max()) <= 4e-2 * float(q.abs().max()) + 1e-3, (p.shape, float((p - q).abs().max()), float(q.abs().max()))
+
+
+def test_cl_entry_points_refuse_what_they_are_not_built_for():
+    """The channels-last entry points answer CPLXAMD_ESHAPE / EALIGN / EINVAL for unsupported calls (the host then
+    falls back to the padded-grid or generic kernels) instead of computing something else."""
+    from cplxmodule_amd import _lib
+    from cplxmodule_amd._lib import ptr, stream_ptr
+    lib = _lib.load()
+    dev, bf = "cuda", torch.bfloat16
+    B, C, H, W = 1, 64, 8, 32
+    x = torch.zeros(B, H, W, C, device=dev, dtype=bf)
+    y = torch.zeros(B, H, W, 64, device=dev, dtype=bf)
+    wp = torch.zeros(int(lib.cplxamd_conv2d_cl_pack_bytes(64, C, 3, 3)), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(int(lib.cplxamd_conv2d_cl_ws_bytes(64)), dtype=torch.uint8, device=dev)
+
+    def conv(C_=C, N=64, KH=3, KW=3, pad=1, dil=1, xin=x, mode=0, ws_=ws):
+        return lib.cplxamd_conv2d_cl(ptr(xin), ptr(xin), ptr(wp), None, None, ptr(y), ptr(y), B, H, W, C_, N, KH, KW, dil, dil,
+                                     pad, pad, mode, ptr(ws_), ws_.numel(), stream_ptr())
+    class E:                                             # include/cplxamd.h
+        EINVAL, EALIGN, ESHAPE = -1, -2, -3
+    assert conv() == 0
+    assert conv(KW=5, pad=2) == E.ESHAPE                 # kernel width
+    assert conv(C_=24) == E.ESHAPE                       # channels not a multiple of 16
+    assert conv(N=32) == E.ESHAPE                        # output channels not a multiple of 64
+    assert conv(C_=32) == 0                              # KH * C / 16 = 6 is fine ...
+    assert conv(C_=16) == E.ESHAPE                       # ... 3 is not a multiple of 6
+    assert conv(pad=2) == E.ESHAPE                       # more than `same`
+    assert conv(mode=2) == E.EINVAL
+    assert conv(xin=x.view(-1)[4:].view(-1)) == E.EALIGN  # 8-byte aligned plane
+    assert conv(ws_=ws[:16]) == E.EINVAL
+    g = torch.zeros(B, H, W, 64, device=dev, dtype=bf)
+    dw = torch.zeros(64, 64, 3, 3, device=dev)
+    wsw = torch.zeros(int(lib.cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, 64, 64)), dtype=torch.uint8, device=dev)
+
+    def wgrad(W_=W, Ci=64, KH=3, dil=1, pad=1):
+        return lib.cplxamd_conv2d_cl_wgrad(ptr(g), ptr(g), ptr(x), ptr(x), None, ptr(dw), ptr(dw), B, H, W_, Ci, 64, KH, 3, dil, dil,
+                                           pad, pad, ptr(wsw), wsw.numel(), stream_ptr())
+    assert wgrad() == 0
+    assert wgrad(W_=24) == E.ESHAPE and wgrad(Ci=32) == E.ESHAPE and wgrad(KH=1) == E.ESHAPE and wgrad(pad=2) == E.ESHAPE
+    assert lib.cplxamd_cl_to_nchw(ptr(x), ptr(y), 1, 12, 64, stream_ptr()) == E.ESHAPE
+    torch.cuda.synchronize()
