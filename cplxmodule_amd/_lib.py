@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -65,6 +65,12 @@ SIGNATURES = {
     "cplxamd_conv2d_nhwc_wgrad": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P, _L, _P],
     "cplxamd_conv2d_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_L] + [_I] * 5 + [_P],
     "cplxamd_cl_to_nchw": [_P, _P, _L, _I, _L, _P],
+    "cplxamd_conv2d_clr_pack_bytes": [_I, _I, _I, _I],
+    "cplxamd_conv2d_clr_ws_bytes": [_I],
+    "cplxamd_conv2d_clr_pack": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "cplxamd_conv2d_clr": [_P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _P],
+    "cplxamd_conv2d_clr_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
+    "cplxamd_conv2d_clr_wgrad": [_P, _P, _P, _I, _P, _L] + [_I] * 10 + [_P, _L, _P],
     "cplxamd_conv2d_cl_pack_bytes": [_I, _I, _I, _I],
     "cplxamd_conv2d_cl_ws_bytes": [_I],
     "cplxamd_conv2d_cl_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -105,7 +111,8 @@ _RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes": c_int64,
              "cplxamd_conv2d_cl_pack_bytes": c_int64, "cplxamd_conv2d_cl_ws_bytes": c_int64,
-             "cplxamd_conv2d_cl_wgrad_ws_bytes": c_int64}
+             "cplxamd_conv2d_cl_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_clr_pack_bytes": c_int64,
+             "cplxamd_conv2d_clr_ws_bytes": c_int64, "cplxamd_conv2d_clr_wgrad_ws_bytes": c_int64}
 
 _lib = None
 

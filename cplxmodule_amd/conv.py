@@ -248,6 +248,41 @@ def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False):
     return yr, yi
 
 
+def cl_conv_real(x, w, b, geom, dgrad=False):
+    """Real-valued cl_conv (csrc/conv_cl_real.hip): the variance path of the LRT layers and the real VD / ARD layers."""
+    B, Ci, Co, H, W, KH, KW = (geom[i] for i in range(7))
+    C, N = (Co, Ci) if dgrad else (Ci, Co)
+    x = to_channels_last(x)
+    lib = _lib.load()
+    wp = torch.empty(int(lib.cplxamd_conv2d_clr_pack_bytes(N, C, KH, KW)), dtype=torch.uint8, device=x.device)
+    call("cplxamd_conv2d_clr_pack", ptr(w), ptr(wp), Co, Ci, KH, KW, int(dgrad), stream_ptr())
+    Ho = H + 2 * geom[9] - geom[11] * (KH - 1)
+    Wo = W + 2 * geom[10] - geom[12] * (KW - 1)
+    oshape = (B, N, H, W) if dgrad else (B, N, Ho, Wo)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    ws = _scratch(x.device, int(lib.cplxamd_conv2d_clr_ws_bytes(N)))
+    call("cplxamd_conv2d_clr", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9],
+         geom[10], int(dgrad), ptr(ws), ws.numel(), stream_ptr())
+    return y
+
+
+def cl_wgrad_real(g, x, geom, w_shape, emul=None, emul_exp=False):
+    """dW (float32 [Co, Ci, 3, 3]) = (sum g x) * emul (or * exp(emul)) from channels-last planes."""
+    B, Ci, Co, H, W = (geom[i] for i in range(5))
+    g, x = to_channels_last(g), to_channels_last(x)
+    ws = _scratch(g.device, int(_lib.load().cplxamd_conv2d_clr_wgrad_ws_bytes(B, H, W, Ci, Co)))
+    dw = torch.empty(w_shape, dtype=torch.float32, device=g.device)
+    call("cplxamd_conv2d_clr_wgrad", ptr(g), ptr(x), ptr(emul), int(emul_exp), ptr(dw), B, H, W, Ci, Co, geom[5], geom[6],
+         geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr())
+    return dw
+
+
+def _cl_layer_ok(geom, *tensors):
+    """A whole layer (forward, data gradient, weight gradient) on the channels-last kernels?"""
+    return (all(t is None or t.dtype == torch.bfloat16 for t in tensors) and _cl_ok(geom) and _cl_ok(geom, dgrad=True)
+            and _cl_wgrad_ok(geom))
+
+
 def _pack_rows(w, swap):
     """[Co, Ci, KH, KW] -> [KH][KW][C/v][N][v] for the shifted-row kernels (v = 16 bf16 or 4 float32 =
     one MFMA operand load): (C, N) = (Ci, Co) for the forward, (Co, Ci) with both spatial dims
@@ -497,9 +532,18 @@ class RealConv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, groups):
         require_device(x, w, b)
+        geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
+        ctx.cl = _cl_layer_ok(geom, x)
+        if ctx.cl:
+            ctx.x_planar = x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last)
+            x = to_channels_last(x)
+            wc = ops.cast(w.contiguous(), x.dtype)
+            y = cl_conv_real(x, wc, None if b is None else b.contiguous(), geom)
+            ctx.save_for_backward(x, wc)
+            ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, b is not None, w.shape, x.shape
+            return y
         x = x.contiguous()
         wc = ops.cast(w.contiguous(), x.dtype)
-        geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
         y, _, xp = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom,
                             oshape, keep_grid=True)
         ctx.grid = xp is not None and _rows_wgrad_ok(geom, False, x.dtype)
@@ -510,9 +554,22 @@ class RealConv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, wc = ctx.saved_tensors
-        g = g.contiguous()
         need = ctx.needs_input_grad
         dx = dw = db = None
+        if ctx.cl:
+            hint = ops.colsum_hint(g)
+            g = to_channels_last(g)
+            if need[0]:
+                dx = cl_conv_real(g, wc, None, ctx.geom, dgrad=True)
+                if ctx.x_planar:
+                    dx = from_channels_last(dx)
+            if need[1]:
+                dw = cl_wgrad_real(g, x, ctx.geom, ctx.wshape)
+            if ctx.has_bias and need[2]:
+                B, Co, H, W = g.shape
+                db = hint if hint is not None else ops.colsum(g.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+            return dx, dw, db, None, None, None, None
+        g = g.contiguous()
         gp = _shared_grad_grid(g, None, ctx.geom, need[0], need[1])
         if need[0]:
             dx, _ = conv_dgrad(g, None, wc, None, ctx.geom, ctx.xshape, gp=gp)
@@ -555,15 +612,24 @@ class CplxConv2dLRTFn(torch.autograd.Function):
     def forward(ctx, xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i, seed, offset, stride, padding,
                 dilation, groups):
         require_device(xr, xi, wr, wi, br, bi, ls2, eps_r, eps_i)
-        xr, xi = xr.contiguous(), xi.contiguous()
+        geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
+        ctx.cl = _cl_layer_ok(geom, xr, xi)
+        if ctx.cl:      # channels-last end to end: mean conv, variance conv, noise injection all on [B][H][W][C] planes
+            ctx.x_planar = xr.is_contiguous() and not xr.is_contiguous(memory_format=torch.channels_last)
+            xr, xi = to_channels_last(xr), to_channels_last(xi)
+        else:
+            xr, xi = xr.contiguous(), xi.contiguous()
         dt = xr.dtype
         wcr, wci = ops.cast(wr.contiguous(), dt), ops.cast(wi.contiguous(), dt)
-        geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
-        mur, mui = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape)
         a = ops.abs2(xr, xi)
         S = ops.exp(ls2.contiguous(), out_dtype=dt)
-        s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
+        if ctx.cl:
+            mur, mui = cl_conv(xr, xi, wcr, wci, b[0], b[1], geom)
+            s2 = cl_conv_real(a, S, None, geom)
+        else:
+            mur, mui = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape)
+            s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
         s2 = ops.cast(s2, torch.float32)
         eps = None if eps_r is None else (eps_r, eps_i)
         yr, yi = ops.reparam_fwd(mur, mui, s2, eps, seed, offset, inplace=True)
@@ -575,11 +641,31 @@ class CplxConv2dLRTFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gr, gi):
         xr, xi, wcr, wci, ls2, s2, a, S, eps_r, eps_i = ctx.saved_tensors
-        gr, gi = gr.contiguous(), gi.contiguous()
         need = ctx.needs_input_grad
         eps = None if eps_r is None else (eps_r, eps_i)
-        gs2 = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype)
         dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
+        if ctx.cl:
+            geom = ctx.geom
+            hint_r, hint_i = ops.colsum_hint(gr), ops.colsum_hint(gi)
+            gr, gi = to_channels_last(gr), to_channels_last(gi)
+            gs2 = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype)
+            if need[0] or need[1]:
+                dxr, dxi = cl_conv(gr, gi, wcr, wci, None, None, geom, dgrad=True)
+                ga = cl_conv_real(gs2, S, None, geom, dgrad=True)
+                ops.lrt_dx_accum(dxr, dxi, xr, xi, ga)
+                if ctx.x_planar:
+                    dxr, dxi = from_channels_last(dxr), from_channels_last(dxi)
+            if need[2] or need[3]:
+                dwr, dwi = cl_wgrad(gr, gi, xr, xi, geom, ctx.wshape)
+            if ctx.has_bias and (need[4] or need[5]):
+                B, Co, H, W = gr.shape
+                dbr = hint_r if hint_r is not None else ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+                dbi = hint_i if hint_i is not None else ops.colsum(gi.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+            if need[6]:
+                dls2 = cl_wgrad_real(gs2, a, geom, ctx.wshape, emul=ls2.contiguous(), emul_exp=True)
+            return (dxr, dxi, dwr, dwi, dbr, dbi, dls2) + (None,) * 8
+        gr, gi = gr.contiguous(), gi.contiguous()
+        gs2 = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype)
         if need[0] or need[1]:
             dxr, dxi = conv_dgrad(gr, gi, wcr, wci, ctx.geom, xr.shape)
             ga, _ = conv_dgrad(gs2, None, S, None, ctx.geom, xr.shape)
@@ -614,14 +700,23 @@ class RealConv2dLRTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, ls2, eps, seed, offset, stride, padding, dilation, groups):
         require_device(x, w, b, ls2, eps)
-        x = x.contiguous()
+        geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
+        ctx.cl = _cl_layer_ok(geom, x)
+        if ctx.cl:
+            ctx.x_planar = x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last)
+            x = to_channels_last(x)
+        else:
+            x = x.contiguous()
         dt = x.dtype
         wc = ops.cast(w.contiguous(), dt)
-        geom, oshape = _geom(x.shape, w.shape, stride, padding, dilation, groups)
-        mu, _ = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom, oshape)
         a = ops.abs2(x)
         S = ops.exp(ls2.contiguous(), out_dtype=dt)
-        s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
+        if ctx.cl:
+            mu = cl_conv_real(x, wc, None if b is None else b.contiguous(), geom)
+            s2 = cl_conv_real(a, S, None, geom)
+        else:
+            mu, _ = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom, oshape)
+            s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
         s2 = ops.cast(s2, torch.float32)
         y, _ = ops.reparam_fwd(mu, None, s2, eps, seed, offset, inplace=True)
         ctx.save_for_backward(x, wc, ls2, s2, a, S, eps)
@@ -632,10 +727,29 @@ class RealConv2dLRTFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, wc, ls2, s2, a, S, eps = ctx.saved_tensors
-        g = g.contiguous()
         need = ctx.needs_input_grad
-        gs2 = ops.reparam_bwd(g, None, s2, eps, ctx.seed, ctx.offset, out_dtype=x.dtype)
         dx = dw = db = dls2 = None
+        if ctx.cl:
+            geom = ctx.geom
+            hint = ops.colsum_hint(g)
+            g = to_channels_last(g)
+            gs2 = ops.reparam_bwd(g, None, s2, eps, ctx.seed, ctx.offset, out_dtype=x.dtype)
+            if need[0]:
+                dx = cl_conv_real(g, wc, None, geom, dgrad=True)
+                ga = cl_conv_real(gs2, S, None, geom, dgrad=True)
+                ops.lrt_dx_accum(dx, None, x, None, ga)
+                if ctx.x_planar:
+                    dx = from_channels_last(dx)
+            if need[1]:
+                dw = cl_wgrad_real(g, x, geom, ctx.wshape)
+            if ctx.has_bias and need[2]:
+                B, Co, H, W = g.shape
+                db = hint if hint is not None else ops.colsum(g.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+            if need[3]:
+                dls2 = cl_wgrad_real(gs2, a, geom, ctx.wshape, emul=ls2.contiguous(), emul_exp=True)
+            return (dx, dw, db, dls2) + (None,) * 7
+        g = g.contiguous()
+        gs2 = ops.reparam_bwd(g, None, s2, eps, ctx.seed, ctx.offset, out_dtype=x.dtype)
         if need[0]:
             dx, _ = conv_dgrad(g, None, wc, None, ctx.geom, x.shape)
             ga, _ = conv_dgrad(gs2, None, S, None, ctx.geom, x.shape)

@@ -52,7 +52,7 @@ def cast(t, dtype):
     if t.dtype == dtype:
         return t
     require_device(t)
-    t = t.contiguous()
+    t = _cf(t, _layout_of(t))             # (elementwise: any one dense layout; a channels-last tensor stays so)
     out = torch.empty_like(t, dtype=dtype)
     call("cplxamd_cast", ptr(t), ptr(out), t.numel(), dtype_code(t), dtype_code(out), stream_ptr())
     return out
@@ -105,7 +105,8 @@ def colsum2(tr, ti, out=None):
 def abs2(xr, xi=None, out_dtype=None):
     """xr^2 + xi^2 (or xr^2), cplxmodule/nn/relevance/complex/base.py:51."""
     require_device(xr, xi)
-    xr, xi = _c(xr), _c(xi)
+    fmt = _layout_of(xr)
+    xr, xi = _cf(xr, fmt), _cf(xi, fmt)
     out = torch.empty_like(xr, dtype=out_dtype or xr.dtype)
     call("cplxamd_abs2", ptr(xr), ptr(xi), ptr(out), xr.numel(), dtype_code(xr),
          dtype_code(out), stream_ptr())
@@ -262,11 +263,12 @@ def _al16(t):
 def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
     """y = mu + eps * sqrt(max(s2, 1e-8)); eps=(eps_r, eps_i) / eps_r tensor or None (Philox)."""
     require_device(mu_r, mu_i, s2)
-    mu_r, mu_i, s2 = _al16(_c(mu_r)), _al16(_c(mu_i)), _al16(_f32(_c(s2)))
+    fmt = _layout_of(mu_r)               # all operands in the layout of mu (the kernel walks the storage linearly)
+    mu_r, mu_i, s2 = _al16(_cf(mu_r, fmt)), _al16(_cf(mu_i, fmt)), _al16(_f32(_cf(s2, fmt)))
     e_r = e_i = None
     if eps is not None:
         e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
-        e_r, e_i = _c(cast(e_r, mu_r.dtype)), (None if e_i is None else _c(cast(e_i, mu_r.dtype)))
+        e_r, e_i = _cf(cast(e_r, mu_r.dtype), fmt), (None if e_i is None else _cf(cast(e_i, mu_r.dtype), fmt))
         e_r, e_i = _al16(e_r), _al16(e_i)
     y_r = mu_r if inplace else torch.empty_like(mu_r)
     y_i = None if mu_i is None else (mu_i if inplace else torch.empty_like(mu_i))
@@ -278,11 +280,12 @@ def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
 
 def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float32):
     require_device(g_r, g_i, s2)
-    g_r, g_i, s2 = _al16(_c(g_r)), _al16(_c(g_i)), _al16(_f32(_c(s2)))
+    fmt = _layout_of(s2)                 # the layout the forward ran in (s2 is its saved tensor)
+    g_r, g_i, s2 = _al16(_cf(g_r, fmt)), _al16(_cf(g_i, fmt)), _al16(_f32(_cf(s2, fmt)))
     e_r = e_i = None
     if eps is not None:
         e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
-        e_r, e_i = _c(cast(e_r, g_r.dtype)), (None if e_i is None else _c(cast(e_i, g_r.dtype)))
+        e_r, e_i = _cf(cast(e_r, g_r.dtype), fmt), (None if e_i is None else _cf(cast(e_i, g_r.dtype), fmt))
         e_r, e_i = _al16(e_r), _al16(e_i)
     g_s2 = torch.empty_like(s2, dtype=out_dtype)
     sd, of, st = _noise_args(seed, offset)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 4
+#define CPLXAMD_ABI_VERSION 5
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -377,6 +377,21 @@ int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co
 int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                             float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
                             int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, void* stream);
+/* REAL-valued twins of the three entry points above (csrc/conv_cl_real.hip, conv_cl_wgrad_real.hip): one plane each,
+ * same shapes and conditions.  They carry the variance path of the local-reparameterization convolution layers
+ * (conv of |x|^2 with exp(log_sigma2): nn/relevance/complex/base.py:120-135, real/base.py:116-163) and the real
+ * Conv2dVD / ARD layers; cplxamd_conv2d_clr_wgrad can multiply the result by emul or exp(emul) ([Co][Ci][3][3] float32:
+ * d log_sigma2 = (sum g |x|^2) * exp(log_sigma2)). */
+int64_t cplxamd_conv2d_clr_pack_bytes(int N, int C, int KH, int KW);
+int64_t cplxamd_conv2d_clr_ws_bytes(int N);
+int cplxamd_conv2d_clr_pack(const void* w, void* out, int Co, int Ci, int KH, int KW, int dgrad, void* stream);
+int cplxamd_conv2d_clr(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int H, int W, int C,
+                       int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws,
+                       int64_t ws_bytes, void* stream);
+int64_t cplxamd_conv2d_clr_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co);
+int cplxamd_conv2d_clr_wgrad(const void* g, const void* x, const float* emul, int emul_exp, float* dw, int64_t B, int H,
+                             int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, void* ws,
+                             int64_t ws_bytes, void* stream);
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);
