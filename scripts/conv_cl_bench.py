@@ -61,7 +61,13 @@ def k_dgrad():
          1, 1, PAD, PAD, 1, ptr(ws), ws.numel(), stream_ptr())
 
 
+a_cl = (xr_cl.float() ** 2).to(bf).contiguous(memory_format=torch.channels_last)
+S_w = torch.rand(Co, C, 3, 3, device=dev).mul(0.01).to(bf)
+RF = 0.25                                            # real flops = complex / 4
 rows = [("cl kernel fwd (+bias)", k_fwd), ("cl kernel dgrad", k_dgrad),
+        ("cl REAL fwd (x0.25 flop)", lambda: conv.cl_conv_real(a_cl, S_w, None, geom)),
+        ("cl REAL dgrad (x0.25 flop)", lambda: conv.cl_conv_real(gr_cl, S_w, None, geom, dgrad=True)),
+        ("cl REAL wgrad (x0.25 flop)", lambda: conv.cl_wgrad_real(gr_cl, a_cl, geom, wr.shape)),
         ("cl wgrad (+ slab reduce)", lambda: conv.cl_wgrad(gr_cl, gi_cl, xr_cl, xi_cl, geom, wr.shape)),
         ("cl fwd incl. weight pack", lambda: conv.cl_conv(xr_cl, xi_cl, wr, wi, br, bi, geom)),
         ("r01 fwd (2 pads + conv_nhwc)", lambda: conv.conv_fwd(xr, xi, wr, wi, br, bi, geom, oshape)),
@@ -73,4 +79,5 @@ if os.environ.get("ONLY"):
 print(f"# B={B} C={C} Co={Co} {H}x{W} 3x3 pad {PAD}: {flop / 1e12:.3f} TFLOP per launch; median ms (min) [TF/s, frac of 2.5 PF/s]")
 for name, fn in rows:
     med, mn = timeit(fn)
-    print(f"{name:34s} {med:8.4f} ({mn:.4f})  [{flop / med / 1e9:7.1f}  {flop / med / 1e9 / 2500:.3f}]")
+    fl = flop * (RF if "REAL" in name else 1.0)
+    print(f"{name:34s} {med:8.4f} ({mn:.4f})  [{fl / med / 1e9:7.1f}  {fl / med / 1e9 / 2500:.3f}]")
