@@ -124,12 +124,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg3-batch", type=int, default=32)
     ap.add_argument("--cfg4-batch", type=int, default=1 << 20)
-    ap.add_argument("--cfg3-layout", default="channels_last", choices=["channels_last", "nchw"])
+    ap.add_argument("--cfg3-layout", default=None, choices=["channels_last", "nchw"],
+                    help="default: channels_last for bf16 (the kernels' layout), nchw for float32 (planar kernels)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
-    jobs = [("cfg1", cfg1), ("cfg1g", cfg1_graph), ("cfg3f", lambda: cfg3(a.cfg3_batch, torch.float32, a.cfg3_layout)),
-            ("cfg3b", lambda: cfg3(a.cfg3_batch, torch.bfloat16, a.cfg3_layout)),
+    jobs = [("cfg1", cfg1), ("cfg1g", cfg1_graph), ("cfg3f", lambda: cfg3(a.cfg3_batch, torch.float32, a.cfg3_layout or "nchw")),
+            ("cfg3b", lambda: cfg3(a.cfg3_batch, torch.bfloat16, a.cfg3_layout or "channels_last")),
             ("cfg4b", lambda: cfg4(a.cfg4_batch, torch.bfloat16)),
             ("cfg4f", lambda: cfg4(a.cfg4_batch // 4, torch.float32))]
     for name, fn in jobs:
