@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -49,6 +49,8 @@ SIGNATURES = {
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],
     "cplxamd_cplx_maxpool2d_fwd": [_P, _P, _P, _P, _P, _P, _I, _P],
     "cplxamd_cplx_maxpool2d_bwd": [_P, _P, _P, _P, _P, _P, _I, _P],
+    "cplxamd_cplx_maxpool2d_fwd_cl": [_P, _P, _P, _P, _P, _P, _I, _P],
+    "cplxamd_cplx_maxpool2d_bwd_cl": [_P, _P, _P, _P, _P, _P, _I, _P],
     "cplxamd_bilinear_reduce_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_bilinear_reduce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_deinterleave": [_P, _P, _P, _L, _I, _P],

@@ -14,15 +14,19 @@ struct PoolP {
   int B, C, H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
 };
 
-template <typename T>
+// CL: channels-last storage ([B][H][W][C], consecutive threads = consecutive channels of one output pixel); the kept
+// index is the pixel h * W + w either way.
+template <typename T, bool CL>
 __global__ __launch_bounds__(256) void cplx_maxpool_fwd_kernel(const T* zr, const T* zi, T* yr, T* yi,
                                                                int32_t* idx, PoolP p, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
-    const int ow = (int)(o % p.Wo), oh = (int)((o / p.Wo) % p.Ho);
-    const int64_t bc = o / ((int64_t)p.Wo * p.Ho);
-    const T* pr = zr + bc * p.H * p.W;
-    const T* pi = zi + bc * p.H * p.W;
+    const int64_t op = CL ? o / p.C : o;                       // output pixel index (x channel for planar)
+    const int ow = (int)(op % p.Wo), oh = (int)((op / p.Wo) % p.Ho);
+    const int64_t bc = op / ((int64_t)p.Wo * p.Ho);            // CL: image b; planar: b * C + c
+    const int64_t ps = CL ? p.C : 1;                           // pixel stride
+    const T* pr = zr + (CL ? bc * p.H * p.W * p.C + (o - op * p.C) : bc * p.H * p.W);
+    const T* pi = zi + (CL ? bc * p.H * p.W * p.C + (o - op * p.C) : bc * p.H * p.W);
     float best = -INFINITY, br = 0.f, bi = 0.f;
     int bidx = -1;
     for (int i = 0; i < p.kh; ++i) {
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(256) void cplx_maxpool_fwd_kernel(const T* zr, cons
       for (int j = 0; j < p.kw; ++j) {
         const int w = ow * p.sw - p.pw + j * p.dw;
         if (w < 0 || w >= p.W) continue;
-        const float a = io<T>::ld(pr + h * p.W + w), b = io<T>::ld(pi + h * p.W + w);
+        const float a = io<T>::ld(pr + (int64_t)(h * p.W + w) * ps), b = io<T>::ld(pi + (int64_t)(h * p.W + w) * ps);
         const float m = rn_sqrt(fmaf(b, b, a * a));
         if (bidx < 0 || m > best || m != m) {
           best = m; br = a; bi = b; bidx = h * p.W + w;
@@ -46,14 +50,16 @@ __global__ __launch_bounds__(256) void cplx_maxpool_fwd_kernel(const T* zr, cons
 
 __device__ __forceinline__ int cdiv_floor(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <typename T>
+template <typename T, bool CL>
 __global__ __launch_bounds__(256) void cplx_maxpool_bwd_kernel(const T* gr, const T* gi,
                                                                const int32_t* idx, T* dzr, T* dzi,
                                                                PoolP p, int64_t n_in) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_in; e += stride) {
-    const int w = (int)(e % p.W), h = (int)((e / p.W) % p.H);
-    const int64_t bc = e / ((int64_t)p.W * p.H);
+    const int64_t ep = CL ? e / p.C : e;
+    const int w = (int)(ep % p.W), h = (int)((ep / p.W) % p.H);
+    const int64_t bc = ep / ((int64_t)p.W * p.H);
+    const int64_t ps = CL ? p.C : 1, ch = CL ? e - ep * p.C : 0;
     const int me = h * p.W + w;
     // output rows whose window can contain h: oh*sh - ph <= h <= oh*sh - ph + (kh-1)*dh
     int oh0 = cdiv_floor(h + p.ph - (p.kh - 1) * p.dh + p.sh - 1, p.sh), oh1 = cdiv_floor(h + p.ph, p.sh);
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void cplx_maxpool_bwd_kernel(const T* gr, cons
     const int64_t ob = bc * p.Ho * p.Wo;
     for (int oh = oh0; oh <= oh1; ++oh)
       for (int ow = ow0; ow <= ow1; ++ow) {
-        const int64_t o = ob + (int64_t)oh * p.Wo + ow;
+        const int64_t o = (ob + (int64_t)oh * p.Wo + ow) * ps + ch;
         if (idx[o] == me) { ar += io<T>::ld(gr + o); ai += io<T>::ld(gi + o); }
       }
     io<T>::st(dzr + e, ar);
@@ -79,8 +85,8 @@ using namespace cplxamd;
 extern "C" {
 
 // pool = int[14]: B, C, H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw  (Ho / Wo as torch computes them)
-int cplxamd_cplx_maxpool2d_fwd(const void* zr, const void* zi, void* yr, void* yi, int32_t* idx,
-                               const int* pool, int dtype, void* stream) {
+static int maxpool_fwd(const void* zr, const void* zi, void* yr, void* yi, int32_t* idx, const int* pool, int dtype,
+                       bool cl, void* stream) {
   if (!zr || !zi || !yr || !yi || !idx || !pool) return CPLXAMD_EINVAL;
   PoolP p{pool[0], pool[1], pool[2], pool[3], pool[4], pool[5], pool[6], pool[7], pool[8], pool[9],
           pool[10], pool[11], pool[12], pool[13]};
@@ -92,17 +98,27 @@ int cplxamd_cplx_maxpool2d_fwd(const void* zr, const void* zi, void* yr, void* y
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int grid = stream_grid(n, 256);
-  if (dtype == CPLXAMD_F32)
-    cplx_maxpool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)zr, (const float*)zi, (float*)yr, (float*)yi, idx, p, n);
-  else if (dtype == CPLXAMD_BF16)
-    cplx_maxpool_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)zr, (const bf16_t*)zi, (bf16_t*)yr, (bf16_t*)yi, idx, p, n);
+#define MP(T, L) cplx_maxpool_fwd_kernel<T, L><<<grid, 256, 0, st>>>((const T*)zr, (const T*)zi, (T*)yr, (T*)yi, idx, p, n)
+  if (dtype == CPLXAMD_F32) { if (cl) MP(float, true); else MP(float, false); }
+  else if (dtype == CPLXAMD_BF16) { if (cl) MP(bf16_t, true); else MP(bf16_t, false); }
   else return CPLXAMD_EINVAL;
+#undef MP
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
 
-int cplxamd_cplx_maxpool2d_bwd(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi,
+int cplxamd_cplx_maxpool2d_fwd(const void* zr, const void* zi, void* yr, void* yi, int32_t* idx,
                                const int* pool, int dtype, void* stream) {
+  return maxpool_fwd(zr, zi, yr, yi, idx, pool, dtype, false, stream);
+}
+/* the same on channels-last planes ([B][H][W][C] in, [B][Ho][Wo][C] out, idx too) */
+int cplxamd_cplx_maxpool2d_fwd_cl(const void* zr, const void* zi, void* yr, void* yi, int32_t* idx,
+                                  const int* pool, int dtype, void* stream) {
+  return maxpool_fwd(zr, zi, yr, yi, idx, pool, dtype, true, stream);
+}
+
+static int maxpool_bwd(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi, const int* pool, int dtype,
+                       bool cl, void* stream) {
   if (!gr || !gi || !dzr || !dzi || !idx || !pool) return CPLXAMD_EINVAL;
   PoolP p{pool[0], pool[1], pool[2], pool[3], pool[4], pool[5], pool[6], pool[7], pool[8], pool[9],
           pool[10], pool[11], pool[12], pool[13]};
@@ -111,13 +127,22 @@ int cplxamd_cplx_maxpool2d_bwd(const void* gr, const void* gi, const int32_t* id
   if (n <= 0) return n == 0 ? 0 : CPLXAMD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = stream_grid(n, 256);
-  if (dtype == CPLXAMD_F32)
-    cplx_maxpool_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)gr, (const float*)gi, idx, (float*)dzr, (float*)dzi, p, n);
-  else if (dtype == CPLXAMD_BF16)
-    cplx_maxpool_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)gr, (const bf16_t*)gi, idx, (bf16_t*)dzr, (bf16_t*)dzi, p, n);
+#define MP(T, L) cplx_maxpool_bwd_kernel<T, L><<<grid, 256, 0, st>>>((const T*)gr, (const T*)gi, idx, (T*)dzr, (T*)dzi, p, n)
+  if (dtype == CPLXAMD_F32) { if (cl) MP(float, true); else MP(float, false); }
+  else if (dtype == CPLXAMD_BF16) { if (cl) MP(bf16_t, true); else MP(bf16_t, false); }
   else return CPLXAMD_EINVAL;
+#undef MP
   CPLXAMD_CHECK_LAUNCH();
   return 0;
+}
+
+int cplxamd_cplx_maxpool2d_bwd(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi,
+                               const int* pool, int dtype, void* stream) {
+  return maxpool_bwd(gr, gi, idx, dzr, dzi, pool, dtype, false, stream);
+}
+int cplxamd_cplx_maxpool2d_bwd_cl(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi,
+                                  const int* pool, int dtype, void* stream) {
+  return maxpool_bwd(gr, gi, idx, dzr, dzi, pool, dtype, true, stream);
 }
 
 }  // extern "C"

@@ -1198,17 +1198,19 @@ class CplxMaxPool2dFn(torch.autograd.Function):
     def forward(ctx, zr, zi, kernel, stride, padding, dilation, ceil_mode):
         import ctypes
         require_device(zr, zi)
-        zr, zi = _c(zr), _c(zi)
+        ctx.fmt = fmt = _layout_of(zr)       # channels-last in -> channels-last out (and index map)
+        zr, zi = _cf(zr, fmt), _cf(zi, fmt)
         B, C, H, W = zr.shape
         (kh, kw), (sh, sw), (ph, pw), (dh, dw) = kernel, stride, padding, dilation
         if ph > kh // 2 or pw > kw // 2:
             raise RuntimeError("pad should be at most half of effective kernel size")
         Ho, Wo = _pool_out(H, kh, sh, ph, dh, ceil_mode), _pool_out(W, kw, sw, pw, dw, ceil_mode)
         pool = (ctypes.c_int * 14)(B, C, H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw)
-        yr = torch.empty(B, C, Ho, Wo, dtype=zr.dtype, device=zr.device)
+        yr = torch.empty((B, C, Ho, Wo), dtype=zr.dtype, device=zr.device, memory_format=fmt)
         yi = torch.empty_like(yr)
-        idx = torch.empty(B, C, Ho, Wo, dtype=torch.int32, device=zr.device)
-        call("cplxamd_cplx_maxpool2d_fwd", ptr(zr), ptr(zi), ptr(yr), ptr(yi), ptr(idx), pool,
+        idx = torch.empty((B, C, Ho, Wo), dtype=torch.int32, device=zr.device, memory_format=fmt)
+        ctx.sfx = sfx = "_cl" if fmt == torch.channels_last else ""
+        call("cplxamd_cplx_maxpool2d_fwd" + sfx, ptr(zr), ptr(zi), ptr(yr), ptr(yi), ptr(idx), pool,
              dtype_code(zr), stream_ptr())
         ctx.save_for_backward(idx)
         ctx.pool, ctx.in_shape = pool, zr.shape
@@ -1217,9 +1219,9 @@ class CplxMaxPool2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gr, gi):
         (idx,) = ctx.saved_tensors
-        gr, gi = _c(gr), _c(gi)
-        dzr = torch.empty(ctx.in_shape, dtype=gr.dtype, device=gr.device)
+        gr, gi = _cf(gr, ctx.fmt), _cf(gi, ctx.fmt)
+        dzr = torch.empty(ctx.in_shape, dtype=gr.dtype, device=gr.device, memory_format=ctx.fmt)
         dzi = torch.empty_like(dzr)
-        call("cplxamd_cplx_maxpool2d_bwd", ptr(gr), ptr(gi), ptr(idx), ptr(dzr), ptr(dzi), ctx.pool,
+        call("cplxamd_cplx_maxpool2d_bwd" + ctx.sfx, ptr(gr), ptr(gi), ptr(idx), ptr(dzr), ptr(dzi), ctx.pool,
              dtype_code(gr), stream_ptr())
         return dzr, dzi, None, None, None, None, None

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 5
+#define CPLXAMD_ABI_VERSION 6
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -457,6 +457,12 @@ int cplxamd_cplx_maxpool2d_fwd(const void* zr, const void* zi, void* yr, void* y
                                const int* pool, int dtype, void* stream);
 int cplxamd_cplx_maxpool2d_bwd(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi,
                                const int* pool, int dtype, void* stream);
+/* the same pair on channels-last planes ([B][H][W][C] in, [B][Ho][Wo][C] out and idx): a pooling layer inside a
+ * channels-last convolution stack needs no layout copy */
+int cplxamd_cplx_maxpool2d_fwd_cl(const void* zr, const void* zi, void* yr, void* yi, int32_t* idx,
+                                  const int* pool, int dtype, void* stream);
+int cplxamd_cplx_maxpool2d_bwd_cl(const void* gr, const void* gi, const int32_t* idx, void* dzr, void* dzi,
+                                  const int* pool, int dtype, void* stream);
 
 /* Bilinear layers: cplx.bilinear (cplx.py:1062-1087), the variance term of
  * CplxBilinearGaussian / BilinearGaussian (nn/relevance/complex/base.py:59-84, real/base.py:52-77).

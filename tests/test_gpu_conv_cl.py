@@ -293,3 +293,23 @@ def test_cl_entry_points_refuse_what_they_are_not_built_for():
     assert wgrad(W_=24) == E.ESHAPE and wgrad(Ci=32) == E.ESHAPE and wgrad(KH=1) == E.ESHAPE and wgrad(pad=2) == E.ESHAPE
     assert lib.cplxamd_cl_to_nchw(ptr(x), ptr(y), 1, 12, 64, stream_ptr()) == E.ESHAPE
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_channels_last_matches_planar(dtype):
+    """Abs-max pooling on channels-last planes: same outputs (bit for bit), same gradients, layout kept."""
+    from cplxmodule_amd import Cplx, cplx
+    torch.manual_seed(5)
+    a, b = torch.randn(2, 24, 13, 17, device="cuda").to(dtype), torch.randn(2, 24, 13, 17, device="cuda").to(dtype)
+    for kw in (dict(kernel_size=2), dict(kernel_size=3, stride=2, padding=1), dict(kernel_size=(2, 3), stride=(1, 2), ceil_mode=True)):
+        outs = []
+        for fmt in (torch.contiguous_format, torch.channels_last):
+            zr, zi = (t.contiguous(memory_format=fmt).clone().requires_grad_(True) for t in (a, b))
+            y = cplx.max_pool2d(Cplx(zr, zi), **kw)
+            if fmt == torch.channels_last:
+                assert y.real.is_contiguous(memory_format=fmt) and not y.real.is_contiguous()
+            g1, g2 = torch.ones_like(y.real) * 0.5, torch.ones_like(y.imag) * 2
+            torch.autograd.backward((y.real, y.imag), (g1, g2))
+            outs.append((y.real.detach(), y.imag.detach(), zr.grad, zi.grad))
+        for p, q in zip(*outs):
+            assert torch.equal(p.contiguous(), q.contiguous())
