@@ -220,6 +220,20 @@ def from_channels_last(t):
     return t.contiguous()
 
 
+class ToChannelsLastFn(torch.autograd.Function):
+    """Differentiable to_channels_last for callers outside the conv Functions: forward and backward are the LDS-tile
+    transposes (the gradient goes back in the layout the input came in)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.planar = t.is_contiguous() and not t.is_contiguous(memory_format=torch.channels_last)
+        return to_channels_last(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return from_channels_last(g) if ctx.planar else g
+
+
 def _cl_pack(wr, wi, dgrad):
     """bf16 weight planes [Co, Ci, KH, KW] -> the per-stage LDS images of conv_cl.hip."""
     Co, Ci, KH, KW = wr.shape
@@ -600,9 +614,31 @@ def cplx_conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, group
     elif padding_mode != "zeros":
         raise ValueError("padding_mode must be 'zeros' or 'circular'.")
     br, bi = (None, None) if bias is None else (bias.real, bias.imag)
+    if _pointwise_cl(xr, xi, weight.real, stride, padding, groups):
+        # a 1 x 1 convolution on channels-last planes IS the linear layer on [B H W, C] rows: the complex GEMM kernels
+        # (forward, both gradients, bias column sums), no copies, channels-last out
+        B, C, H, W = xr.shape
+        Co = weight.real.shape[0]
+        rows = lambda t: ToChannelsLastFn.apply(t).permute(0, 2, 3, 1)  # noqa: E731  ([B, H, W, C] view of the storage)
+        yr, yi = ops.CplxLinearFn.apply(rows(xr), rows(xi), weight.real.reshape(Co, C), weight.imag.reshape(Co, C), br, bi)
+        return Cplx(yr.permute(0, 3, 1, 2), yi.permute(0, 3, 1, 2))
     yr, yi = CplxConv2dFn.apply(xr, xi, weight.real, weight.imag, br, bi, stride, padding,
                                 dilation, groups)
     return Cplx(yr, yi)
+
+
+def _pointwise_cl(xr, xi, w, stride, padding, groups):
+    """1 x 1, stride 1, no padding, one group, bf16 images that are channels-last already or large enough to pay for
+    one conversion."""
+    if not _CL_ENABLED or xr.dim() != 4 or xr.dtype != torch.bfloat16 or xi.dtype != torch.bfloat16 or not xr.is_cuda:
+        return False
+    if tuple(w.shape[2:]) != (1, 1) or _pair(stride) != (1, 1) or _pair(padding) != (0, 0) or groups != 1:
+        return False
+    B, C, H, W = xr.shape
+    if B * H * W == 0 or C % 8 or w.shape[0] % 8:
+        return False
+    is_cl = xr.is_contiguous(memory_format=torch.channels_last) and not xr.is_contiguous()
+    return is_cl or _CL_FORCE or 8.0 * B * H * W * C * w.shape[0] >= _CL_MIN_FLOP
 
 
 class CplxConv2dLRTFn(torch.autograd.Function):

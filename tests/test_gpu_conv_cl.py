@@ -313,3 +313,35 @@ def test_maxpool_channels_last_matches_planar(dtype):
             outs.append((y.real.detach(), y.imag.detach(), zr.grad, zi.grad))
         for p, q in zip(*outs):
             assert torch.equal(p.contiguous(), q.contiguous())
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_pointwise_conv_runs_as_linear_layer(layout):
+    """1 x 1 convolution on channels-last bf16 images = the complex GEMM on [B H W, C] rows: outputs and all gradients
+    against the oracle, output channels-last."""
+    from gpu_util import T, N, bf16_round
+    from cplxmodule_amd import Cplx, cplx
+    rs = np.random.RandomState(31)
+    B, Ci, Co, H, W = 2, 64, 96, 9, 20
+    xr, xi = bf16_round(rs.randn(B, Ci, H, W)), bf16_round(rs.randn(B, Ci, H, W))
+    wr, wi = bf16_round(rs.randn(Co, Ci, 1, 1) * 0.1), bf16_round(rs.randn(Co, Ci, 1, 1) * 0.1)
+    br, bi = rs.randn(Co).astype(np.float32), rs.randn(Co).astype(np.float32)
+    q = lambda a: T(a, torch.bfloat16)  # noqa: E731
+    txr, txi = q(xr), q(xi)
+    if layout == "channels_last":
+        txr, txi = txr.contiguous(memory_format=torch.channels_last), txi.contiguous(memory_format=torch.channels_last)
+    txr, txi = txr.requires_grad_(True), txi.requires_grad_(True)
+    twr, twi, tbr, tbi = (T(a).requires_grad_(True) for a in (wr, wi, br, bi))
+    y = cplx.conv2d(Cplx(txr, txi), Cplx(twr, twi), Cplx(tbr, tbi))
+    assert y.real.is_contiguous(memory_format=torch.channels_last) and not y.real.is_contiguous()
+    f = np.float64
+    yr, yi = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f), br.astype(f), bi.astype(f))
+    np.testing.assert_allclose(N(y.real), yr, rtol=1e-2, atol=1e-2 * np.abs(yr).max())
+    np.testing.assert_allclose(N(y.imag), yi, rtol=1e-2, atol=1e-2 * np.abs(yi).max())
+    gr, gi = bf16_round(rs.randn(*yr.shape)), bf16_round(rs.randn(*yr.shape))
+    ((y.real * q(gr)).sum() + (y.imag * q(gi)).sum()).backward()
+    bw = orc.cplx_conv2d_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), wr.astype(f), wi.astype(f))
+    got = dict(dxr=txr.grad, dxi=txi.grad, dwr=twr.grad, dwi=twi.grad, dbr=tbr.grad, dbi=tbi.grad)
+    for n, t in got.items():
+        assert tuple(t.shape) == bw[n].shape
+        np.testing.assert_allclose(N(t), bw[n], rtol=2e-2, atol=2e-2 * np.abs(bw[n]).max(), err_msg=n)
