@@ -345,3 +345,57 @@ def test_pointwise_conv_runs_as_linear_layer(layout):
     for n, t in got.items():
         assert tuple(t.shape) == bw[n].shape
         np.testing.assert_allclose(N(t), bw[n], rtol=2e-2, atol=2e-2 * np.abs(bw[n]).max(), err_msg=n)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_cl_conv_random_geometries_vs_float32_kernels(seed):
+    """Property test: random stride-1 3 x 3 geometries (image sizes incl. tiny ones and widths that are / are not
+    multiples of 32, paddings from 0 to `same`, dilations 1-2 per axis, 32-128 channels, 1-3 column tiles) through the
+    channels-last kernels vs the exact float32 planar kernels on the same bf16-rounded operands: forward, data
+    gradient, weight gradient, bias gradient."""
+    from cplxmodule_amd import Cplx, cplx, conv
+    rs = np.random.RandomState(500 + seed)
+    B = int(rs.randint(1, 4))
+    Ci, Co = int(rs.choice([32, 64, 96, 128])), int(rs.choice([64, 128, 192]))
+    dh, dw = int(rs.randint(1, 3)), int(rs.randint(1, 3))
+    ph, pw = int(rs.randint(0, dh + 1)), int(rs.randint(0, dw + 1))
+    H = int(rs.randint(2 * dh + 1 - 2 * ph + 1 if 2 * dh + 1 - 2 * ph > 0 else 1, 40))
+    W = int(rs.choice([32, 64, 96])) if seed % 2 == 0 else int(rs.randint(max(2 * dw + 1 - 2 * pw + 1, 2), 70))
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16().to("cuda")  # noqa: E731
+    xr, xi = mk(B, Ci, H, W), mk(B, Ci, H, W)
+    wr, wi = (mk(Co, Ci, 3, 3).float() * 0.1).bfloat16().float(), (mk(Co, Ci, 3, 3).float() * 0.1).bfloat16().float()
+    br, bi = mk(Co).float(), mk(Co).float()
+    kw_ = dict(stride=1, padding=(ph, pw), dilation=(dh, dw))
+    geom, _ = conv._geom(xr.shape, wr.shape, 1, (ph, pw), (dh, dw), 1)
+    outs = []
+    for dt in (torch.bfloat16, torch.float32):
+        leaves = [t.to(dt).clone().requires_grad_(True) for t in (xr, xi)] + [t.clone().requires_grad_(True) for t in (wr, wi, br, bi)]
+        y = cplx.conv2d(Cplx(leaves[0], leaves[1]), Cplx(leaves[2], leaves[3]), Cplx(leaves[4], leaves[5]), **kw_)
+        if dt == torch.bfloat16 and conv._cl_wgrad_ok(geom) and conv._cl_ok(geom):
+            assert y.real.is_contiguous(memory_format=torch.channels_last)
+        gg = torch.Generator(device="cpu").manual_seed(1000 + seed)
+        gr = torch.randn(y.real.shape, generator=gg).bfloat16().to("cuda")
+        gi = torch.randn(y.real.shape, generator=gg).bfloat16().to("cuda")
+        torch.autograd.backward((y.real, y.imag), (gr.to(dt), gi.to(dt)))
+        outs.append([y.real.float(), y.imag.float()] + [t.grad.float() for t in leaves])
+    names = ["yr", "yi", "dxr", "dxi", "dwr", "dwi", "dbr", "dbi"]
+    for n, a, b in zip(names, *outs):
+        scale = float(b.detach().abs().max()) + 1e-6
+        tol = 2e-2 if n[0] == "y" or n[1] == "x" else 1e-3       # bf16-rounded outputs vs fp32-accumulated gradients
+        assert float((a.detach() - b.detach()).abs().max()) <= tol * scale, (n, seed, B, Ci, Co, dh, dw, ph, pw, H, W)
+    # the forward / data-gradient kernel directly, also where the layer as a whole stays planar (image width not a
+    # multiple of 32, 32 input channels)
+    ref = outs[1]
+    wb = (wr.bfloat16(), wi.bfloat16())
+    if conv._cl_ok(geom):
+        y2 = conv.cl_conv(xr, xi, wb[0], wb[1], br, bi, geom)
+        for got, want in zip(y2, ref[:2]):
+            assert float((got.float() - want.detach()).abs().max()) <= 2e-2 * float(want.detach().abs().max()) + 1e-6, ("fwd", seed)
+    if conv._cl_ok(geom, dgrad=True):
+        gg = torch.Generator(device="cpu").manual_seed(1000 + seed)
+        gr = torch.randn(ref[0].shape, generator=gg).bfloat16().to("cuda")
+        gi = torch.randn(ref[0].shape, generator=gg).bfloat16().to("cuda")
+        d2 = conv.cl_conv(gr, gi, wb[0], wb[1], None, None, geom, dgrad=True)
+        for got, want in zip(d2, ref[2:4]):
+            assert float((got.float() - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-6, ("dgrad", seed)
