@@ -172,14 +172,15 @@ def _cl_ok(geom, dgrad=False):
 
 
 def _cl_wgrad_ok(geom):
-    """3 x 3 `same` convolution, image width a multiple of the 32-pixel stage, channel counts multiples of 64."""
+    """3 x 3 convolution with padding up to `same`, channel counts multiples of 64 (any image width: a row's last
+    32-pixel stage may be short)."""
     B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups = (geom[i] for i in range(14))
     if not _CL_ENABLED or sh != 1 or sw != 1 or groups != 1 or KH != 3 or KW != 3 or ph > dh or pw > dw or dw > 4:
         return False
     if H + 2 * ph - 2 * dh <= 0 or W + 2 * pw - 2 * dw <= 0:
         return False
     P = B * H * W
-    if W % 32 or Ci % 64 or Co % 64 or P == 0 or P >= 2 ** 31 or (P + ph * W + 64) * max(Ci, Co) * 2 >= 2 ** 32 - 64:
+    if Ci % 64 or Co % 64 or P == 0 or P >= 2 ** 31 or (P + ph * W + 64) * max(Ci, Co) * 2 >= 2 ** 32 - 64:
         return False
     return _CL_FORCE or 8.0 * P * Ci * Co * 9 >= _CL_MIN_FLOP
 

@@ -15,10 +15,11 @@
 // same three X windows (one per kernel row, 32 + halo pixels each): 40 KiB per 32-pixel stage and 288 MFMAs.
 // LDS reads per MFMA are 20 % above the 64 x 64 tile's (one G fragment pair feeds 4.5 blocks).
 //
-// Borders without masks in the K loop.  With W % 32 == 0 a stage lies inside one image row, so (a) a kernel row that
-// leaves the image does so for the whole stage and (b) the only window rows a column tap must not see are the first
-// p_w rows of the first stage of an image row and the last p_w rows of its last stage -- and those LDS rows are read
-// by no other tap.  The LDS-DMA is `buffer_load ... lds`: a lane whose row must read as zero is simply given an
+// Borders without masks in the K loop.  Stages walk the image rows, ceil(W / 32) per row (the last one short when
+// W % 32 != 0: its missing pixels have no G -- out of range, zeros -- and contribute nothing), so a stage lies inside
+// one image row: (a) a kernel row that leaves the image does so for the whole stage and (b) the only window rows a
+// column tap must not see are the first p_w rows of the first stage of an image row and the rows behind the last
+// pixel + p_w of its last stage -- and those LDS rows are read by no other tap of a pixel that has a G.  The LDS-DMA is `buffer_load ... lds`: a lane whose row must read as zero is simply given an
 // out-of-range offset and the hardware writes zeros (scripts/r02/bufload_oob.hip).  Rows before / after the tensor
 // fall out of range by themselves.
 //
@@ -54,6 +55,7 @@ struct Args {
   uint32_t g_bytes, x_bytes;
   int H, W, Co, Ci, dil_h, dil_w, pad_h, pad_w;      // H x W: the input image = the grid the pixel loop walks
   int Ho, Wo;                                        // the output image (<= H x W, top-left aligned on the grid)
+  int strips;                                        // stages per image row: ceil(W / 32)
   int nstages, per_split, splits, tiles_ci;
 };
 
@@ -151,8 +153,7 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
     uint32_t f = 8u;
     if (u >= 15 || r >= KR + 2 * g.dil_w) f |= 1u;
     if (r < g.pad_w) f |= 2u;
-    if (r >= KR + g.pad_w) f |= 4u;
-    vflag[j] = f;
+    vflag[j] = f | ((uint32_t)r << 8);               // (bits 8..: the window row, for the bottom rows of a short stage)
   }
   const i32x4 rs_xr = make_rsrc(g.x_r, g.x_bytes), rs_xi = make_rsrc(g.x_i, g.x_bytes);
   const uint32_t smem_off = lds_offset_of(smem);
@@ -171,13 +172,16 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   nt = nt < g.per_split ? nt : g.per_split;
   nt = __builtin_amdgcn_readfirstlane(nt);
   int d_t = 0;                                       // stages issued so far
-  uint32_t d_q0 = (uint32_t)t0 * KR;                 // first pixel of the stage at the pointer
+  // stages walk the image rows; a row takes ceil(W / 32) of them, the last one short when W % 32 != 0 (its missing
+  // pixels have no G: out of range, zeros)
+  uint32_t d_q0;                                     // first pixel of the stage at the pointer
   int d_w0, d_h, d_b;
   {
-    const uint32_t row = d_q0 / (uint32_t)g.W;
-    d_w0 = (int)(d_q0 - row * (uint32_t)g.W);
+    const uint32_t row = (uint32_t)t0 / (uint32_t)g.strips;
+    d_w0 = (int)((uint32_t)t0 - row * (uint32_t)g.strips) * KR;
     d_b = (int)(row / (uint32_t)g.H);
     d_h = (int)(row - (uint32_t)d_b * (uint32_t)g.H);
+    d_q0 = row * (uint32_t)g.W + (uint32_t)d_w0;
   }
   auto issue_piece = [&](int j, uint32_t slot_off) __attribute__((always_inline)) {
     const bool live = d_t < nt;                      // stages past the end: everything out of range (zeros)
@@ -190,7 +194,11 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
     } else {
       const int kh = kh_of[j];
       const int hh = d_h + kh * g.dil_h - g.pad_h;
-      uint32_t sf = 1u | (d_w0 == 0 ? 2u : 0u) | (d_w0 + KR == g.W ? 4u : 0u) | ((hh < 0 || hh >= g.H || !live) ? 8u : 0u);
+      // window rows that would show the next image row's pixels: from (pixels left in this image row) + p_w on
+      const uint32_t nval = (uint32_t)(g.W - d_w0 < KR ? g.W - d_w0 : KR);
+      const uint32_t bottom = d_w0 + KR >= g.W ? nval + (uint32_t)g.pad_w : 0x7fffffu;
+      uint32_t sf = 1u | (d_w0 == 0 ? 2u : 0u) | ((hh < 0 || hh >= g.H || !live) ? 8u : 0u);
+      if ((vflag[j] >> 8) >= bottom) sf |= 8u;
       const uint32_t soff = (d_q0 - (uint32_t)g.pad_w + (uint32_t)((kh * g.dil_h - g.pad_h) * g.W)) * rb_x;
       const uint32_t v = (vflag[j] & sf) ? OOB : vo[j] + soff;
       buf_lds16(j < 3 ? rs_xr : rs_xi, v, slot_off + dst[j]);
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   };
   auto advance = [&]() __attribute__((always_inline)) {
     ++d_t; d_q0 += KR; d_w0 += KR;
-    if (d_w0 == g.W) { d_w0 = 0; if (++d_h == g.H) { d_h = 0; ++d_b; } }
+    if (d_w0 >= g.W) { d_q0 -= (uint32_t)(d_w0 - g.W); d_w0 = 0; if (++d_h == g.H) { d_h = 0; ++d_b; } }
   };
 
   // ---- one stage: 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity) ---------------
@@ -371,7 +379,7 @@ extern "C" {
 
 static int clw_shape_ok(int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
                         int pad_w) {
-  if (KH != 3 || KW != 3 || W % clw::KR || Ci % 64 || Co % 64 || pad_h < 0 || pad_w < 0 || pad_h > dil_h ||
+  if (KH != 3 || KW != 3 || Ci % 64 || Co % 64 || pad_h < 0 || pad_w < 0 || pad_h > dil_h ||
       pad_w > dil_w || dil_w > 4 || H + 2 * pad_h - 2 * dil_h <= 0 || W + 2 * pad_w - 2 * dil_w <= 0)
     return 0;
   const int64_t P = B * H * W;
@@ -381,10 +389,10 @@ static int clw_shape_ok(int64_t B, int H, int W, int Ci, int Co, int KH, int KW,
 }
 
 int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co) {
-  if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || W % clw::KR) return 0;
+  if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
   const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
   int per_split = 0;
-  const int splits = clw::plan(B * H * W / clw::KR, tiles, per_split);
+  const int splits = clw::plan(B * H * ((W + clw::KR - 1) / clw::KR), tiles, per_split);
   return (int64_t)splits * tiles * clw::NBLK * 2048 * 4;
 }
 
@@ -410,7 +418,8 @@ int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, c
   g.Ho = H + 2 * pad_h - 2 * dil_h; g.Wo = W + 2 * pad_w - 2 * dil_w;
   g.g_bytes = (uint32_t)(B * g.Ho * g.Wo * Co * 2); g.x_bytes = (uint32_t)(P * Ci * 2);
   g.H = H; g.W = W; g.Co = Co; g.Ci = Ci; g.dil_h = dil_h; g.dil_w = dil_w; g.pad_h = pad_h; g.pad_w = pad_w;
-  g.nstages = (int)(P / clw::KR);
+  g.strips = (W + clw::KR - 1) / clw::KR;
+  g.nstages = (int)(B * H * g.strips);
   g.tiles_ci = Ci / 64;
   const int tiles = (Co / 64) * g.tiles_ci;
   g.splits = clw::plan(g.nstages, tiles, g.per_split);

@@ -32,6 +32,7 @@ struct Args {
   uint32_t g_bytes, x_bytes;
   int H, W, Co, Ci, dil_h, dil_w, pad_h, pad_w;      // H x W: the input image = the grid the pixel loop walks
   int Ho, Wo;                                        // the output image (<= H x W, top-left aligned on the grid)
+  int strips;                                        // stages per image row: ceil(W / 32)
   int nstages, per_split, splits, tiles_ci;
 };
 
@@ -128,8 +129,7 @@ __global__ __launch_bounds__(NT) void conv_clr_wgrad_kernel(Args g) {
     uint32_t f = 8u;
     if (u >= 15 || r >= KR + 2 * g.dil_w) f |= 1u;
     if (r < g.pad_w) f |= 2u;
-    if (r >= KR + g.pad_w) f |= 4u;
-    vflag[j] = f;
+    vflag[j] = f | ((uint32_t)r << 8);               // (bits 8..: the window row, for the bottom rows of a short stage)
   }
   const i32x4 rs_xr = make_rsrc(g.x_r, g.x_bytes);
   const uint32_t smem_off = lds_offset_of(smem);
@@ -147,13 +147,16 @@ __global__ __launch_bounds__(NT) void conv_clr_wgrad_kernel(Args g) {
   nt = nt < g.per_split ? nt : g.per_split;
   nt = __builtin_amdgcn_readfirstlane(nt);
   int d_t = 0;                                       // stages issued so far
-  uint32_t d_q0 = (uint32_t)t0 * KR;                 // first pixel of the stage at the pointer
+  // stages walk the image rows; a row takes ceil(W / 32) of them, the last one short when W % 32 != 0 (its missing
+  // pixels have no G: out of range, zeros)
+  uint32_t d_q0;                                     // first pixel of the stage at the pointer
   int d_w0, d_h, d_b;
   {
-    const uint32_t row = d_q0 / (uint32_t)g.W;
-    d_w0 = (int)(d_q0 - row * (uint32_t)g.W);
+    const uint32_t row = (uint32_t)t0 / (uint32_t)g.strips;
+    d_w0 = (int)((uint32_t)t0 - row * (uint32_t)g.strips) * KR;
     d_b = (int)(row / (uint32_t)g.H);
     d_h = (int)(row - (uint32_t)d_b * (uint32_t)g.H);
+    d_q0 = row * (uint32_t)g.W + (uint32_t)d_w0;
   }
   auto issue_piece = [&](int j, uint32_t slot_off) __attribute__((always_inline)) {
     const bool live = d_t < nt;                      // stages past the end: everything out of range (zeros)
@@ -166,7 +169,11 @@ __global__ __launch_bounds__(NT) void conv_clr_wgrad_kernel(Args g) {
     } else {
       const int kh = kh_of[j];
       const int hh = d_h + kh * g.dil_h - g.pad_h;
-      uint32_t sf = 1u | (d_w0 == 0 ? 2u : 0u) | (d_w0 + KR == g.W ? 4u : 0u) | ((hh < 0 || hh >= g.H || !live) ? 8u : 0u);
+      // window rows that would show the next image row's pixels: from (pixels left in this image row) + p_w on
+      const uint32_t nval = (uint32_t)(g.W - d_w0 < KR ? g.W - d_w0 : KR);
+      const uint32_t bottom = d_w0 + KR >= g.W ? nval + (uint32_t)g.pad_w : 0x7fffffu;
+      uint32_t sf = 1u | (d_w0 == 0 ? 2u : 0u) | ((hh < 0 || hh >= g.H || !live) ? 8u : 0u);
+      if ((vflag[j] >> 8) >= bottom) sf |= 8u;
       const uint32_t soff = (d_q0 - (uint32_t)g.pad_w + (uint32_t)((kh * g.dil_h - g.pad_h) * g.W)) * rb_x;
       const uint32_t v = (vflag[j] & sf) ? OOB : vo[j] + soff;
       buf_lds16(rs_xr, v, slot_off + dst[j]);
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(NT) void conv_clr_wgrad_kernel(Args g) {
   };
   auto advance = [&]() __attribute__((always_inline)) {
     ++d_t; d_q0 += KR; d_w0 += KR;
-    if (d_w0 == g.W) { d_w0 = 0; if (++d_h == g.H) { d_h = 0; ++d_b; } }
+    if (d_w0 >= g.W) { d_q0 -= (uint32_t)(d_w0 - g.W); d_w0 = 0; if (++d_h == g.H) { d_h = 0; ++d_b; } }
   };
 
   // ---- one stage: 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity) ---------------
@@ -336,7 +343,7 @@ extern "C" {
 
 static int clwr_shape_ok(int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
                          int pad_w) {
-  if (KH != 3 || KW != 3 || W % clwr::KR || Ci % 64 || Co % 64 || pad_h < 0 || pad_w < 0 || pad_h > dil_h ||
+  if (KH != 3 || KW != 3 || Ci % 64 || Co % 64 || pad_h < 0 || pad_w < 0 || pad_h > dil_h ||
       pad_w > dil_w || dil_w > 4 || H + 2 * pad_h - 2 * dil_h <= 0 || W + 2 * pad_w - 2 * dil_w <= 0)
     return 0;
   const int64_t P = B * H * W;
@@ -346,10 +353,10 @@ static int clwr_shape_ok(int64_t B, int H, int W, int Ci, int Co, int KH, int KW
 }
 
 int64_t cplxamd_conv2d_clr_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co) {
-  if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || W % clwr::KR) return 0;
+  if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
   const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
   int per_split = 0;
-  const int splits = clwr::plan(B * H * W / clwr::KR, tiles, per_split);
+  const int splits = clwr::plan(B * H * ((W + clwr::KR - 1) / clwr::KR), tiles, per_split);
   return (int64_t)splits * tiles * clwr::NBLK * 1024 * 4;
 }
 
@@ -373,7 +380,8 @@ int cplxamd_conv2d_clr_wgrad(const void* g_, const void* x, const float* emul, i
   g.Ho = H + 2 * pad_h - 2 * dil_h; g.Wo = W + 2 * pad_w - 2 * dil_w;
   g.g_bytes = (uint32_t)(B * g.Ho * g.Wo * Co * 2); g.x_bytes = (uint32_t)(P * Ci * 2);
   g.H = H; g.W = W; g.Co = Co; g.Ci = Ci; g.dil_h = dil_h; g.dil_w = dil_w; g.pad_h = pad_h; g.pad_w = pad_w;
-  g.nstages = (int)(P / clwr::KR);
+  g.strips = (W + clwr::KR - 1) / clwr::KR;
+  g.nstages = (int)(B * H * g.strips);
   g.tiles_ci = Ci / 64;
   const int tiles = (Co / 64) * g.tiles_ci;
   g.splits = clwr::plan(g.nstages, tiles, g.per_split);

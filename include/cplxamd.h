@@ -361,7 +361,7 @@ int cplxamd_conv2d_nhwc_wgrad_f32(const void* gp_r, const void* gp_i, const void
  *       (x = output gradient [B][Ho][Wo][C = Co], y = input gradient [B][H][W][N = Ci]; H, W, pad_* still the forward's).
  *       Needs C % 16 == 0, N % 64 == 0, (KH * C / 16) % 6 == 0; ws >= cplxamd_conv2d_cl_ws_bytes(N).
  *   cplxamd_conv2d_cl_wgrad: dW[Co][Ci][3][3] (float32 planes, optionally times emul) from x [B][H][W][Ci] and
- *       g [B][Ho][Wo][Co]; needs KH = KW = 3, W % 32 == 0, Ci % 64 == Co % 64 == 0;
+ *       g [B][Ho][Wo][Co]; needs KH = KW = 3, Ci % 64 == Co % 64 == 0 (any image width);
  *       ws >= cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, Ci, Co).  Deterministic (fixed-order slab reduction).
  *   cplxamd_cl_to_nchw: channels-last [B][S][C] -> planar [B][C][S] (bf16; C % 8 == S % 8 == 0): the way back for a
  *       caller whose tensors are plain contiguous (the other direction is cplxamd_nhwc_pad with zero padding). */

@@ -57,8 +57,8 @@ def test_cl_conv_vs_oracle(case, layout):
     kw_ = dict(stride=1, padding=cfg["padding"], dilation=cfg["dilation"], groups=1)
     geom, _ = conv._geom(txr.shape, twr.shape, 1, cfg["padding"], cfg["dilation"], 1)
     assert conv._cl_ok(geom) and conv._cl_ok(geom, dgrad=True) == (Ci % 64 == 0 and (kh * (Co // 16)) % 6 == 0)
-    if case.startswith(("wgrad_cl", "valid_padding", "half_padding")):
-        assert conv._cl_wgrad_ok(geom)
+    if Ci % 64 == 0 and Co % 64 == 0 and (kh, kw) == (3, 3):
+        assert conv._cl_wgrad_ok(geom)               # any image width
     y = cplx.conv2d(Cplx(txr, txi), Cplx(twr, twi), Cplx(tbr, tbi), **kw_)
     if not conv._cl_wgrad_ok(geom):                  # such a layer stays planar as a whole; the kernel itself is
         assert not y.real.is_contiguous(memory_format=torch.channels_last) or y.real.is_contiguous()   # checked below
@@ -290,7 +290,7 @@ def test_cl_entry_points_refuse_what_they_are_not_built_for():
         return lib.cplxamd_conv2d_cl_wgrad(ptr(g), ptr(g), ptr(x), ptr(x), None, ptr(dw), ptr(dw), B, H, W_, Ci, 64, KH, 3, dil, dil,
                                            pad, pad, ptr(wsw), wsw.numel(), stream_ptr())
     assert wgrad() == 0
-    assert wgrad(W_=24) == E.ESHAPE and wgrad(Ci=32) == E.ESHAPE and wgrad(KH=1) == E.ESHAPE and wgrad(pad=2) == E.ESHAPE
+    assert wgrad(Ci=32) == E.ESHAPE and wgrad(KH=1) == E.ESHAPE and wgrad(pad=2) == E.ESHAPE
     assert lib.cplxamd_cl_to_nchw(ptr(x), ptr(y), 1, 12, 64, stream_ptr()) == E.ESHAPE
     torch.cuda.synchronize()
 
@@ -360,7 +360,7 @@ def test_cl_conv_random_geometries_vs_float32_kernels(seed):
     dh, dw = int(rs.randint(1, 3)), int(rs.randint(1, 3))
     ph, pw = int(rs.randint(0, dh + 1)), int(rs.randint(0, dw + 1))
     H = int(rs.randint(2 * dh + 1 - 2 * ph + 1 if 2 * dh + 1 - 2 * ph > 0 else 1, 40))
-    W = int(rs.choice([32, 64, 96])) if seed % 2 == 0 else int(rs.randint(max(2 * dw + 1 - 2 * pw + 1, 2), 70))
+    W = int(rs.choice([32, 64, 96])) if seed % 4 == 0 else int(rs.randint(max(2 * dw + 1 - 2 * pw + 1, 2), 70))
     g = torch.Generator(device="cpu").manual_seed(seed)
     mk = lambda *s: torch.randn(*s, generator=g).bfloat16().to("cuda")  # noqa: E731
     xr, xi = mk(B, Ci, H, W), mk(B, Ci, H, W)

@@ -24,6 +24,8 @@ CASES = {
     "valid": dict(B=3, Ci=64, Co=128, H=9, W=64, padding=0, dilation=1),
     "dil2_half_pad": dict(B=2, Ci=128, Co=64, H=11, W=32, padding=(1, 2), dilation=2),
     "many_tiles": dict(B=2, Ci=64, Co=64, H=40, W=96, padding=1, dilation=1),
+    "width_28": dict(B=3, Ci=64, Co=64, H=28, W=28, padding=1, dilation=1),
+    "width_50_valid_dil2": dict(B=2, Ci=64, Co=64, H=12, W=50, padding=(0, 1), dilation=(1, 2)),
 }
 
 
