@@ -5,6 +5,7 @@ Reference: cplx.conv2d -> convnd (cplxmodule/cplx.py:770-838), CplxConvNdGaussia
 (nn/relevance/complex/base.py:120-135), ConvNdGaussianMixin (nn/relevance/real/base.py:116-163).
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -150,6 +151,7 @@ def grad_grid(gr, gi, geom):
 # ---- channels-last end to end (csrc/conv_cl.hip): 3 x 3-style "same" convolutions, stride 1, groups 1 -------- #
 _CL_FORCE = False            # tests: take the kernels on tiny shapes too
 _CL_ENABLED = True
+_CL_PATCH = os.environ.get("CPLXAMD_CL_PATCH", "1") != "0"      # conv_cl2.hip where it applies (A/B: set to 0)
 _CL_MIN_FLOP = 4e9
 
 
@@ -258,8 +260,11 @@ def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False):
     yr = torch.empty(oshape, dtype=xr.dtype, device=xr.device, memory_format=torch.channels_last)
     yi = torch.empty_like(yr)
     ws = _scratch(xr.device, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(N)))
-    call("cplxamd_conv2d_cl", ptr(xr), ptr(xi), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, N, KH, KW,
-         geom[11], geom[12], geom[9], geom[10], int(dgrad), ptr(ws), ws.numel(), stream_ptr())
+    args = (ptr(xr), ptr(xi), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9],
+            geom[10], int(dgrad), ptr(ws), ws.numel(), stream_ptr())
+    # dilation 1: the 2-d-patch kernel (activations staged once per channel slice for all nine taps); else the row kernel
+    if not (_CL_PATCH and try_call("cplxamd_conv2d_cl2", *args)):
+        call("cplxamd_conv2d_cl", *args)
     return yr, yi
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 6
+#define CPLXAMD_ABI_VERSION 7
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -373,6 +373,12 @@ int cplxamd_conv2d_cl_pack(const void* w_r, const void* w_i, void* out, int Co, 
 int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
                       void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
                       int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream);
+/* cplxamd_conv2d_cl for dilation 1 in its 2-d-patch form (csrc/conv_cl2.hip: a 16 x 32 pixel tile stages the 18 x 34 input
+ * patch once per 16-channel slice for all nine taps): same arguments, same packed weights, same results; needs KH = KW = 3,
+ * dilation 1, C % 32 == 0 -- CPLXAMD_ESHAPE otherwise. */
+int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                       void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                       int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream);
 int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co);
 int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                             float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,

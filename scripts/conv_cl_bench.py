@@ -48,16 +48,17 @@ yr = torch.empty((B, Co, Ho, Wo), dtype=bf, device=dev, memory_format=torch.chan
 yi = torch.empty_like(yr)
 dxr = torch.empty((B, C, H, W), dtype=bf, device=dev, memory_format=torch.channels_last)
 dxi = torch.empty_like(dxr)
+ENTRY = os.environ.get("ENTRY", "cplxamd_conv2d_cl")
 ws = torch.empty(int(_lib.load().cplxamd_conv2d_cl_ws_bytes(Co)), dtype=torch.uint8, device=dev)
 
 
 def k_fwd():
-    call("cplxamd_conv2d_cl", ptr(xr_cl), ptr(xi_cl), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, Co, 3, 3,
+    call(ENTRY, ptr(xr_cl), ptr(xi_cl), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, Co, 3, 3,
          1, 1, PAD, PAD, 0, ptr(ws), ws.numel(), stream_ptr())
 
 
 def k_dgrad():
-    call("cplxamd_conv2d_cl", ptr(gr_cl), ptr(gi_cl), ptr(wpd), None, None, ptr(dxr), ptr(dxi), B, H, W, Co, C, 3, 3,
+    call(ENTRY, ptr(gr_cl), ptr(gi_cl), ptr(wpd), None, None, ptr(dxr), ptr(dxi), B, H, W, Co, C, 3, 3,
          1, 1, PAD, PAD, 1, ptr(ws), ws.numel(), stream_ptr())
 
 
