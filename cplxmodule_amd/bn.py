@@ -45,11 +45,32 @@ def _prep(xr, xi):
     return xr, xi, _geom(xr), False
 
 
+def _sync_group(process_group, training):
+    """The process group whose ranks share batch statistics, or None: local statistics (the reference's behaviour
+    per process).  `process_group` True = the default group."""
+    import torch.distributed as dist
+    from . import dp
+    if not training or process_group is None or process_group is False or not dp.is_initialized():
+        return None
+    group = dist.group.WORLD if process_group is True else process_group
+    return group if (dist.get_world_size(group) > 1 or dp.FORCE_COLLECTIVES) else None
+
+
+def _sum_over_ranks(t, group):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 class CplxBatchNormFn(torch.autograd.Function):
-    """cplx_batch_norm (cplxmodule/nn/modules/batchnorm.py:189-278) incl. whiten2x2 (:62-123)."""
+    """cplx_batch_norm (cplxmodule/nn/modules/batchnorm.py:189-278) incl. whiten2x2 (:62-123).
+
+    `process_group` (None = the reference's local-batch statistics): training-mode statistics over the batches of all
+    ranks of the group (optional SyncBN) -- the [F][5] forward moments and the [F][6] backward sums,
+    each with the position count in the same float64 buffer, cross the ranks in ONE all-reduce per pass; the gradients
+    of weight / bias stay local sums (the data-parallel exchange averages them like any other parameter)."""
 
     @staticmethod
-    def forward(ctx, xr, xi, weight, bias, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, xr, xi, weight, bias, running_mean, running_var, training, momentum, eps, process_group=None):
         require_device(xr, xi, weight, bias, running_mean, running_var)
         if not training and running_mean is None:
             raise ValueError("evaluation mode requires running statistics")
@@ -59,9 +80,21 @@ class CplxBatchNormFn(torch.autograd.Function):
         ws = _ws(xr.device, F)
         w = None if weight is None else weight.detach().contiguous()
         b = None if bias is None else bias.detach().contiguous()
-        call("cplxamd_bn_fwd", ptr(xr), ptr(xi), ptr(yr), ptr(yi), B, F, S, ptr(w), ptr(b),
-             ptr(running_mean), ptr(running_var), ptr(saved), int(training), dtype_code(xr),
-             momentum, eps, ptr(ws), ws.numel(), stream_ptr())
+        ctx.group = _sync_group(process_group, training)
+        if ctx.group is not None:
+            m = torch.empty(F * 5 + 1, dtype=torch.float64, device=xr.device)
+            m[-1] = float(B * S)
+            call("cplxamd_bn_moments", ptr(xr), ptr(xi), None, None, None, B, F, S, dtype_code(xr), ptr(m), ptr(ws),
+                 ws.numel(), stream_ptr())
+            _sum_over_ranks(m, ctx.group)
+            ctx.count = m[-1:].clone()
+            call("cplxamd_bn_fwd_sync", ptr(xr), ptr(xi), ptr(yr), ptr(yi), B, F, S, ptr(w), ptr(b),
+                 ptr(running_mean), ptr(running_var), ptr(saved), dtype_code(xr), momentum, eps, ptr(m),
+                 ptr(ctx.count), ptr(ws), ws.numel(), stream_ptr())
+        else:
+            call("cplxamd_bn_fwd", ptr(xr), ptr(xi), ptr(yr), ptr(yi), B, F, S, ptr(w), ptr(b),
+                 ptr(running_mean), ptr(running_var), ptr(saved), int(training), dtype_code(xr),
+                 momentum, eps, ptr(ws), ws.numel(), stream_ptr())
         ctx.save_for_backward(xr, xi, w, saved)
         ctx.training, ctx.affine = training, weight is not None
         return yr, yi
@@ -87,10 +120,20 @@ class CplxBatchNormFn(torch.autograd.Function):
         sums = None
         if ctx.cl and _lib.load().cplxamd_bn_rows_path(B, F, S):
             sums = torch.empty(2, F, dtype=torch.float32, device=xr.device)
-        call("cplxamd_bn_bwd_sums", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S,
-             ptr(w), ptr(saved), ptr(dw), ptr(db), int(ctx.training), dtype_code(xr), ptr(sums), ptr(ws),
-             ws.numel(), stream_ptr())
+        if ctx.group is not None:
+            local = torch.empty(F * 6, dtype=torch.float64, device=xr.device)
+            call("cplxamd_bn_moments", ptr(xr), ptr(xi), ptr(gr), ptr(gi), ptr(saved), B, F, S, dtype_code(xr),
+                 ptr(local), ptr(ws), ws.numel(), stream_ptr())
+            total = local.clone()
+            _sum_over_ranks(total, ctx.group)
+            call("cplxamd_bn_bwd_sync", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S, ptr(w),
+                 ptr(saved), ptr(dw), ptr(db), dtype_code(xr), ptr(sums), ptr(total), ptr(local), ptr(ctx.count),
+                 ptr(ws), ws.numel(), stream_ptr())
+        else:
+            call("cplxamd_bn_bwd_sums", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S,
+                 ptr(w), ptr(saved), ptr(dw), ptr(db), int(ctx.training), dtype_code(xr), ptr(sums), ptr(ws),
+                 ws.numel(), stream_ptr())
         if sums is not None:
             ops.attach_colsum(dxr, sums[0])
             ops.attach_colsum(dxi, sums[1])
-        return dxr, dxi, dw, db, None, None, None, None, None
+        return dxr, dxi, dw, db, None, None, None, None, None, None

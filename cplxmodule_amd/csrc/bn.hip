@@ -288,13 +288,39 @@ __device__ __forceinline__ Whiten inv_sqrt_2x2(double a, double b, double d) {
   return Whiten{(d + s) / t, -b / t, (a + s) / t};
 }
 
+// Cross-rank statistics (the optional SyncBN row): the moment totals of one rank leave the library
+// as [F][NS] doubles (`moments_out`), the caller sums them over the ranks (one all-reduce of F * NS + 1 doubles,
+// the last one the position count) and the finalize + apply passes run from the summed totals (`moments_in`,
+// `count_dev` on the device: no host round trip).  Backward: the affine parameters' gradients stay LOCAL sums
+// (`local_in`; the data-parallel gradient exchange averages them like every other parameter gradient), the input
+// gradient uses the totals of all ranks.
+struct BnSync {
+  double* moments_out = nullptr;
+  const double* moments_in = nullptr;
+  const double* local_in = nullptr;
+  const double* count_dev = nullptr;
+};
+
+template <int NS>
+__global__ __launch_bounds__(64) void bn_collapse(const double* partial, int chunks, int F, double* out) {
+  const int f = blockIdx.x;
+  double s[NS];
+  for (int j = 0; j < NS; ++j) s[j] = 0.0;
+  for (int c = threadIdx.x; c < chunks; c += 64)
+    for (int j = 0; j < NS; ++j) s[j] += partial[((int64_t)c * F + f) * NS + j];
+  for (int j = 0; j < NS; ++j) s[j] = wave_sum(s[j]);
+  if (threadIdx.x == 0)
+    for (int j = 0; j < NS; ++j) out[(int64_t)f * NS + j] = s[j];
+}
+
 // forward finalize: one wave per feature (lanes stride over the chunk partials, wave reduction,
 // lane 0 does the per-feature algebra)
 __global__ __launch_bounds__(64) void bn_fwd_finalize(const double* partial, int chunks, int F, double count,
                                 const float* weight, const float* bias, float* running_mean,
                                 float* running_var, int training, float momentum, float eps,
-                                float* saved, float* coef) {
+                                float* saved, float* coef, const double* count_dev) {
   const int f = blockIdx.x;
+  if (count_dev) count = *count_dev;
   double mu, mv, vuu, vuv, vvv;
   double s[5] = {0, 0, 0, 0, 0};
   if (training) {
@@ -338,8 +364,10 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize(const double* partial, int
 
 __global__ __launch_bounds__(64) void bn_bwd_finalize(const double* partial, int chunks, int F, double count,
                                 const float* weight, const float* saved, int training,
-                                float* dweight, float* dbias, float* coef) {
+                                float* dweight, float* dbias, float* coef, const double* local,
+                                const double* count_dev) {
   const int f = blockIdx.x;
+  if (count_dev) count = *count_dev;
   double s[6] = {0, 0, 0, 0, 0, 0};
   for (int c = threadIdx.x; c < chunks; c += 64)
     for (int j = 0; j < 6; ++j) s[j] += partial[((int64_t)c * F + f) * 6 + j];
@@ -351,13 +379,17 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize(const double* partial, int
   if (weight) {
     w00 = weight[f]; w01 = weight[F + f]; w10 = weight[2 * F + f]; w11 = weight[3 * F + f];
   }
-  if (dweight) {
-    dweight[0 * F + f] = (float)(p * Suu + q * Suv);   // sum gou zu
-    dweight[1 * F + f] = (float)(q * Suu + w * Suv);   // sum gou zv
-    dweight[2 * F + f] = (float)(p * Svu + q * Svv);   // sum gov zu
-    dweight[3 * F + f] = (float)(q * Svu + w * Svv);   // sum gov zv
+  {
+    // parameter gradients: this rank's sums when the statistics are shared between ranks (BnSync::local_in)
+    const double* l = local ? local + (int64_t)f * 6 : s;
+    if (dweight) {
+      dweight[0 * F + f] = (float)(p * l[2] + q * l[3]);   // sum gou zu
+      dweight[1 * F + f] = (float)(q * l[2] + w * l[3]);   // sum gou zv
+      dweight[2 * F + f] = (float)(p * l[4] + q * l[5]);   // sum gov zu
+      dweight[3 * F + f] = (float)(q * l[4] + w * l[5]);   // sum gov zv
+    }
+    if (dbias) { dbias[f] = (float)l[0]; dbias[F + f] = (float)l[1]; }
   }
-  if (dbias) { dbias[f] = (float)Sgu; dbias[F + f] = (float)Sgv; }
   float* c = coef + (int64_t)f * kBwdCoef;
   c[0] = saved[f]; c[1] = saved[F + f];
   // gzu = w00 gou + w10 gov ; gzv = w01 gou + w11 gov ; gu = p gzu + q gzv + ... ; gv = q gzu + w gzv + ...
@@ -481,7 +513,7 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
                   void* yi, int64_t B, int F, int64_t S, const float* weight, const float* bias,
                   float* running_mean, float* running_var, float* saved, float* dweight,
                   float* dbias, int training, float momentum, float eps, void* ws,
-                  hipStream_t st, float* dx_sums = nullptr) {
+                  hipStream_t st, float* dx_sums = nullptr, BnSync sync = BnSync()) {
   const BnGeom g = bn_geom(B, F, S);
   double* partial = (double*)ws;
   float* coef = (float*)((char*)ws + bn_coef_off(F));
@@ -493,7 +525,7 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
     chunks = (int)(want < kBnRowChunks ? want : kBnRowChunks);
   }
   constexpr int NS = BWD ? 6 : 5;
-  const bool need_reduce = BWD ? true : (training != 0);
+  const bool need_reduce = (BWD ? true : (training != 0)) && !sync.moments_in;
   if (need_reduce) {
     if (rows) {
       bn_reduce_rows<T, NS, BWD><<<chunks, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi,
@@ -509,13 +541,20 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
     }
     CPLXAMD_CHECK_LAUNCH();
   }
+  if (sync.moments_out) {                              // first half of a cross-rank pass: this rank's totals only
+    bn_collapse<NS><<<F, 64, 0, st>>>(partial, chunks, F, sync.moments_out);
+    CPLXAMD_CHECK_LAUNCH();
+    return 0;
+  }
   const double count = (double)B * (double)S;
+  const double* totals = sync.moments_in ? sync.moments_in : partial;
+  const int tchunks = sync.moments_in ? 1 : chunks;
   if (!BWD)
-    bn_fwd_finalize<<<F, 64, 0, st>>>(partial, chunks, F, count, weight, bias, running_mean,
-                                        running_var, training, momentum, eps, saved, coef);
+    bn_fwd_finalize<<<F, 64, 0, st>>>(totals, tchunks, F, count, weight, bias, running_mean,
+                                        running_var, training, momentum, eps, saved, coef, sync.count_dev);
   else
-    bn_bwd_finalize<<<F, 64, 0, st>>>(partial, chunks, F, count, weight, saved, training,
-                                        dweight, dbias, coef);
+    bn_bwd_finalize<<<F, 64, 0, st>>>(totals, tchunks, F, count, weight, saved, training,
+                                        dweight, dbias, coef, sync.local_in, sync.count_dev);
   CPLXAMD_CHECK_LAUNCH();
   if (rows) {
     const int RL = kBnT / (F / 8);
@@ -619,6 +658,76 @@ int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const vo
     return bn_run<bf16_t, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr,
                                 nullptr, const_cast<float*>(saved), dweight, dbias, training, 0.f,
                                 0.f, ws, st, dx_sums);
+  return CPLXAMD_EINVAL;
+}
+
+/* ---- statistics shared between ranks (see BnSync): moments -> [caller: all-reduce] -> *_sync ------------------- */
+int cplxamd_bn_moments(const void* xr, const void* xi, const void* gr, const void* gi, const float* saved,
+                       int64_t B, int F, int64_t S, int dtype, double* moments, void* ws, int64_t ws_bytes,
+                       void* stream) {
+  if (!xr || !xi || !moments || !ws || B <= 0 || F <= 0 || S <= 0) return CPLXAMD_EINVAL;
+  if ((gr == nullptr) != (gi == nullptr) || (gr && !saved)) return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  BnSync sync;
+  sync.moments_out = moments;
+  float* sv = const_cast<float*>(saved);
+  if (dtype == CPLXAMD_F32)
+    return gr ? bn_run<float, true>(xr, xi, gr, gi, nullptr, nullptr, B, F, S, nullptr, nullptr, nullptr, nullptr, sv,
+                                    nullptr, nullptr, 1, 0.f, 0.f, ws, st, nullptr, sync)
+              : bn_run<float, false>(xr, xi, nullptr, nullptr, nullptr, nullptr, B, F, S, nullptr, nullptr, nullptr,
+                                     nullptr, sv, nullptr, nullptr, 1, 0.f, 0.f, ws, st, nullptr, sync);
+  if (dtype == CPLXAMD_BF16)
+    return gr ? bn_run<bf16_t, true>(xr, xi, gr, gi, nullptr, nullptr, B, F, S, nullptr, nullptr, nullptr, nullptr, sv,
+                                     nullptr, nullptr, 1, 0.f, 0.f, ws, st, nullptr, sync)
+              : bn_run<bf16_t, false>(xr, xi, nullptr, nullptr, nullptr, nullptr, B, F, S, nullptr, nullptr, nullptr,
+                                      nullptr, sv, nullptr, nullptr, 1, 0.f, 0.f, ws, st, nullptr, sync);
+  return CPLXAMD_EINVAL;
+}
+
+int cplxamd_bn_fwd_sync(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F, int64_t S,
+                        const float* weight, const float* bias, float* running_mean, float* running_var,
+                        float* saved, int dtype, float momentum, float eps, const double* moments,
+                        const double* count, void* ws, int64_t ws_bytes, void* stream) {
+  if (!xr || !xi || !yr || !yi || !saved || !ws || !moments || !count || B <= 0 || F <= 0 || S <= 0)
+    return CPLXAMD_EINVAL;
+  if ((weight == nullptr) != (bias == nullptr)) return CPLXAMD_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  BnSync sync;
+  sync.moments_in = moments;
+  sync.count_dev = count;
+  if (dtype == CPLXAMD_F32)
+    return bn_run<float, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias, running_mean, running_var,
+                                saved, nullptr, nullptr, 1, momentum, eps, ws, st, nullptr, sync);
+  if (dtype == CPLXAMD_BF16)
+    return bn_run<bf16_t, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias, running_mean, running_var,
+                                 saved, nullptr, nullptr, 1, momentum, eps, ws, st, nullptr, sync);
+  return CPLXAMD_EINVAL;
+}
+
+int cplxamd_bn_bwd_sync(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr, void* dxi,
+                        int64_t B, int F, int64_t S, const float* weight, const float* saved, float* dweight,
+                        float* dbias, int dtype, float* dx_sums, const double* moments, const double* local_moments,
+                        const double* count, void* ws, int64_t ws_bytes, void* stream) {
+  if (dx_sums && !bn_rows_ok(B, F, S)) return CPLXAMD_ESHAPE;
+  if (!gr || !gi || !xr || !xi || !dxr || !dxi || !saved || !ws || !moments || !local_moments || !count || B <= 0 ||
+      F <= 0 || S <= 0)
+    return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  BnSync sync;
+  sync.moments_in = moments;
+  sync.local_in = local_moments;
+  sync.count_dev = count;
+  float* sv = const_cast<float*>(saved);
+  if (dtype == CPLXAMD_F32)
+    return bn_run<float, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr, nullptr, sv, dweight, dbias,
+                               1, 0.f, 0.f, ws, st, dx_sums, sync);
+  if (dtype == CPLXAMD_BF16)
+    return bn_run<bf16_t, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr, nullptr, sv, dweight, dbias,
+                                1, 0.f, 0.f, ws, st, dx_sums, sync);
   return CPLXAMD_EINVAL;
 }
 

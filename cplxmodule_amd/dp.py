@@ -215,6 +215,18 @@ def all_reduce_scalar_mean(value):
     return out
 
 
+def convert_sync_batchnorm(module, process_group=True):
+    """Make every complex batch-norm layer of `module` share its training-mode batch statistics between the ranks
+    of `process_group` (True = the default group, None = back to the reference's local statistics): SURVEY 8(e)'s
+    optional SyncBN.  Per layer and pass ONE all-reduce of 5 F + 1 (forward) / 6 F (backward) float64 values -- 2.6 kB
+    for 64 features; nothing changes in evaluation mode or outside an initialised process group.  Returns `module`."""
+    from .nn.modules.batchnorm import _CplxBatchNorm
+    for m in module.modules():
+        if isinstance(m, _CplxBatchNorm):
+            m.process_group = process_group
+    return module
+
+
 class DataParallel(torch.nn.Module):
     """Thin wrapper: forward = module forward on the local shard; call `zero_grad()` before and
     `sync_gradients()` after backward.  Gradients are the MEAN over ranks (torch DDP convention).

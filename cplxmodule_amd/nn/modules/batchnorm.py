@@ -2,7 +2,8 @@
 
 Layer contract of cplxmodule/nn/modules/batchnorm.py:281-407: affine weight [2,2,F] (init I2),
 bias [2,F], running_mean [2,F], running_var [2,2,F] (init I2), num_batches_tracked; momentum=None
-selects the cumulative average; statistics are those of the local batch (no cross-rank sync).
+selects the cumulative average; statistics are those of the local batch unless `process_group` is set
+(cplxmodule_amd.dp.convert_sync_batchnorm: SURVEY 8(e)'s optional cross-rank statistics).
 """
 import torch
 
@@ -11,18 +12,23 @@ from ... import cplx
 
 
 def cplx_batch_norm(input, running_mean, running_var, weight=None, bias=None, training=True,
-                    momentum=0.1, eps=1e-5):
-    """Functional form (batchnorm.py:189-278).  Running statistics are updated in place."""
+                    momentum=0.1, eps=1e-5, *, process_group=None):
+    """Functional form (batchnorm.py:189-278).  Running statistics are updated in place.
+    process_group (not in the reference; None = its behaviour): share the training-mode batch statistics between
+    the ranks of that torch.distributed group (True = the default group), see bn.CplxBatchNormFn."""
     assert (running_mean is None) == (running_var is None)
     assert (weight is None) == (bias is None)
     from ... import bn
     yr, yi = bn.CplxBatchNormFn.apply(input.real, input.imag, weight, bias, running_mean,
-                                      running_var, bool(training), float(momentum), float(eps))
+                                      running_var, bool(training), float(momentum), float(eps), process_group)
     return cplx.Cplx(yr, yi)
 
 
 class _CplxBatchNorm(CplxToCplx):
     _dims = ()
+    # None: statistics of the local batch (the reference); a process group / True: shared between its ranks in
+    # training mode (set by cplxmodule_amd.dp.convert_sync_batchnorm; not part of the state dict)
+    process_group = None
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True,
                  track_running_stats=True):
@@ -71,7 +77,8 @@ class _CplxBatchNorm(CplxToCplx):
             if self.momentum is None:
                 factor = 1.0 / float(self.num_batches_tracked)
         return cplx_batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias,
-                               self.training or not self.track_running_stats, factor, self.eps)
+                               self.training or not self.track_running_stats, factor, self.eps,
+                               process_group=self.process_group)
 
     def extra_repr(self):
         return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, "

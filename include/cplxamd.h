@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 7
+#define CPLXAMD_ABI_VERSION 8
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -430,6 +430,29 @@ int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const vo
                         void* dxi, int64_t B, int F, int64_t S, const float* weight,
                         const float* saved, float* dweight, float* dbias, int training, int dtype,
                         float* dx_sums, void* ws, int64_t ws_bytes, void* stream);
+
+/* Batch statistics shared between data-parallel ranks ("optional SyncBN"; the reference normalises
+ * with the statistics of the local batch only, nn/modules/batchnorm.py:70-99).  A pass is split around ONE
+ * all-reduce issued by the caller:
+ *   cplxamd_bn_moments  -> this rank's totals, double [F][5] = sum u, v, u^2, v^2, u v (gr == gi == NULL) or
+ *                          double [F][6] = the backward sums of g and g x (x - mean) (gr, gi, saved given);
+ *   [caller: all-reduce(SUM) of the totals and of the position count B * S, both staying on the device]
+ *   cplxamd_bn_fwd_sync / cplxamd_bn_bwd_sync -> finalize + apply from the summed totals (`moments`) and `count`
+ *                          (device pointer to ONE double).  Backward: dweight / dbias are this rank's sums (from
+ *                          `local_moments`, the array cplxamd_bn_moments wrote before the all-reduce) -- the gradient
+ *                          exchange averages them like every other parameter gradient -- while dX uses the totals.
+ * Always training-mode statistics; everything else as cplxamd_bn_fwd / cplxamd_bn_bwd_sums. */
+int cplxamd_bn_moments(const void* xr, const void* xi, const void* gr, const void* gi, const float* saved,
+                       int64_t B, int F, int64_t S, int dtype, double* moments, void* ws, int64_t ws_bytes,
+                       void* stream);
+int cplxamd_bn_fwd_sync(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F, int64_t S,
+                        const float* weight, const float* bias, float* running_mean, float* running_var,
+                        float* saved, int dtype, float momentum, float eps, const double* moments,
+                        const double* count, void* ws, int64_t ws_bytes, void* stream);
+int cplxamd_bn_bwd_sync(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr, void* dxi,
+                        int64_t B, int F, int64_t S, const float* weight, const float* saved, float* dweight,
+                        float* dbias, int dtype, float* dx_sums, const double* moments, const double* local_moments,
+                        const double* count, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * layout converters and the non-GEMM layers either side of the path.

@@ -19,6 +19,57 @@ from cplxmodule_amd.nn import relevance as rel
 from cplxmodule_amd.nn.relevance import noise
 
 
+def check_sync_batchnorm(rank, world, dev):
+    """Batch statistics shared between the ranks (dp.convert_sync_batchnorm) == the same layer, local statistics,
+    on the concatenation of all ranks' batches: outputs, input gradients and running statistics of this rank's rows;
+    weight / bias gradients summed over the ranks == the full-batch ones.  Ranks hold batches of different sizes."""
+    from cplxmodule_amd import nn
+    worst = 0.0
+    cases = [("2d fp32", torch.float32, (6, 24), None, nn.CplxBatchNorm1d, 1e-5),
+             ("planes fp32", torch.float32, (3, 12, 9, 7), None, nn.CplxBatchNorm2d, 1e-5),
+             ("rows bf16 channels-last", torch.bfloat16, (2, 64, 48, 64), torch.channels_last, nn.CplxBatchNorm2d, 2e-2),
+             ("rows fp32 channels-last", torch.float32, (2, 32, 48, 64), torch.channels_last, nn.CplxBatchNorm2d, 1e-5)]
+    for name, dt, shape, fmt, cls, tol in cases:
+        sizes = [shape[0] + r for r in range(world)]                      # rank r holds shape[0] + r samples
+        g = torch.Generator(device="cpu").manual_seed(len(name))
+        mk = lambda n: (torch.randn(n, *shape[1:], generator=g) * 1.5 + 0.3).to(dt).to(dev)  # noqa: E731
+        full = [mk(sum(sizes)) for _ in range(4)]                         # xr, xi, gr, gi of the whole batch
+        if fmt is not None:
+            full = [t.contiguous(memory_format=fmt) for t in full]
+        lo = sum(sizes[:rank])
+        mine = [t[lo:lo + sizes[rank]] for t in full]
+        if fmt is not None:
+            mine = [t.contiguous(memory_format=fmt) for t in mine]
+        torch.manual_seed(3)
+        F = shape[1]
+        outs = []
+        for sync, (xr, xi, gr, gi) in ((False, full), (True, mine)):
+            bn = cls(F).to(dev)
+            with torch.no_grad():
+                bn.weight.copy_(torch.eye(2, device=dev).unsqueeze(-1) + 0.1 * torch.arange(4 * F, device=dev).view(2, 2, F) / (4 * F))
+                bn.bias.copy_(torch.linspace(-1, 1, 2 * F, device=dev).view(2, F))
+            if sync:
+                dp.convert_sync_batchnorm(bn)
+            bn.train()
+            xr, xi = xr.clone().requires_grad_(True), xi.clone().requires_grad_(True)
+            y = bn(Cplx(xr, xi))
+            torch.autograd.backward((y.real, y.imag), (gr, gi))
+            outs.append(dict(yr=y.real.detach().float(), yi=y.imag.detach().float(), dxr=xr.grad.float(), dxi=xi.grad.float(),
+                             dw=bn.weight.grad.clone(), db=bn.bias.grad.clone(), rm=bn.running_mean.clone(),
+                             rv=bn.running_var.clone()))
+        ref, got = outs
+        for k in ("dw", "db"):
+            dist.all_reduce(got[k])
+        for k in ("yr", "yi", "dxr", "dxi"):
+            ref[k] = ref[k][lo:lo + sizes[rank]]
+        for k, want in ref.items():
+            t = tol if k in ("yr", "yi", "dxr", "dxi") else max(1e-5, tol * 0.05)
+            err = float((got[k] - want).abs().max() / (want.abs().max() + 1e-12))
+            worst = max(worst, err if dt == torch.float32 else 0.0)
+            assert err < t, (name, k, err)
+    return worst
+
+
 def main():
     rccl1 = "--rccl1" in sys.argv
     torch.cuda.set_device(0)
@@ -120,6 +171,7 @@ def main():
     assert nb >= 3, nb
     check(net, run_net_same_stats, ref5, 5e-4, overlap=False)
     worst = max(worst, w5)
+    worst = max(worst, check_sync_batchnorm(rank, world, dev))
     kl_mean = dp.all_reduce_scalar_mean(sum(rel.penalties(layer)))
     assert torch.isfinite(kl_mean)
     if rank == 0:

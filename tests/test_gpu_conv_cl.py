@@ -399,3 +399,52 @@ def test_cl_conv_random_geometries_vs_float32_kernels(seed):
         d2 = conv.cl_conv(gr, gi, wb[0], wb[1], None, None, geom, dgrad=True)
         for got, want in zip(d2, ref[2:4]):
             assert float((got.float() - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-6, ("dgrad", seed)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,pad", [
+    (1, 32, 64, 3, 3, (1, 1)),            # one partial tile
+    (2, 64, 64, 16, 32, (1, 1)),          # exactly one full tile per image
+    (2, 32, 128, 17, 33, (1, 1)),         # one row / one column past the tile: four tiles, three of them slivers
+    (3, 96, 64, 50, 70, (0, 1)),          # valid rows, same columns (output smaller than the input)
+    (2, 64, 192, 35, 45, (1, 0)),
+    (2, 128, 64, 20, 40, (0, 0)),
+    (5, 64, 64, 130, 200, (1, 1)),        # 5 * 9 * 7 = 315 tiles x 1 column tile: more tiles than workgroups
+    (9, 32, 128, 100, 100, (1, 1)),       # 9 * 7 * 4 = 252 tiles x 2 column tiles: two tiles per workgroup
+])
+def test_patch_kernel_matches_row_kernel(B, Ci, Co, H, W, pad):
+    """conv_cl2.hip (2-D patch per 16-channel slice) against conv_cl.hip (row shifts, itself checked against the
+    oracle above) on the same operands, forward and data gradient: the two accumulate the 9 * Ci terms in a different
+    order in fp32 and round once to bf16, so they agree to one bf16 step of the largest output."""
+    from cplxmodule_amd import conv
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16().to("cuda")  # noqa: E731
+    wr, wi = (mk(Co, Ci, 3, 3).float() * 0.1).bfloat16(), (mk(Co, Ci, 3, 3).float() * 0.1).bfloat16()
+    br, bi = mk(Co).float(), mk(Co).float()
+    geom, _ = conv._geom((B, Ci, H, W), wr.shape, 1, pad, 1, 1)
+    Ho, Wo = H + 2 * pad[0] - 2, W + 2 * pad[1] - 2
+    cl = lambda *s: mk(*s).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    jobs = [("fwd", (cl(B, Ci, H, W), cl(B, Ci, H, W), wr, wi, br, bi, geom), {})]
+    if Co % 32 == 0 and Ci % 64 == 0:
+        jobs.append(("dgrad", (cl(B, Co, Ho, Wo), cl(B, Co, Ho, Wo), wr, wi, None, None, geom), dict(dgrad=True)))
+    old = conv._CL_PATCH
+    try:
+        for name, a, k in jobs:
+            conv._CL_PATCH = True
+            seen = []
+            real_try = conv.try_call
+            def spy(n, *aa):
+                seen.append((n, real_try(n, *aa)))
+                return seen[-1][1]
+            conv.try_call = spy
+            try:
+                got = conv.cl_conv(*a, **k)
+            finally:
+                conv.try_call = real_try
+            assert seen == [("cplxamd_conv2d_cl2", True)], name          # the patch kernel took it
+            conv._CL_PATCH = False
+            want = conv.cl_conv(*a, **k)
+            for p, q in zip(got, want):
+                assert p.shape == q.shape and bool(torch.isfinite(p.float()).all())
+                assert float((p.float() - q.float()).abs().max()) <= 2 ** -7 * float(q.float().abs().max()), name
+    finally:
+        conv._CL_PATCH = old

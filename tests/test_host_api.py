@@ -169,3 +169,19 @@ def test_noise_state():
     with pytest.raises(ValueError):
         noise.set_mode("numpy")
     assert cplxmodule_amd.__version__
+
+
+def test_convert_sync_batchnorm_is_a_flag_outside_the_state_dict():
+    """dp.convert_sync_batchnorm marks the complex batch-norm layers only; parameters, buffers and the state-dict keys
+    (the reference's, nn/modules/batchnorm.py:302-320) are untouched, and without a process group the layer keeps the
+    local-batch statistics path (bn._sync_group -> None)."""
+    from cplxmodule_amd import bn, dp
+    net = torch.nn.Sequential(nn.CplxConv2d(2, 4, 3), nn.CplxBatchNorm2d(4), nn.CplxBatchNorm1d(4))
+    keys = list(net.state_dict())
+    assert all(m.process_group is None for m in net if isinstance(m, nn.CplxBatchNorm2d))
+    assert dp.convert_sync_batchnorm(net) is net
+    assert net[1].process_group is True and net[2].process_group is True and not hasattr(net[0], "process_group")
+    assert list(net.state_dict()) == keys
+    assert bn._sync_group(True, True) is None and bn._sync_group(True, False) is None     # no process group here
+    dp.convert_sync_batchnorm(net, None)
+    assert net[1].process_group is None
