@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -36,6 +36,8 @@ SIGNATURES = {
     "cplxamd_expi_bwd": [_P, _P, _P, _L, _P],
     "cplxamd_lrt_reparam_fwd": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _L, _I, _P],
     "cplxamd_lrt_reparam_bwd": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _I, _P],
+    "cplxamd_lrt_reparam_fwd_ex": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _L, _I, _I, _P],
+    "cplxamd_lrt_reparam_bwd_ex": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _I, _I, _P],
     "cplxamd_philox_advance": [_P, _P, _P],
     "cplxamd_philox_normal": [_P, _P, _U, _U, _L, _P],
     "cplxamd_cgemm": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,

@@ -672,7 +672,6 @@ class CplxConv2dLRTFn(torch.autograd.Function):
         else:
             mur, mui = conv_fwd(xr, xi, wcr, wci, b[0], b[1], geom, oshape)
             s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
-        s2 = ops.cast(s2, torch.float32)
         eps = None if eps_r is None else (eps_r, eps_i)
         yr, yi = ops.reparam_fwd(mur, mui, s2, eps, seed, offset, inplace=True)
         ctx.save_for_backward(xr, xi, wcr, wci, ls2, s2, a, S, eps_r, eps_i)
@@ -759,7 +758,6 @@ class RealConv2dLRTFn(torch.autograd.Function):
         else:
             mu, _ = conv_fwd(x, None, wc, None, None if b is None else b.contiguous(), None, geom, oshape)
             s2, _ = conv_fwd(a, None, S, None, None, None, geom, oshape)
-        s2 = ops.cast(s2, torch.float32)
         y, _ = ops.reparam_fwd(mu, None, s2, eps, seed, offset, inplace=True)
         ctx.save_for_backward(x, wc, ls2, s2, a, S, eps)
         ctx.geom, ctx.has_bias, ctx.wshape = geom, b is not None, w.shape

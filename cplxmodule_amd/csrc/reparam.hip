@@ -111,9 +111,9 @@ template <typename T> __device__ __forceinline__ float lrt_std_t(float s2) {
   return lrt_std(s2);
 }
 
-template <typename T, bool CPLX, bool PHILOX>
+template <typename T, typename TS, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
-    const T* mu_r, const T* mu_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
+    const T* mu_r, const T* mu_i, const TS* s2, const T* eps_r, const T* eps_i, uint64_t seed,
     uint64_t offset, const uint64_t* state, T* y_r, T* y_i, int64_t n) {
   if (PHILOX && state) { seed = state[0]; offset = state[1]; }   // device-resident stream position
   // 8 outputs per thread and iteration: all loads first (one 16-B access per bf16 plane, two per
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
         er = io<T>::ld(eps_r + e);
         if (CPLX) ei = io<T>::ld(eps_i + e);
       }
-      const float sd = lrt_std_t<T>(s2[e]);
+      const float sd = lrt_std_t<T>(io<TS>::ld(s2 + e));
       io<T>::st(y_r + e, io<T>::ld(mu_r + e) + er * sd);
       if (CPLX) io<T>::st(y_i + e, io<T>::ld(mu_i + e) + ei * sd);
     }
@@ -168,9 +168,9 @@ template <typename T> __device__ __forceinline__ float lrt_gs2_t(float gs, float
   return lrt_gs2(gs, s2);
 }
 
-template <typename T, typename TG, bool CPLX, bool PHILOX>
+template <typename T, typename TG, typename TS, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
-    const T* g_r, const T* g_i, const float* s2, const T* eps_r, const T* eps_i, uint64_t seed,
+    const T* g_r, const T* g_i, const TS* s2, const T* eps_r, const T* eps_i, uint64_t seed,
     uint64_t offset, const uint64_t* state, TG* g_s2, int64_t n) {
   if (PHILOX && state) { seed = state[0]; offset = state[1]; }
   const int64_t n8 = n >> 3;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
       }
       float gs = io<T>::ld(g_r + e) * er;
       if (CPLX) gs = gs + io<T>::ld(g_i + e) * ei;
-      io<TG>::st(g_s2 + e, lrt_gs2_t<T>(gs, s2[e]));
+      io<TG>::st(g_s2 + e, lrt_gs2_t<T>(gs, io<TS>::ld(s2 + e)));
     }
   }
 }
@@ -226,15 +226,15 @@ __global__ __launch_bounds__(kRpThreads) void philox_normal_kernel(float* er, fl
   }
 }
 
-template <typename T>
-static int launch_fwd(const void* mu_r, const void* mu_i, const float* s2, const void* eps_r,
+template <typename T, typename TS>
+static int launch_fwd(const void* mu_r, const void* mu_i, const void* s2, const void* eps_r,
                       const void* eps_i, uint64_t seed, uint64_t offset, const uint64_t* state,
                       void* y_r, void* y_i, int64_t n, hipStream_t st) {
   const int grid = stream_grid(n >> 3, kRpThreads);
   const bool cplx = mu_i != nullptr, philox = eps_r == nullptr;
 #define RP_FWD(C, P)                                                                       \
-  reparam_fwd_kernel<T, C, P><<<grid, kRpThreads, 0, st>>>(                                \
-      (const T*)mu_r, (const T*)mu_i, s2, (const T*)eps_r, (const T*)eps_i, seed, offset,  \
+  reparam_fwd_kernel<T, TS, C, P><<<grid, kRpThreads, 0, st>>>(                            \
+      (const T*)mu_r, (const T*)mu_i, (const TS*)s2, (const T*)eps_r, (const T*)eps_i, seed, offset,  \
       state, (T*)y_r, (T*)y_i, n)
   if (cplx && philox) RP_FWD(true, true);
   else if (cplx) RP_FWD(true, false);
@@ -245,15 +245,15 @@ static int launch_fwd(const void* mu_r, const void* mu_i, const float* s2, const
   return 0;
 }
 
-template <typename T, typename TG>
-static int launch_bwd(const void* g_r, const void* g_i, const float* s2, const void* eps_r,
+template <typename T, typename TG, typename TS>
+static int launch_bwd(const void* g_r, const void* g_i, const void* s2, const void* eps_r,
                       const void* eps_i, uint64_t seed, uint64_t offset, const uint64_t* state,
                       void* g_s2, int64_t n, hipStream_t st) {
   const int grid = stream_grid(n >> 3, kRpThreads);
   const bool cplx = g_i != nullptr, philox = eps_r == nullptr;
 #define RP_BWD(C, P)                                                                      \
-  reparam_bwd_kernel<T, TG, C, P><<<grid, kRpThreads, 0, st>>>(                           \
-      (const T*)g_r, (const T*)g_i, s2, (const T*)eps_r, (const T*)eps_i, seed, offset,   \
+  reparam_bwd_kernel<T, TG, TS, C, P><<<grid, kRpThreads, 0, st>>>(                       \
+      (const T*)g_r, (const T*)g_i, (const TS*)s2, (const T*)eps_r, (const T*)eps_i, seed, offset,   \
       state, (TG*)g_s2, n)
   if (cplx && philox) RP_BWD(true, true);
   else if (cplx) RP_BWD(true, false);
@@ -281,20 +281,52 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" {
 
-int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
-                            const void* eps_r, const void* eps_i, uint64_t seed,
-                            uint64_t offset, const uint64_t* state, void* y_r, void* y_i,
-                            int64_t n, int dtype, void* stream) {
+int cplxamd_lrt_reparam_fwd_ex(const void* mu_r, const void* mu_i, const void* s2,
+                               const void* eps_r, const void* eps_i, uint64_t seed,
+                               uint64_t offset, const uint64_t* state, void* y_r, void* y_i,
+                               int64_t n, int dtype, int s2_dtype, void* stream) {
   if (!mu_r || !s2 || !y_r || n < 0) return CPLXAMD_EINVAL;
   if (!al16(mu_r) || !al16(mu_i) || !al16(s2) || !al16(eps_r) || !al16(eps_i) || !al16(y_r) || !al16(y_i))
     return CPLXAMD_EALIGN;
   if ((mu_i == nullptr) != (y_i == nullptr)) return CPLXAMD_EINVAL;
   if (eps_r && mu_i && !eps_i) return CPLXAMD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CPLXAMD_F32)
-    return launch_fwd<float>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, st);
-  if (dtype == CPLXAMD_BF16)
-    return launch_fwd<bf16_t>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, st);
+  if (dtype == CPLXAMD_F32 && s2_dtype == CPLXAMD_F32)
+    return launch_fwd<float, float>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, st);
+  if (dtype == CPLXAMD_BF16 && s2_dtype == CPLXAMD_F32)
+    return launch_fwd<bf16_t, float>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, st);
+  if (dtype == CPLXAMD_BF16 && s2_dtype == CPLXAMD_BF16)
+    return launch_fwd<bf16_t, bf16_t>(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, st);
+  return CPLXAMD_EINVAL;
+}
+
+int cplxamd_lrt_reparam_fwd(const void* mu_r, const void* mu_i, const float* s2,
+                            const void* eps_r, const void* eps_i, uint64_t seed,
+                            uint64_t offset, const uint64_t* state, void* y_r, void* y_i,
+                            int64_t n, int dtype, void* stream) {
+  return cplxamd_lrt_reparam_fwd_ex(mu_r, mu_i, s2, eps_r, eps_i, seed, offset, state, y_r, y_i, n, dtype,
+                                    CPLXAMD_F32, stream);
+}
+
+int cplxamd_lrt_reparam_bwd_ex(const void* g_r, const void* g_i, const void* s2,
+                               const void* eps_r, const void* eps_i, uint64_t seed,
+                               uint64_t offset, const uint64_t* state, void* g_s2, int64_t n,
+                               int dtype, int gs2_dtype, int s2_dtype, void* stream) {
+  if (!g_r || !s2 || !g_s2 || n < 0) return CPLXAMD_EINVAL;
+  if (eps_r && g_i && !eps_i) return CPLXAMD_EINVAL;
+  if (!al16(g_r) || !al16(g_i) || !al16(s2) || !al16(eps_r) || !al16(eps_i) || !al16(g_s2))
+    return CPLXAMD_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CPLXAMD_F32 && gs2_dtype == CPLXAMD_F32 && s2_dtype == CPLXAMD_F32)
+    return launch_bwd<float, float, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
+  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_F32 && s2_dtype == CPLXAMD_F32)
+    return launch_bwd<bf16_t, float, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
+  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_BF16 && s2_dtype == CPLXAMD_F32)
+    return launch_bwd<bf16_t, bf16_t, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
+  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_BF16 && s2_dtype == CPLXAMD_BF16)
+    return launch_bwd<bf16_t, bf16_t, bf16_t>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
+  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_F32 && s2_dtype == CPLXAMD_BF16)
+    return launch_bwd<bf16_t, float, bf16_t>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
   return CPLXAMD_EINVAL;
 }
 
@@ -302,18 +334,8 @@ int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
                             const void* eps_r, const void* eps_i, uint64_t seed,
                             uint64_t offset, const uint64_t* state, void* g_s2, int64_t n,
                             int dtype, int gs2_dtype, void* stream) {
-  if (!g_r || !s2 || !g_s2 || n < 0) return CPLXAMD_EINVAL;
-  if (eps_r && g_i && !eps_i) return CPLXAMD_EINVAL;
-  if (!al16(g_r) || !al16(g_i) || !al16(s2) || !al16(eps_r) || !al16(eps_i) || !al16(g_s2))
-    return CPLXAMD_EALIGN;
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == CPLXAMD_F32 && gs2_dtype == CPLXAMD_F32)
-    return launch_bwd<float, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
-  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_F32)
-    return launch_bwd<bf16_t, float>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
-  if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_BF16)
-    return launch_bwd<bf16_t, bf16_t>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, st);
-  return CPLXAMD_EINVAL;
+  return cplxamd_lrt_reparam_bwd_ex(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, dtype, gs2_dtype,
+                                    CPLXAMD_F32, stream);
 }
 
 int cplxamd_philox_advance(uint64_t* state, uint64_t* used, void* stream) {

@@ -260,11 +260,21 @@ def _al16(t):
     return t if t is None or t.data_ptr() % 16 == 0 else t.clone()
 
 
+def _s2(s2, like):
+    """The variance operand of the noise injection: float32, or bf16 as the variance GEMM / convolution of a bf16
+    layer wrote it (kept as it is: no float32 copy of a [B, O] tensor)."""
+    return s2 if (s2.dtype == torch.bfloat16 and like.dtype == torch.bfloat16) else _f32(s2)
+
+
+def _s2_dtype(x):
+    return torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+
+
 def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
     """y = mu + eps * sqrt(max(s2, 1e-8)); eps=(eps_r, eps_i) / eps_r tensor or None (Philox)."""
     require_device(mu_r, mu_i, s2)
     fmt = _layout_of(mu_r)               # all operands in the layout of mu (the kernel walks the storage linearly)
-    mu_r, mu_i, s2 = _al16(_cf(mu_r, fmt)), _al16(_cf(mu_i, fmt)), _al16(_f32(_cf(s2, fmt)))
+    mu_r, mu_i, s2 = _al16(_cf(mu_r, fmt)), _al16(_cf(mu_i, fmt)), _al16(_s2(_cf(s2, fmt), mu_r))
     e_r = e_i = None
     if eps is not None:
         e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
@@ -273,15 +283,15 @@ def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
     y_r = mu_r if inplace else torch.empty_like(mu_r)
     y_i = None if mu_i is None else (mu_i if inplace else torch.empty_like(mu_i))
     sd, of, st = _noise_args(seed, offset)
-    call("cplxamd_lrt_reparam_fwd", ptr(mu_r), ptr(mu_i), ptr(s2), ptr(e_r), ptr(e_i), sd,
-         of, st, ptr(y_r), ptr(y_i), mu_r.numel(), dtype_code(mu_r), stream_ptr())
+    call("cplxamd_lrt_reparam_fwd_ex", ptr(mu_r), ptr(mu_i), ptr(s2), ptr(e_r), ptr(e_i), sd,
+         of, st, ptr(y_r), ptr(y_i), mu_r.numel(), dtype_code(mu_r), dtype_code(s2), stream_ptr())
     return y_r, y_i
 
 
 def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float32):
     require_device(g_r, g_i, s2)
     fmt = _layout_of(s2)                 # the layout the forward ran in (s2 is its saved tensor)
-    g_r, g_i, s2 = _al16(_cf(g_r, fmt)), _al16(_cf(g_i, fmt)), _al16(_f32(_cf(s2, fmt)))
+    g_r, g_i, s2 = _al16(_cf(g_r, fmt)), _al16(_cf(g_i, fmt)), _al16(_s2(_cf(s2, fmt), g_r))
     e_r = e_i = None
     if eps is not None:
         e_r, e_i = eps if isinstance(eps, (tuple, list)) else (eps, None)
@@ -289,8 +299,8 @@ def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float3
         e_r, e_i = _al16(e_r), _al16(e_i)
     g_s2 = torch.empty_like(s2, dtype=out_dtype)
     sd, of, st = _noise_args(seed, offset)
-    call("cplxamd_lrt_reparam_bwd", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,
-         ptr(g_s2), g_r.numel(), dtype_code(g_r), dtype_code(g_s2), stream_ptr())
+    call("cplxamd_lrt_reparam_bwd_ex", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,
+         ptr(g_s2), g_r.numel(), dtype_code(g_r), dtype_code(g_s2), dtype_code(s2), stream_ptr())
     return g_s2
 
 
@@ -557,7 +567,9 @@ class CplxLinearLRTFn(torch.autograd.Function):
         ctx.wc, ctx.S = (wcr, wci), S
         mur, mui = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
         a = abs2(x2r, x2i)                                   # [B,I], activation dtype
-        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)            # float32 [B,O]
+        # [B,O]; bf16 layers keep the variance in bf16 (2 bytes per output less in the GEMM epilogue and in both noise
+        # passes; sigma enters y = mu + eps sigma, itself rounded to bf16, with a relative error of 2^-10)
+        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I, out_dtype=_s2_dtype(x2r))
         eps = None
         if eps_r is not None:
             eps = (eps_r.reshape(B, O), eps_i.reshape(B, O))
@@ -707,7 +719,7 @@ class RealLinearLRTFn(torch.autograd.Function):
         ctx.wb, ctx.S = wb, S
         mu = rgemm(x2, (I, 1), wb, (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
         a = abs2(x2)
-        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I)
+        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I, out_dtype=_s2_dtype(x2))
         e = None if eps is None else eps.reshape(B, O)
         y, _ = reparam_fwd(mu, None, s2, e, seed, offset, inplace=True)
         ctx.save_for_backward(x2, w, ls2, s2, a, eps, b)

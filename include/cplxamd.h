@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 8
+#define CPLXAMD_ABI_VERSION 9
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -141,6 +141,18 @@ int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
                             const void* eps_r, const void* eps_i, uint64_t seed,
                             uint64_t offset, const uint64_t* state, void* g_s2, int64_t n,
                             int dtype, int gs2_dtype, void* stream);
+
+/* The same two with the element type of s2 as an argument (`s2_dtype`: float32, or bf16 together with bf16
+ * mu / g): the variance GEMM / convolution of a bf16 layer writes s2 in bf16, 2 bytes per output less in each
+ * direction and no float32 [B, O] tensor kept for the backward. */
+int cplxamd_lrt_reparam_fwd_ex(const void* mu_r, const void* mu_i, const void* s2,
+                               const void* eps_r, const void* eps_i, uint64_t seed,
+                               uint64_t offset, const uint64_t* state, void* y_r, void* y_i,
+                               int64_t n, int dtype, int s2_dtype, void* stream);
+int cplxamd_lrt_reparam_bwd_ex(const void* g_r, const void* g_i, const void* s2,
+                               const void* eps_r, const void* eps_i, uint64_t seed,
+                               uint64_t offset, const uint64_t* state, void* g_s2, int64_t n,
+                               int dtype, int gs2_dtype, int s2_dtype, void* stream);
 
 /* used[0..1] = state[0..1]; state[1] += 1  (device-resident noise stream position) */
 int cplxamd_philox_advance(uint64_t* state, uint64_t* used, void* stream);

@@ -188,6 +188,35 @@ def test_reparam_given_noise(ops, dtype, cplx):
     assert N(gs2)[1] == 0 and N(gs2)[0] != 0  # clamp gradient: blocked below, passed AT 1e-8
 
 
+@pytest.mark.parametrize("cplx", (True, False))
+@pytest.mark.parametrize("philox_", (False, True))
+def test_reparam_bf16_variance_operand(ops, cplx, philox_):
+    """bf16 layers hand the variance over in bf16 (cplxamd_lrt_reparam_{fwd,bwd}_ex, s2_dtype = bf16): on
+    bf16-representable values the results are BIT-identical to the float32-s2 entry points (the kernels widen s2 to
+    float32 first), incl. the clamp (1e-8 itself is not representable: its bf16 neighbours fall on either side), the
+    scalar tail and the in-kernel noise; a float32 s2 with a bf16 mu is still accepted."""
+    from gpu_util import T
+    rs = np.random.RandomState(21)
+    n = 8 * 517 + 5
+    bf = torch.bfloat16
+    s2 = T(np.exp(rs.uniform(-25, 2, n)).astype(np.float32)).to(bf)
+    lo = torch.tensor([1e-8], device="cuda").to(bf)                       # nearest bf16 value to 1e-8
+    s2[:4] = torch.stack([lo[0], lo[0] * 1.0078125, lo[0] * 0.9921875, torch.zeros((), device="cuda", dtype=bf)])
+    mu_r, mu_i, gr, gi, er, ei = (T(rs.randn(n).astype(np.float32)).to(bf) for _ in range(6))
+    eps = None if philox_ else ((er, ei) if cplx else er)
+    kw = dict(seed=5, offset=9)
+    a = ops.reparam_fwd(mu_r, mu_i if cplx else None, s2, eps, **kw)
+    b = ops.reparam_fwd(mu_r, mu_i if cplx else None, s2.float(), eps, **kw)
+    assert torch.equal(a[0], b[0]) and (not cplx or torch.equal(a[1], b[1]))
+    for out in (torch.bfloat16, torch.float32):
+        ga = ops.reparam_bwd(gr, gi if cplx else None, s2, eps, out_dtype=out, **kw)
+        gb = ops.reparam_bwd(gr, gi if cplx else None, s2.float(), eps, out_dtype=out, **kw)
+        assert ga.dtype == out and torch.equal(ga, gb)
+    below = s2.float() < 1e-8
+    assert bool(below[:4].any()) and bool((~below[:4]).any())
+    assert bool((ga[below] == 0).all()) and bool((ga[~below][:64] != 0).any())
+
+
 def test_reparam_philox_fwd_bwd_consistent(ops):
     from gpu_util import T, N
     rs = np.random.RandomState(12)
