@@ -781,7 +781,7 @@ template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL, bool
 static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
   using C = Cfg<CPLX, BIG>;
   // read-only tuning knobs, set once from the environment (A/B experiments only)
-  static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 2),
+  static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 4),
                    dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
   static const int ldsepi = env_int("CPLXAMD_GEMM_LDSEPI", 1);   // A/B switch of the LDS-staged epilogue
@@ -837,7 +837,7 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   if (g.bias_r && (!aligned16(g.bias_r) || (CPLX && !aligned16(g.bias_i)))) return 0;
   constexpr int smem = 3 * C::STAGE_BYTES + 16384;
   GemmArgs a = g;
-  static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 2);
+  static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
   a.group_m = gm > 0 ? gm : 1;
   if constexpr (kInstantiated) {
     auto go = [&](auto RR) -> int {
