@@ -828,7 +828,9 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   // instantiated for the layouts the layers launch with a plain epilogue: forward (N,N), input gradient (N,T)
   // -- the weight gradients carry the fused KL accumulate and stay on the one-tile kernel
   constexpr bool kBf16Out = sizeof(TOUT) == 2;
-  constexpr bool kInstantiated = !TA && (CPLX ? (CONJ == TB && kBf16Out) : (TB == kBf16Out));
+  // (real: (N,N) with either output type -- the bf16 layers' mean GEMM and, since they keep the variance in bf16, their
+  //  variance GEMM; the float32-out (N,N) form serves float32 s2 callers -- and (N,T) bf16)
+  constexpr bool kInstantiated = !TA && (CPLX ? (CONJ == TB && kBf16Out) : (kBf16Out || !TB));
   if (!kInstantiated) return 0;
   const int64_t tiles = (int64_t)(g.M / C::BM) * (g.N / C::BN);
   if (tiles <= ncu || tiles > 0x7fffffff) return 0;

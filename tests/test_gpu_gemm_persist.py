@@ -1,6 +1,6 @@
 """The persistent bf16 GEMM (csrc/gemm_bf16_persist.h) on shapes that take it (full tiles, more output tiles than
 CUs) for all three ring phases R = (K / 32) % 3 and both instantiated layouts (complex: forward (N,N) and input
-gradient (N,T) conj, bf16 out; real: forward (N,N) fp32 out and input gradient (N,T) bf16 out), with and without
+gradient (N,T) conj, bf16 out; real: forward (N,N) fp32 / bf16 out and input gradient (N,T) bf16 out), with and without
 bias: against float64 numpy on sampled rows, and bit for bit against the one-tile-per-workgroup kernel -- both
 run the same MFMA sequence per output element -- which is reached through an output with ldc = N + 4 (rows not
 16-byte aligned: the persistent launcher declines those)."""
@@ -47,6 +47,14 @@ def test_persistent_forward_layout(K, bias):
     call("cplxamd_rgemm", ptr(ar), K, 1, ptr(br), K, 1, ptr(b_r) if bias else None, None, ptr(ps), N + 1, M, N, K,
          BF16, F32, 0, None, 0, stream_ptr())
     assert torch.equal(ps[:, :N], s2) and not ps[:, N:].any()
+    # real forward, bf16 out (mean GEMM of the real layers; variance GEMM of every bf16 LRT layer)
+    mu = ops.rgemm(ar, (K, 1), br, (K, 1), M, N, K, bias=b_r if bias else None, out_dtype=bf)
+    assert np.abs(_f(mu[rows]) - ref).max() <= 6e-3 * np.abs(ref).max()
+    assert torch.equal(mu, s2.to(bf))                                   # same accumulators, one rounding
+    pm = torch.zeros(M, N + 4, device=dev, dtype=bf)
+    call("cplxamd_rgemm", ptr(ar), K, 1, ptr(br), K, 1, ptr(b_r) if bias else None, None, ptr(pm), N + 4, M, N, K,
+         BF16, BF16, 0, None, 0, stream_ptr())
+    assert torch.equal(pm[:, :N], mu) and not pm[:, N:].any()
 
 
 @pytest.mark.parametrize("kt", [126, 127, 128])               # K tiles of the contraction over O: R = 0, 1, 2
