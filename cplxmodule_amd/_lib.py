@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -38,6 +38,8 @@ SIGNATURES = {
     "cplxamd_lrt_reparam_bwd": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _I, _P],
     "cplxamd_lrt_reparam_fwd_ex": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _L, _I, _I, _P],
     "cplxamd_lrt_reparam_bwd_ex": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _I, _I, _P],
+    "cplxamd_lrt_reparam_bwd_cols_ws_bytes": [_L, _I],
+    "cplxamd_lrt_reparam_bwd_cols": [_P, _P, _P, _P, _P, _U, _U, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _L, _P],
     "cplxamd_philox_advance": [_P, _P, _P],
     "cplxamd_philox_normal": [_P, _P, _U, _U, _L, _P],
     "cplxamd_cgemm": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,
@@ -113,7 +115,7 @@ SIGNATURES = {
     "cplxamd_bn_fwd_sync": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _L, _P],
     "cplxamd_bn_bwd_sync": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P],
 }
-_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
+_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_lrt_reparam_bwd_cols_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,
              "cplxamd_cgemm3m_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,

@@ -689,7 +689,14 @@ class CplxConv2dLRTFn(torch.autograd.Function):
             geom = ctx.geom
             hint_r, hint_i = ops.colsum_hint(gr), ops.colsum_hint(gi)
             gr, gi = to_channels_last(gr), to_channels_last(gi)
-            gs2 = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype)
+            want_b = ctx.has_bias and (need[4] or need[5])
+            if want_b and (hint_r is None or hint_i is None):
+                # the bias gradient (per-channel sums of G) comes out of the pass that reads G for d s2
+                Bn, Co_, Hn, Wn = gr.shape
+                gs2, hint_r, hint_i = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype,
+                                                      bias_sums=(Bn * Hn * Wn, Co_))
+            else:
+                gs2 = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype)
             if need[0] or need[1]:
                 dxr, dxi = cl_conv(gr, gi, wcr, wci, None, None, geom, dgrad=True)
                 ga = cl_conv_real(gs2, S, None, geom, dgrad=True)
@@ -698,10 +705,8 @@ class CplxConv2dLRTFn(torch.autograd.Function):
                     dxr, dxi = from_channels_last(dxr), from_channels_last(dxi)
             if need[2] or need[3]:
                 dwr, dwi = cl_wgrad(gr, gi, xr, xi, geom, ctx.wshape)
-            if ctx.has_bias and (need[4] or need[5]):
-                B, Co, H, W = gr.shape
-                dbr = hint_r if hint_r is not None else ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))
-                dbi = hint_i if hint_i is not None else ops.colsum(gi.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+            if want_b:
+                dbr, dbi = hint_r, hint_i
             if need[6]:
                 dls2 = cl_wgrad_real(gs2, a, geom, ctx.wshape, emul=ls2.contiguous(), emul_exp=True)
             return (dxr, dxi, dwr, dwi, dbr, dbi, dls2) + (None,) * 8
@@ -773,7 +778,13 @@ class RealConv2dLRTFn(torch.autograd.Function):
             geom = ctx.geom
             hint = ops.colsum_hint(g)
             g = to_channels_last(g)
-            gs2 = ops.reparam_bwd(g, None, s2, eps, ctx.seed, ctx.offset, out_dtype=x.dtype)
+            want_b = ctx.has_bias and need[2]
+            if want_b and hint is None:
+                Bn, Co_, Hn, Wn = g.shape
+                gs2, hint, _ = ops.reparam_bwd(g, None, s2, eps, ctx.seed, ctx.offset, out_dtype=x.dtype,
+                                               bias_sums=(Bn * Hn * Wn, Co_))
+            else:
+                gs2 = ops.reparam_bwd(g, None, s2, eps, ctx.seed, ctx.offset, out_dtype=x.dtype)
             if need[0]:
                 dx = cl_conv_real(g, wc, None, geom, dgrad=True)
                 ga = cl_conv_real(gs2, S, None, geom, dgrad=True)
@@ -782,9 +793,8 @@ class RealConv2dLRTFn(torch.autograd.Function):
                     dx = from_channels_last(dx)
             if need[1]:
                 dw = cl_wgrad_real(g, x, geom, ctx.wshape)
-            if ctx.has_bias and need[2]:
-                B, Co, H, W = g.shape
-                db = hint if hint is not None else ops.colsum(g.permute(0, 2, 3, 1).reshape(B * H * W, Co))
+            if want_b:
+                db = hint
             if need[3]:
                 dls2 = cl_wgrad_real(gs2, a, geom, ctx.wshape, emul=ls2.contiguous(), emul_exp=True)
             return (dx, dw, db, dls2) + (None,) * 7

@@ -213,6 +213,137 @@ __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
   }
 }
 
+// The same backward on a [rows][cols] matrix (the storage of a [B, O] gradient, or of channels-last [B H W][C]
+// planes) that ALSO sums g_r / g_i per column -- the bias gradient of the layer (dbr = sum_b G_r), which
+// otherwise costs one more pass over the two gradient planes.  A thread owns 8 consecutive columns; TX = min(cols / 8,
+// 256) threads span a row (strip of 2048 columns), TY = 256 / TX rows per step; the grid is (strips, row chunks).  The
+// element -> Philox counter mapping is that of the flat kernel (linear index), so both draw identical noise.
+// partial: [chunks][planes][cols] float32, summed in fixed order by reparam_cols_final (deterministic).
+template <typename T, typename TG, typename TS, bool CPLX, bool PHILOX>
+__global__ __launch_bounds__(kRpThreads) void reparam_bwd_cols_kernel(
+    const T* g_r, const T* g_i, const TS* s2, const T* eps_r, const T* eps_i, uint64_t seed,
+    uint64_t offset, const uint64_t* state, TG* g_s2, int64_t rows, int cols, int64_t rows_per_chunk,
+    float* partial) {
+  __shared__ float red[kRpThreads * 16];
+  if (PHILOX && state) { seed = state[0]; offset = state[1]; }
+  const int CG = cols >> 3;
+  const int TX = CG < kRpThreads ? CG : kRpThreads, TY = kRpThreads / TX;
+  const int tx = (int)threadIdx.x % TX, ty = (int)threadIdx.x / TX;
+  const int col = (int)blockIdx.x * (kRpThreads * 8) + tx * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+  constexpr int NP = CPLX ? 2 : 1;
+  float acc[NP][8];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[p][c] = 0.0f;
+  for (int64_t r = r0 + ty; r < r1; r += TY) {
+    const int64_t i = (r * cols + col) >> 3;
+    const f8 s = ld8(s2 + 8 * i);
+    const f8 gr = ld8(g_r + 8 * i);
+    f8 gi, er, ei, o;
+    if (CPLX) gi = ld8(g_i + 8 * i);
+    if (!PHILOX) {
+      er = ld8(eps_r + 8 * i);
+      if (CPLX) ei = ld8(eps_i + 8 * i);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (PHILOX) noise_vec<CPLX>(2 * i + h, seed, offset, er.h[h], ei.h[h]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gs = gr.h[h].v[j] * er.h[h].v[j];
+        if (CPLX) gs = gs + gi.h[h].v[j] * ei.h[h].v[j];
+        o.h[h].v[j] = lrt_gs2_t<T>(gs, s.h[h].v[j]);
+        acc[0][4 * h + j] += gr.h[h].v[j];
+        if (CPLX) acc[NP - 1][4 * h + j] += gi.h[h].v[j];
+      }
+    }
+    st8(g_s2 + 8 * i, o);
+  }
+  float* dst = partial + (int64_t)blockIdx.y * NP * cols;
+  if (TY == 1) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      st4(dst + (int64_t)p * cols + col, f4{{acc[p][0], acc[p][1], acc[p][2], acc[p][3]}});
+      st4(dst + (int64_t)p * cols + col + 4, f4{{acc[p][4], acc[p][5], acc[p][6], acc[p][7]}});
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[((ty * NP + p) * TX + tx) * 8 + c] = acc[p][c];
+  __syncthreads();
+  // (TY > 1 means one strip: cols = TX * 8)
+  for (int f = (int)threadIdx.x; f < NP * cols; f += kRpThreads) {
+    const int p = f / cols, c = f % cols;
+    float t = 0.0f;
+    for (int l = 0; l < TY; ++l) t += red[((l * NP + p) * TX) * 8 + c];
+    dst[(int64_t)p * cols + c] = t;
+  }
+}
+
+// out_r[c] / out_i[c] = sum over chunks of partial[chunk][plane][c]: 16 columns per block, 64 chunk lanes, fixed order
+__global__ __launch_bounds__(1024) void reparam_cols_final(const float* partial, int chunks, int cols, int planes,
+                                                           float* out_r, float* out_i) {
+  __shared__ float red[64][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx, n = planes * cols;
+  float acc = 0.f;
+  if (c < n)
+    for (int j = ty; j < chunks; j += 64) acc += partial[(int64_t)j * n + c];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) t += red[l][tx];
+    if (c < cols) out_r[c] = t;
+    else out_i[c - cols] = t;
+  }
+}
+
+struct ColsPlan { int strips, chunks; int64_t rows_per_chunk; };
+static bool cols_plan(int64_t rows, int cols, ColsPlan& p) {
+  if (rows <= 0 || cols < 8 || cols % 8) return false;
+  const int cg = cols / 8;
+  if (cg < kRpThreads ? (kRpThreads % cg != 0) : (cols % (kRpThreads * 8) != 0)) return false;
+  if (rows * (int64_t)cols >= ((int64_t)1 << 40)) return false;
+  p.strips = cg < kRpThreads ? 1 : cols / (kRpThreads * 8);
+  const int ty = cg < kRpThreads ? kRpThreads / cg : 1;
+  // >= 16 row steps per thread, at most 2048 workgroups
+  int64_t chunks = rows / (16 * (int64_t)ty);
+  const int64_t cap = 2048 / p.strips > 0 ? 2048 / p.strips : 1;
+  if (chunks > cap) chunks = cap;
+  if (chunks < 1) chunks = 1;
+  int64_t rpc = (rows + chunks - 1) / chunks;
+  rpc = (rpc + ty - 1) / ty * ty;
+  p.rows_per_chunk = rpc;
+  p.chunks = (int)((rows + rpc - 1) / rpc);
+  return p.chunks <= 65535;
+}
+
+template <typename T, typename TG, typename TS>
+static int launch_bwd_cols(const void* g_r, const void* g_i, const void* s2, const void* eps_r,
+                           const void* eps_i, uint64_t seed, uint64_t offset, const uint64_t* state,
+                           void* g_s2, int64_t rows, int cols, const ColsPlan& p, float* partial, hipStream_t st) {
+  const dim3 grid((unsigned)p.strips, (unsigned)p.chunks);
+  const bool cplx = g_i != nullptr, philox = eps_r == nullptr;
+#define RP_BWDC(C, P)                                                                          \
+  reparam_bwd_cols_kernel<T, TG, TS, C, P><<<grid, kRpThreads, 0, st>>>(                       \
+      (const T*)g_r, (const T*)g_i, (const TS*)s2, (const T*)eps_r, (const T*)eps_i, seed, offset, \
+      state, (TG*)g_s2, rows, cols, p.rows_per_chunk, partial)
+  if (cplx && philox) RP_BWDC(true, true);
+  else if (cplx) RP_BWDC(true, false);
+  else if (philox) RP_BWDC(false, true);
+  else RP_BWDC(false, false);
+#undef RP_BWDC
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
 template <bool CPLX>
 __global__ __launch_bounds__(kRpThreads) void philox_normal_kernel(float* er, float* ei,
                                                                    uint64_t seed, uint64_t offset,
@@ -336,6 +467,43 @@ int cplxamd_lrt_reparam_bwd(const void* g_r, const void* g_i, const float* s2,
                             int dtype, int gs2_dtype, void* stream) {
   return cplxamd_lrt_reparam_bwd_ex(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, n, dtype, gs2_dtype,
                                     CPLXAMD_F32, stream);
+}
+
+int64_t cplxamd_lrt_reparam_bwd_cols_ws_bytes(int64_t rows, int cols) {
+  ColsPlan p;
+  if (!cols_plan(rows, cols, p)) return 0;
+  return (int64_t)p.chunks * 2 * cols * (int64_t)sizeof(float);
+}
+
+int cplxamd_lrt_reparam_bwd_cols(const void* g_r, const void* g_i, const void* s2,
+                                 const void* eps_r, const void* eps_i, uint64_t seed,
+                                 uint64_t offset, const uint64_t* state, void* g_s2, int64_t rows,
+                                 int cols, int dtype, int gs2_dtype, int s2_dtype, float* sum_r,
+                                 float* sum_i, void* ws, int64_t ws_bytes, void* stream) {
+  if (!g_r || !s2 || !g_s2 || !sum_r || !ws || rows < 0) return CPLXAMD_EINVAL;
+  if ((g_i == nullptr) != (sum_i == nullptr)) return CPLXAMD_EINVAL;
+  if (eps_r && g_i && !eps_i) return CPLXAMD_EINVAL;
+  ColsPlan p;
+  if (!cols_plan(rows, cols, p)) return CPLXAMD_ESHAPE;
+  if (!al16(g_r) || !al16(g_i) || !al16(s2) || !al16(eps_r) || !al16(eps_i) || !al16(g_s2) || !al16(ws))
+    return CPLXAMD_EALIGN;
+  if (ws_bytes < cplxamd_lrt_reparam_bwd_cols_ws_bytes(rows, cols)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  int rc = CPLXAMD_EINVAL;
+#define RP_GO(T, TG, TS) \
+  rc = launch_bwd_cols<T, TG, TS>(g_r, g_i, s2, eps_r, eps_i, seed, offset, state, g_s2, rows, cols, p, partial, st)
+  if (dtype == CPLXAMD_F32 && gs2_dtype == CPLXAMD_F32 && s2_dtype == CPLXAMD_F32) RP_GO(float, float, float);
+  else if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_F32 && s2_dtype == CPLXAMD_F32) RP_GO(bf16_t, float, float);
+  else if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_BF16 && s2_dtype == CPLXAMD_F32) RP_GO(bf16_t, bf16_t, float);
+  else if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_BF16 && s2_dtype == CPLXAMD_BF16) RP_GO(bf16_t, bf16_t, bf16_t);
+  else if (dtype == CPLXAMD_BF16 && gs2_dtype == CPLXAMD_F32 && s2_dtype == CPLXAMD_BF16) RP_GO(bf16_t, float, bf16_t);
+#undef RP_GO
+  if (rc) return rc;
+  const int planes = g_i ? 2 : 1;
+  reparam_cols_final<<<(planes * cols + 15) / 16, 1024, 0, st>>>(partial, p.chunks, cols, planes, sum_r, sum_i);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
 }
 
 int cplxamd_philox_advance(uint64_t* state, uint64_t* used, void* stream) {

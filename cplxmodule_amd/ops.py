@@ -7,7 +7,7 @@ complex tensors are (real, imag) pairs of equal-shaped planes (cplxmodule/cplx.p
 import torch
 
 from . import _lib
-from ._lib import call, dtype_code, ptr, require_device, scratch_key, stream_ptr
+from ._lib import call, dtype_code, ptr, require_device, scratch_key, stream_ptr, try_call
 
 _ws_cache = {}
 
@@ -288,7 +288,29 @@ def reparam_fwd(mu_r, mu_i, s2, eps=None, seed=0, offset=0, inplace=False):
     return y_r, y_i
 
 
-def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float32):
+def _colsum_ws(device, nbytes):
+    key = scratch_key(device)
+    buf = _colsum_ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _colsum_ws_cache[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    return buf
+
+
+_colsum_ws_cache = {}
+
+
+def _as_rows(t, rows, cols):
+    """[rows, cols] view of the storage of a dense tensor ([B, O] as it is, channels-last planes as [B H W][C])."""
+    if t.dim() == 4 and not t.is_contiguous():
+        t = t.permute(0, 2, 3, 1)
+    return t.reshape(rows, cols)
+
+
+def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float32, bias_sums=None):
+    """d s2 of the noise injection.  bias_sums = (rows, cols[, (out_r, out_i)]): the operands are [rows][cols] matrices as
+    stored (a [B, O] gradient; channels-last planes as [B H W][C]) and the per-column sums of g_r / g_i -- the bias
+    gradient of the layer -- come out of the same pass: returns (g_s2, sum_r, sum_i); shapes the fused kernel does not
+    take run the flat kernel + the column-sum kernels."""
     require_device(g_r, g_i, s2)
     fmt = _layout_of(s2)                 # the layout the forward ran in (s2 is its saved tensor)
     g_r, g_i, s2 = _al16(_cf(g_r, fmt)), _al16(_cf(g_i, fmt)), _al16(_s2(_cf(s2, fmt), g_r))
@@ -299,6 +321,30 @@ def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float3
         e_r, e_i = _al16(e_r), _al16(e_i)
     g_s2 = torch.empty_like(s2, dtype=out_dtype)
     sd, of, st = _noise_args(seed, offset)
+    if bias_sums is not None:
+        rows, cols = int(bias_sums[0]), int(bias_sums[1])
+        assert rows * cols == g_r.numel()
+        outs = bias_sums[2] if len(bias_sums) > 2 and bias_sums[2] is not None else (None, None)
+        ok = lambda t: t is not None and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == cols  # noqa: E731
+        sum_r = outs[0] if ok(outs[0]) else torch.empty(cols, dtype=torch.float32, device=g_r.device)
+        sum_i = None if g_i is None else (outs[1] if ok(outs[1]) else torch.empty(cols, dtype=torch.float32, device=g_r.device))
+        need = int(_lib.load().cplxamd_lrt_reparam_bwd_cols_ws_bytes(rows, cols))
+        fused = need > 0
+        if fused:
+            ws = _colsum_ws(g_r.device, need)
+            fused = try_call("cplxamd_lrt_reparam_bwd_cols", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,
+                             ptr(g_s2), rows, cols, dtype_code(g_r), dtype_code(g_s2), dtype_code(s2), ptr(sum_r),
+                             ptr(sum_i), ptr(ws), ws.numel(), stream_ptr())
+        if not fused:
+            call("cplxamd_lrt_reparam_bwd_ex", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,
+                 ptr(g_s2), g_r.numel(), dtype_code(g_r), dtype_code(g_s2), dtype_code(s2), stream_ptr())
+            colsum(_as_rows(g_r, rows, cols), out=sum_r)
+            if g_i is not None:
+                colsum(_as_rows(g_i, rows, cols), out=sum_i)
+        for dst, src in zip(outs, (sum_r, sum_i)):
+            if dst is not None and src is not None and dst is not src:
+                dst.copy_(src.view_as(dst))
+        return g_s2, (outs[0] if outs[0] is not None else sum_r), (None if g_i is None else (outs[1] if outs[1] is not None else sum_i))
     call("cplxamd_lrt_reparam_bwd_ex", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,
          ptr(g_s2), g_r.numel(), dtype_code(g_r), dtype_code(g_s2), dtype_code(s2), stream_ptr())
     return g_s2
@@ -599,9 +645,13 @@ class CplxLinearLRTFn(torch.autograd.Function):
         g2i = torch.zeros(B, O, dtype=x2r.dtype, device=x2r.device) if gi is None else gi.reshape(B, O).contiguous()
         eps = None if eps_r is None else (eps_r.reshape(B, O), eps_i.reshape(B, O))
         dt = x2r.dtype
-        gs2 = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt)
         # parameter gradients first: under data parallelism their bucket's all-reduce overlaps dX
         want_w, want_b = need[2] or need[3], ctx.has_bias and (need[4] or need[5])
+        if want_b:          # the bias gradient (column sums of G) rides in the pass that reads G for d s2
+            gs2, dbr, dbi = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt,
+                                        bias_sums=(B, O, (grad_buffer(br), grad_buffer(bi))))
+        else:
+            gs2 = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt)
         ls2c = _c(ls2)
         if klg is not None and klg is ctx.klg and want_w and need[6]:
             # dW = G^T conj(X) + g_kl * dW_kl and dls2 = (gs2^T |x|^2) exp(ls2) + g_kl * dls2_kl, in place.
@@ -624,8 +674,6 @@ class CplxLinearLRTFn(torch.autograd.Function):
                 if dwr is not None:
                     dwr.add_(klg[1] * gkl)
                     dwi.add_(klg[2] * gkl)
-        if want_b:
-            dbr, dbi = colsum2(g2r, g2i, out=(grad_buffer(br), grad_buffer(bi)))
         _announce(ls2 if dls2 is not None else None, wr if dwr is not None else None,
                   wi if dwi is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
         if need[0] or need[1]:
@@ -748,7 +796,11 @@ class RealLinearLRTFn(torch.autograd.Function):
         g2 = g.reshape(B, O).contiguous()
         dt = x2.dtype
         e = None if eps is None else eps.reshape(B, O)
-        gs2 = reparam_bwd(g2, None, s2, e, ctx.seed, ctx.offset, out_dtype=dt)
+        if ctx.has_bias and need[2]:
+            gs2, db, _ = reparam_bwd(g2, None, s2, e, ctx.seed, ctx.offset, out_dtype=dt,
+                                     bias_sums=(B, O, (grad_buffer(b), None)))
+        else:
+            gs2 = reparam_bwd(g2, None, s2, e, ctx.seed, ctx.offset, out_dtype=dt)
         ls2c = _c(ls2)
         if klg is not None and klg is ctx.klg and need[1] and need[3]:
             dls2, dw = klg
@@ -768,8 +820,6 @@ class RealLinearLRTFn(torch.autograd.Function):
                     dls2.add_(klg[0] * gkl)
                 if dw is not None:
                     dw.add_(klg[1] * gkl)
-        if ctx.has_bias and need[2]:
-            db = colsum(g2, out=grad_buffer(b))
         _announce(ls2 if dls2 is not None else None, w if dw is not None else None, b if db is not None else None)
         if need[0]:
             dx = _real_linear_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), dt)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 9
+#define CPLXAMD_ABI_VERSION 10
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -153,6 +153,19 @@ int cplxamd_lrt_reparam_bwd_ex(const void* g_r, const void* g_i, const void* s2,
                                const void* eps_r, const void* eps_i, uint64_t seed,
                                uint64_t offset, const uint64_t* state, void* g_s2, int64_t n,
                                int dtype, int gs2_dtype, int s2_dtype, void* stream);
+
+/* cplxamd_lrt_reparam_bwd_ex on a [rows][cols] matrix (a [B, O] gradient, or channels-last [B H W][C] planes) that
+ * also returns the column sums of g_r / g_i -- the layer's bias gradient (dbr = sum_b G_r, cplx.py:646 under autograd)
+ * -- without another pass over the gradient: sum_r / sum_i float32 [cols] (sum_i NULL for a real layer, g_i NULL).
+ * Same noise as the flat entry point (the counter is the linear element index).  cols % 8 == 0 and cols / 8 a divisor
+ * of 256 or cols a multiple of 2048, else CPLXAMD_ESHAPE (call the flat entry point + cplxamd_colsum).
+ * ws: cplxamd_lrt_reparam_bwd_cols_ws_bytes(rows, cols) bytes, 16-byte aligned. */
+int64_t cplxamd_lrt_reparam_bwd_cols_ws_bytes(int64_t rows, int cols);
+int cplxamd_lrt_reparam_bwd_cols(const void* g_r, const void* g_i, const void* s2,
+                                 const void* eps_r, const void* eps_i, uint64_t seed,
+                                 uint64_t offset, const uint64_t* state, void* g_s2, int64_t rows,
+                                 int cols, int dtype, int gs2_dtype, int s2_dtype, float* sum_r,
+                                 float* sum_i, void* ws, int64_t ws_bytes, void* stream);
 
 /* used[0..1] = state[0..1]; state[1] += 1  (device-resident noise stream position) */
 int cplxamd_philox_advance(uint64_t* state, uint64_t* used, void* stream);

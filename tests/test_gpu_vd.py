@@ -217,6 +217,49 @@ def test_reparam_bf16_variance_operand(ops, cplx, philox_):
     assert bool((ga[below] == 0).all()) and bool((ga[~below][:64] != 0).any())
 
 
+@pytest.mark.parametrize("rows,cols", [(100, 8), (37, 64), (4099, 64), (513, 2048), (300, 4096), (64, 6144), (50, 24),
+                                       (33, 40)])
+@pytest.mark.parametrize("mode", ["cplx_philox_bf16", "cplx_given_f32", "real_philox_f32", "real_given_bf16"])
+def test_reparam_bwd_with_bias_sums(ops, rows, cols, mode):
+    """cplxamd_lrt_reparam_bwd_cols: d s2 bit-identical to the flat kernel (same element -> Philox counter mapping),
+    column sums of the gradient planes (the layer's bias gradient) against float64; (50, 24) and (33, 40) are shapes
+    the fused kernel declines (cols / 8 does not divide 256): the wrapper then runs the flat kernel + cplxamd_colsum."""
+    from cplxmodule_amd import _lib
+    cplx, philox_, bf = mode.startswith("cplx"), "philox" in mode, mode.endswith("bf16")
+    dt = torch.bfloat16 if bf else torch.float32
+    g = torch.Generator(device="cpu").manual_seed(rows * 7 + cols)
+    mk = lambda: torch.randn(rows, cols, generator=g).to(dt).to("cuda")  # noqa: E731
+    gr, gi = mk(), (mk() if cplx else None)
+    s2 = (torch.rand(rows, cols, generator=g) * 2).to(dt).to("cuda")
+    s2[0, :4] = 0
+    eps = None if philox_ else ((mk(), mk()) if cplx else mk())
+    kw = dict(seed=11, offset=3, out_dtype=dt)
+    flat = ops.reparam_bwd(gr, gi, s2, eps, **kw)
+    out_r = torch.full((cols,), float("nan"), device="cuda")
+    out_i = torch.full((cols,), float("nan"), device="cuda") if cplx else None
+    got, sr, si = ops.reparam_bwd(gr, gi, s2, eps, bias_sums=(rows, cols, (out_r, out_i)), **kw)
+    assert torch.equal(got, flat)
+    assert sr is out_r and (si is out_i)
+    takes = int(_lib.load().cplxamd_lrt_reparam_bwd_cols_ws_bytes(rows, cols)) > 0
+    assert takes == ((cols // 8 < 256 and 256 % (cols // 8) == 0) or cols % 2048 == 0)
+    for t, s in ((gr, sr), (gi, si)):
+        if t is None:
+            continue
+        ref = t.double().sum(0)
+        scale = t.double().abs().sum(0).max()
+        assert float((s.double() - ref).abs().max()) <= 2e-6 * float(scale)
+    # sums allocated by the wrapper, 4-d channels-last planes ([B H W][C] rows)
+    if cols == 64 and rows == 4099:
+        B, H, W = 2, 5, 7
+        c4 = lambda t: None if t is None else t[: B * H * W].reshape(B, H, W, cols).permute(0, 3, 1, 2)  # noqa: E731
+        e4 = None if eps is None else (tuple(c4(e) for e in eps) if cplx else c4(eps))
+        g4, sr4, si4 = ops.reparam_bwd(c4(gr), c4(gi), c4(s2), e4, bias_sums=(B * H * W, cols), **kw)
+        assert g4.shape == (B, cols, H, W) and g4.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(g4.permute(0, 2, 3, 1).reshape(-1, cols), flat[: B * H * W])
+        np.testing.assert_allclose(sr4.cpu().numpy(), gr[: B * H * W].double().sum(0).cpu().numpy(), rtol=0,
+                                   atol=2e-6 * float(gr.double().abs().sum(0).max()))
+
+
 def test_reparam_philox_fwd_bwd_consistent(ops):
     from gpu_util import T, N
     rs = np.random.RandomState(12)
