@@ -76,7 +76,7 @@ rows = [("cl kernel fwd (+bias)", k_fwd), ("cl kernel dgrad", k_dgrad),
         ("r01 wgrad (4 pads + kernel)", lambda: conv.conv_wgrad(gr_n, gi_n, xr, xi, geom, wr.shape)),
         ("NCHW -> channels-last copy x2", lambda: (conv.to_channels_last(xr), conv.to_channels_last(xi)))]
 if os.environ.get("ONLY"):
-    rows = [r for r in rows if r[0].startswith(os.environ["ONLY"])]
+    rows = [r for r in rows if r[0].startswith(tuple(os.environ["ONLY"].split(",")))]
 print(f"# B={B} C={C} Co={Co} {H}x{W} 3x3 pad {PAD}: {flop / 1e12:.3f} TFLOP per launch; median ms (min) [TF/s, frac of 2.5 PF/s]")
 for name, fn in rows:
     med, mn = timeit(fn)
