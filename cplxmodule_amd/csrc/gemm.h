@@ -46,6 +46,13 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st);
 int launch_gemm_bf16_gauss(const GemmArgs& g, int out_dtype, hipStream_t st);
 int64_t gemm_bf16_gauss_ws_bytes(int M, int N, int K);
 
+// Run-time switch of the persistent form (cplxamd_gemm_set_persistent; 1 at start).  A persistent launch owns every CU for
+// its whole duration and gives workgroup j the tiles j, j + #CU, ...: if other kernels hold some CUs (an RCCL all-reduce
+// overlapping the backward pass), the workgroups that find no CU start only when the first ones END, and the launch
+// takes twice as long.  One workgroup per tile degrades by the share of CUs taken instead: the data-parallel hook turns
+// the persistent form off while its collectives are in flight.
+extern int g_gemm_persistent;
+
 // workspace the bf16 path wants for split-K at this shape (0: no split-K)
 int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx);
 

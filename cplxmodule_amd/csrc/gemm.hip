@@ -1,9 +1,18 @@
 // C-ABI dispatch for the complex / real GEMM entry points (include/cplxamd.h).
 #include "gemm.h"
 
+namespace cplxamd {
+int g_gemm_persistent = 1;
+}
 using namespace cplxamd;
 
 extern "C" {
+
+int cplxamd_gemm_set_persistent(int on) {
+  const int prev = g_gemm_persistent;
+  g_gemm_persistent = on ? 1 : 0;
+  return prev;
+}
 
 /* scratch the bf16 path wants for split-K at this shape (0 = none) */
 int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype) {

@@ -816,7 +816,7 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   static const int enabled = env_int("CPLXAMD_GEMM_PERSIST", 1);
 #endif
   static int ncu = 0;
-  if (!enabled) return 0;
+  if (!enabled || !g_gemm_persistent) return 0;
   if (ncu == 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||

@@ -20,6 +20,14 @@ GEMMs (`ops.dp_hook.early_ready`), which gives the single-layer headline config 
 waits inside backward: `sync_gradients()` waits for all buckets, reduces what never completed
 (parameters without a gradient contribute zeros) and hands out the averaged views.
 
+Sharing the chip.  While a bucket's all-reduce is in flight its RCCL kernels hold CUs next to the rest of the backward
+pass.  The persistent GEMM launches (one workgroup per CU, tiles dealt out statically) would wait for those CUs with
+their last workgroups -- until the first ones END -- so the hook switches the GEMMs to one workgroup per tile
+(`cplxamd_gemm_set_persistent(0)`, bit-identical results, 1-2 % slower alone) from the first asynchronous launch until
+`sync_gradients()` has waited for all of them.  (The persistent channels-last convolution kernels have no such switch:
+for convolution-heavy models on several GPUs use `overlap=False`, or expect the kernels that overlap a collective
+to run long.)
+
 The collective is the only cross-rank traffic: forward / backward kernels never communicate.  The KL
 penalty is a function of the replicated weights only, so its gradient is identical on every rank and the
 mean leaves it unchanged; `all_reduce_scalar_mean` is the north star's "scalar KL term".
@@ -124,6 +132,7 @@ class BucketHook:
         self.buckets = buckets
         self.overlap = overlap
         self.pending = []          # (bucket, work, needs_division)
+        self._shared_chip = False  # collectives in flight next to compute kernels (see _launch)
 
     # -- storage for gradients (zero-copy path of the linear layers) ---------------------------
     def view_for(self, param):
@@ -141,8 +150,21 @@ class BucketHook:
 
     def _launch(self, b, async_op):
         b.launched = True
+        if async_op and not self._shared_chip and dist.get_backend() == "nccl":
+            # RCCL's kernels are about to hold CUs next to the rest of the backward pass: a persistent GEMM launch
+            # (one workgroup per CU for its whole duration) would wait for them with its last workgroups and take
+            # twice as long, one workgroup per tile just runs on the CUs that are left (csrc/gemm.h)
+            from . import _lib
+            _lib.load().cplxamd_gemm_set_persistent(0)
+            self._shared_chip = True
         work, div = _all_reduce(b.flat, async_op)
         self.pending.append((b, work if async_op else None, div))
+
+    def _chip_is_ours(self):
+        if self._shared_chip:
+            from . import _lib
+            _lib.load().cplxamd_gemm_set_persistent(1)
+            self._shared_chip = False
 
     def early_ready(self, *params):
         """Called from inside a layer's backward: the gradients of `params` have been written into
@@ -172,6 +194,7 @@ class BucketHook:
 
     # -- step boundary --------------------------------------------------------------------------
     def reset(self):
+        self._chip_is_ours()
         self.pending = []
         for b in self.buckets.buckets:
             b.reset()
@@ -196,6 +219,7 @@ class BucketHook:
                 work.wait()
             if div:
                 b.flat.div_(dist.get_world_size())
+        self._chip_is_ours()
         for b in bk.buckets:
             for n, p, off, numel in b.entries:
                 if p.grad is not None or p.data_ptr() in b.ready:
@@ -276,4 +300,6 @@ class DataParallel(torch.nn.Module):
         self._handles = []
         if ops.dp_hook is self.hook:
             ops.dp_hook = None
+        if self.hook is not None:
+            self.hook._chip_is_ours()
         self.hook = None

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 10
+#define CPLXAMD_ABI_VERSION 11
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -211,6 +211,12 @@ int cplxamd_cgemm_ex(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_c
                      const float* beta, int algo, void* ws, int64_t ws_bytes, void* stream);
 
 int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
+
+/* Process-wide switch of the persistent form of the bf16 GEMM kernels (returns the previous setting; 1 at start).
+ * Persistent launches assume the whole chip: turn them off (0) while other kernels are expected to hold CUs -- e.g. an
+ * RCCL all-reduce overlapping the backward pass -- and the GEMMs run one workgroup per tile, which shares CUs gracefully.
+ * Results are bit-identical either way (tests/test_gpu_gemm_persist.py). */
+int cplxamd_gemm_set_persistent(int on);
 
 /* Optional scratch for split-K (few output tiles, long K -- e.g. the weight gradient at batch
  * 2^20, or a 10-output head): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be NULL

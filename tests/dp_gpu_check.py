@@ -115,12 +115,18 @@ def main():
         return out
 
     def check(module, run_fn, ref, tol, **kw):
+        from cplxmodule_amd import _lib
+        lib = _lib.load()
         model = dp.DataParallel(module, **kw)
         worst = 0.0
         for _ in range(2):                                   # two steps: the buckets are reused
             model.zero_grad()
             run_fn()
+            # persistent GEMM launches are off exactly while RCCL collectives are in flight (dp.BucketHook._launch)
+            in_flight = dist.get_backend() == "nccl" and kw.get("overlap", True) and any(b.launched for b in model.buckets.buckets)
+            assert lib.cplxamd_gemm_set_persistent(0 if in_flight else 1) == (0 if in_flight else 1)
             model.sync_gradients()
+            assert lib.cplxamd_gemm_set_persistent(1) == 1
             for n, p in module.named_parameters():
                 if n not in ref:
                     assert p.grad is None, n
