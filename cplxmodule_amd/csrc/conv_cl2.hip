@@ -206,6 +206,30 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
   // the other set; `issue` puts this tap's LDS-DMA pieces behind the groups
   auto mfma_sub = [&](int st, int ras, int rkh, int rkw, bool do_read, auto issue) __attribute__((always_inline)) {
     bf16x8 nai[2];
+#ifndef CPLXAMD_CL2_ORD1   // first products of all four blocks, then the second ones (8 groups, one fragment read each): -0.7 % against four blocks x four products
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (ph == 1 && j == 0) nai[i] = neg_frag(ai[st][i]);
+          if (ph == 0) {
+            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ar[st][i], acc_r[i][j], 0, 0, 0);
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ai[st][i], acc_i[i][j], 0, 0, 0);
+          } else {
+            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[st][j], nai[i], acc_r[i][j], 0, 0, 0);
+            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[st][j], ar[st][i], acc_i[i][j], 0, 0, 0);
+          }
+          const int g8 = ph * 4 + i * 2 + j;
+          __builtin_amdgcn_sched_barrier(0);
+          if (do_read) read_one(st ^ 1, ras, rkh, rkw, g8);
+          __builtin_amdgcn_sched_barrier(0);
+          if (g8 & 1) issue(g8 >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -422,6 +422,44 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       int q = q0;
       // tiles past the end re-load the last one into a free slot: no branch in the K loop
       const int k0s = (kDbg & 32) ? 0 : (tile < nt ? tile : nt - 1) * BK;
+#ifndef CPLXAMD_GEMM_ORD1   // complex: first products of all blocks, then the second ones (see gemm_bf16_persist.h)
+      if constexpr (CPLX) {
+        constexpr int NG = 2 * IB * JB;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int i = 0; i < IB; ++i)
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+              if (!(kDbg & 2)) {
+                if (ph == 0) {
+                  acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+                  acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+                } else if (CONJ) {
+                  acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+                  acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+                } else {
+                  acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+                  acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+                }
+              }
+              constexpr int PER = (NFRAG + NG - 1) / NG;
+              const int g0 = (ph * IB * JB + i * JB + j) * PER;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int r = 0; r < PER; ++r)
+                if (g0 + r < NFRAG) read_one(rbuf, rks, g0 + r);
+              __builtin_amdgcn_sched_barrier(0);
+              if (q < q1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(kDbg & 1)) stage_q(slot, k0s, q);
+                __builtin_amdgcn_sched_barrier(0);
+                ++q;
+              }
+            }
+        return;
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll

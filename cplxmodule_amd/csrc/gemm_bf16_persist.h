@@ -157,6 +157,47 @@ __global__ __launch_bounds__((Cfg<CPLX, false>::NT)) void gemm_bf16_persist_kern
       for (int i = 0; i < IB; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
     }
     int q = q0;
+#ifndef CPLXAMD_GEMM_ORD1   // the two products into one accumulator 8 MFMAs apart (ORD1: 2 apart, blocks one after the other)
+    if constexpr (CPLX) {
+      constexpr int NG = 2 * IB * JB;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+#pragma unroll
+          for (int j = 0; j < JB; ++j) {
+            if (ph == 0) {
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+            } else if (CONJ) {
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+            } else {
+              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+            }
+            const int gidx = ph * IB * JB + i * JB + j;
+            constexpr int PER = (NFRAG + NG - 1) / NG;
+            const int g0 = gidx * PER;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < PER; ++r)
+              if (do_read && g0 + r < NFRAG) read_one(rbase, rks, g0 + r);
+            __builtin_amdgcn_sched_barrier(0);
+            const int left = NG - gidx;
+            int n_now = (q1 - q + left - 1) / left;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              if (r < n_now && q < q1) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_piece(dsoff, next, kk, q);
+                __builtin_amdgcn_sched_barrier(0);
+                ++q;
+              }
+          }
+      return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < IB; ++i)
 #pragma unroll
