@@ -161,8 +161,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// (BIG: one wave per SIMD.  The second launch-bound argument says so: with dynamic shared memory the compiler cannot see
+//  that only one 256-thread workgroup fits a CU, budgets 128 registers for an occupancy of four and spills the 256
+//  accumulators to scratch -- which is what the r01 measurements of the BIG variants actually timed.)
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL, bool BIG = false>
-__global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArgs g) {
+__global__ __launch_bounds__((Cfg<CPLX, BIG>::NT), (BIG ? 1 : 2)) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<CPLX, BIG>;
   constexpr int NT = C::NT;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
         }
     }
   }
-  auto apply_bias = [&]() {
+  auto apply_bias = [&]() __attribute__((always_inline)) {
     if (!bias_in_acc) return;
 #pragma unroll
     for (int i = 0; i < IB; ++i)
@@ -257,7 +260,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
 #pragma unroll
   for (int j = 0; j < C::PB; ++j) vob[j] = piece_voff<BN, TB, NT>(ldb, n0, g.N, j);
   // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
-  auto stage_q = [&](int buf, int k0, int q) {
+  auto stage_q = [&](int buf, int k0, int q) __attribute__((always_inline)) {
     k0 += kbase;
     const uint32_t s = smem_off + (uint32_t)(buf * C::STAGE_BYTES) + wave_lds;
     if (q < C::PA)
@@ -271,23 +274,23 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       lds_dma16_sv(piece_base<TB>(Bi, ldb, n0, k0), vob[q - 2 * C::PA - C::PB],
                    s + 2 * C::A_BYTES + C::B_BYTES + (q - 2 * C::PA - C::PB) * NT * 16);
   };
-  auto stage_all = [&](int buf, int k0) {
+  auto stage_all = [&](int buf, int k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < C::LOADS; ++q) stage_q(buf, k0, q);
   };
 
-  auto a_frag = [&](const char* plane, int i, int ks) -> bf16x8 {
+  auto a_frag = [&](const char* plane, int i, int ks) __attribute__((always_inline)) -> bf16x8 {
     if (TA) return frag_t<BM>(plane, wm + i * 32 + 16 * lg, ks * 16 + 8 * lk, l15);
     return frag_n(plane, wm + i * 32 + l31, ks * 2 + lk);
   };
-  auto b_frag = [&](const char* plane, int j, int ks) -> bf16x8 {
+  auto b_frag = [&](const char* plane, int j, int ks) __attribute__((always_inline)) -> bf16x8 {
     if (TB) return frag_t<BN>(plane, wn + j * 32 + 16 * lg, ks * 16 + 8 * lk, l15);
     return frag_n(plane, wn + j * 32 + l31, ks * 2 + lk);
   };
 
   // tile in ring slot `buf`: all fragments of both K sub-steps are requested up front, then
   // 32 MFMAs; one LDS-DMA piece of the tile at knext after each (i, j) MFMA group
-  auto compute = [&](int buf, int nbuf, int knext, bool do_stage, bool do_mfma) {
+  auto compute = [&](int buf, int nbuf, int knext, bool do_stage, bool do_mfma) __attribute__((always_inline)) {
     const char* sA = smem + buf * C::STAGE_BYTES;
     const char* sB = sA + C::A_BYTES;
     const char* sAi = sB + C::B_BYTES;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     //   S4 read F[0] <- (tile t+1, ks 0)         S5 16 MFMAs on F[1] + first half of tile t+3's pieces
     // (S1 / S4 are not bursts: their ds_reads are dealt out behind the MFMA groups of S2 / S5)
     bf16x8 ar[2][IB], br[2][JB], ai[2][IB], bi[2][JB];       // [ks][block]
-    auto read_half = [&](int buf, int ks) {
+    auto read_half = [&](int buf, int ks) __attribute__((always_inline)) {
       const char* sA = smem + buf * C::STAGE_BYTES;
       const char* sB = sA + C::A_BYTES;
       const char* sAi = sB + C::B_BYTES;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     };
     // one fragment of (slot buf, sub-step ks), in the order the MFMA groups need them
     constexpr int NFRAG = CPLX ? 2 * IB + 4 : IB + JB;
-    auto read_one = [&](int buf, int ks, int idx) {
+    auto read_one = [&](int buf, int ks, int idx) __attribute__((always_inline)) {
       const char* sA = smem + buf * C::STAGE_BYTES;
       const char* sB = sA + C::A_BYTES;
       const char* sAi = sB + C::B_BYTES;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
       }
     };
     constexpr int H = (C::LOADS + 1) / 2;                     // pieces issued in S5; the rest in S2
-    auto mfma_half = [&](int ks, int slot, int tile, int q0, int q1, int rbuf, int rks) {
+    auto mfma_half = [&](int ks, int slot, int tile, int q0, int q1, int rbuf, int rks) __attribute__((always_inline)) {
       bf16x8 nai[IB];
       if (CPLX) {
 #pragma unroll
@@ -509,7 +512,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
     if (wid >= 4) __builtin_amdgcn_s_setprio(1);              // static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
 #endif
     // one K tile in ring slot `cur`
-    auto tile_body = [&](int cur, int nx1, int nx2, int t) {
+    auto tile_body = [&](int cur, int nx1, int nx2, int t) __attribute__((always_inline)) {
       mfma_half(0, nx2, t + 2, H, C::LOADS, cur, 1);          // S1 + S2
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // S3: this wave's F[1] is in registers
       if (kDbg & 1) wait_vmcnt<0>(); else if (!(kDbg & 64)) wait_vmcnt<C::LOADS>();   // always LOADS younger pieces in flight
@@ -705,7 +708,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT)) void gemm_bf16_kernel(GemmArg
   // one 32-row block of the wave tile; `i` is a compile-time constant (an `#pragma unroll`ed loop
   // over i was left rolled by the compiler for some of the 128-row real variants, which sent the
   // whole accumulator array to scratch)
-  auto store_block = [&](auto I) {
+  auto store_block = [&](auto I) __attribute__((always_inline)) {
     constexpr int i = decltype(I)::value;
     const int row = m0 + wm + i * 32 + l31;
     if (row >= g.M) return;
@@ -913,6 +916,9 @@ static int launch_kernel(const GemmArgs& g, hipStream_t st) {
   // kernel source: build with -DCPLXAMD_GEMM_CLASSIC to select it) and Cfg<true, BIG> (4 waves of
   // 128 x 64 at one wave per SIMD: 0.905 ms vs 0.86 ms on the headline shape with the final loop) were
   // measured slower; leaving them out halves the compile time.
+#ifdef GEMM_CPLX_BIG      // experiment: complex kernel as 4 waves of 128 x 64 complex (one wave per SIMD, 256 accumulators)
+  if constexpr (CPLX) return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true, true>(g, st);
+#endif
 #ifdef GEMM_REAL_BIG      // experiment: real kernel as 4 waves of 128 x 128 (one wave per SIMD, the vendor's shape):
                           // 0.296 / 0.314 / 0.247 ms vs 0.271 / 0.244 / 0.225 ms on the three variance GEMMs -- slower
   if constexpr (!CPLX) return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true, true>(g, st);
