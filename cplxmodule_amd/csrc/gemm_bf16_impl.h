@@ -53,7 +53,9 @@ constexpr int BK = 32, STAGES = 3;
 // 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no epilogue stores (accumulators kept live),
 // 16 no sign XOR (WRONG results: bounds what removing the XORs could buy), 32 every LDS-DMA piece re-reads K tile 0
 // (cache-hot source: separates the memory system's share of the staging cost from issue + LDS-write cost),
-// 64 never wait for the LDS-DMA (racy: the share of the counted vmcnt waits)
+// 64 never wait for the LDS-DMA (racy: the share of the counted vmcnt waits),
+// 128 K-contiguous operands requested as whole 128-byte lines, 8 chunks per row (WRONG data, same byte count: what the
+// half-line requests of a 32-deep K tile cost -- profiles/r02_gemm_ablation.md section 7)
 #ifndef CPLXAMD_GEMM_DBG_BUILD
 #define CPLXAMD_GEMM_DBG_BUILD 0
 #endif
@@ -91,6 +93,12 @@ template <int ROWS, bool T, int NT>
 __device__ __forceinline__ uint32_t piece_voff(int64_t ld, int row0, int rows, int j) {
   const int p = j * NT + (int)threadIdx.x;
   if (!T) {
+    if (kDbg & 128) {   // experiment (wrong data): the same bytes as whole 128-byte lines, 8 chunks per row
+      const int row = p >> 3;
+      int grow = row0 + row;
+      grow = grow < rows ? grow : rows - 1;
+      return (uint32_t)(((int64_t)(grow - row0) * ld + (p & 7) * 8) * 2);
+    }
     const int row = p >> 2;
     const int kc = (p & 3) ^ ((row >> 2) & 3);
     int grow = row0 + row;

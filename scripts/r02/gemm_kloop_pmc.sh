@@ -21,8 +21,8 @@ for f in glob.glob("gpurun_out/pmck_*/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "gemm_bf16" in r["Kernel_Name"]:
             dur[v].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
-order = [v for v in ["0", "16", "4", "64", "68", "1", "5", "2", "34", "66", "3"] if dur.get(v)]
-names = {"34": "no MFMA, hot source", "66": "no MFMA, no vmcnt wait", "3": "no MFMA, no LDS-DMA", "0": "full", "16": "no XOR", "4": "no barrier", "64": "no vmcnt wait", "68": "no barrier, no wait", "1": "no LDS-DMA", "5": "no DMA, no barrier", "2": "no MFMA"}
+order = [v for v in ["0", "16", "4", "64", "68", "1", "5", "2", "34", "66", "3", "130"] if dur.get(v)]
+names = {"130": "no MFMA, whole-line requests", "34": "no MFMA, hot source", "66": "no MFMA, no vmcnt wait", "3": "no MFMA, no LDS-DMA", "0": "full", "16": "no XOR", "4": "no barrier", "64": "no vmcnt wait", "68": "no barrier, no wait", "1": "no LDS-DMA", "5": "no DMA, no barrier", "2": "no MFMA"}
 med = lambda x: sorted(x)[len(x) // 2] if x else float("nan")
 print(f"{'build':22s} {'cycles/XCD':>11s} {'us':>8s} {'GHz':>6s} {'MFMA busy':>10s} {'WAIT_ANY/WAVE':>14s} {'WAIT_LDS/WAVE':>14s}")
 for v in order:
