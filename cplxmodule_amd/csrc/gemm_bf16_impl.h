@@ -113,8 +113,8 @@ __device__ __forceinline__ uint32_t piece_voff(int64_t ld, int row0, int rows, i
   return (uint32_t)(((int64_t)k * ld + (col - row0)) * 2);
 }
 template <bool T>
-__device__ __forceinline__ const bf16_t* piece_base(const bf16_t* plane, int64_t ld, int row0, int k0) {
-  return T ? plane + (int64_t)k0 * ld + row0 : plane + (int64_t)row0 * ld + k0;
+__device__ __forceinline__ const bf16_t* piece_base(const bf16_t* plane, int64_t ld, int row0, int k0, int64_t kmul = 1) {
+  return T ? plane + (int64_t)k0 * ld + row0 : plane + (int64_t)row0 * ld + (int64_t)k0 * kmul;
 }
 
 // 8 consecutive k of matrix row `row` (k chunk kc of 4) from an "N" image
@@ -261,6 +261,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT), (BIG ? 1 : 2)) void gemm_bf16
   // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
   const uint32_t smem_off = lds_offset_of(smem);
   const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024u;  // 64 lanes x 16 B
+  const int64_t akm = TA ? 1 : g.a_kmul, bkm = TB ? 1 : g.b_kmul;       // K-panel-major operands (gemm.h)
   // this lane's byte offset of every piece (the two planes of an operand share it)
   uint32_t voa[C::PA], vob[C::PB];
 #pragma unroll
@@ -272,14 +273,14 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT), (BIG ? 1 : 2)) void gemm_bf16
     k0 += kbase;
     const uint32_t s = smem_off + (uint32_t)(buf * C::STAGE_BYTES) + wave_lds;
     if (q < C::PA)
-      lds_dma16_sv(piece_base<TA>(Ar, lda, m0, k0), voa[q], s + q * NT * 16);
+      lds_dma16_sv(piece_base<TA>(Ar, lda, m0, k0, akm), voa[q], s + q * NT * 16);
     else if (q < C::PA + C::PB)
-      lds_dma16_sv(piece_base<TB>(Br, ldb, n0, k0), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
+      lds_dma16_sv(piece_base<TB>(Br, ldb, n0, k0, bkm), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
     else if (q < 2 * C::PA + C::PB)
-      lds_dma16_sv(piece_base<TA>(Ai, lda, m0, k0), voa[q - C::PA - C::PB],
+      lds_dma16_sv(piece_base<TA>(Ai, lda, m0, k0, akm), voa[q - C::PA - C::PB],
                    s + C::A_BYTES + C::B_BYTES + (q - C::PA - C::PB) * NT * 16);
     else
-      lds_dma16_sv(piece_base<TB>(Bi, ldb, n0, k0), vob[q - 2 * C::PA - C::PB],
+      lds_dma16_sv(piece_base<TB>(Bi, ldb, n0, k0, bkm), vob[q - 2 * C::PA - C::PB],
                    s + 2 * C::A_BYTES + C::B_BYTES + (q - 2 * C::PA - C::PB) * NT * 16);
   };
   auto stage_all = [&](int buf, int k0) __attribute__((always_inline)) {

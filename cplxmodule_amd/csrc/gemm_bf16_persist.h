@@ -76,6 +76,7 @@ __global__ __launch_bounds__((Cfg<CPLX, false>::NT)) void gemm_bf16_persist_kern
 
   const uint32_t smem_off = lds_offset_of(smem);
   const uint32_t wave_lds = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024u;
+  const int64_t akm = TA ? 1 : g.a_kmul, bkm = TB ? 1 : g.b_kmul;       // K-panel-major operands (gemm.h)
   // per-lane byte offsets of the LDS-DMA pieces: full tiles only, so they do not depend on the tile
   uint32_t voa[C::PA], vob[C::PB];
 #pragma unroll
@@ -103,14 +104,14 @@ __global__ __launch_bounds__((Cfg<CPLX, false>::NT)) void gemm_bf16_persist_kern
     const int mm = next ? m0n : m0, nn = next ? n0n : n0;
     const uint32_t s = slot_off + wave_lds;
     if (q < C::PA)
-      lds_dma16_sv(piece_base<TA>(Ar, lda, mm, kk), voa[q], s + q * NT * 16);
+      lds_dma16_sv(piece_base<TA>(Ar, lda, mm, kk, akm), voa[q], s + q * NT * 16);
     else if (q < C::PA + C::PB)
-      lds_dma16_sv(piece_base<TB>(Br, ldb, nn, kk), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
+      lds_dma16_sv(piece_base<TB>(Br, ldb, nn, kk, bkm), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
     else if (q < 2 * C::PA + C::PB)
-      lds_dma16_sv(piece_base<TA>(Ai, lda, mm, kk), voa[q - C::PA - C::PB],
+      lds_dma16_sv(piece_base<TA>(Ai, lda, mm, kk, akm), voa[q - C::PA - C::PB],
                    s + C::A_BYTES + C::B_BYTES + (q - C::PA - C::PB) * NT * 16);
     else
-      lds_dma16_sv(piece_base<TB>(Bi, ldb, nn, kk), vob[q - 2 * C::PA - C::PB],
+      lds_dma16_sv(piece_base<TB>(Bi, ldb, nn, kk, bkm), vob[q - 2 * C::PA - C::PB],
                    s + 2 * C::A_BYTES + C::B_BYTES + (q - 2 * C::PA - C::PB) * NT * 16);
   };
 
