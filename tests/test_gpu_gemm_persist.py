@@ -127,3 +127,24 @@ def test_panel_major_operands_bit_identical(K):
     # shapes the panel kernels do not take are refused, not mis-read
     assert not try_call("cplxamd_rgemm_panel", ptr(apr), K, 1, Mp + 64, ptr(bpr), K, 1, Np, None, ptr(y), Np, Mp - 8, Np, K,
                         BF16, BF16, stream_ptr())
+
+
+def test_persistent_switch_is_bit_identical_and_restores():
+    """cplxamd_gemm_set_persistent(0) (what the data-parallel hook does while RCCL collectives are in flight) selects
+    the one-workgroup-per-tile kernels: same results bit for bit; the call returns the previous setting."""
+    from cplxmodule_amd import ops, _lib
+    lib = _lib.load()
+    dev, bf = "cuda", torch.bfloat16
+    torch.manual_seed(5)
+    K = 416
+    ar, ai = (torch.randn(M, K, device=dev).to(bf) for _ in range(2))
+    br, bi = (torch.randn(N, K, device=dev).mul(0.1).to(bf) for _ in range(2))
+    on = ops.cgemm(ar, ai, (K, 1), br, bi, (K, 1), M, N, K, out_dtype=bf)
+    assert lib.cplxamd_gemm_set_persistent(0) == 1
+    try:
+        off = ops.cgemm(ar, ai, (K, 1), br, bi, (K, 1), M, N, K, out_dtype=bf)
+        assert lib.cplxamd_gemm_set_persistent(0) == 0
+    finally:
+        assert lib.cplxamd_gemm_set_persistent(1) == 0
+    assert lib.cplxamd_gemm_set_persistent(1) == 1
+    assert torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])
