@@ -15,18 +15,22 @@ Exchange.  Every parameter carries a post-accumulate-grad hook.  When its gradie
 layers' backward asks `ops.grad_buffer(param)` for its output storage; one copy otherwise -- conv / BN
 parameters are small) and counts it ready; the bucket's `all_reduce(AVG)` is launched asynchronously as
 soon as its last parameter is ready, so it overlaps the rest of the backward pass (earlier layers).
-The LRT linear layers additionally announce their parameter gradients BEFORE their own input-gradient
-GEMMs (`ops.dp_hook.early_ready`), which gives the single-layer headline config its overlap.  Nothing
-waits inside backward: `sync_gradients()` waits for all buckets, reduces what never completed
-(parameters without a gradient contribute zeros) and hands out the averaged views.
+A collective is launched ONLY from a parameter's post-accumulate-grad hook, i.e. when autograd has summed
+every path into that leaf (an in-loss weight regulariser, the stand-alone KL node, a shared use): a
+gradient that is still being accumulated is never reduced.  The LRT linear layers additionally ANNOUNCE
+their parameter gradients before their own input-gradient GEMMs (`ops.dp_hook.early_ready`): the
+announcement records a HIP event behind the weight-gradient kernels, and a bucket whose gradients all
+arrived in place waits for that event only -- on a side stream -- so its all-reduce still overlaps the
+layer's own input-gradient GEMMs (the host runs ahead of the device), which gives the single-layer
+headline config its overlap.  Nothing waits inside backward: `sync_gradients()` waits for all buckets,
+reduces what never completed (parameters without a gradient contribute zeros) and hands out the
+averaged views.
 
 Sharing the chip.  While a bucket's all-reduce is in flight its RCCL kernels hold CUs next to the rest of the backward
 pass.  The persistent GEMM launches (one workgroup per CU, tiles dealt out statically) would wait for those CUs with
-their last workgroups -- until the first ones END -- so the hook switches the GEMMs to one workgroup per tile
-(`cplxamd_gemm_set_persistent(0)`, bit-identical results, 1-2 % slower alone) from the first asynchronous launch until
-`sync_gradients()` has waited for all of them.  (The persistent channels-last convolution kernels have no such switch:
-for convolution-heavy models on several GPUs use `overlap=False`, or expect the kernels that overlap a collective
-to run long.)
+their last workgroups -- until the first ones END -- so the hook switches the GEMMs and the channels-last convolution
+kernels to one workgroup per tile (`cplxamd_gemm_set_persistent(0)`, bit-identical results, 1-2 % slower alone) from the
+first announcement / asynchronous launch until `sync_gradients()` has waited for all of them.
 
 The collective is the only cross-rank traffic: forward / backward kernels never communicate.  The KL
 penalty is a function of the replicated weights only, so its gradient is identical on every rank and the
@@ -73,9 +77,12 @@ class _Bucket:
         self.reset()
 
     def reset(self):
-        self.ready = set()         # data_ptr of the parameters whose gradient is in place
+        self.ready = set()         # id() of the parameters whose FINAL gradient is in its slice
         self.work = None           # async handle once launched
         self.launched = False
+        self.events = []           # HIP events behind the kernels that wrote the slices in place
+        self.dirty = False         # a gradient changed after the bucket's collective was launched
+        self.in_order = False      # a gradient reached its slice by a copy on the current stream
 
 
 class GradBuckets:
@@ -100,7 +107,8 @@ class GradBuckets:
             dev = b.entries[0][1].device
             b.flat = torch.zeros(b.numel, dtype=torch.float32, device=dev)
             for n, p, off, numel in b.entries:
-                self.where[p.data_ptr()] = (b, off, numel, tuple(p.shape))
+                # keyed by the parameter OBJECT: `.to()` / `.data = ...` re-allocations keep the registration
+                self.where[id(p)] = (b, off, numel, tuple(p.shape))
 
     @property
     def names(self):
@@ -109,9 +117,9 @@ class GradBuckets:
     def nbytes(self):
         return sum(b.numel for b in self.buckets) * 4
 
-    def view(self, data_ptr):
-        """A FRESH view of the bucket slice of the parameter at `data_ptr` (None: not registered)."""
-        e = self.where.get(data_ptr)
+    def view(self, param):
+        """A FRESH view of the bucket slice of `param` (None: not registered)."""
+        e = self.where.get(id(param))
         if e is None:
             return None
         b, off, numel, shape = e
@@ -132,33 +140,23 @@ class BucketHook:
         self.buckets = buckets
         self.overlap = overlap
         self.pending = []          # (bucket, work, needs_division)
-        self._shared_chip = False  # collectives in flight next to compute kernels (see _launch)
+        self._shared_chip = False  # collectives in flight next to compute kernels (see _share_chip)
+        self._announced = {}       # id(param) -> HIP event recorded behind the kernels that wrote its slice
+        self._side = None          # stream the early collectives are issued from
 
     # -- storage for gradients (zero-copy path of the linear layers) ---------------------------
     def view_for(self, param):
-        return self.buckets.view(param.data_ptr())
+        return self.buckets.view(param)
 
-    # -- readiness ------------------------------------------------------------------------------
-    def _ready(self, data_ptr):
-        e = self.buckets.where.get(data_ptr)
-        if e is None:
-            return
-        b = e[0]
-        b.ready.add(data_ptr)
-        if self.overlap and not b.launched and len(b.ready) == len(b.entries):
-            self._launch(b, async_op=True)
-
-    def _launch(self, b, async_op):
-        b.launched = True
-        if async_op and not self._shared_chip and dist.get_backend() == "nccl":
-            # RCCL's kernels are about to hold CUs next to the rest of the backward pass: a persistent GEMM launch
+    # -- sharing the chip with RCCL -----------------------------------------------------------------
+    def _share_chip(self):
+        if not self._shared_chip and dist.get_backend() == "nccl":
+            # RCCL's kernels are about to hold CUs next to the rest of the backward pass: a persistent launch
             # (one workgroup per CU for its whole duration) would wait for them with its last workgroups and take
             # twice as long, one workgroup per tile just runs on the CUs that are left (csrc/gemm.h)
             from . import _lib
             _lib.load().cplxamd_gemm_set_persistent(0)
             self._shared_chip = True
-        work, div = _all_reduce(b.flat, async_op)
-        self.pending.append((b, work if async_op else None, div))
 
     def _chip_is_ours(self):
         if self._shared_chip:
@@ -166,63 +164,113 @@ class BucketHook:
             _lib.load().cplxamd_gemm_set_persistent(1)
             self._shared_chip = False
 
+    # -- readiness ------------------------------------------------------------------------------
+    def _ready(self, param, b):
+        b.ready.add(id(param))
+        if self.overlap and not b.launched and len(b.ready) == len(b.entries):
+            self._launch(b, async_op=True)
+
+    def _launch(self, b, async_op):
+        b.launched = True
+        side = None
+        if async_op and b.flat.is_cuda:
+            self._share_chip()
+            if b.events and not b.in_order and dist.get_backend() == "nccl":
+                # every slice was written in place by kernels that precede these events: the collective need not wait
+                # for what the host has queued since (the layer's own input-gradient GEMMs)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=b.flat.device)
+                side = self._side
+                for ev in b.events:
+                    side.wait_event(ev)
+        if side is not None:
+            with torch.cuda.stream(side):
+                work, div = _all_reduce(b.flat, async_op)
+        else:
+            work, div = _all_reduce(b.flat, async_op)
+        self.pending.append((b, work if async_op else None, div))
+
     def early_ready(self, *params):
-        """Called from inside a layer's backward: the gradients of `params` have been written into
-        their `view_for` storage; their bucket may start its all-reduce now, while the layer goes on
-        with its input-gradient GEMMs."""
+        """Called from inside a layer's backward: the data gradients of `params` have been written into their
+        `view_for` storage by kernels already queued.  Nothing is launched here -- other autograd paths may still add
+        to these leaves -- but the stream position is remembered: if the gradient autograd finally delivers IS that
+        storage, its bucket's all-reduce waits for this point only."""
+        if not self.overlap:
+            return
+        ev = None
         for p in params:
-            if p is not None and self.buckets.view(p.data_ptr()) is not None:
-                self._ready(p.data_ptr())
+            if p is None or id(p) not in self.buckets.where:
+                continue
+            if ev is None and p.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._share_chip()       # the kernels queued from here on may run next to a collective
+            # (the version counter is the bucket's: views share it.  Autograd summing another path INTO the announced
+            #  storage after this point bumps it, and the shortcut below is then not taken)
+            self._announced[id(p)] = (ev, self.buckets.where[id(p)][0].flat._version)
 
     def on_grad(self, param):
-        """post-accumulate-grad hook of every registered parameter."""
+        """post-accumulate-grad hook of every registered parameter: `param.grad` is final for this backward."""
         g = param.grad
         if g is None:
             return
-        e = self.buckets.where.get(param.data_ptr())
+        e = self.buckets.where.get(id(param))
         if e is None:
             return
         b, off, numel, shape = e
+        if b.launched:
+            # a second backward pass into an exchanged bucket (not supported: see the module docstring); sync() re-reduces
+            b.dirty = True
+            return
         view = b.flat[off:off + numel].view(shape)
-        if g.data_ptr() != view.data_ptr():
-            if b.launched:
-                # announced early and autograd then cloned the (in-flight) storage: sync() re-points
-                return
+        ev, version = self._announced.pop(id(param), (None, None))
+        if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
             view.copy_(g)
             param.grad = view
-        self._ready(param.data_ptr())
+            b.in_order = True
+        elif ev is None or version != b.flat._version:
+            b.in_order = True      # in place, but not (only) by the kernels in front of a recorded stream position
+        else:
+            b.events.append(ev)
+        self._ready(param, b)
 
     # -- step boundary --------------------------------------------------------------------------
     def reset(self):
         self._chip_is_ours()
         self.pending = []
+        self._announced = {}
         for b in self.buckets.buckets:
             b.reset()
 
     def sync(self):
         bk = self.buckets
-        for b in bk.buckets:
-            if not b.launched:
-                # parameters that received no gradient contribute zeros; a gradient that was produced
-                # but never announced (hooks bypassed) is picked up from .grad
-                for n, p, off, numel in b.entries:
-                    if p.data_ptr() in b.ready:
-                        continue
-                    sl = b.flat[off:off + numel]
-                    if p.grad is None:
-                        sl.zero_()
-                    elif p.grad.data_ptr() != sl.data_ptr():
-                        sl.view_as(p).copy_(p.grad)
-                self._launch(b, async_op=False)
         for b, work, div in self.pending:
             if work is not None:
                 work.wait()
             if div:
                 b.flat.div_(dist.get_world_size())
+        self.pending = []
+        for b in bk.buckets:
+            redo = b.launched and b.dirty
+            if not b.launched or redo:
+                # parameters that received no gradient contribute zeros; a gradient that was produced but never
+                # delivered through the hook (hooks bypassed, or accumulated after the exchange) is taken from .grad
+                for n, p, off, numel in b.entries:
+                    sl = b.flat[off:off + numel]
+                    if p.grad is None:
+                        if id(p) not in b.ready:
+                            sl.zero_()
+                    elif p.grad.data_ptr() != sl.data_ptr():
+                        sl.view_as(p).copy_(p.grad)
+                b.dirty = False
+                self._launch(b, async_op=False)
+        for b, work, div in self.pending:
+            if div:
+                b.flat.div_(dist.get_world_size())
         self._chip_is_ours()
         for b in bk.buckets:
             for n, p, off, numel in b.entries:
-                if p.grad is not None or p.data_ptr() in b.ready:
+                if p.grad is not None or id(p) in b.ready:
                     v = b.flat[off:off + numel].view_as(p)
                     if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                         p.grad = v
@@ -302,4 +350,6 @@ class DataParallel(torch.nn.Module):
             ops.dp_hook = None
         if self.hook is not None:
             self.hook._chip_is_ours()
+            from .nn.relevance.noise import noise
+            noise.fold_rank(0)                         # single-process runs afterwards draw the unfolded stream again
         self.hook = None

@@ -623,24 +623,30 @@ class CplxLinearLRTFn(torch.autograd.Function):
         ctx.save_for_backward(x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi)
         ctx.has_bias = br is not None
         ctx.lead, ctx.seed, ctx.offset = xr.shape[:-1], seed, offset
-        ctx.kl_kind, ctx.kl_used = kl_kind, False
+        ctx.kl_kind = kl_kind
+        ctx.kl_params = (wr, wi, ls2) if kl_kind is not None else None    # (leaves: no cycle through ctx)
         return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O), kl
 
     @staticmethod
     def backward(ctx, gr, gi, gkl=None):
+        need = ctx.needs_input_grad
+        dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
+        if gr is None and gi is None:
+            # only the KL term reached the loss (e.g. `nll.backward(); (c * sum(penalties(model))).backward()`, the
+            # reference's two-call pattern): needs no saved tensor, so it also works after the data backward freed them
+            if gkl is not None and ctx.kl_kind is not None:
+                if ctx.klg is None:          # the buffers hold totals by now: redo the KL part
+                    wr, wi, ls2 = ctx.kl_params
+                    ctx.klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:]
+                dls2, dwr, dwi = (_scaled(gkl, t) for t in ctx.klg)
+            return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
         x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi = ctx.saved_tensors
         O, I = wr.shape
         B = x2r.shape[0]
-        need = ctx.needs_input_grad
-        dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
         klg = None
         if gkl is not None and ctx.kl_kind is not None:
             # (a second backward through a retained graph: the buffers hold totals by then, redo the KL part)
-            klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:] if ctx.kl_used else ctx.klg
-        if gr is None and gi is None:                       # only the KL term reached the loss
-            if klg is not None:
-                dls2, dwr, dwi = (_scaled(gkl, t) for t in klg)
-            return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
+            klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:] if ctx.klg is None else ctx.klg
         g2r = torch.zeros(B, O, dtype=x2r.dtype, device=x2r.device) if gr is None else gr.reshape(B, O).contiguous()
         g2i = torch.zeros(B, O, dtype=x2r.dtype, device=x2r.device) if gi is None else gi.reshape(B, O).contiguous()
         eps = None if eps_r is None else (eps_r.reshape(B, O), eps_i.reshape(B, O))
@@ -653,27 +659,36 @@ class CplxLinearLRTFn(torch.autograd.Function):
         else:
             gs2 = reparam_bwd(g2r, g2i, s2, eps, ctx.seed, ctx.offset, out_dtype=dt)
         ls2c = _c(ls2)
-        if klg is not None and klg is ctx.klg and want_w and need[6]:
-            # dW = G^T conj(X) + g_kl * dW_kl and dls2 = (gs2^T |x|^2) exp(ls2) + g_kl * dls2_kl, in place.
-            # (ctx.klg are views nobody else holds once ctx dies, so autograd adopts them without a copy)
-            dls2, dwr, dwi = klg
-            ctx.klg = None
-            _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), accumulate=True, beta=gkl)
-            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
-            ctx.kl_used = True
-        else:
-            if want_w:
-                dwr, dwi = grad_buffer(wr), grad_buffer(wi)
+        # dW = G^T conj(X) + g_kl * dW_kl and dls2 = (gs2^T |x|^2) exp(ls2) + g_kl * dls2_kl.  While ctx.klg holds the
+        # UNSCALED KL gradients of the forward pass (under data parallelism: in the parameters' bucket slices, the very
+        # storage grad_buffer() hands out), the GEMM epilogues finish the sum in place, per tensor; a tensor whose
+        # gradient is not wanted is left alone.  (ctx.klg are views nobody else holds once ctx dies, so autograd
+        # adopts them without a copy.)
+        fused = klg is not None and klg is ctx.klg
+        # a data-only backward with the KL buffers still pending (the two-call pattern) must not write into them
+        own = (lambda p: torch.empty(p.shape, dtype=torch.float32, device=p.device)) if (ctx.klg is not None and not fused) \
+            else grad_buffer
+        if want_w:
+            if fused:
+                dwr, dwi = klg[1], klg[2]
+                _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), accumulate=True, beta=gkl)
+            else:
+                dwr, dwi = own(wr), own(wi)
                 _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi))
-            if need[6]:
-                dls2 = grad_buffer(ls2)
-                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)  # (gs2^T a) * exp(ls2)
-            if klg is not None:                              # KL requested, but not every gradient is wanted
-                if dls2 is not None:
-                    dls2.add_(klg[0] * gkl)
-                if dwr is not None:
+                if klg is not None:
                     dwr.add_(klg[1] * gkl)
                     dwi.add_(klg[2] * gkl)
+        if need[6]:
+            if fused:
+                dls2 = klg[0]
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
+            else:
+                dls2 = own(ls2)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)  # (gs2^T a) * exp(ls2)
+                if klg is not None:
+                    dls2.add_(klg[0] * gkl)
+        if fused:
+            ctx.klg = None                                   # consumed: the buffers hold totals now
         _announce(ls2 if dls2 is not None else None, wr if dwr is not None else None,
                   wi if dwi is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
         if need[0] or need[1]:
@@ -772,27 +787,32 @@ class RealLinearLRTFn(torch.autograd.Function):
         y, _ = reparam_fwd(mu, None, s2, e, seed, offset, inplace=True)
         ctx.save_for_backward(x2, w, ls2, s2, a, eps, b)
         ctx.has_bias, ctx.lead, ctx.seed, ctx.offset = b is not None, x.shape[:-1], seed, offset
-        ctx.kl_kind, ctx.kl_used = kl_kind, False
+        ctx.kl_kind = kl_kind
+        ctx.kl_params = (w, ls2) if kl_kind is not None else None
         return y.view(*ctx.lead, O), kl
 
     @staticmethod
     def backward(ctx, g, gkl=None):
+        need = ctx.needs_input_grad
+        dx = dw = db = dls2 = None
+        if g is None:                                        # only the KL term reached the loss (see CplxLinearLRTFn)
+            if gkl is not None and ctx.kl_kind is not None:
+                if ctx.klg is None:
+                    w, ls2 = ctx.kl_params
+                    r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
+                    ctx.klg = (r[1], r[2])
+                dls2, dw = _scaled(gkl, ctx.klg[0]), _scaled(gkl, ctx.klg[1])
+            return dx, dw, db, dls2, None, None, None, None
         x2, w, ls2, s2, a, eps, b = ctx.saved_tensors
         O, I = w.shape
         B = x2.shape[0]
-        need = ctx.needs_input_grad
-        dx = dw = db = dls2 = None
         klg = None
         if gkl is not None and ctx.kl_kind is not None:
-            if ctx.kl_used:                                  # second backward through a retained graph
+            if ctx.klg is None:                              # second backward through a retained graph
                 r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
                 klg = (r[1], r[2])
             else:
                 klg = ctx.klg
-        if g is None:                                        # only the KL term reached the loss
-            if klg is not None:
-                dls2, dw = _scaled(gkl, klg[0]), _scaled(gkl, klg[1])
-            return dx, dw, db, dls2, None, None, None, None
         g2 = g.reshape(B, O).contiguous()
         dt = x2.dtype
         e = None if eps is None else eps.reshape(B, O)
@@ -802,24 +822,29 @@ class RealLinearLRTFn(torch.autograd.Function):
         else:
             gs2 = reparam_bwd(g2, None, s2, e, ctx.seed, ctx.offset, out_dtype=dt)
         ls2c = _c(ls2)
-        if klg is not None and klg is ctx.klg and need[1] and need[3]:
-            dls2, dw = klg
-            ctx.klg = None
-            _real_linear_dw(g2, x2, out=dw, accumulate=True, beta=gkl)
-            _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
-            ctx.kl_used = True
-        else:
-            if need[1]:
-                dw = grad_buffer(w)
+        fused = klg is not None and klg is ctx.klg           # per tensor, in place (see CplxLinearLRTFn.backward)
+        own = (lambda p: torch.empty(p.shape, dtype=torch.float32, device=p.device)) if (ctx.klg is not None and not fused) \
+            else grad_buffer
+        if need[1]:
+            if fused:
+                dw = klg[1]
+                _real_linear_dw(g2, x2, out=dw, accumulate=True, beta=gkl)
+            else:
+                dw = own(w)
                 _real_linear_dw(g2, x2, out=dw)
-            if need[3]:
-                dls2 = grad_buffer(ls2)
-                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
-            if klg is not None:
-                if dls2 is not None:
-                    dls2.add_(klg[0] * gkl)
-                if dw is not None:
+                if klg is not None:
                     dw.add_(klg[1] * gkl)
+        if need[3]:
+            if fused:
+                dls2 = klg[0]
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
+            else:
+                dls2 = own(ls2)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
+                if klg is not None:
+                    dls2.add_(klg[0] * gkl)
+        if fused:
+            ctx.klg = None
         _announce(ls2 if dls2 is not None else None, w if dw is not None else None, b if db is not None else None)
         if need[0]:
             dx = _real_linear_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), dt)

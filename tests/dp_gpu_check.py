@@ -134,7 +134,7 @@ def main():
                 err = float((p.grad - ref[n]).abs().max() / (ref[n].abs().max() + 1e-12))
                 worst = max(worst, err)
                 assert err < tol, (n, err, kw)
-                assert p.grad.data_ptr() == model.buckets.view(p.data_ptr()).data_ptr(), n
+                assert p.grad.data_ptr() == model.buckets.view(p).data_ptr(), n
         launched = sum(1 for b in model.buckets.buckets if b.launched)
         model.remove()
         return worst, launched

@@ -55,7 +55,7 @@ def _worker(rank, world, port, out):
             dist.all_reduce(ref)
             ref /= world
             ok &= bool(torch.allclose(p.grad, ref, rtol=1e-6, atol=1e-7))
-            ok &= p.grad.data_ptr() == wrapped.buckets.view(p.data_ptr()).data_ptr()      # .grad IS the bucket slice
+            ok &= p.grad.data_ptr() == wrapped.buckets.view(p).data_ptr()      # .grad IS the bucket slice
         else:
             ok &= p.grad is None                                                           # no gradient -> stays None
     launched_async = sum(1 for b in wrapped.buckets.buckets if b.launched)
@@ -65,7 +65,7 @@ def _worker(rank, world, port, out):
     wrapped.zero_grad()
     w = model.vd.log_sigma2
     buf = ops.grad_buffer(w)
-    assert buf.data_ptr() == wrapped.buckets.view(w.data_ptr()).data_ptr()
+    assert buf.data_ptr() == wrapped.buckets.view(w).data_ptr()
     buf.fill_(float(rank + 1))
     ops._announce(w)
     w.grad = buf
@@ -74,7 +74,43 @@ def _worker(rank, world, port, out):
     early = float(w.grad.mean())                                     # mean of (1, 2) = 1.5
     others_none = all(p.grad is None or n.startswith("fc") or n == "vd.log_sigma2"
                       for n, p in model.named_parameters())
+    # a layer that announces early + ANOTHER autograd path into the same parameter (in-loss regulariser, the
+    # stand-alone KL node): the exchanged gradient must be the sum of both paths (round-2 advisor finding: the
+    # early launch reduced the data term only)
+    class EarlyLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            dw = ops.grad_buffer(w)                   # the bucket slice, as the linear layers do
+            torch.mm(g.t(), x, out=dw)
+            ops._announce(w)
+            return g @ w, dw
+
+    two_path = True
+    for extra_first in (False, True):
+        wrapped.zero_grad()
+        torch.manual_seed(21 + rank)
+        x = torch.randn(11, 7)
+        w1 = model.fc1.weight
+        reg = (w1 ** 3).sum() * (rank + 1.0)
+        data = (EarlyLinear.apply(x, w1) ** 2).sum()
+        loss = reg + data if extra_first else data + reg
+        expect = torch.autograd.grad(loss, w1, retain_graph=True)[0]
+        loss.backward()
+        wrapped.sync_gradients()
+        dist.all_reduce(expect)
+        two_path &= bool(torch.allclose(w1.grad, expect / world, rtol=1e-5, atol=1e-6))
+        two_path &= w1.grad.data_ptr() == wrapped.buckets.view(w1).data_ptr()
+    # a parameter re-allocated after wrapping stays registered (buckets are keyed by the parameter object)
+    model.fc2.bias.data = model.fc2.bias.data.clone()
+    moved = wrapped.buckets.view(model.fc2.bias) is not None
     wrapped.remove()
+    unfolded = noise._rank == 0
     # overlap=False: nothing is launched before sync_gradients
     plain = dp.DataParallel(model, overlap=False, bucket_mb=1.0)
     plain.zero_grad()
@@ -92,7 +128,7 @@ def _worker(rank, world, port, out):
     lo, hi = dp.shard_rows(11)
     kl = dp.all_reduce_scalar_mean(torch.tensor(float(rank)))
     out.put((rank, layout, ok, ok2, first.numpy(), (lo, hi), float(kl), launched_async, early, others_none,
-             none_launched, seeds, ops.dp_hook is None))
+             none_launched, seeds, ops.dp_hook is None, two_path, moved, unfolded))
     dist.destroy_process_group()
 
 
@@ -120,6 +156,8 @@ def test_dp_bucket_allreduce_gloo():
         assert r[2] and r[3], "averaged gradients == hand-averaged gradients (overlap and plain)"
         assert r[7] >= 1, "at least one bucket was all-reduced asynchronously during backward"
         assert abs(r[8] - 1.5) < 1e-6 and r[9] and r[10] and r[12]
+        assert r[13], "two autograd paths into an early-announced parameter: both are in the exchanged gradient"
+        assert r[14] and r[15]
     np.testing.assert_array_equal(r0[4], r1[4])                    # broadcast from rank 0
     assert r0[5] == (0, 6) and r1[5] == (6, 11)
     assert r0[6] == r1[6] == 0.5

@@ -1,0 +1,149 @@
+"""Round-3 GPU tests: regressions for the round-2 advisor findings (two-call backward pattern with the fused KL,
+gradient buffers aliasing the pending KL gradients under a data-parallel hook, log_alpha gradient at exact zeros)
+and the round-3 kernels / entry points.  Everything goes through libcplxamd.so (C ABI via ctypes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layers():
+    from cplxmodule_amd.nn import relevance as rel
+    return {"cplx_vd": (rel.CplxLinearVD, True), "cplx_ard": (rel.CplxLinearARD, True),
+            "real_vd": (rel.LinearVD, False), "real_ard": (rel.LinearARD, False)}
+
+
+def _make(kind, I=96, O=80, dtype=torch.float32, seed=3):
+    from cplxmodule_amd import Cplx
+    from cplxmodule_amd.nn.relevance.noise import noise
+    cls, cplx_ = _layers()[kind]
+    torch.manual_seed(seed)
+    layer = cls(I, O).to("cuda")
+    with torch.no_grad():
+        layer.log_sigma2.uniform_(-6.0, 1.0)
+    noise.manual_seed(11)
+    B = 64
+    if cplx_:
+        x = Cplx(torch.randn(B, I, device="cuda").to(dtype), torch.randn(B, I, device="cuda").to(dtype))
+    else:
+        x = torch.randn(B, I, device="cuda").to(dtype)
+    return layer, x, cplx_
+
+
+def _nll(y, cplx_):
+    return ((y.real.float() ** 2).sum() + (y.imag.float() ** 2).sum()) if cplx_ else (y.float() ** 2).sum()
+
+
+def _grads(layer):
+    return {n: p.grad.detach().clone() for n, p in layer.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("kind", ["cplx_vd", "cplx_ard", "real_vd", "real_ard"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_call_backward_with_fused_kl(kind, dtype):
+    """`nll.backward(); (c * sum(penalties(model))).backward()` -- the reference's two-call pattern -- keeps working
+    once the KL rides in the layer's forward node ('backward through the graph a second time'), in
+    either order, and gives the gradients of the single combined backward."""
+    from cplxmodule_amd.nn.relevance import penalties
+    from cplxmodule_amd.nn.relevance.noise import noise
+    layer, x, cplx_ = _make(kind, dtype=dtype)
+    c = 0.37
+
+    def run(mode):
+        noise.manual_seed(11)
+        layer.zero_grad(set_to_none=True)
+        nll = _nll(layer(x), cplx_)
+        kl = sum(penalties(layer))
+        if mode == "one":
+            (nll + c * kl).backward()
+        elif mode == "nll_first":
+            nll.backward()
+            (c * kl).backward()
+        else:
+            (c * kl).backward()
+            nll.backward()
+        return _grads(layer)
+
+    run("one")                      # arms the fusion
+    ref = run("one")
+    assert layer._kl_fuse, "the fused path is what this test is about"
+    for mode in ("nll_first", "kl_first", "one"):
+        got = run(mode)
+        assert got.keys() == ref.keys()
+        for n in ref:
+            r = ref[n].float().cpu().numpy()
+            np.testing.assert_allclose(got[n].float().cpu().numpy(), r, rtol=2e-5, atol=2e-5 * np.abs(r).max(),
+                                       err_msg=f"{kind} {mode} {n}")
+
+
+class _FakeBuckets:
+    """What dp.BucketHook offers ops: persistent float32 storage per parameter + an announce call."""
+
+    def __init__(self, params):
+        self.store = {id(p): torch.zeros(p.shape, dtype=torch.float32, device=p.device) for p in params}
+        self.announced = []
+
+    def view_for(self, p):
+        t = self.store.get(id(p))
+        return None if t is None else t.view(t.shape)
+
+    def early_ready(self, *params):
+        self.announced += [p for p in params if p is not None]
+
+
+@pytest.mark.parametrize("kind", ["cplx_vd", "real_ard"])
+@pytest.mark.parametrize("frozen", ["log_sigma2", "weight"])
+def test_kl_gradients_do_not_alias_data_gradients_under_dp_hook(kind, frozen):
+    """With a data-parallel hook the pending KL gradients and the data-gradient outputs are views of the SAME bucket
+    slice.  When not every gradient is wanted (frozen log_sigma2 / frozen weight) the backward used to overwrite the
+    KL gradient with the data gradient and then add it to itself scaled (ops.py:671)."""
+    from cplxmodule_amd import ops
+    from cplxmodule_amd.nn.relevance import penalties
+    from cplxmodule_amd.nn.relevance.noise import noise
+    layer, x, cplx_ = _make(kind)
+    for n, p in layer.named_parameters():
+        if n.startswith(frozen):
+            p.requires_grad_(False)
+    c = 0.81
+
+    def run():
+        noise.manual_seed(5)
+        layer.zero_grad(set_to_none=True)
+        (_nll(layer(x), cplx_) + c * sum(penalties(layer))).backward()
+        return _grads(layer)
+
+    run()
+    ref = run()
+    assert layer._kl_fuse and ref
+    ops.dp_hook = _FakeBuckets([p for p in layer.parameters() if p.requires_grad])
+    try:
+        got = run()
+        assert ops.dp_hook.announced
+    finally:
+        ops.dp_hook = None
+    for n in ref:
+        r = ref[n].cpu().numpy()
+        np.testing.assert_allclose(got[n].cpu().numpy(), r, rtol=2e-5, atol=2e-5 * np.abs(r).max(), err_msg=n)
+
+
+@pytest.mark.parametrize("kind", ["real_vd", "cplx_vd"])
+def test_log_alpha_and_penalty_gradient_zero_at_zero_weight(kind):
+    """abs() / norm subgradient: an exactly-zero weight gets gradient 0 from log_alpha and from the penalty,
+    under grad mode too (+-2e12 g for the real kernels)."""
+    layer, _, cplx_ = _make(kind)
+    with torch.no_grad():
+        ws = (layer.weight.real, layer.weight.imag) if cplx_ else (layer.weight,)
+        for w in ws:
+            w[::3, ::5] = 0.0
+    zero = (ws[0] == 0) if not cplx_ else ((ws[0] == 0) & (ws[1] == 0))
+    assert int(zero.sum()) > 50
+    for f in (lambda: layer.log_alpha, lambda: layer.penalty):
+        layer.zero_grad(set_to_none=True)
+        out = f()
+        g = torch.randn_like(out)
+        finite = torch.isfinite(out)
+        (out[finite] * g[finite]).sum().backward()
+        for w in ws:
+            assert torch.isfinite(w.grad).all()
+            assert float(w.grad[zero].abs().max()) == 0.0
