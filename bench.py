@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for "
                     "functional tests of the N > 1 path on a single GPU (with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (tests)")
+    ap.add_argument("--force-collectives", action="store_true", help="world of one: initialise the process group and "
+                    "issue every collective of the N > 1 path anyway (tests: RCCL calls on a single-GPU box)")
     return ap.parse_args()
 
 
@@ -74,11 +76,12 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in ev) / len(ev) if ev else None
 
 
-def cpu_baseline(sample_rows):
+def cpu_baseline(sample_rows, kl_rows=512):
     """The numpy oracle (a port of the reference's op sequence) on the host cores, float32: the
     batch-proportional part (LRT forward + backward) on `sample_rows` of the 8192 rows, the
-    batch-independent part (exact KL forward + backward over the 4096 x 4096 weights, scipy Ei) once;
-    one full step = rows_time * (BATCH / sample_rows) + kl_time."""
+    batch-independent part (exact KL forward + backward, scipy Ei) on `kl_rows` of the 4096 weight rows;
+    one full step = rows_time * (BATCH / sample_rows) + kl_time * (4096 / kl_rows).  (Both parts are linear in
+    their row count; the sample keeps this leg at 1-2 s of a run whose timed region is shorter than that.)"""
     import numpy as np
     from oracle import cplx_oracle as orc
     rs = np.random.RandomState(0)
@@ -95,26 +98,34 @@ def cpu_baseline(sample_rows):
     orc.lrt_cplx_linear_bwd(2 * yr, 2 * yi, xr, xi, wr, wi, ls2, er, ei)
     t_rows = time.perf_counter() - t0
     t0 = time.perf_counter()
-    kl = orc.penalty("cplx_vd", ls2, wr, wi).sum()
-    orc.penalty_bwd("cplx_vd", np.full_like(ls2, KLW), ls2, wr, wi)
-    t_kl = time.perf_counter() - t0
+    kr = min(kl_rows, O)
+    kl = orc.penalty("cplx_vd", ls2[:kr], wr[:kr], wi[:kr]).sum()
+    orc.penalty_bwd("cplx_vd", np.full_like(ls2[:kr], KLW), ls2[:kr], wr[:kr], wi[:kr])
+    t_kl = (time.perf_counter() - t0) * (O / kr)
     assert np.isfinite(kl)
     step = t_rows * (BATCH / B) + t_kl
     return {"value": round(BATCH / step, 2), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"numpy oracle: LRT fwd+bwd on {B} of {BATCH} rows ({t_rows:.2f} s, scaled x{BATCH // B}) + the "
-                      f"full {O}x{I} exact KL fwd+bwd once ({t_kl:.2f} s, scipy expi) = {step:.1f} s per step of {BATCH} rows"}
+            "sample": f"numpy oracle: LRT fwd+bwd on {B} of {BATCH} rows ({t_rows:.2f} s, scaled x{BATCH // B}) + the exact KL "
+                      f"fwd+bwd (scipy expi) on {kr} of {O} weight rows (scaled x{O // kr}: {t_kl:.2f} s) = {step:.1f} s per step "
+                      f"of {BATCH} rows"}
 
 
 def gemm_traffic():
-    """HBM bytes per launch of the complex GEMM from the tracked PMC summary (separate rocprofv3 --pmc
-    passes of this kernel and shape, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE; scripts/r02/pmc_traffic.sh)."""
-    path = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        return float(d["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    """HBM bytes per launch of the complex GEMM from the tracked PMC summary (separate rocprofv3 --pmc passes of the
+    bench's three launches at the bench shape, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE;
+    scripts/r03/pmc_traffic.sh): (mean over the three launches, {launch: bytes}).  PMC counters cannot be read from
+    inside this process, so this is the committed measurement of the same kernels and shapes, not of this run."""
+    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                d = json.load(fh)
+            per = d.get("per_launch")
+            if per:
+                return sum(per.values()) / len(per), per
+            return float(d["traffic_bytes_per_launch"]), None
+        except Exception:
+            continue
+    return None, None
 
 
 def hbm_points(dev):
@@ -148,6 +159,15 @@ def hbm_points(dev):
         t = med(lambda: ops.reparam_bwd(mu_r, mu_i, s2, None, 1, 2, out_dtype=torch.bfloat16))
         out["reparam_bwd@2^20x2048(8B/out bf16, s2 bf16)"] = round(8 * n / t / 1e9, 1)
         del mu_r, mu_i, s2
+        # SURVEY 8(d)'s definition of the target: float32 operands, 20 B per output forward / 16 backward
+        mu_r = torch.zeros(n, dtype=torch.float32, device=dev)
+        mu_i = torch.zeros(n, dtype=torch.float32, device=dev)
+        s2 = torch.full((n,), 0.5, dtype=torch.float32, device=dev)
+        t = med(lambda: ops.reparam_fwd(mu_r, mu_i, s2, None, 1, 2, inplace=True))
+        out["reparam_fwd@2^20x2048(20B/out fp32)"] = round(20 * n / t / 1e9, 1)
+        t = med(lambda: ops.reparam_bwd(mu_r, mu_i, s2, None, 1, 2, out_dtype=torch.float32))
+        out["reparam_bwd@2^20x2048(16B/out fp32)"] = round(16 * n / t / 1e9, 1)
+        del mu_r, mu_i, s2
         m = 16384 * 16384
         wr = torch.randn(m, device=dev) * 0.01
         wi = torch.randn(m, device=dev) * 0.01
@@ -161,7 +181,7 @@ def hbm_points(dev):
     return out
 
 
-def conv_point(dev, batch=64):
+def conv_point(dev, batch=256):
     """BASELINE configs[2] beside the headline (rank 0, N = 1, outside the timed region): CplxConv2d(64, 64, 3) on
     256 x 256 bf16 images + CplxBatchNorm2d, forward + backward, channels-last input, `batch` images per step;
     images/s over 10 steps and the three convolution kernels' share of the dense bf16 MFMA peak (HIP events around
@@ -182,15 +202,15 @@ def conv_point(dev, batch=64):
             x.real.grad = x.imag.grad = None
             y = bn(layer(x))
             torch.autograd.backward((y.real, y.imag), (y.real.detach(), y.imag.detach()))
-        for _ in range(3):
+        for _ in range(2):
             step()
         timer.enabled = True
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(5):
             step()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10
+        dt = (time.perf_counter() - t0) / 5
         flop = 8.0 * batch * 64 * 254 * 254 * 64 * 9
         out = {"workload": f"CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, bf16, batch {batch}, fwd+bwd, channels-last",
                "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flop_per_launch": flop}
@@ -201,6 +221,88 @@ def conv_point(dev, batch=64):
         return out
     except Exception as e:  # pragma: no cover
         return {"error": str(e)[:200]}
+
+
+def cfg4_point(dev, log2_batch=20):
+    """BASELINE configs[3] (rank 0, N = 1, outside the timed region): CplxLinearVD(2048, 2048), bf16 activations, batch
+    2^20, LRT forward + fused KL + full backward, loss = sum |y|^2 + 1e-3 KL; ms per step over 3 steps."""
+    try:
+        from cplxmodule_amd import Cplx
+        from cplxmodule_amd.nn import relevance as rel
+        torch.manual_seed(0)
+        B, F = 1 << log2_batch, 2048
+        layer = rel.CplxLinearVD(F, F).to(dev)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-12, 4)
+        x = Cplx(torch.randn(B, F, device=dev, dtype=torch.bfloat16).requires_grad_(True),
+                 torch.randn(B, F, device=dev, dtype=torch.bfloat16).requires_grad_(True))
+        klw = torch.tensor(KLW, device=dev)
+
+        def step():
+            layer.zero_grad(set_to_none=True)
+            x.real.grad = x.imag.grad = None
+            y = layer(x)
+            kl = sum(rel.penalties(layer))
+            gr, gi = y.real.detach() * 2, y.imag.detach() * 2
+            torch.autograd.backward((y.real, y.imag, kl), (gr, gi, klw))
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        flop = 3 * (8 + 2) * float(B) * F * F
+        return {"workload": f"CplxLinearVD(2048,2048), bf16, batch 2^{log2_batch}, LRT fwd + KL + full bwd",
+                "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1),
+                "tflops_whole_step": round(flop / dt / 1e12, 1),
+                "frac_of_mfma_peak_whole_step": round(flop / dt / 1e12 / BF16_PEAK_TFLOPS, 4)}
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)[:200]}
+
+
+def cfg2_point(dev):
+    """BASELINE configs[1] as written (rank 0, N = 1, outside the timed region): plain CplxLinear(4096, 4096), bf16,
+    batch 8192, forward + backward with the 4-GEMM kernel (`cplx.linear`, one fused 4M launch per pass) and with
+    Gauss's 3-GEMM form (`cplx.linear_3m`): ms per step and samples/s of each, fraction of the MFMA peak on the
+    flop each algorithm must execute (8 / 6 B I O per pass, 3 passes)."""
+    try:
+        from cplxmodule_amd import Cplx, cplx, nn
+        torch.manual_seed(0)
+        layer = nn.CplxLinear(IN_F, OUT_F).to(dev)
+        x = Cplx(torch.randn(BATCH, IN_F, device=dev, dtype=torch.bfloat16).requires_grad_(True),
+                 torch.randn(BATCH, IN_F, device=dev, dtype=torch.bfloat16).requires_grad_(True))
+        out = {"workload": "CplxLinear(4096,4096), bf16, batch 8192, fwd+bwd (dX, dW, db)"}
+        for name, fn, mul in (("4m", cplx.linear, 8.0), ("3m", cplx.linear_3m, 6.0)):
+            def step():
+                layer.zero_grad(set_to_none=True)
+                x.real.grad = x.imag.grad = None
+                y = fn(x, layer.weight, layer.bias)
+                torch.autograd.backward((y.real, y.imag), (y.real.detach(), y.imag.detach()))
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            flop = 3 * mul * BATCH * IN_F * OUT_F
+            out[name] = {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(BATCH / dt, 1),
+                         "frac_of_mfma_peak": round(flop / dt / 1e12 / BF16_PEAK_TFLOPS, 4)}
+        return out
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)[:200]}
+
+
+def _layout_key(prefix):
+    def key(ar, *a, **k):
+        if ar.dtype != torch.bfloat16:
+            return None
+        sa, sb = (a[1], a[4]) if prefix == "cgemm" else (a[0], a[2])
+        return f"{prefix}_{'N' if sa[1] == 1 else 'T'}{'N' if sb[1] == 1 else 'T'}"
+    return key
 
 
 def main():
@@ -215,8 +317,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    grouped = world > 1 or args.force_collectives
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -225,9 +331,11 @@ def main():
     from cplxmodule_amd import Cplx, dp, ops
     from cplxmodule_amd.nn import relevance as rel
     from cplxmodule_amd.nn.relevance import noise
+    dp.FORCE_COLLECTIVES = bool(args.force_collectives)
 
     timer = KernelTimer()
-    timer.wrap(ops, "cgemm", lambda ar, *a, **k: "cgemm" if ar.dtype == torch.bfloat16 else None)
+    timer.wrap(ops, "cgemm", _layout_key("cgemm"))       # forward NN, input gradient NT, weight gradient TT
+    timer.wrap(ops, "rgemm", _layout_key("rgemm"))
     timer.wrap(ops, "prep_kl", lambda *a, **k: "prep_kl" if a[4] else None)
     timer.wrap(ops, "reparam_fwd", lambda *a, **k: "reparam_fwd")
     timer.wrap(ops, "reparam_bwd", lambda *a, **k: "reparam_bwd")
@@ -253,12 +361,12 @@ def main():
         gy_r, gy_i = y.real.detach() * 2, y.imag.detach() * 2      # d(sum |y|^2)/dy
         torch.autograd.backward((y.real, y.imag, kl), (gy_r, gy_i, klw))
         model.sync_gradients()
-        return dp.all_reduce_scalar_mean(kl) if world > 1 else kl
+        return dp.all_reduce_scalar_mean(kl) if grouped else kl
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
@@ -269,12 +377,12 @@ def main():
         kl = step()
         marks[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if grouped:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
@@ -282,7 +390,11 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        gemm_ms = timer.mean_ms("cgemm")
+        launches = {k: round(timer.mean_ms(k), 4) for k in sorted(timer.spans) if k[1:5] == "gemm"}
+        cg = [v for k, v in launches.items() if k.startswith("cgemm")]
+        gemm_ms = sum(cg) / len(cg) if cg else None
+        traffic, traffic_per = gemm_traffic() if B == BATCH else (None, None)
+        real_flops = 2.0 * B * IN_F * OUT_F
         flops = 8.0 * B * IN_F * OUT_F          # algorithmic flop of ONE 4M complex GEMM launch
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
         nw = IN_F * OUT_F
@@ -304,8 +416,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM: fwd NN, dgrad NT, wgrad TT = 3 launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,
-                         "traffic": gemm_traffic() if B == BATCH else None, "flop_per_launch": flops,
-                         "avg_launch_ms": round(gemm_ms, 4) if gemm_ms else None},
+                         "traffic": traffic, "traffic_per_launch": traffic_per, "flop_per_launch": flops,
+                         "avg_launch_ms": round(gemm_ms, 4) if gemm_ms else None,
+                         # every GEMM launch of the step: forward NN, input gradient NT, weight gradient TT; complex
+                         # (8 B I O flop) and the real variance GEMMs (2 B I O flop)
+                         "launch_ms": launches,
+                         "launch_frac": {k: round((flops if k[0] == "c" else real_flops) / (v * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4)
+                                         for k, v in launches.items()}},
             "hbm_kernels_GBps": {
                 # in-step: operand prep + KL sum + KL gradients in one pass (12 B read, 6 + 12 B written)
                 "prep_kl_fused(30B/elt)": round(30 * nw / (pk * 1e-3) / 1e9, 1) if pk else None,
@@ -316,10 +433,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["hbm_kernels_GBps"].update(hbm_points(dev))
+            line["cfg2_linear"] = cfg2_point(dev)
             line["conv_cfg3"] = conv_point(dev)
+            line["cfg4_lrt"] = cfg4_point(dev)
             line["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

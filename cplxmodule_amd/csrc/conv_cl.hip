@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
 
 namespace cplxamd {
 namespace cl {
@@ -696,7 +697,8 @@ int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, co
   }
   const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n;
   if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
-  int grid = ntiles < ncu ? (int)ntiles : ncu;
+  // chip shared with RCCL collectives (cplxamd_gemm_set_persistent(0), gemm.h): one workgroup per tile
+  int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
   // Start stagger.  A tile takes ~ NS stages x 2 waves per SIMD x 48 MFMAs x 32 clocks / 0.5; the workgroups that get
   // one tile less than the longest ones (ntiles % grid != 0) have that much slack: their starts are spread over it.
   g.stagger = 0; g.stagger_from = 0;

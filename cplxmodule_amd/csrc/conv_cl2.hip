@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
 
 namespace cplxamd {
 namespace cl2 {
@@ -488,7 +489,9 @@ int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, c
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
     ncu = n & ~7;
   }
-  const int grid = ntiles < ncu ? (int)ntiles : ncu;
+  // chip shared with RCCL collectives (cplxamd_gemm_set_persistent(0), gemm.h): one workgroup per tile -- a launch that
+  // expects every CU for its whole duration would wait for the held ones with its last workgroups
+  const int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cl2::SMEM);

@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
 
 namespace cplxamd {
 namespace clr {
@@ -605,7 +606,8 @@ int cplxamd_conv2d_clr(const void* x, const void* w_packed, const float* bias, v
   }
   const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n;
   if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
-  int grid = ntiles < ncu ? (int)ntiles : ncu;
+  // chip shared with RCCL collectives (cplxamd_gemm_set_persistent(0), gemm.h): one workgroup per tile
+  int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
   g.stagger = 0; g.stagger_from = 0;
   if (ntiles > 2 * grid && ntiles % grid) {
     const int64_t tile_clk = (int64_t)g.NS * 2 * 24 * 32 * 2;

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
 
 namespace cplxamd {
 namespace clwr {
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
   dw[i] = emul ? acc * (emul_exp ? __expf(emul[i]) : emul[i]) : acc;
 }
 
-static int plan(int64_t nstages, int tiles, int& per_split) {
+// shared: the chip is shared with RCCL collectives (cplxamd_gemm_set_persistent(0)): twice as many, half as long splits,
+// so that the workgroups that find their CU taken do not make the launch take two rounds (the workspace is always sized
+// for this plan)
+static int plan(int64_t nstages, int tiles, int& per_split, bool shared) {
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0, n = 0;
@@ -328,6 +332,7 @@ static int plan(int64_t nstages, int tiles, int& per_split) {
   }
   int64_t s = ncu / tiles;                            // one workgroup per CU (120 KiB of LDS each), one round
   if (s < 1) s = 1;
+  if (shared) s *= 2;
   const int64_t maxs = (nstages + 15) / 16;           // >= 16 stages per split
   if (s > maxs) s = maxs;
   per_split = (int)((nstages + s - 1) / s);
@@ -356,7 +361,7 @@ int64_t cplxamd_conv2d_clr_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int C
   if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
   const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
   int per_split = 0;
-  const int splits = clwr::plan(B * H * ((W + clwr::KR - 1) / clwr::KR), tiles, per_split);
+  const int splits = clwr::plan(B * H * ((W + clwr::KR - 1) / clwr::KR), tiles, per_split, true);
   return (int64_t)splits * tiles * clwr::NBLK * 1024 * 4;
 }
 
@@ -384,7 +389,7 @@ int cplxamd_conv2d_clr_wgrad(const void* g_, const void* x, const float* emul, i
   g.nstages = (int)(B * H * g.strips);
   g.tiles_ci = Ci / 64;
   const int tiles = (Co / 64) * g.tiles_ci;
-  g.splits = clwr::plan(g.nstages, tiles, g.per_split);
+  g.splits = clwr::plan(g.nstages, tiles, g.per_split, !g_gemm_persistent);
   constexpr int smem = 3 * clwr::STAGE;
   static bool attr_set = false;
   if (!attr_set) {

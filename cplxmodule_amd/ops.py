@@ -510,6 +510,22 @@ def _scaled(beta, t):
     return None if t is None else t * beta
 
 
+def _saved(ctx):
+    """ctx.saved_tensors of an LRT node whose KL output shares the node (KLFusion).  A backward pass of the KL term
+    alone goes through this node too, and autograd then frees the node's saved activations like after any backward
+    pass: `kl.backward()` FOLLOWED BY `nll.backward()` needs `retain_graph=True` on the first call (the other order,
+    and the usual single `(nll + c * kl).backward()`, need nothing)."""
+    try:
+        return ctx.saved_tensors
+    except RuntimeError as e:
+        if getattr(ctx, "kl_only_ran", False):
+            raise RuntimeError(
+                "the layer's KL term was back-propagated on its own BEFORE the data term; the fused KL shares the layer's "
+                "autograd node, so that pass freed the saved activations: call nll.backward() first, use one combined "
+                "backward, or pass retain_graph=True to the KL backward") from e
+        raise
+
+
 # Data-parallel hook (cplxmodule_amd.dp.BucketHook): when set, the linear layers' backward writes the
 # parameter gradients straight into their all-reduce bucket (`grad_buffer`) and announces them
 # (`early_ready`) BEFORE its input-gradient GEMMs, so the RCCL all-reduce of a full bucket overlaps them.
@@ -639,8 +655,9 @@ class CplxLinearLRTFn(torch.autograd.Function):
                     wr, wi, ls2 = ctx.kl_params
                     ctx.klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:]
                 dls2, dwr, dwi = (_scaled(gkl, t) for t in ctx.klg)
+            ctx.kl_only_ran = True
             return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
-        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi = ctx.saved_tensors
+        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi = _saved(ctx)
         O, I = wr.shape
         B = x2r.shape[0]
         klg = None
@@ -802,8 +819,9 @@ class RealLinearLRTFn(torch.autograd.Function):
                     r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
                     ctx.klg = (r[1], r[2])
                 dls2, dw = _scaled(gkl, ctx.klg[0]), _scaled(gkl, ctx.klg[1])
+            ctx.kl_only_ran = True
             return dx, dw, db, dls2, None, None, None, None
-        x2, w, ls2, s2, a, eps, b = ctx.saved_tensors
+        x2, w, ls2, s2, a, eps, b = _saved(ctx)
         O, I = w.shape
         B = x2.shape[0]
         klg = None

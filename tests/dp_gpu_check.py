@@ -102,6 +102,7 @@ def main():
     def hand_average(module, run_fn):
         """plain local gradients (no wrapper), averaged with explicit all-reduces"""
         ops.dp_hook = None
+        noise.fold_rank(rank)                                # (DataParallel.remove() undoes the fold: same noise as under the wrapper)
         module.zero_grad(set_to_none=True)
         run_fn()
         out = {}

@@ -43,8 +43,9 @@ def _grads(layer):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_two_call_backward_with_fused_kl(kind, dtype):
     """`nll.backward(); (c * sum(penalties(model))).backward()` -- the reference's two-call pattern -- keeps working
-    once the KL rides in the layer's forward node ('backward through the graph a second time'), in
-    either order, and gives the gradients of the single combined backward."""
+    once the KL rides in the layer's forward node ('backward through the graph a second time'), and gives
+    the gradients of the single combined backward; the reverse order works with retain_graph=True on the KL pass and
+    says so otherwise."""
     from cplxmodule_amd.nn.relevance import penalties
     from cplxmodule_amd.nn.relevance.noise import noise
     layer, x, cplx_ = _make(kind, dtype=dtype)
@@ -61,7 +62,8 @@ def test_two_call_backward_with_fused_kl(kind, dtype):
             nll.backward()
             (c * kl).backward()
         else:
-            (c * kl).backward()
+            # the KL alone first: it runs through the layer's node, so the graph must be retained for the data term
+            (c * kl).backward(retain_graph=True)
             nll.backward()
         return _grads(layer)
 
@@ -75,6 +77,12 @@ def test_two_call_backward_with_fused_kl(kind, dtype):
             r = ref[n].float().cpu().numpy()
             np.testing.assert_allclose(got[n].float().cpu().numpy(), r, rtol=2e-5, atol=2e-5 * np.abs(r).max(),
                                        err_msg=f"{kind} {mode} {n}")
+    noise.manual_seed(11)
+    layer.zero_grad(set_to_none=True)
+    nll, kl = _nll(layer(x), cplx_), sum(penalties(layer))
+    kl.backward()
+    with pytest.raises(RuntimeError, match="retain_graph=True to the KL backward"):
+        nll.backward()
 
 
 class _FakeBuckets:
@@ -147,3 +155,81 @@ def test_log_alpha_and_penalty_gradient_zero_at_zero_weight(kind):
         for w in ws:
             assert torch.isfinite(w.grad).all()
             assert float(w.grad[zero].abs().max()) == 0.0
+
+
+def _bench_line(stdout):
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_py_runs_with_two_ranks_and_with_rccl():
+    """bench.py itself with N > 1 (the first SCALE run must not be the first run of that code): two gloo
+    ranks sharing this GPU (init, barrier, bucket exchange, scalar KL all-reduce, MAX-reduce of the elapsed time,
+    the JSON line), and one RCCL rank with every collective of the N > 1 path forced on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--batch", "512", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--share-device"] + common,
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = _bench_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024 and line["config"]["parallelism"] == "dp2"
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert np.isfinite(line["value"]) and line["value"] > 0 and np.isfinite(line["kl"])
+    assert abs(line["value"] - 2 * 512 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-3 * line["value"]
+    assert "cpu_baseline" not in line and line["roofline"]["avg_launch_ms"] > 0
+    env1 = dict(env, MASTER_PORT="29549")
+    env1.pop("RANK", None); env1.pop("WORLD_SIZE", None); env1.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--backend", "nccl",
+                        "--force-collectives"] + common, env=env1, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = _bench_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 512 and np.isfinite(line["value"])
+
+
+@pytest.mark.parametrize("layer_kind", ["cplx", "cplx_vd"])
+def test_conv_kernels_one_workgroup_per_tile_switch(layer_kind):
+    """`cplxamd_gemm_set_persistent(0)` -- what the data-parallel hook selects while RCCL collectives are in flight --
+    also makes the channels-last convolution kernels launch one workgroup per tile (forward, data gradient) / twice
+    as many split slabs (weight gradient): forward and data gradient bit-identical, weight gradient equal up to the
+    float32 order of the slab sums.  More tiles than CUs, so the two forms really differ."""
+    from cplxmodule_amd import Cplx, _lib, nn
+    from cplxmodule_amd.nn import relevance as rel
+    from cplxmodule_amd.nn.relevance.noise import noise
+    lib = _lib.load()
+    torch.manual_seed(0)
+    layer = (nn.CplxConv2d(64, 64, 3, padding=1) if layer_kind == "cplx" else rel.CplxConv2dVD(64, 64, 3, padding=1)).to("cuda")
+    mk = lambda: (torch.randn(8, 64, 96, 128, device="cuda").bfloat16()  # noqa: E731
+                  .contiguous(memory_format=torch.channels_last).requires_grad_(True))
+    x = Cplx(mk(), mk())                      # 8 x 6 x 4 = 192 patch tiles... x column tiles: see the assert below
+    g = (torch.randn(8, 64, 96, 128, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last),
+         torch.randn(8, 64, 96, 128, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last))
+
+    def run():
+        noise.manual_seed(3)
+        layer.zero_grad(set_to_none=True)
+        x.real.grad = x.imag.grad = None
+        y = layer(x)
+        torch.autograd.backward((y.real, y.imag), g)
+        grads = {n: p.grad.clone() for n, p in layer.named_parameters()}
+        return y.real.detach().clone(), y.imag.detach().clone(), x.real.grad.clone(), x.imag.grad.clone(), grads
+
+    try:
+        assert lib.cplxamd_gemm_set_persistent(1) == 1
+        a = run()
+        assert lib.cplxamd_gemm_set_persistent(0) == 1
+        b = run()
+    finally:
+        lib.cplxamd_gemm_set_persistent(1)
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    for n in a[4]:
+        r = a[4][n].float().cpu().numpy()
+        np.testing.assert_allclose(b[4][n].float().cpu().numpy(), r, rtol=1e-5, atol=1e-5 * np.abs(r).max(), err_msg=n)
