@@ -56,6 +56,10 @@ constexpr int BK = 32, STAGES = 3;
 // 64 never wait for the LDS-DMA (racy: the share of the counted vmcnt waits),
 // 128 K-contiguous operands requested as whole 128-byte lines, 8 chunks per row (WRONG data, same byte count: what the
 // half-line requests of a 32-deep K tile cost -- profiles/r02_gemm_ablation.md section 7)
+// 256 (with 2; forward layout; WRONG data, same byte and instruction count): the two halves of every 128-byte line are
+// requested by BACK-TO-BACK instructions of one wave instead of one K tile (48 KiB of other lines) apart: even K tiles
+// fetch both 32-deep halves of rows 0..BM/2, odd ones of the other rows -- what a ring that issues the halves of a
+// line pairwise would get from the L1 (profiles/r03_gemm_pair_issue.txt)
 #ifndef CPLXAMD_GEMM_DBG_BUILD
 #define CPLXAMD_GEMM_DBG_BUILD 0
 #endif
@@ -94,6 +98,18 @@ __device__ __forceinline__ uint32_t piece_voff(int64_t ld, int row0, int rows, i
   const int p = j * NT + (int)threadIdx.x;
   if (!T) {
     if (kDbg & 128) {   // experiment (wrong data): the same bytes as whole 128-byte lines, 8 chunks per row
+      const int row = p >> 3;
+      int grow = row0 + row;
+      grow = grow < rows ? grow : rows - 1;
+      return (uint32_t)(((int64_t)(grow - row0) * ld + (p & 7) * 8) * 2);
+    }
+    if ((kDbg & 256) && ROWS * 4 / NT == 2) {   // two pieces per plane: piece 1 = the other half line of piece 0's rows
+      const int row = (p - j * NT) >> 2;
+      int grow = row0 + row;
+      grow = grow < rows ? grow : rows - 1;
+      return (uint32_t)(((int64_t)(grow - row0) * ld + (p & 3) * 8 + j * 32) * 2);
+    }
+    if ((kDbg & 256) && ROWS * 4 / NT == 1) {   // one piece per plane: whole lines of half the rows
       const int row = p >> 3;
       int grow = row0 + row;
       grow = grow < rows ? grow : rows - 1;
@@ -271,16 +287,26 @@ __global__ __launch_bounds__((Cfg<CPLX, BIG>::NT), (BIG ? 1 : 2)) void gemm_bf16
   // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
   auto stage_q = [&](int buf, int k0, int q) __attribute__((always_inline)) {
     k0 += kbase;
+    int ma = m0, nb = n0;
+    if ((kDbg & 512) && C::LOADS == 6) {   // with 256: the two halves of a line three instructions (24 KiB per CU) apart
+      constexpr int perm[6] = {0, 3, 2, 1, 4, 5};
+      q = perm[q];
+    }
+    if (kDbg & 256) {                 // pair-issue experiment: K tile t -> 64-deep position t / 2, row half t & 1
+      const int t = k0 / BK;
+      k0 = (t >> 1) * 64;
+      ma += (t & 1) * (BM / 2); nb += (t & 1) * (BN / 2);
+    }
     const uint32_t s = smem_off + (uint32_t)(buf * C::STAGE_BYTES) + wave_lds;
     if (q < C::PA)
-      lds_dma16_sv(piece_base<TA>(Ar, lda, m0, k0, akm), voa[q], s + q * NT * 16);
+      lds_dma16_sv(piece_base<TA>(Ar, lda, ma, k0, akm), voa[q], s + q * NT * 16);
     else if (q < C::PA + C::PB)
-      lds_dma16_sv(piece_base<TB>(Br, ldb, n0, k0, bkm), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
+      lds_dma16_sv(piece_base<TB>(Br, ldb, nb, k0, bkm), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
     else if (q < 2 * C::PA + C::PB)
-      lds_dma16_sv(piece_base<TA>(Ai, lda, m0, k0, akm), voa[q - C::PA - C::PB],
+      lds_dma16_sv(piece_base<TA>(Ai, lda, ma, k0, akm), voa[q - C::PA - C::PB],
                    s + C::A_BYTES + C::B_BYTES + (q - C::PA - C::PB) * NT * 16);
     else
-      lds_dma16_sv(piece_base<TB>(Bi, ldb, n0, k0, bkm), vob[q - 2 * C::PA - C::PB],
+      lds_dma16_sv(piece_base<TB>(Bi, ldb, nb, k0, bkm), vob[q - 2 * C::PA - C::PB],
                    s + 2 * C::A_BYTES + C::B_BYTES + (q - 2 * C::PA - C::PB) * NT * 16);
   };
   auto stage_all = [&](int buf, int k0) __attribute__((always_inline)) {
