@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for "
                     "functional tests of the N > 1 path on a single GPU (with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (tests)")
+    ap.add_argument("--graph", choices=("on", "off"), default=os.environ.get("CPLXAMD_BENCH_GRAPH", "on"),
+                    help="on (default): the step is captured ONCE in a hipGraph after the warm-up steps and every timed step is a "
+                    "replay of it (same kernels, same work, fresh Philox noise per replay; with N > 1 the RCCL all-reduces "
+                    "are graph nodes); off: eager launches.  A capture that fails falls back to eager.")
     ap.add_argument("--force-collectives", action="store_true", help="world of one: initialise the process group and "
                     "issue every collective of the N > 1 path anyway (tests: RCCL calls on a single-GPU box)")
     return ap.parse_args()
@@ -318,11 +322,19 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     grouped = world > 1 or args.force_collectives
+    # RCCL prints a version banner to STDOUT when a communicator is created; this process owes its caller exactly one
+    # JSON line there, so stdout points at stderr until the communicator exists (end of the warm-up)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL's kernels must get CUs NEXT TO the input-gradient GEMMs they are meant to overlap: on an equal-priority
+        # queue they were dispatched only after the GEMM queue had drained (profiles/r03_dp_timeline.txt)
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -363,18 +375,40 @@ def main():
         model.sync_gradients()
         return dp.all_reduce_scalar_mean(kl) if grouped else kl
 
-    for _ in range(args.warmup):
-        step()
+    graphed, mode = None, "eager"
+    if args.graph == "on" and (not grouped or args.backend == "nccl"):   # (gloo collectives synchronise on the host)
+        # W eager warm-up steps on the capture stream, then ONE capture; the timed steps replay it.  (HIP events cannot be
+        # recorded inside a replayed graph on ROCm -- "External events are disallowed" -- so the per-launch GEMM times of
+        # `roofline` are taken with HIP events around the same launches in ten eager steps right after the timed region.)
+        from cplxmodule_amd.utils.graphs import GraphedStep
+        noise.set_mode("philox-device")            # Philox position in device memory: fresh noise per replay
+        try:
+            graphed = GraphedStep(step, modules=[layer], warmup=args.warmup)
+            graphed.replay()                        # (first replay: graph upload)
+            torch.cuda.synchronize()
+            mode = "hipGraph replay"
+        except Exception as e:  # pragma: no cover - capture refused: measure the eager path
+            sys.stderr.write(f"bench.py: hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}); eager launches\n")
+            graphed = None
+            noise.set_mode("philox")
+    if graphed is None:
+        for _ in range(args.warmup):
+            step()
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    sys.stdout.flush()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)             # (the banner sits in the C library's stdout buffer)
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    timer.enabled = graphed is None
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        kl = step()
+        kl = graphed.replay() if graphed is not None else step()
         marks[i + 1].record()
     torch.cuda.synchronize()
     if grouped:
@@ -382,6 +416,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    if graphed is not None:
+        timer.enabled = True       # the same launches, eager, HIP events around each: ten steps
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        timer.enabled = False
     if grouped:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -412,7 +452,7 @@ def main():
             "config": {"workload": "CplxLinearVD 4096->4096, bf16 activations / fp32 master weights, "
                                    f"batch {B} per GPU, LRT fwd + KL + full bwd (BASELINE configs[1] + VD)",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "kl_weight": KLW, "noise": "in-kernel Philox4x32-7"},
+                       "kl_weight": KLW, "noise": "in-kernel Philox4x32-7", "launch": mode},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM: fwd NN, dgrad NT, wgrad TT = 3 launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,

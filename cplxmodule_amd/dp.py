@@ -82,6 +82,7 @@ class _Bucket:
         self.launched = False
         self.events = []           # HIP events behind the kernels that wrote the slices in place
         self.dirty = False         # a gradient changed after the bucket's collective was launched
+        self.early = False         # launched on the side stream, behind the announced stream position only
         self.in_order = False      # a gradient reached its slice by a copy on the current stream
 
 
@@ -183,9 +184,13 @@ class BucketHook:
                 side = self._side
                 for ev in b.events:
                     side.wait_event(ev)
+        b.early = side is not None     # (introspection: the collective was ordered behind the announced position only)
         if side is not None:
             with torch.cuda.stream(side):
                 work, div = _all_reduce(b.flat, async_op)
+            # join the side stream again (it holds no work of its own: the collective runs on the backend's stream, which
+            # `work.wait()` joins in sync()): a step captured into a hipGraph must not end with an unjoined fork
+            torch.cuda.current_stream(b.flat.device).wait_stream(side)
         else:
             work, div = _all_reduce(b.flat, async_op)
         self.pending.append((b, work if async_op else None, div))

@@ -51,44 +51,44 @@ class Net(torch.nn.Module):
         return abs(z)                       # logits = modulus of the 10 complex outputs
 
 
-def train_graph(model, x, y, steps, klw, lr):
-    """The whole step -- forward, loss + KL, backward, Adam -- captured once in a hipGraph and
-    replayed: the model is launch-bound (tens of small kernels per layer), so this is where a HIP
-    graph replaces what a tracing compiler would be used for.  The LRT noise position lives on the
-    device ("philox-device"), so every replay draws fresh noise."""
+def train_graph(model, x, y, steps, klw, lr, wrap=False):
+    """The whole step -- forward, loss + KL, backward [, gradient exchange], Adam -- captured once in a hipGraph
+    (cplxmodule_amd.utils.graphs.GraphedStep) and replayed: the model is launch-bound (tens of small kernels per
+    layer), so this is where a HIP graph replaces what a tracing compiler would be used for.  The LRT noise position
+    lives on the device ("philox-device"), so every replay draws fresh noise.  With `wrap` the step runs under
+    dp.DataParallel and the bucket all-reduces (RCCL kernels) are part of the captured graph."""
+    from cplxmodule_amd.utils.graphs import GraphedStep
     rel.noise.set_mode("philox-device")
+    par = dp.DataParallel(model) if wrap else None
     opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True)
     model.train()
+    hist = []
 
     def step():
+        if par is not None:
+            par.zero_grad()
+        opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.cross_entropy(model(x), y)
         kl = sum(rel.penalties(model), torch.zeros((), device=y.device))
         (loss + klw * kl).backward()
+        if par is not None:
+            par.sync_gradients()
         opt.step()
         return loss.detach(), kl.detach()
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    hist = []
-    with torch.cuda.stream(side):
-        for _ in range(3):                                  # warm-up: allocator, caches, Adam state
-            opt.zero_grad(set_to_none=True)
-            hist.append(step())
-    torch.cuda.current_stream().wait_stream(side)
-    opt.zero_grad(set_to_none=True)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        out = step()
+    g = GraphedStep(step, modules=[model], warmup=3)       # warm-up: allocator, caches, Adam state (3 real steps)
     for _ in range(steps - 3):
-        g.replay()
+        out = g.replay()
         hist.append((out[0].clone(), out[1].clone()))       # no host sync inside the loop
     rel.noise.set_mode("philox")
+    if par is not None:
+        par.remove()
     return [(float(a), float(b)) for a, b in hist]
 
 
 def train(model, x, y, steps, klw, lr, wrap, graph=False):
-    if graph and not wrap:
-        return train_graph(model, x, y, steps, klw, lr)
+    if graph:
+        return train_graph(model, x, y, steps, klw, lr, wrap)
     par = dp.DataParallel(model) if wrap else None
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     model.train()
