@@ -332,8 +332,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        # RCCL's kernels must get CUs NEXT TO the input-gradient GEMMs they are meant to overlap: on an equal-priority
-        # queue they were dispatched only after the GEMM queue had drained (profiles/r03_dp_timeline.txt)
+        # RCCL's kernels must run NEXT TO the input-gradient GEMMs they are meant to overlap: a normal-priority stream can
+        # share the compute stream's hardware queue and then runs in queue order (profiles/r03_dp_timeline.txt)
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

@@ -51,6 +51,19 @@ def is_initialized():
     return dist.is_available() and dist.is_initialized()
 
 
+def init_process_group(backend="nccl", device=None, **kwargs):
+    """torch.distributed.init_process_group with what the overlap of this module needs: RCCL's stream on a
+    high-priority hardware queue (TORCH_NCCL_HIGH_PRIORITY=1, read when the process group is created; on the compute
+    stream's queue its kernels run in queue order, i.e. not next to the GEMMs they are meant to overlap) and the
+    loop-back rendezvous address of a single node as the default."""
+    import os
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl" and device is not None:
+        kwargs.setdefault("device_id", torch.device(device))
+    return dist.init_process_group(backend, **kwargs)
+
+
 def _exchanging():
     return is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
@@ -180,7 +193,12 @@ class BucketHook:
                 # every slice was written in place by kernels that precede these events: the collective need not wait
                 # for what the host has queued since (the layer's own input-gradient GEMMs)
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=b.flat.device)
+                    # HIGH priority: ROCm multiplexes HIP streams over a few hardware queues, and a normal-priority side
+                    # stream may share the compute stream's queue -- its event record then sits BEHIND the input-gradient
+                    # GEMMs already queued there and the collective starts after them (profiles/r03_dp_timeline.txt);
+                    # high-priority streams get a queue of their own.  The process group's stream must be high-priority
+                    # too (TORCH_NCCL_HIGH_PRIORITY=1 before init_process_group: dp.init_process_group does it).
+                    self._side = torch.cuda.Stream(device=b.flat.device, priority=-1)
                 side = self._side
                 for ev in b.events:
                     side.wait_event(ev)

@@ -122,7 +122,7 @@ def main(argv=None):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dp.init_process_group("nccl", device=dev)           # (RCCL's stream on its own hardware queue: see dp.py)
     rank = dist.get_rank() if world > 1 else 0
     torch.manual_seed(0)
     x, y = synthetic_complex_mnist(a.batch, dev, seed=100 + rank)
