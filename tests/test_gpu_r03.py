@@ -233,3 +233,72 @@ def test_conv_kernels_one_workgroup_per_tile_switch(layer_kind):
     for n in a[4]:
         r = a[4][n].float().cpu().numpy()
         np.testing.assert_allclose(b[4][n].float().cpu().numpy(), r, rtol=1e-5, atol=1e-5 * np.abs(r).max(), err_msg=n)
+
+
+def test_graphed_step_after_eager_steps_matches_eager():
+    """utils.graphs.GraphedStep: capture AFTER eager steps on the default stream (their autograd state -- the cached fused
+    KL holds the previous graph, whose AccumulateGrad nodes belong to the default stream -- used to make the capture
+    crash in hipStreamEndCapture); every replay draws fresh noise and equals the eager step from the same position."""
+    from cplxmodule_amd import Cplx
+    from cplxmodule_amd.nn import relevance as rel
+    from cplxmodule_amd.nn.relevance.noise import noise
+    from cplxmodule_amd.utils.graphs import GraphedStep
+    torch.manual_seed(5)
+    layer = rel.CplxLinearVD(256, 192).to("cuda")
+    x = Cplx(torch.randn(512, 256, device="cuda").bfloat16().requires_grad_(True),
+             torch.randn(512, 256, device="cuda").bfloat16().requires_grad_(True))
+    klw = torch.tensor(1e-2, device="cuda")
+
+    def step():
+        layer.zero_grad(set_to_none=True)
+        x.real.grad = x.imag.grad = None
+        y = layer(x)
+        kl = sum(rel.penalties(layer))
+        torch.autograd.backward((y.real, y.imag, kl), (y.real.detach() * 2, y.imag.detach() * 2, klw))
+        return y.real, kl
+
+    noise.manual_seed(21)
+    try:
+        noise.set_mode("philox-device")
+        for _ in range(3):
+            out = step()                     # eager, default stream; `out` and the layer's KL cache keep the graph alive
+        del out
+        g = GraphedStep(step, modules=[layer], warmup=2)
+        state = noise.device_state(torch.device("cuda"))
+        seen = []
+        for _ in range(3):
+            pos = int(state[1].item())
+            yr, kl = g.replay()
+            torch.cuda.synchronize()
+            seen.append((pos, yr.clone(), float(kl), layer.log_sigma2.grad.clone(), x.real.grad.clone()))
+        assert [p for p, *_ in seen] == [seen[0][0] + k for k in range(3)]
+        assert not torch.equal(seen[0][1], seen[1][1])
+        noise.set_mode("philox")
+        for pos, yr, kl, gls2, gx in seen:
+            noise.counter = pos - 1
+            e_yr, e_kl = step()
+            assert torch.equal(e_yr, yr) and float(e_kl) == kl
+            assert torch.equal(layer.log_sigma2.grad, gls2) and torch.equal(x.real.grad, gx)
+    finally:
+        noise.set_mode("philox")
+
+
+def test_cfg5_data_parallel_step_as_one_graph_rccl():
+    """BASELINE configs[4]'s train step (conv + BN + ReLU stack, ARD head, loss + KL, backward, bucket all-reduce over
+    RCCL -- world of one, collectives forced --, Adam) captured in ONE hipGraph and replayed."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r03", "cfg5_graph.py"), "--rccl1", "--batch", "64",
+                        "--width", "8"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    m = re.search(r"rccl1 batch 64 width 8: eager ms/step \[([^\]]*)\]  graph replay \[([^\]]*)\]  buckets (\d+)  loss ([\d.]+) -> ([\d.]+)",
+                  r.stdout)
+    assert m, r.stdout[-2000:]
+    eager = [float(v) for v in m.group(1).split(",")]
+    graph = [float(v) for v in m.group(2).split(",")]
+    assert int(m.group(3)) >= 1 and np.isfinite(float(m.group(5)))
+    assert min(graph) < min(eager), (eager, graph)          # launch-bound model: the replay must be the faster form
