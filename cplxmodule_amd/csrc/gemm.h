@@ -11,15 +11,10 @@ struct GemmArgs {
   void* c_r; void* c_i; int64_t ldc;
   int M, N, K;
   int conj_b, accumulate;
-  // K-panel-major operands (bf16 kernels, "N" layout only): element (row, k) of A at
-  // ((k / 32) * a_kmul + row) * 32 + k % 32 with a_rs = 32, a_cs = 1 -- every 32-deep K tile of the operand's rows is
-  // one contiguous block, so an LDS-DMA request covers whole 128-byte lines.  1 = ordinary row-major (k advances by 1).
-  int64_t a_kmul = 1, b_kmul = 1;
   int order = 1, group_m = 4, lds_epilogue = 1;   // bf16 kernel knobs (gemm_bf16_impl.h; env CPLXAMD_GEMM_*)
   // split-K (bf16 kernel, fp32 output): block (split, tile) covers K range [split*kchunk, ...)
   // and writes slab `split` of the workspace; a second kernel reduces the slabs.
   int splits = 1; int kchunk = 0; void* ws = nullptr; int64_t ws_bytes = 0;
-  int dbg = 0;   // ablation bits (CPLXAMD_GEMM_DBG): 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no barrier
   // Gauss 3M combine (real bf16 kernel only): this launch computes t3 = (Ar+Ai)(Br+Bi'); with the
   // dense fp32 slabs t1 = Ar Br and T2 = Ai Bi the epilogue stores
   //   c_r = t1 - gsign T2 + bias_r,   c_i = t3 - t1 - gsign T2 + bias_i      (gsign = -1: conj(B))

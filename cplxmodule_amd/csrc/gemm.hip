@@ -58,49 +58,6 @@ int cplxamd_cgemm_ex(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_c
   return launch_gemm_generic<true>(g, in_dtype, out_dtype, st);
 }
 
-/* K-panel-major operands (include/cplxamd.h): the bf16 MFMA kernels only, full tiles only -- CPLXAMD_ESHAPE otherwise
- * (there is no generic fallback for this layout) */
-static int panel_args(GemmArgs& g, int64_t a_panel_rows, int64_t b_panel_rows, int in_dtype) {
-  if (in_dtype != CPLXAMD_BF16 || a_panel_rows < 0 || b_panel_rows < 0) return CPLXAMD_EINVAL;
-  if ((g.M % 256) || (g.N % 256) || (g.K % 32) || g.M <= 0 || g.N <= 0 || g.K < 32 * 12) return CPLXAMD_ESHAPE;
-  if (a_panel_rows) {
-    if (a_panel_rows < g.M || (a_panel_rows % 8)) return CPLXAMD_EINVAL;
-    g.a_rs = 32; g.a_cs = 1; g.a_kmul = a_panel_rows;
-  }
-  if (b_panel_rows) {
-    if (b_panel_rows < g.N || (b_panel_rows % 8)) return CPLXAMD_EINVAL;
-    g.b_rs = 32; g.b_cs = 1; g.b_kmul = b_panel_rows;
-  }
-  return 0;
-}
-
-int cplxamd_cgemm_panel(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs, int64_t a_panel_rows,
-                        const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs, int64_t b_panel_rows,
-                        const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
-                        int M, int N, int K, int conj_b, int in_dtype, int out_dtype, void* stream) {
-  if (!a_r || !a_i || !b_r || !b_i || !c_r || !c_i) return CPLXAMD_EINVAL;
-  if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
-  if ((bias_r == nullptr) != (bias_i == nullptr)) return CPLXAMD_EINVAL;
-  GemmArgs g{a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, bias_r, bias_i, nullptr,
-             c_r, c_i, ldc, M, N, K, conj_b ? 1 : 0, 0};
-  const int rc = panel_args(g, a_panel_rows, b_panel_rows, in_dtype);
-  if (rc) return rc;
-  return launch_gemm_bf16<true>(g, out_dtype, (hipStream_t)stream);
-}
-
-int cplxamd_rgemm_panel(const void* a, int64_t a_rs, int64_t a_cs, int64_t a_panel_rows,
-                        const void* b, int64_t b_rs, int64_t b_cs, int64_t b_panel_rows,
-                        const float* bias, void* c, int64_t ldc, int M, int N, int K, int in_dtype, int out_dtype,
-                        void* stream) {
-  if (!a || !b || !c) return CPLXAMD_EINVAL;
-  if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
-  GemmArgs g{a, nullptr, a_rs, a_cs, b, nullptr, b_rs, b_cs, bias, nullptr, nullptr,
-             c, nullptr, ldc, M, N, K, 0, 0};
-  const int rc = panel_args(g, a_panel_rows, b_panel_rows, in_dtype);
-  if (rc) return rc;
-  return launch_gemm_bf16<false>(g, out_dtype, (hipStream_t)stream);
-}
-
 int cplxamd_cgemm_batched(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs, int64_t a_bs,
                           const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs, int64_t b_bs,
                           void* c_r, void* c_i, int64_t ldc, int64_t c_bs, int batch, int M, int N, int K,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 12
+#define CPLXAMD_ABI_VERSION 13
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -222,25 +222,6 @@ int cplxamd_gemm_set_persistent(int on);
  * 2^20, or a 10-output head): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be NULL
  * (no split-K).  With split-K the float32 result is a sum of per-split partial sums. */
 int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype);
-
-/* The bf16 GEMMs with K-PANEL-MAJOR operands.  A 32-deep K tile of a row-major operand is 64 bytes per row -- half a
- * 128-byte line per LDS-DMA request, and the request stream, not the matrix cores, bounds the K loop
- * (profiles/r02_gemm_ablation.md section 7).  In the panel layout [K / 32][panel_rows][32] (element (row, k) at
- * ((k / 32) * panel_rows + row) * 32 + k % 32) every K tile of a tile's rows is one contiguous block and every request
- * whole lines.  a_panel_rows / b_panel_rows > 0: that operand is given in the panel layout (its stride arguments are
- * ignored), 0: ordinary strides as in cplxamd_cgemm (K-contiguous or K-major).  bf16 operands, M and N multiples of 256,
- * K a multiple of 32 and >= 384; CPLXAMD_ESHAPE otherwise (no generic fallback reads this layout).  Results are bit-identical
- * to the row-major launch.  Measured (8192 x 4096 x 4096): complex forward 0.801 -> 0.761 ms with both operands in panel
- * layout (B only: 0.788), real forward 0.219 -> 0.204 ms -- worth it for operands that are packed once (fixed weights);
- * the layers do not use it: writing panel copies of activations every step costs what it saves. */
-int cplxamd_cgemm_panel(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs, int64_t a_panel_rows,
-                        const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs, int64_t b_panel_rows,
-                        const float* bias_r, const float* bias_i, void* c_r, void* c_i, int64_t ldc,
-                        int M, int N, int K, int conj_b, int in_dtype, int out_dtype, void* stream);
-int cplxamd_rgemm_panel(const void* a, int64_t a_rs, int64_t a_cs, int64_t a_panel_rows,
-                        const void* b, int64_t b_rs, int64_t b_cs, int64_t b_panel_rows,
-                        const float* bias, void* c, int64_t ldc, int M, int N, int K, int in_dtype, int out_dtype,
-                        void* stream);
 
 /* Batched complex GEMM (Cplx.__matmul__ on [..., M, K] @ [..., K, N], cplx.py:167-181): `batch`
  * independent products in ONE launch of the exact-f32 MFMA kernel (any strides, any dtype pair);

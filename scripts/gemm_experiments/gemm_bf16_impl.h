@@ -28,13 +28,11 @@
 //    panels) so the tiles resident on one XCD share A / B panels in that XCD's private L2.
 //  * accumulator tiles are kept transposed (B fragment as the first MFMA operand) so each lane
 //    owns 4 consecutive output columns: 8-byte (bf16) / 16-byte (fp32) stores.
-//  * rolling half-tile pipeline: the s_barrier sits in the middle of a tile, when the wave still holds the second K sub-step's
+//  * rolling half-tile pipeline (the classic per-tile one: build with -DCPLXAMD_GEMM_CLASSIC): the
+//    s_barrier sits in the middle of a tile, when the wave still holds the second K sub-step's
 //    fragments in registers, so the MFMA pipe runs across the barrier and across the LDS latency
 //    of the next tile's first fragments (+2-4 % on N(0,1) data, +6 % on zero-filled operands).
 //  * few output tiles + long K (wgrad at batch 2^20): split-K into fp32 slabs + a reduce kernel.
-// Experiment variants of this file (compile-time ablation bits, the classic per-tile pipeline, one-wave-per-SIMD tiles,
-// alternative MFMA orders) live in scripts/gemm_experiments/ (scripts/ab_build.sh builds them); this header holds the
-// production kernels only.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -49,16 +47,36 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32, STAGES = 3;
+// ablation bits are COMPILE-TIME (-DCPLXAMD_GEMM_DBG_BUILD=n): as run-time tests they put a branch
+// around every MFMA group and LDS-DMA piece, which splits the K loop into ~30 basic blocks and makes
+// the compiler's s_waitcnt placement conservative (it waited for the NEXT tile's fragments).
+// 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no epilogue stores (accumulators kept live),
+// 16 no sign XOR (WRONG results: bounds what removing the XORs could buy), 32 every LDS-DMA piece re-reads K tile 0
+// (cache-hot source: separates the memory system's share of the staging cost from issue + LDS-write cost),
+// 64 never wait for the LDS-DMA (racy: the share of the counted vmcnt waits),
+// 128 K-contiguous operands requested as whole 128-byte lines, 8 chunks per row (WRONG data, same byte count: what the
+// half-line requests of a 32-deep K tile cost -- profiles/r02_gemm_ablation.md section 7)
+// 256 (with 2; forward layout; WRONG data, same byte and instruction count): the two halves of every 128-byte line are
+// requested by BACK-TO-BACK instructions of one wave instead of one K tile (48 KiB of other lines) apart: even K tiles
+// fetch both 32-deep halves of rows 0..BM/2, odd ones of the other rows -- what a ring that issues the halves of a
+// line pairwise would get from the L1 (profiles/r03_gemm_pair_issue.txt)
+#ifndef CPLXAMD_GEMM_DBG_BUILD
+#define CPLXAMD_GEMM_DBG_BUILD 0
+#endif
+constexpr int kDbg = CPLXAMD_GEMM_DBG_BUILD;
+
 // complex: 256 x 128 tile, 4 x 2 waves of 64 x 64 (2 x 2 MFMA tiles x {re, im} = 128 accumulators);
 // real: 256 x 256 tile, 2 x 4 waves of 128 x 64 (4 x 2 MFMA tiles = 128 accumulators) -- with one
 // MFMA chain per staged byte instead of four, the real kernel needs the larger tile to keep the
 // LDS-DMA pieces and ds_reads per MFMA where the complex kernel has them.
-template <bool CPLX>
+// BIG (complex only, experiment): the same 256 x 128 tile on 4 waves of 128 x 64 (4 x 2 MFMA tiles x
+// {re, im} = 256 accumulators), one wave per SIMD -- 25 % fewer LDS reads per MFMA.
+template <bool CPLX, bool BIG = false>
 struct Cfg {
-  static constexpr int NT = 512;
-  static constexpr int IB = CPLX ? 2 : 4;                       // 32-row MFMA blocks per wave
-  static constexpr int JB = 2;                                  // 32-column MFMA blocks per wave
-  static constexpr int WM = CPLX ? 4 : 2, WN = CPLX ? 2 : 4;    // waves along M / N
+  static constexpr int NT = BIG ? 256 : 512;
+  static constexpr int IB = BIG ? 4 : (CPLX ? 2 : 4);           // 32-row MFMA blocks per wave
+  static constexpr int JB = (!CPLX && BIG) ? 4 : 2;             // 32-column MFMA blocks per wave
+  static constexpr int WM = BIG ? 2 : (CPLX ? 4 : 2), WN = CPLX ? 2 : (BIG ? 2 : 4);    // waves along M / N
   static constexpr int BM = 32 * IB * WM, BN = 32 * JB * WN;
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = (CPLX ? 2 : 1) * (A_BYTES + B_BYTES);
@@ -79,6 +97,24 @@ template <int ROWS, bool T, int NT>
 __device__ __forceinline__ uint32_t piece_voff(int64_t ld, int row0, int rows, int j) {
   const int p = j * NT + (int)threadIdx.x;
   if (!T) {
+    if (kDbg & 128) {   // experiment (wrong data): the same bytes as whole 128-byte lines, 8 chunks per row
+      const int row = p >> 3;
+      int grow = row0 + row;
+      grow = grow < rows ? grow : rows - 1;
+      return (uint32_t)(((int64_t)(grow - row0) * ld + (p & 7) * 8) * 2);
+    }
+    if ((kDbg & 256) && ROWS * 4 / NT == 2) {   // two pieces per plane: piece 1 = the other half line of piece 0's rows
+      const int row = (p - j * NT) >> 2;
+      int grow = row0 + row;
+      grow = grow < rows ? grow : rows - 1;
+      return (uint32_t)(((int64_t)(grow - row0) * ld + (p & 3) * 8 + j * 32) * 2);
+    }
+    if ((kDbg & 256) && ROWS * 4 / NT == 1) {   // one piece per plane: whole lines of half the rows
+      const int row = p >> 3;
+      int grow = row0 + row;
+      grow = grow < rows ? grow : rows - 1;
+      return (uint32_t)(((int64_t)(grow - row0) * ld + (p & 7) * 8) * 2);
+    }
     const int row = p >> 2;
     const int kc = (p & 3) ^ ((row >> 2) & 3);
     int grow = row0 + row;
@@ -121,23 +157,41 @@ __device__ __forceinline__ bf16x8 frag_t(const char* lds_plane, int rb, int kb, 
 }
 
 __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
+  if (kDbg & 16) return v;
   uint4 u = __builtin_bit_cast(uint4, v);
   u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
   return __builtin_bit_cast(bf16x8, u);
 }
 
-// 16-byte epilogue stores (plain: nontemporal stores measured no gain for outputs a later kernel reads)
-__device__ __forceinline__ void nt_store16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
-__device__ __forceinline__ void nt_store16(float* p, const f4& a) { st4(p, a); }
+// streaming (nontemporal) 16-byte stores for epilogue outputs that a LATER kernel reads (-DCPLXAMD_GEMM_NT to enable)
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(void* p, uint4 v) {
+#ifdef CPLXAMD_GEMM_NT
+  __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(p));
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void nt_store16(float* p, const f4& a) {
+#ifdef CPLXAMD_GEMM_NT
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f32x4_nt{a.v[0], a.v[1], a.v[2], a.v[3]}, reinterpret_cast<f32x4_nt*>(p));
+#else
+  st4(p, a);
+#endif
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
-__global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs g) {
+// (BIG: one wave per SIMD.  The second launch-bound argument says so: with dynamic shared memory the compiler cannot see
+//  that only one 256-thread workgroup fits a CU, budgets 128 registers for an occupancy of four and spills the 256
+//  accumulators to scratch -- which is what the r01 measurements of the BIG variants actually timed.)
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL, bool BIG = false>
+__global__ __launch_bounds__((Cfg<CPLX, BIG>::NT), (BIG ? 1 : 2)) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using C = Cfg<CPLX>;
+  using C = Cfg<CPLX, BIG>;
   constexpr int NT = C::NT;
 
   // ---- tile coordinates: split-K slice, XCD-contiguous grouped order ------------------------
@@ -232,16 +286,26 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
   // piece q (0 .. LOADS-1) of the K tile starting at k0 into ring slot buf
   auto stage_q = [&](int buf, int k0, int q) __attribute__((always_inline)) {
     k0 += kbase;
+    int ma = m0, nb = n0;
+    if ((kDbg & 512) && C::LOADS == 6) {   // with 256: the two halves of a line three instructions (24 KiB per CU) apart
+      constexpr int perm[6] = {0, 3, 2, 1, 4, 5};
+      q = perm[q];
+    }
+    if (kDbg & 256) {                 // pair-issue experiment: K tile t -> 64-deep position t / 2, row half t & 1
+      const int t = k0 / BK;
+      k0 = (t >> 1) * 64;
+      ma += (t & 1) * (BM / 2); nb += (t & 1) * (BN / 2);
+    }
     const uint32_t s = smem_off + (uint32_t)(buf * C::STAGE_BYTES) + wave_lds;
     if (q < C::PA)
-      lds_dma16_sv(piece_base<TA>(Ar, lda, m0, k0), voa[q], s + q * NT * 16);
+      lds_dma16_sv(piece_base<TA>(Ar, lda, ma, k0), voa[q], s + q * NT * 16);
     else if (q < C::PA + C::PB)
-      lds_dma16_sv(piece_base<TB>(Br, ldb, n0, k0), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
+      lds_dma16_sv(piece_base<TB>(Br, ldb, nb, k0), vob[q - C::PA], s + C::A_BYTES + (q - C::PA) * NT * 16);
     else if (q < 2 * C::PA + C::PB)
-      lds_dma16_sv(piece_base<TA>(Ai, lda, m0, k0), voa[q - C::PA - C::PB],
+      lds_dma16_sv(piece_base<TA>(Ai, lda, ma, k0), voa[q - C::PA - C::PB],
                    s + C::A_BYTES + C::B_BYTES + (q - C::PA - C::PB) * NT * 16);
     else
-      lds_dma16_sv(piece_base<TB>(Bi, ldb, n0, k0), vob[q - 2 * C::PA - C::PB],
+      lds_dma16_sv(piece_base<TB>(Bi, ldb, nb, k0), vob[q - 2 * C::PA - C::PB],
                    s + 2 * C::A_BYTES + C::B_BYTES + (q - 2 * C::PA - C::PB) * NT * 16);
   };
   auto stage_all = [&](int buf, int k0) __attribute__((always_inline)) {
@@ -258,11 +322,82 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
     return frag_n(plane, wn + j * 32 + l31, ks * 2 + lk);
   };
 
+  // tile in ring slot `buf`: all fragments of both K sub-steps are requested up front, then
+  // 32 MFMAs; one LDS-DMA piece of the tile at knext after each (i, j) MFMA group
+  auto compute = [&](int buf, int nbuf, int knext, bool do_stage, bool do_mfma) __attribute__((always_inline)) {
+    const char* sA = smem + buf * C::STAGE_BYTES;
+    const char* sB = sA + C::A_BYTES;
+    const char* sAi = sB + C::B_BYTES;
+    const char* sBi = sAi + C::A_BYTES;
+    bf16x8 ar[2][IB], br[2][JB], ai[2][IB], bi[2][JB];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        ar[ks][i] = a_frag(sA, i, ks);
+        if (CPLX) ai[ks][i] = a_frag(sAi, i, ks);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        br[ks][j] = b_frag(sB, j, ks);
+        if (CPLX) bi[ks][j] = b_frag(sBi, j, ks);
+      }
+    }
+    int q = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 nai[IB];
+      if (CPLX) {
+        // no conj: re -= Ai Bi, im += Ar Bi ; conj(B): re += Ai Bi, im -= Ar Bi
+#pragma unroll
+        for (int i = 0; i < IB; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
+      }
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+          if (do_mfma) {
+            // B fragment first: the accumulator holds the TRANSPOSED 32x32 tile
+            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+            if (CPLX) {
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+              if (CONJ) {
+                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+              } else {
+                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+              }
+            }
+          }
+          if (q < C::LOADS) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_stage) stage_q(nbuf, knext, q);
+            __builtin_amdgcn_sched_barrier(0);
+            ++q;
+          }
+        }
+    }
+  };
+
   const int klen = g.splits > 1 ? ((g.K - kbase) < g.kchunk ? (g.K - kbase) : g.kchunk) : g.K;
   // pinned to a scalar register: in the real kernel the compiler otherwise carries the trip count (and
   // with it the clamped K position of every LDS-DMA piece) in VGPRs
   const int nt = __builtin_amdgcn_readfirstlane(klen / BK);
-  {
+  if (!ROLL) {
+    stage_all(0, 0);
+    if (nt > 1) stage_all(1, BK);
+    apply_bias();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      // own LDS-DMA of tile t landed (tile t+1 may stay in flight), then every wave's did
+      if ((kDbg & 1) || t + 1 >= nt) wait_vmcnt<0>(); else wait_vmcnt<C::LOADS>();
+      if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();        // ... and ring slot (t-1) % 3 is free for tile t+2
+      int nxt = cur + 2; nxt = nxt >= 3 ? nxt - 3 : nxt;
+      compute(cur, nxt, (t + 2) * BK, t + 2 < nt && !(kDbg & 1), !(kDbg & 2));
+      cur = cur + 1 == 3 ? 0 : cur + 1;
+    }
+  } else {
     // Rolling half-tile pipeline: the barrier sits in the MIDDLE of a tile, when the wave still
     // holds the fragments of the tile's second K sub-step in registers, so the MFMA pipe keeps
     // running across the barrier and across the LDS latency of the next tile's first fragments.
@@ -323,8 +458,8 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
       }
       int q = q0;
       // tiles past the end re-load the last one into a free slot: no branch in the K loop
-      const int k0s = (tile < nt ? tile : nt - 1) * BK;
-      // complex: first products of all blocks, then the second ones (see gemm_bf16_persist.h)
+      const int k0s = (kDbg & 32) ? 0 : (tile < nt ? tile : nt - 1) * BK;
+#ifndef CPLXAMD_GEMM_ORD1   // complex: first products of all blocks, then the second ones (see gemm_bf16_persist.h)
       if constexpr (CPLX) {
         constexpr int NG = 2 * IB * JB;
 #pragma unroll
@@ -333,15 +468,17 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
           for (int i = 0; i < IB; ++i)
 #pragma unroll
             for (int j = 0; j < JB; ++j) {
-              if (ph == 0) {
-                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
-                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
-              } else if (CONJ) {
-                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
-              } else {
-                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+              if (!(kDbg & 2)) {
+                if (ph == 0) {
+                  acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+                  acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+                } else if (CONJ) {
+                  acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+                  acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+                } else {
+                  acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+                  acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+                }
               }
               constexpr int PER = (NFRAG + NG - 1) / NG;
               const int g0 = (ph * IB * JB + i * JB + j) * PER;
@@ -352,26 +489,29 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
               __builtin_amdgcn_sched_barrier(0);
               if (q < q1) {
                 __builtin_amdgcn_sched_barrier(0);
-                stage_q(slot, k0s, q);
+                if (!(kDbg & 1)) stage_q(slot, k0s, q);
                 __builtin_amdgcn_sched_barrier(0);
                 ++q;
               }
             }
         return;
       }
+#endif
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
-          if (CPLX) {
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
-            if (CONJ) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
-            } else {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+          if (!(kDbg & 2)) {
+            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+            if (CPLX) {
+              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+              if (CONJ) {
+                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
+                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+              } else {
+                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
+                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+              }
             }
           }
           {  // the other half's fragments: a few ds_reads behind every MFMA group instead of one burst of
@@ -386,7 +526,7 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
           }
           if (q < q1) {
             __builtin_amdgcn_sched_barrier(0);
-            stage_q(slot, k0s, q);
+            if (!(kDbg & 1)) stage_q(slot, k0s, q);
             __builtin_amdgcn_sched_barrier(0);
             ++q;
           }
@@ -398,17 +538,22 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
     if (nt > 1) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     read_half(0, 0);
+    if (!(kDbg & 1)) {
 #pragma unroll
-    for (int q = 0; q < H; ++q) stage_q(2, (nt > 2 ? 2 : nt - 1) * BK, q);
+      for (int q = 0; q < H; ++q) stage_q(2, (nt > 2 ? 2 : nt - 1) * BK, q);
+    }
+#ifdef CPLXAMD_GEMM_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(1);              // static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
     // one K tile in ring slot `cur`
     auto tile_body = [&](int cur, int nx1, int nx2, int t) __attribute__((always_inline)) {
       mfma_half(0, nx2, t + 2, H, C::LOADS, cur, 1);          // S1 + S2
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // S3: this wave's F[1] is in registers
-      wait_vmcnt<C::LOADS>();                                 // always LOADS younger pieces in flight
-      __builtin_amdgcn_s_barrier();
+      if (kDbg & 1) wait_vmcnt<0>(); else if (!(kDbg & 64)) wait_vmcnt<C::LOADS>();   // always LOADS younger pieces in flight
+      if (!(kDbg & 4)) __builtin_amdgcn_s_barrier();
       mfma_half(1, cur, t + 3, 0, H, nx1, 0);                 // S4 + S5 (slot of tile t is free now; past the end the reads hit a stale slot, unused)
     };
-    // (-2.0 % on the three bench launches, same-process A/B, profiles/r02_gemm_ablation.md)
+#ifndef CPLXAMD_GEMM_NO_UNROLL3   // (-2.0 % on the three bench launches, same-process A/B, profiles/r02_gemm_ablation.md)
     // ring position as a compile-time constant: the K loop is unrolled by the ring depth so that every
     // LDS address is (per-lane base of the slot) + immediate and every M0 value one scalar add
     int t = 0;
@@ -419,8 +564,33 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
     }
     if (t < nt) tile_body(0, 1, 2, t);
     if (t + 1 < nt) tile_body(1, 2, 0, t + 1);
+#else
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int nx1 = cur + 1 == 3 ? 0 : cur + 1;
+      const int nx2 = nx1 + 1 == 3 ? 0 : nx1 + 1;
+      tile_body(cur, nx1, nx2, t);
+      cur = nx1;
+    }
+#endif
+#ifdef CPLXAMD_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
 
+  if (kDbg & 8) {   // ablation: no stores; the accumulators stay live
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (a 512-bit "v" operand is not a valid constraint in the host pass)
+        asm volatile("" ::"v"(acc_r[i][j]));
+        if (CPLX) asm volatile("" ::"v"(acc_i[i][j]));
+#endif
+      }
+    wait_vmcnt<0>();
+    return;
+  }
   // ---- epilogue.  Transposed 32x32 C/D layout: output row = lane & 31, output columns
   // 8 q + 4 (lane >> 5) + {0..3} for register group q: one 8-B (bf16) / 16-B (fp32) store each.
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
@@ -682,25 +852,26 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool ROLL, bool BIG = false>
 static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
-  using C = Cfg<CPLX>;
+  using C = Cfg<CPLX, BIG>;
   // read-only tuning knobs, set once from the environment (A/B experiments only)
-  static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
+  static const int order = env_int("CPLXAMD_GEMM_ORDER", 1), gm = env_int("CPLXAMD_GEMM_GROUP_M", 4),
+                   dbg = env_int("CPLXAMD_GEMM_DBG", 0);
   GemmArgs g = g0;
   static const int ldsepi = env_int("CPLXAMD_GEMM_LDSEPI", 1);   // A/B switch of the LDS-staged epilogue
   g.lds_epilogue = ldsepi;
-  g.order = order; g.group_m = gm > 0 ? gm : 1;
+  g.order = order; g.group_m = gm > 0 ? gm : 1; (void)dbg;
   const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   if (tiles * g.splits > 0x7fffffff) return CPLXAMD_ESHAPE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB, ROLL, BIG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
+  gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB, ROLL, BIG><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -712,9 +883,13 @@ namespace cplxamd {
 // persistent form (gemm_bf16_persist.h): more than one round of full tiles, plain (bias-only) epilogue
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
-  using C = Cfg<CPLX>;
+  using C = Cfg<CPLX, false>;
   taken = false;
-  static const int enabled = env_int("CPLXAMD_GEMM_PERSIST", 1);     // (A/B at run time)
+#ifdef CPLXAMD_GEMM_NO_PERSIST       // (A/B builds; at run time: CPLXAMD_GEMM_PERSIST=0)
+  static const int enabled = 0;
+#else
+  static const int enabled = env_int("CPLXAMD_GEMM_PERSIST", 1);
+#endif
   static int ncu = 0;
   if (!enabled || !g_gemm_persistent) return 0;
   if (ncu == 0) {
@@ -771,7 +946,22 @@ static int launch_kernel(const GemmArgs& g, hipStream_t st) {
     const int rc = launch_persist<TOUT, CPLX, CONJ, TA, TB>(g, st, taken);
     if (rc || taken) return rc;
   }
-  return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB>(g, st);
+  // Only the rolling pipeline is instantiated.  The classic per-tile pipeline (ROLL = false, kept in the
+  // kernel source: build with -DCPLXAMD_GEMM_CLASSIC to select it) and Cfg<true, BIG> (4 waves of
+  // 128 x 64 at one wave per SIMD: 0.905 ms vs 0.86 ms on the headline shape with the final loop) were
+  // measured slower; leaving them out halves the compile time.
+#ifdef GEMM_CPLX_BIG      // experiment: complex kernel as 4 waves of 128 x 64 complex (one wave per SIMD, 256 accumulators)
+  if constexpr (CPLX) return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true, true>(g, st);
+#endif
+#ifdef GEMM_REAL_BIG      // experiment: real kernel as 4 waves of 128 x 128 (one wave per SIMD, the vendor's shape):
+                          // 0.296 / 0.314 / 0.247 ms vs 0.271 / 0.244 / 0.225 ms on the three variance GEMMs -- slower
+  if constexpr (!CPLX) return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true, true>(g, st);
+#endif
+#ifdef CPLXAMD_GEMM_CLASSIC
+  return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, false>(g, st);
+#else
+  return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB, true>(g, st);
+#endif
 }
 
 template <typename TOUT, bool CPLX, bool CONJ>

@@ -34,9 +34,9 @@ namespace cplxamd {
 enum { PB_NORMAL = 0, PB_FIRST0 = 1, PB_FIRST1 = 2, PB_T3 = 3, PB_T2 = 4, PB_LAST = 5 };
 
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, int R>
-__global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(GemmArgs g) {
+__global__ __launch_bounds__((Cfg<CPLX, false>::NT)) void gemm_bf16_persist_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using C = Cfg<CPLX>;
+  using C = Cfg<CPLX, false>;
   constexpr int NT = C::NT, BM = C::BM, BN = C::BN, IB = C::IB, JB = C::JB, L = C::LOADS;
   constexpr int H = (L + 1) / 2;
   constexpr int NPL = CPLX ? 2 : 1;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(Gemm
       for (int i = 0; i < IB; ++i) nai[i] = neg_frag(CONJ ? ar[ks][i] : ai[ks][i]);
     }
     int q = q0;
-    // complex: the two products into one accumulator are 8 MFMAs apart (blocks one after the other: +0.9 %)
+#ifndef CPLXAMD_GEMM_ORD1   // the two products into one accumulator 8 MFMAs apart (ORD1: 2 apart, blocks one after the other)
     if constexpr (CPLX) {
       constexpr int NG = 2 * IB * JB;
 #pragma unroll
@@ -197,6 +197,7 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(Gemm
           }
       return;
     }
+#endif
 #pragma unroll
     for (int i = 0; i < IB; ++i)
 #pragma unroll

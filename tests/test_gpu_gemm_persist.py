@@ -85,50 +85,6 @@ def test_persistent_input_gradient_layout(kt):
     assert torch.equal(px[:, :I], dx) and not px[:, I:].any()
 
 
-@pytest.mark.parametrize("K", [384, 448])
-def test_panel_major_operands_bit_identical(K):
-    """cplxamd_cgemm_panel / cplxamd_rgemm_panel: operands given as [K / 32][rows][32] panels (whole-line LDS-DMA
-    requests) -- the same MFMA sequence per output element, so the results equal the row-major launch bit for bit, for
-    each combination of panel / row-major operands, the forward (N,N) and the input-gradient (N,T, conj) layouts, with
-    a padded panel (panel_rows > rows of the problem) and a bias."""
-    from cplxmodule_amd import ops
-    from cplxmodule_amd._lib import BF16, call, try_call, ptr, stream_ptr
-    dev, bf = "cuda", torch.bfloat16
-    Mp, Np = 2048, 1024
-    torch.manual_seed(K)
-    ar, ai = (torch.randn(Mp, K, device=dev).to(bf) for _ in range(2))
-    br, bi = (torch.randn(Np, K, device=dev).mul(0.1).to(bf) for _ in range(2))
-    b_r, b_i = torch.randn(Np, device=dev), torch.randn(Np, device=dev)
-
-    def panel(t, rows_total):
-        out = torch.zeros(t.shape[1] // 32, rows_total, 32, device=dev, dtype=bf)
-        out[:, : t.shape[0]] = t.view(t.shape[0], -1, 32).permute(1, 0, 2)
-        return out
-    apr, api = panel(ar, Mp + 64), panel(ai, Mp + 64)           # padded: panel_rows > M
-    bpr, bpi = panel(br, Np), panel(bi, Np)
-    ref = ops.cgemm(ar, ai, (K, 1), br, bi, (K, 1), Mp, Np, K, bias=(b_r, b_i), out_dtype=bf)
-    yr, yi = (torch.empty(Mp, Np, device=dev, dtype=bf) for _ in range(2))
-    for (a0, a1, ap), (b0, b1, bp) in (((ar, ai, 0), (bpr, bpi, Np)), ((apr, api, Mp + 64), (br, bi, 0)),
-                                       ((apr, api, Mp + 64), (bpr, bpi, Np))):
-        yr.zero_(); yi.zero_()
-        call("cplxamd_cgemm_panel", ptr(a0), ptr(a1), K, 1, ap, ptr(b0), ptr(b1), K, 1, bp, ptr(b_r), ptr(b_i), ptr(yr),
-             ptr(yi), Np, Mp, Np, K, 0, BF16, BF16, stream_ptr())
-        assert torch.equal(yr, ref[0]) and torch.equal(yi, ref[1])
-    wr, wi = (torch.randn(K, Np, device=dev).mul(0.1).to(bf) for _ in range(2))          # read K-major
-    ref = ops.cgemm(ar, ai, (K, 1), wr, wi, (1, Np), Mp, Np, K, conj_b=True, out_dtype=bf)
-    call("cplxamd_cgemm_panel", ptr(apr), ptr(api), K, 1, Mp + 64, ptr(wr), ptr(wi), 1, Np, 0, None, None, ptr(yr), ptr(yi),
-         Np, Mp, Np, K, 1, BF16, BF16, stream_ptr())
-    assert torch.equal(yr, ref[0]) and torch.equal(yi, ref[1])
-    ref = ops.rgemm(ar, (K, 1), br, (K, 1), Mp, Np, K, bias=b_r, out_dtype=bf)
-    y = torch.empty(Mp, Np, device=dev, dtype=bf)
-    call("cplxamd_rgemm_panel", ptr(apr), K, 1, Mp + 64, ptr(bpr), K, 1, Np, ptr(b_r), ptr(y), Np, Mp, Np, K, BF16, BF16,
-         stream_ptr())
-    assert torch.equal(y, ref)
-    # shapes the panel kernels do not take are refused, not mis-read
-    assert not try_call("cplxamd_rgemm_panel", ptr(apr), K, 1, Mp + 64, ptr(bpr), K, 1, Np, None, ptr(y), Np, Mp - 8, Np, K,
-                        BF16, BF16, stream_ptr())
-
-
 def test_persistent_switch_is_bit_identical_and_restores():
     """cplxamd_gemm_set_persistent(0) (what the data-parallel hook does while RCCL collectives are in flight) selects
     the one-workgroup-per-tile kernels: same results bit for bit; the call returns the previous setting."""
