@@ -941,10 +941,122 @@ def gen_trajectory():
     save("trajectory", d)
 
 
+def gen_trajectory_conv():
+    """BASELINE configs[4] in miniature, pinned to the reference: a Deep-Complex-Net style stack
+    (CplxConv2d + CplxBatchNorm2d + split ReLU) x 2 with a complex linear head, trained with the reference's own
+    modules through dense -> ARD -> masked (tests/test_relevance.py:98-253 / tests/test_mnist.py:199-245 harness
+    shape), 12 Adam steps per phase on fixed synthetic complex images.  Track "head": only the head is
+    CplxLinear -> CplxLinearARD -> CplxLinearMasked.  Track "conv": the second convolution is
+    CplxConv2d -> CplxConv2dARD -> CplxConv2dMasked as well (the conv LRT path, nn/relevance/complex/base.py:120-135).
+    Stored: data, every phase's initial state dict, the raw noise draws, per step (loss, ce, kl, sparsity@tau),
+    batch-norm running statistics, final parameters and masks."""
+    import torch.nn.functional as F
+    from collections import OrderedDict
+    from cplxmodule.nn import CplxToCplx, masked
+    from cplxmodule.nn.utils.sparsity import sparsity
+    import warnings
+    warnings.simplefilter("ignore")
+    d = {}
+    N_STEPS, B, HW, C1, C2, NCLS = 12, 16, 12, 4, 8, 10
+    tau = 0.73105
+    threshold = float(np.log(tau) - np.log(1 - tau))
+    d["threshold"] = np.array(threshold)
+    tape = []
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def rec_randn(*a, **k):
+        t = real_randn(*a, **k)
+        tape.append(npy(t))
+        return t
+
+    def rec_randn_like(x, **k):
+        t = real_randn_like(x, **k)
+        tape.append(npy(t))
+        return t
+
+    class Net(torch.nn.Module):
+        def __init__(self, conv2, head):
+            super().__init__()
+            self.features = torch.nn.Sequential(OrderedDict([
+                ("conv1", CplxConv2d(1, C1, 3, padding=1)), ("bn1", CplxBatchNorm2d(C1)), ("act1", CplxToCplx[torch.nn.ReLU]()),
+                ("conv2", conv2(C1, C2, 3, stride=2, padding=1)), ("bn2", CplxBatchNorm2d(C2)), ("act2", CplxToCplx[torch.nn.ReLU]())]))
+            self.head = head(C2 * (HW // 2) * (HW // 2), NCLS)
+
+        def forward(self, x):
+            z = self.features(x)
+            z = self.head(cplx.Cplx(z.real.flatten(1), z.imag.flatten(1)))
+            return abs(z)
+
+    tracks = {
+        "head": ([CplxConv2d] * 3, [CplxLinear, rel.CplxLinearARD, masked.CplxLinearMasked], [0.0, 2e-3, 0.0]),
+        "conv": ([CplxConv2d, rel.CplxConv2dARD, masked.CplxConv2dMasked],
+                 [CplxLinear, rel.CplxLinearARD, masked.CplxLinearMasked], [0.0, 2e-3, 0.0]),
+    }
+    g = torch.Generator().manual_seed(77)
+    protos = torch.rand(NCLS, HW, HW, generator=g)
+    labels = torch.randint(0, NCLS, (B,), generator=g)
+    imgs = protos[labels] + 0.3 * torch.rand(B, HW, HW, generator=g)
+    z = torch.fft.fft2(imgs) / HW
+    xr, xi = z.real.unsqueeze(1).float().contiguous(), z.imag.unsqueeze(1).float().contiguous()
+    d["xr"], d["xi"], d["labels"] = npy(xr), npy(xi), npy(labels)
+    x = cplx.Cplx(xr, xi)
+    for tname, (convs, heads, klws) in tracks.items():
+        prev = None
+        for ph, (conv2, head, klw) in enumerate(zip(convs, heads, klws)):
+            torch.manual_seed(300 + ph)
+            model = Net(conv2, head)
+            k = f"{tname}_p{ph}_"
+            if prev is not None:
+                state_dict = prev.state_dict()
+                masks = rel.compute_ard_masks(prev, hard=False, threshold=threshold)
+                state_dict, masks = masked.binarize_masks(state_dict, masks)
+                model.load_state_dict(state_dict, strict=False)
+                if ph == 2:
+                    model = masked.deploy_masks(model, state_dict=masks)
+                    for kk, v in masks.items():
+                        d[k + "deploy_" + kk] = npy(v)
+            if ph == 1:
+                with torch.no_grad():
+                    for m in model.modules():
+                        if hasattr(m, "log_sigma2"):
+                            m.log_sigma2.uniform_(-8.0, 1.0)
+            for kk, v in model.state_dict().items():
+                d[k + "init_" + kk] = npy(v)
+            model.train()
+            optim = torch.optim.Adam(model.parameters(), lr=2e-3)
+            rows = []
+            tape.clear()
+            torch.randn, torch.randn_like = rec_randn, rec_randn_like
+            try:
+                for _ in range(N_STEPS):
+                    optim.zero_grad()
+                    ce = F.cross_entropy(model(x), labels)
+                    kl_d = sum(rel.penalties(model, reduction="sum"), torch.zeros(()))
+                    loss = ce + klw * kl_d
+                    loss.backward()
+                    optim.step()
+                    f_sp = sparsity(model, hard=True, threshold=threshold)
+                    rows.append([float(loss), float(ce), float(kl_d), float(f_sp)])
+            finally:
+                torch.randn, torch.randn_like = real_randn, real_randn_like
+            d[k + "traj"] = np.array(rows, dtype=np.float64)
+            d[k + "klw"] = np.array(klw)
+            d[k + "n_tape"] = np.array(len(tape))
+            for j, t in enumerate(tape):
+                d[k + f"tape_{j:03d}"] = t
+            for kk, v in model.state_dict().items():
+                d[k + "final_" + kk] = npy(v)
+            fm = rel.compute_ard_masks(model, hard=False, threshold=threshold)
+            for kk, v in fm.items():
+                d[k + "finalmask_" + kk] = npy(v)
+            prev = model
+    save("trajectory_conv", d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reproducible summation order
     gens = dict(linear=gen_linear, lrt_linear=gen_lrt_linear, penalty=gen_penalty, conv=gen_conv,
                 batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear, conv3d=gen_conv3d, conv_transpose=gen_conv_transpose,
-                r02=gen_r02, trajectory=gen_trajectory)
+                r02=gen_r02, trajectory=gen_trajectory, trajectory_conv=gen_trajectory_conv)
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

@@ -45,7 +45,7 @@ def test_batchnorm_layer_golden(golden, name, cls):
     np.testing.assert_allclose(N(y.real), g[k + "eval_yr"], **_tol(g[k + "eval_yr"]))
     ((y.real * T(g[s + "gr"])).sum() + (y.imag * T(g[s + "gi"])).sum()).backward()
     for n, t in dict(dxr=xr.grad, dxi=xi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
-        np.testing.assert_allclose(N(t), g[k + "eval_" + n], **_tol(g[k + "eval_" + n], 1e-4), err_msg=n)
+        np.testing.assert_allclose(N(t), g[k + "eval_" + n], **_tol(g[k + "eval_" + n]), err_msg=n)
 
 
 def test_batchnorm_functional_and_cma(golden):
@@ -58,8 +58,8 @@ def test_batchnorm_functional_and_cma(golden):
     y = cplx_batch_norm(Cplx(xr, xi), None, None, None, None, True, 0.1, 1e-3)
     np.testing.assert_allclose(N(y.real), g[k + "yr"], **_tol(g[k + "yr"]))
     ((y.real * T(g[k + "gr"])).sum() + (y.imag * T(g[k + "gi"])).sum()).backward()
-    np.testing.assert_allclose(N(xr.grad), g[k + "dxr"], **_tol(g[k + "dxr"], 1e-4))
-    np.testing.assert_allclose(N(xi.grad), g[k + "dxi"], **_tol(g[k + "dxi"], 1e-4))
+    np.testing.assert_allclose(N(xr.grad), g[k + "dxr"], **_tol(g[k + "dxr"]))
+    np.testing.assert_allclose(N(xi.grad), g[k + "dxi"], **_tol(g[k + "dxi"]))
     bn = nn.CplxBatchNorm1d(3, momentum=None, affine=False).to("cuda")
     bn.train()
     for step in range(2):
@@ -100,7 +100,9 @@ def test_batchnorm_vs_oracle_shapes(shape):
     ((y.real * T(gr)).sum() + (y.imag * T(gi)).sum()).backward()
     bw = orc.cplx_batch_norm_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), None, None, W.astype(f), True, 1e-5)
     for n, t in dict(dxr=txr.grad, dxi=txi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
-        np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], 1e-4), err_msg=n)
+        # dweight / dbias are sums of up to 10^6 products of mixed sign held against a float64 oracle: float32
+        # accumulation (ours and the reference's alike) leaves ~4e-5 of the largest entry; dX is elementwise
+        np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], 1e-4 if n in ("dweight", "dbias") else 4e-5), err_msg=n)
     # whitening property without affine
     bn2 = cls(F_, affine=False).to("cuda")
     z = bn2(Cplx(T(xr), T(xi)))
@@ -148,7 +150,7 @@ def test_batchnorm_channels_last_rows_kernels(shape, dtype):
     torch.autograd.backward((y.real, y.imag), (cl(gr), cl(gi)))
     bw = orc.cplx_batch_norm_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), None, None, W.astype(f), True, 1e-5)
     for n, t in dict(dxr=txr.grad, dxi=txi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
-        r = 1e-4 if dtype == "f32" else (2e-2 if n[1] == "x" else 1e-3)
+        r = 2e-5 if dtype == "f32" else (2e-2 if n[1] == "x" else 1e-3)
         np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], r), err_msg=n)
     bn.eval()
     z = bn(Cplx(cl(xr), cl(xi)))
