@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -48,6 +48,7 @@ SIGNATURES = {
                          _I, _I, _P, _I, _P, _L, _P],
     "cplxamd_rgemm_ex": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P],
     "cplxamd_vd_prep_kl": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "cplxamd_cgemm_lrt_dx": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_cgemm_batched": [_P, _P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],

@@ -58,6 +58,19 @@ int cplxamd_cgemm_ex(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_c
   return launch_gemm_generic<true>(g, in_dtype, out_dtype, st);
 }
 
+int cplxamd_cgemm_lrt_dx(const void* g_r, const void* g_i, int64_t g_rs, int64_t g_cs,
+                         const void* w_r, const void* w_i, int64_t w_rs, int64_t w_cs,
+                         const void* x_r, const void* x_i, const void* ga, int64_t ldx,
+                         void* dx_r, void* dx_i, int64_t ldc, int M, int N, int K, int dtype, void* stream) {
+  if (!g_r || !g_i || !w_r || !w_i || !x_r || !x_i || !ga || !dx_r || !dx_i) return CPLXAMD_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || ldc < N || ldx < N) return CPLXAMD_EINVAL;
+  if (dtype != CPLXAMD_BF16) return CPLXAMD_ESHAPE;
+  GemmArgs g{g_r, g_i, g_rs, g_cs, w_r, w_i, w_rs, w_cs, nullptr, nullptr, nullptr,
+             dx_r, dx_i, ldc, M, N, K, 1, 0};
+  g.fx_r = x_r; g.fx_i = x_i; g.fga = ga; g.fld = ldx;
+  return launch_gemm_bf16<true>(g, CPLXAMD_BF16, (hipStream_t)stream);
+}
+
 int cplxamd_cgemm_batched(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs, int64_t a_bs,
                           const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs, int64_t b_bs,
                           void* c_r, void* c_i, int64_t ldc, int64_t c_bs, int batch, int M, int N, int K,

@@ -725,6 +725,8 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   }
   const GemmArgs& g = g0;
   if (g.splits > 1 || g.g1 || g.emul || g.accumulate || (g.M % C::BM) || (g.N % C::BN) || g.K / BK < 12) return 0;
+  if (g.fga && (!(CPLX && CONJ && TB && sizeof(TOUT) == 2) || (g.fld & 7) || !aligned16(g.fga) || !aligned16(g.fx_r) ||
+                !aligned16(g.fx_i) || g.bias_r)) return 0;      // (the caller runs the two-kernel path)
   // instantiated for the layouts the layers launch with a plain epilogue: forward (N,N), input gradient (N,T)
   // -- the weight gradients carry the fused KL accumulate and stay on the one-tile kernel
   constexpr bool kBf16Out = sizeof(TOUT) == 2;
@@ -742,8 +744,23 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
   a.group_m = gm > 0 ? gm : 1;
   if constexpr (kInstantiated) {
+    constexpr bool kFusable = CPLX && CONJ && TB && kBf16Out;      // the LRT input gradient (gemm.h: fga)
     auto go = [&](auto RR) -> int {
       constexpr int R = decltype(RR)::value;
+      if constexpr (kFusable) {
+        if (g.fga) {
+          static bool attr_set_f = false;
+          if (!attr_set_f) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr_set_f = true;
+          }
+          gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R, true><<<dim3((unsigned)ncu), C::NT, smem, st>>>(a);
+          CPLXAMD_CHECK_LAUNCH();
+          return 0;
+        }
+      }
       static bool attr_set = false;
       if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R>,
@@ -771,6 +788,7 @@ static int launch_kernel(const GemmArgs& g, hipStream_t st) {
     const int rc = launch_persist<TOUT, CPLX, CONJ, TA, TB>(g, st, taken);
     if (rc || taken) return rc;
   }
+  if (g.fga) return CPLXAMD_ESHAPE;     // the fused epilogue exists in the persistent kernel only: never dropped silently
   return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB>(g, st);
 }
 

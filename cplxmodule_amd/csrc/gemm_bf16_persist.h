@@ -33,8 +33,9 @@ namespace cplxamd {
 
 enum { PB_NORMAL = 0, PB_FIRST0 = 1, PB_FIRST1 = 2, PB_T3 = 3, PB_T2 = 4, PB_LAST = 5 };
 
-template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, int R>
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, int R, bool FUSE = false>
 __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(GemmArgs g) {
+  static_assert(!FUSE || (CPLX && sizeof(TOUT) == 2), "the fused LRT input gradient is the complex bf16-out kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<CPLX>;
   constexpr int NT = C::NT, BM = C::BM, BN = C::BN, IB = C::IB, JB = C::JB, L = C::LOADS;
@@ -285,6 +286,69 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(Gemm
     char* reg = smem + 3 * C::STAGE_BYTES + wid * 2048;
     constexpr int PITCH = 144;                               // 128 B of payload + 16 B pad per staged row
     const int r8 = l31 >> 3, rr = l31 & 7;
+    if constexpr (FUSE) {
+      // C = acc + 2 X (*) ga (gemm.h).  The operands of two rounds (16 rows) -- 2 x (ga, x_r, x_i), 16 bytes per lane each,
+      // the lane's own store position -- are requested together BEFORE those rounds' stores: vmcnt retires loads and
+      // stores in issue order, so a load issued behind a store waits for the store's acknowledgement; batching makes
+      // that happen three times per tile instead of once per round.
+      const bf16_t* fxr = reinterpret_cast<const bf16_t*>(g.fx_r);
+      const bf16_t* fxi = reinterpret_cast<const bf16_t*>(g.fx_i);
+      const bf16_t* fga = reinterpret_cast<const bf16_t*>(g.fga);
+      // batches of two rounds (16 rows): 6 loads = 24 registers in flight, 4 stores per batch
+#pragma unroll
+      for (int hb = 0; hb < IB * 2; ++hb) {
+        const int i = hb >> 1, rbase = (hb & 1) * 2;
+        uint4 lga[2], lxr[2], lxi[2];
+        // address = wave-uniform base (scalar registers) + ONE 32-bit per-lane offset for all six loads
+        const uint32_t loff = (uint32_t)(((lane >> 3) * (int)g.fld + (lane & 7) * 8) * 2);
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          const int64_t ub = ((int64_t)(m0 + wm + i * 32 + (rbase + rd) * 8) * g.fld + n0 + wn) * 2;
+          const uint32_t ulo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+          const uint32_t uhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)ub >> 32));
+          const int64_t u = (int64_t)(((uint64_t)uhi << 32) | ulo);
+          lga[rd] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(fga) + u + loff);
+          lxr[rd] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(fxr) + u + loff);
+          lxi[rd] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(fxi) + u + loff);
+        }
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          const int round = rbase + rd;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            if (r8 == round) {
+#pragma unroll
+              for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  f4 x;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) x.v[e] = pl ? acc_i[CPLX ? i : 0][j][4 * q + e] : acc_r[i][j][4 * q + e];
+                  st4(reinterpret_cast<bf16_t*>(reg + rr * PITCH + (j * 32 + 8 * q + 4 * lk) * 2), x);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint4 val = *reinterpret_cast<const uint4*>(reg + (lane >> 3) * PITCH + (lane & 7) * 16);
+            const uint4 xv = pl ? lxi[rd] : lxr[rd];
+            const uint32_t vw[4] = {val.x, val.y, val.z, val.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+            const uint32_t gw[4] = {lga[rd].x, lga[rd].y, lga[rd].z, lga[rd].w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d0 = __uint_as_float(vw[e] << 16), d1 = __uint_as_float(vw[e] & 0xffff0000u);
+              const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+              const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
+              ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
+            }
+            TOUT* out = reinterpret_cast<TOUT*>(pl ? g.c_i : g.c_r);
+            const int row = m0 + wm + i * 32 + round * 8 + (lane >> 3), col = n0 + wn + (lane & 7) * 8;
+            nt_store16(reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col, uint4{ow[0], ow[1], ow[2], ow[3]});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
       TOUT* out = reinterpret_cast<TOUT*>(pl ? g.c_i : g.c_r);

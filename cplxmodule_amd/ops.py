@@ -4,6 +4,8 @@ Everything here launches libcplxamd.so kernels on the current HIP stream; torch 
 to allocate outputs and to hook the kernels into autograd.  Shapes follow the reference:
 complex tensors are (real, imag) pairs of equal-shaped planes (cplxmodule/cplx.py:10-52).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -477,6 +479,27 @@ def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype, algo=0):
                  algo=algo if gauss_ok(B, I, O) and I % 8 == 0 else 0)
 
 
+_LRT_DX_FUSE = os.environ.get("CPLXAMD_LRT_DX_FUSE", "1") != "0"     # (A/B switch; results are bit-identical)
+
+
+def _cplx_lrt_dx(g2r, g2i, wr, wi, x2r, x2i, ga):
+    """Input gradient of the complex LRT layer: dX = G conj(W) + 2 X (*) ga in ONE launch when the persistent bf16
+    kernel takes the shape (cplxamd_cgemm_lrt_dx: the elementwise term rides in its epilogue), otherwise the GEMM and
+    the accumulate pass -- bit-identical results either way (tests/test_gpu_r03.py)."""
+    B, O = g2r.shape
+    I = wr.shape[1]
+    if (_LRT_DX_FUSE and _is_bf16(g2r) and _is_bf16(x2r) and _is_bf16(ga) and _is_bf16(wr) and I % 8 == 0 and O % 8 == 0
+            and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (g2r, g2i, wr, wi, x2r, x2i, ga))):
+        dxr = torch.empty(B, I, dtype=torch.bfloat16, device=g2r.device)
+        dxi = torch.empty_like(dxr)
+        if try_call("cplxamd_cgemm_lrt_dx", ptr(g2r), ptr(g2i), O, 1, ptr(wr), ptr(wi), 1, I, ptr(x2r), ptr(x2i), ptr(ga), I,
+                    ptr(dxr), ptr(dxi), I, B, I, O, dtype_code(g2r), stream_ptr()):
+            return dxr, dxi
+    dxr, dxi = _cplx_linear_dx(g2r, g2i, wr, wi, x2r.dtype)
+    lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
+    return dxr, dxi
+
+
 def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0, accumulate=False, beta=None, emul=None):
     """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]; both operands
     are K-major as stored (the bf16 kernel reads them through ds_read_b64_tr_b16).
@@ -709,9 +732,8 @@ class CplxLinearLRTFn(torch.autograd.Function):
         _announce(ls2 if dls2 is not None else None, wr if dwr is not None else None,
                   wi if dwi is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
         if need[0] or need[1]:
-            dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], dt)
             ga = _real_linear_dx(gs2, ctx.S, dt)             # gs2 . S -> [B,I]
-            lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
+            dxr, dxi = _cplx_lrt_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r, x2i, ga)   # G conj(W) + 2 x ga
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
 

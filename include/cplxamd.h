@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 13
+#define CPLXAMD_ABI_VERSION 14
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -222,6 +222,19 @@ int cplxamd_gemm_set_persistent(int on);
  * 2^20, or a 10-output head): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be NULL
  * (no split-K).  With split-K the float32 result is a sum of per-split partial sums. */
 int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int out_dtype);
+
+/* Input gradient of the complex LRT linear layer in ONE launch (nn/relevance/complex/base.py:43-56
+ * differentiated):  dX = G conj(W) + 2 X (*) ga,  G [M, K] the output gradient, W [K, N] the bf16 weight as stored
+ * ([O, I] row-major: w_rs = 1 over n ... pass the strides of W read as B[n, k], i.e. (1, I)), X [M, N] the layer
+ * input and ga = d s2 . exp(log_sigma2) [M, N] (cplxamd_rgemm), all bf16, X / ga with row pitch ldx.  The elementwise
+ * term rides in the epilogue of the persistent complex kernel (same arithmetic as cplxamd_cgemm followed by
+ * cplxamd_lrt_dx_accum: bit-identical results), which saves the 7 plane passes of that second kernel.
+ * CPLXAMD_ESHAPE when the persistent kernel does not take the launch (partial tiles, fewer tiles than CUs, unaligned
+ * operands, cplxamd_gemm_set_persistent(0)): run the two calls instead -- nothing is dropped silently. */
+int cplxamd_cgemm_lrt_dx(const void* g_r, const void* g_i, int64_t g_rs, int64_t g_cs,
+                         const void* w_r, const void* w_i, int64_t w_rs, int64_t w_cs,
+                         const void* x_r, const void* x_i, const void* ga, int64_t ldx,
+                         void* dx_r, void* dx_i, int64_t ldc, int M, int N, int K, int dtype, void* stream);
 
 /* Batched complex GEMM (Cplx.__matmul__ on [..., M, K] @ [..., K, N], cplx.py:167-181): `batch`
  * independent products in ONE launch of the exact-f32 MFMA kernel (any strides, any dtype pair);

@@ -302,3 +302,45 @@ def test_cfg5_data_parallel_step_as_one_graph_rccl():
     graph = [float(v) for v in m.group(2).split(",")]
     assert int(m.group(3)) >= 1 and np.isfinite(float(m.group(5)))
     assert min(graph) < min(eager), (eager, graph)          # launch-bound model: the replay must be the faster form
+
+
+@pytest.mark.parametrize("O", [4096, 4064, 4128])          # contraction over O: (O / 32) % 3 = 2, 1, 0 -> all three ring phases
+def test_fused_lrt_input_gradient_is_bit_identical(O):
+    """cplxamd_cgemm_lrt_dx: dX = G conj(W) + 2 X (*) ga in the epilogue of the persistent complex (N,T) kernel ==
+    cplxamd_cgemm followed by cplxamd_lrt_dx_accum, bit for bit; shapes the persistent kernel does not take are
+    declined (CPLXAMD_ESHAPE), never computed without the elementwise term."""
+    from cplxmodule_amd import _lib, ops
+    from cplxmodule_amd._lib import BF16, ptr, stream_ptr, try_call
+    dev, bf = "cuda", torch.bfloat16
+    B, I = 8192, 2048                                        # 32 x 16 = 512 tiles of 256 x 128: two rounds on 256 CUs
+    torch.manual_seed(O)
+    gr, gi = (torch.randn(B, O, device=dev).to(bf) for _ in range(2))
+    wr, wi = (torch.randn(O, I, device=dev).mul(0.02).to(bf) for _ in range(2))
+    xr, xi = (torch.randn(B, I, device=dev).to(bf) for _ in range(2))
+    ga = torch.randn(B, I, device=dev).mul(0.3).to(bf)
+    dxr, dxi = torch.empty(B, I, device=dev, dtype=bf), torch.empty(B, I, device=dev, dtype=bf)
+    assert try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga), I,
+                    ptr(dxr), ptr(dxi), I, B, I, O, BF16, stream_ptr()), "the persistent kernel must take this shape"
+    rr, ri = ops._cplx_linear_dx(gr, gi, wr, wi, bf)
+    ops.lrt_dx_accum(rr, ri, xr, xi, ga)
+    assert torch.equal(dxr, rr) and torch.equal(dxi, ri)
+    # against float64 on sampled rows (one bf16 rounding of the GEMM result + one of the sum)
+    rows = torch.randint(0, B, (8,), device=dev)
+    G = (gr[rows].double() + 1j * gi[rows].double()).cpu().numpy()
+    W = (wr.double() + 1j * wi.double()).cpu().numpy()
+    ref = G @ W.conj() + 2 * (xr[rows].double() + 1j * xi[rows].double()).cpu().numpy() * ga[rows].double().cpu().numpy()
+    got = (dxr[rows].double() + 1j * dxi[rows].double()).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1.2e-2 * np.abs(ref).max()
+    # declined, not mis-computed: partial tiles / one workgroup per tile selected
+    small = torch.empty(8192 - 8, I, device=dev, dtype=bf)
+    assert not try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga), I,
+                        ptr(small), ptr(small), I, B - 8, I, O, BF16, stream_ptr())
+    lib = _lib.load()
+    try:
+        lib.cplxamd_gemm_set_persistent(0)
+        assert not try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga),
+                            I, ptr(dxr), ptr(dxi), I, B, I, O, BF16, stream_ptr())
+        a, b = ops._cplx_lrt_dx(gr, gi, wr, wi, xr, xi, ga)      # the host wrapper then runs the two calls
+        assert torch.equal(a, rr) and torch.equal(b, ri)
+    finally:
+        lib.cplxamd_gemm_set_persistent(1)
