@@ -8,6 +8,11 @@ R=/root/repo; O=$R/gpurun_out/r03; mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python $R/scripts/rocprof_summary.py $O/prof_bench/*/*_results.db > $O/bench_n1_kernel_stats.txt
 rm -rf $O/prof_bench
+# the same command without the extra points of the line (cfg2 / cfg3 / cfg4 / HBM sizes / CPU leg share kernel names with the
+# headline step and would blur its per-kernel averages): the headline step's kernels only
+rocprofv3 --kernel-trace --stats -d $O/prof_head -- python $R/bench.py --no-cpu-baseline > $O/bench_n1_headline.json 2> $O/bench_n1_headline.err
+python $R/scripts/rocprof_summary.py $O/prof_head/*/*_results.db > $O/bench_n1_headline_kernel_stats.txt
+rm -rf $O/prof_head
 for c in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
   n=$(echo $c | tr ' ' '_')
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$n -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --graph off > $O/pmc_$n.log 2>&1
