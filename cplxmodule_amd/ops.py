@@ -480,6 +480,7 @@ def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype, algo=0):
 
 
 _LRT_DX_FUSE = os.environ.get("CPLXAMD_LRT_DX_FUSE", "1") != "0"     # (A/B switch; results are bit-identical)
+_EARLY_W = os.environ.get("CPLXAMD_DP_EARLY_W", "1") != "0"           # (A/B switch: announce dW before the variance dW)
 
 
 def _cplx_lrt_dx(g2r, g2i, wr, wi, x2r, x2i, ga):
@@ -718,6 +719,10 @@ class CplxLinearLRTFn(torch.autograd.Function):
                 if klg is not None:
                     dwr.add_(klg[1] * gkl)
                     dwi.add_(klg[2] * gkl)
+            # two thirds of the layer's gradient bytes are final here: their buckets' all-reduces may start under the
+            # variance weight gradient already (0.25 ms earlier than behind the announcement below)
+            if _EARLY_W:
+                _announce(wr, wi)
         if need[6]:
             if fused:
                 dls2 = klg[0]
@@ -729,8 +734,9 @@ class CplxLinearLRTFn(torch.autograd.Function):
                     dls2.add_(klg[0] * gkl)
         if fused:
             ctx.klg = None                                   # consumed: the buffers hold totals now
-        _announce(ls2 if dls2 is not None else None, wr if dwr is not None else None,
-                  wi if dwi is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
+        if not _EARLY_W:
+            _announce(wr if dwr is not None else None, wi if dwi is not None else None)
+        _announce(ls2 if dls2 is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
         if need[0] or need[1]:
             ga = _real_linear_dx(gs2, ctx.S, dt)             # gs2 . S -> [B,I]
             dxr, dxi = _cplx_lrt_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r, x2i, ga)   # G conj(W) + 2 x ga
