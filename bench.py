@@ -386,7 +386,7 @@ def main():
         from cplxmodule_amd.utils.graphs import GraphedStep
         noise.set_mode("philox-device")            # Philox position in device memory: fresh noise per replay
         try:
-            graphed = GraphedStep(step, modules=[layer], warmup=args.warmup)
+            graphed = GraphedStep(step, modules=[layer], warmup=max(args.warmup, 3))   # (>= 3: communicators, allocator, KL fusion)
             graphed.replay()                        # (first replay: graph upload)
             torch.cuda.synchronize()
             mode = "hipGraph replay"
