@@ -60,7 +60,7 @@ def train_graph(model, x, y, steps, klw, lr, wrap=False):
     from cplxmodule_amd.utils.graphs import GraphedStep
     rel.noise.set_mode("philox-device")
     par = dp.DataParallel(model) if wrap else None
-    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, fused=True)   # one multi-tensor kernel per step, not 80 tiny ones
     model.train()
     hist = []
 
@@ -90,7 +90,7 @@ def train(model, x, y, steps, klw, lr, wrap, graph=False):
     if graph:
         return train_graph(model, x, y, steps, klw, lr, wrap)
     par = dp.DataParallel(model) if wrap else None
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, fused=True)
     model.train()
     hist = []
     for _ in range(steps):

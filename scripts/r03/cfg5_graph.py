@@ -26,7 +26,7 @@ net = ts.Net(rel.CplxLinearARD, a.width).to(dev)
 x, y = ts.synthetic_complex_mnist(a.batch, dev, seed=100)
 par = dp.DataParallel(net, bucket_mb=1.0) if a.rccl1 else None
 rel.noise.set_mode("philox-device")
-opt = torch.optim.Adam(net.parameters(), lr=2e-3, capturable=True)
+opt = torch.optim.Adam(net.parameters(), lr=2e-3, capturable=True, fused=True)
 net.train()
 
 def step():
