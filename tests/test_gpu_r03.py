@@ -344,3 +344,18 @@ def test_fused_lrt_input_gradient_is_bit_identical(O):
         assert torch.equal(a, rr) and torch.equal(b, ri)
     finally:
         lib.cplxamd_gemm_set_persistent(1)
+
+
+def test_bucket_all_reduce_runs_beside_the_gemms():
+    """tests/dp_overlap_check.py: an all_reduce issued as dp.BucketHook issues it (high-priority side stream behind a
+    mid-stream event, RCCL's stream high-priority via dp.init_process_group) overlaps the GEMMs queued after the event;
+    with equal-priority streams it ran after them (round-3 finding, profiles/r03_dp_timeline.txt)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TORCH_NCCL_HIGH_PRIORITY", None)
+    r = subprocess.run([sys.executable, os.path.join(here, "dp_overlap_check.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "overlap OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
