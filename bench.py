@@ -475,7 +475,7 @@ def main():
                 "reparam_fwd(10B/out bf16, s2 bf16)": round(10 * nout / (rp_f * 1e-3) / 1e9, 1) if rp_f else None,
                 "reparam_bwd(8B/out bf16, s2 bf16)": round(8 * nout / (rp_b * 1e-3) / 1e9, 1) if rp_b else None,
                 "peak": HBM_PEAK_GBS},
-            "kl": round(float(kl), 3),
+            "kl": round(float(kl.detach()), 3),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["hbm_kernels_GBps"].update(hbm_points(dev))
