@@ -26,6 +26,15 @@ namespace cplxamd {
 
 constexpr int kRpThreads = 256;
 
+// A value every lane read from the same address, pinned to scalar registers: the compiler cannot prove that a loaded
+// stream position is wave-uniform and would otherwise run Philox's key schedule (2 adds per round) on the vector ALU --
+// 14 of ~70 instructions per call in kernels that PMC shows 93 % VALU-busy (profiles/r03_reparam_pmc.txt).
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
 struct u32x4 { uint32_t v[4]; };
 
 __device__ __forceinline__ u32x4 philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
@@ -56,7 +65,9 @@ __device__ __forceinline__ float u01(uint32_t x) {
 // scale = 1 for real noise, 1/sqrt(2) for complex
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float scale, float& z0,
                                            float& z1) {
-  const float r = scale * __builtin_amdgcn_sqrtf(-2.0f * __logf(u01(a)));
+  // scale * sqrt(-2 ln u) = sqrt((-2 ln 2 scale^2) log2 u): v_log_f32 is a base-2 logarithm, so the natural-log
+  // conversion, the factor -2 and the scale are ONE multiplication under the square root
+  const float r = __builtin_amdgcn_sqrtf((-1.3862943611198906f * scale * scale) * __builtin_amdgcn_logf(u01(a)));
   const float ang = u01(b);                  // in revolutions: v_sin/v_cos take x / 2 pi
   z0 = r * __builtin_amdgcn_cosf(ang);
   z1 = r * __builtin_amdgcn_sinf(ang);
@@ -115,7 +126,7 @@ template <typename T, typename TS, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_fwd_kernel(
     const T* mu_r, const T* mu_i, const TS* s2, const T* eps_r, const T* eps_i, uint64_t seed,
     uint64_t offset, const uint64_t* state, T* y_r, T* y_i, int64_t n) {
-  if (PHILOX && state) { seed = state[0]; offset = state[1]; }   // device-resident stream position
+  if (PHILOX && state) { seed = uniform64(state[0]); offset = uniform64(state[1]); }   // device-resident stream position
   // 8 outputs per thread and iteration: all loads first (one 16-B access per bf16 plane, two per
   // float32 plane), then 2 x 4 outputs; the tail (< 8 elements) is done one element per thread
   const int64_t n8 = n >> 3;
@@ -172,7 +183,7 @@ template <typename T, typename TG, typename TS, bool CPLX, bool PHILOX>
 __global__ __launch_bounds__(kRpThreads) void reparam_bwd_kernel(
     const T* g_r, const T* g_i, const TS* s2, const T* eps_r, const T* eps_i, uint64_t seed,
     uint64_t offset, const uint64_t* state, TG* g_s2, int64_t n) {
-  if (PHILOX && state) { seed = state[0]; offset = state[1]; }
+  if (PHILOX && state) { seed = uniform64(state[0]); offset = uniform64(state[1]); }
   const int64_t n8 = n >> 3;
   const int64_t stride = (int64_t)gridDim.x * kRpThreads;
   for (int64_t i = (int64_t)blockIdx.x * kRpThreads + threadIdx.x; i < n8; i += stride) {
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(kRpThreads) void reparam_bwd_cols_kernel(
     uint64_t offset, const uint64_t* state, TG* g_s2, int64_t rows, int cols, int64_t rows_per_chunk,
     float* partial) {
   __shared__ float red[kRpThreads * 16];
-  if (PHILOX && state) { seed = state[0]; offset = state[1]; }
+  if (PHILOX && state) { seed = uniform64(state[0]); offset = uniform64(state[1]); }
   const int CG = cols >> 3;
   const int TX = CG < kRpThreads ? CG : kRpThreads, TY = kRpThreads / TX;
   const int tx = (int)threadIdx.x % TX, ty = (int)threadIdx.x / TX;
