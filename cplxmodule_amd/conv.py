@@ -268,6 +268,29 @@ def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False):
     return yr, yi
 
 
+_LRT_DX_FUSE = os.environ.get("CPLXAMD_LRT_DX_FUSE", "1") != "0"      # (A/B: set to 0 for the two launches)
+
+
+def cl_conv_lrt_dx(gr, gi, wr, wi, geom, xr, xi, ga):
+    """Input gradient of a local-reparameterization convolution on channels-last planes,
+    dx = dgrad(g; w) + 2 x (*) ga: one launch (cplxamd_conv2d_cl2_lrt_dx, the sum formed in the data-gradient kernel's
+    epilogue) where the 2-d-patch kernel applies, else the data gradient followed by `ops.lrt_dx_accum` (same bits)."""
+    B, Ci, Co, H, W, KH, KW = (geom[i] for i in range(7))
+    if _LRT_DX_FUSE and _CL_PATCH and ga.dtype == xr.dtype == torch.bfloat16 and KH == KW == 3 and geom[11] == geom[12] == 1:
+        gr, gi, ga = to_channels_last(gr), to_channels_last(gi), to_channels_last(ga)
+        xr, xi = to_channels_last(xr), to_channels_last(xi)
+        wp = _cl_pack(wr, wi, True)
+        dxr = torch.empty((B, Ci, H, W), dtype=xr.dtype, device=xr.device, memory_format=torch.channels_last)
+        dxi = torch.empty_like(dxr)
+        ws = _scratch(xr.device, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(Ci)))
+        if try_call("cplxamd_conv2d_cl2_lrt_dx", ptr(gr), ptr(gi), ptr(wp), ptr(xr), ptr(xi), ptr(ga), ptr(dxr), ptr(dxi),
+                    B, H, W, Co, Ci, geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr()):
+            return dxr, dxi
+    dxr, dxi = cl_conv(gr, gi, wr, wi, None, None, geom, dgrad=True)
+    ops.lrt_dx_accum(dxr, dxi, xr, xi, ga)
+    return dxr, dxi
+
+
 def cl_conv_real(x, w, b, geom, dgrad=False):
     """Real-valued cl_conv (csrc/conv_cl_real.hip): the variance path of the LRT layers and the real VD / ARD layers."""
     B, Ci, Co, H, W, KH, KW = (geom[i] for i in range(7))
@@ -698,9 +721,8 @@ class CplxConv2dLRTFn(torch.autograd.Function):
             else:
                 gs2 = ops.reparam_bwd(gr, gi, s2, eps, ctx.seed, ctx.offset, out_dtype=xr.dtype)
             if need[0] or need[1]:
-                dxr, dxi = cl_conv(gr, gi, wcr, wci, None, None, geom, dgrad=True)
                 ga = cl_conv_real(gs2, S, None, geom, dgrad=True)
-                ops.lrt_dx_accum(dxr, dxi, xr, xi, ga)
+                dxr, dxi = cl_conv_lrt_dx(gr, gi, wcr, wci, geom, xr, xi, ga)
                 if ctx.x_planar:
                     dxr, dxi = from_channels_last(dxr), from_channels_last(dxi)
             if need[2] or need[3]:

@@ -49,6 +49,7 @@ struct Args {
   const float* bias_r; const float* bias_i;
   void* y_r; void* y_i;                      // [B][Ho][Wo][Cout] bf16
   void* dump;
+  const void* fx_r; const void* fx_i; const void* fga;   // FUSE: y += 2 fx (*) fga, all laid out like y
   uint32_t x_bytes, w_bytes;
   int B, Hi, Wi, Ho, Wo, C, Cout, pad_h, pad_w;
   int C16, NS, tiles_x, tiles_y, tiles_n;
@@ -83,6 +84,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, uint32_t bytes) {
 
 enum { FL_NORMAL = 0, FL_FIRST0 = 1, FL_LAST = 2, FL_FIRST1 = 3 };
 
+// FUSE: the input gradient of the local-reparameterization layers in one pass, y = conv(x; w) + 2 fx (*) fga per plane
+// (the mean-path data gradient plus the variance path's d|x|^2 term; util.hip dx_accum_kernel's arithmetic on the
+// bf16-rounded convolution result, so the fused and the two-launch forms agree to the last bit).
+template <bool FUSE>
 __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntiles = g.B * g.tiles_y * g.tiles_x * g.tiles_n;
@@ -324,6 +329,75 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     constexpr int PITCH = 128;
     const int r16 = q31 >> 4, rr = q31 & 15;
     const int64_t ldc = g.Cout;
+    if constexpr (FUSE) {
+      // per (tile row i, 16-pixel half): the operands of its four stores -- 2 x (fga, fx_r, fx_i) at the lanes' own
+      // store positions -- are requested together before the staging (vmcnt retires loads and stores in issue order:
+      // one store-acknowledgement wait per batch, as in gemm_bf16_persist.h)
+      const uint32_t loff = (uint32_t)(((ln >> 3) * (int)ldc + (ln & 7) * 8) * 2);
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+        const int i = hb >> 1, half = hb & 1;
+        const int y = tc.y0 + 2 * w_ + i;
+        uint4 lga[2], lxr[2], lxi[2];
+        bool okl[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const int xb = tc.x0 + half * 16 + sub * 8, x = xb + (ln >> 3);
+          okl[sub] = y < g.Ho && x < g.Wo;
+          // lanes beyond the image edge read the batch's first pixel (their results go to the dump buffer)
+          const int64_t ub = (y < g.Ho && xb < g.Wo) ? ((((int64_t)tc.b * g.Ho + y) * g.Wo + xb) * ldc + tc.nt * BN) * 2 : 0;
+          const uint32_t ulo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+          const uint32_t uhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)ub >> 32));
+          const int64_t u = (int64_t)(((uint64_t)uhi << 32) | ulo);
+          const uint32_t lo = okl[sub] ? loff : 0u;
+          lga[sub] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.fga) + u + lo);
+          lxr[sub] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.fx_r) + u + lo);
+          lxi[sub] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.fx_i) + u + lo);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          bf16_t* out = reinterpret_cast<bf16_t*>(pl ? g.y_i : g.y_r);
+          if (r16 == half) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                f4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x.v[e] = pl ? acc_i[i][j][4 * q + e] : acc_r[i][j][4 * q + e];
+                st4(reinterpret_cast<bf16_t*>(reg + rr * PITCH + (((8 * j + 2 * q + qk) ^ rr) << 3)), x);
+              }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const int sr = sub * 8 + (ln >> 3);
+            const uint4 raw = *reinterpret_cast<const uint4*>(reg + sr * PITCH + (((ln & 7) ^ (sr >> 1)) << 4));
+            const bool odd = (ln >> 3) & 1;
+            const uint4 val = odd ? uint4{raw.z, raw.w, raw.x, raw.y} : raw;
+            const uint4 xv = pl ? lxi[sub] : lxr[sub];
+            const uint32_t vw[4] = {val.x, val.y, val.z, val.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+            const uint32_t gw[4] = {lga[sub].x, lga[sub].y, lga[sub].z, lga[sub].w};
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t ow;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d0 = __uint_as_float(vw[e] << 16), d1 = __uint_as_float(vw[e] & 0xffff0000u);
+              const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+              const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
+              ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
+            }
+            const int x = tc.x0 + half * 16 + sub * 8 + (ln >> 3);
+            const int col = tc.nt * BN + (ln & 7) * 8;
+            bf16_t* dst = okl[sub] ? out + (((int64_t)tc.b * g.Ho + y) * g.Wo + x) * ldc + col
+                                   : reinterpret_cast<bf16_t*>(g.dump) + (int64_t)(w_ * 64 + i * 32 + half * 16 + sub * 8 + (ln >> 3)) * ldc + col;
+            __builtin_nontemporal_store(ow, reinterpret_cast<u32x4_t*>(dst));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       bf16_t* out = reinterpret_cast<bf16_t*>(pl ? g.y_i : g.y_r);
@@ -454,11 +528,10 @@ extern "C" {
 int64_t cplxamd_conv2d_cl_pack_bytes(int N, int C, int KH, int KW);
 int64_t cplxamd_conv2d_cl_ws_bytes(int Cout);
 
-// Same arguments and semantics as cplxamd_conv2d_cl (weights packed by cplxamd_conv2d_cl_pack); built for KH = KW = 3,
-// dilation 1, C % 32 == 0, N % 64 == 0 -- CPLXAMD_ESHAPE otherwise (the caller then takes cplxamd_conv2d_cl).
-int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
-                       void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
-                       int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream) {
+static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                      const void* fx_r, const void* fx_i, const void* fga, void* y_r, void* y_i, int64_t B, int H, int W, int C,
+                      int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes,
+                      void* stream) {
   if (!x_r || !x_i || !w_packed || !y_r || !y_i || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || pad_h < 0 || pad_w < 0 ||
       (bias_r == nullptr) != (bias_i == nullptr) || (mode != 0 && mode != 1))
     return CPLXAMD_EINVAL;
@@ -468,11 +541,13 @@ int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, c
   if (B == 0) return 0;
   if (B * H * W * C * 2 >= (int64_t)0xF0000000 || B >= 65536) return CPLXAMD_ESHAPE;
   auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (!a16(x_r) || !a16(x_i) || !a16(w_packed) || !a16(y_r) || !a16(y_i) || !a16(ws) || (bias_r && (!a16(bias_r) || !a16(bias_i))))
+  if (!a16(x_r) || !a16(x_i) || !a16(w_packed) || !a16(y_r) || !a16(y_i) || !a16(ws) || (bias_r && (!a16(bias_r) || !a16(bias_i))) ||
+      !a16(fx_r) || !a16(fx_i) || !a16(fga))
     return CPLXAMD_EALIGN;
   if (!ws || ws_bytes < cplxamd_conv2d_cl_ws_bytes(N)) return CPLXAMD_EINVAL;
   cl2::Args g{};
   g.x_r = x_r; g.x_i = x_i; g.w = w_packed; g.bias_r = bias_r; g.bias_i = bias_i; g.y_r = y_r; g.y_i = y_i; g.dump = ws;
+  g.fx_r = fx_r; g.fx_i = fx_i; g.fga = fga;
   g.B = (int)B;
   g.Hi = mode ? Hs : H; g.Wi = mode ? Ws : W; g.Ho = mode ? H : Hs; g.Wo = mode ? W : Ws;
   g.pad_h = mode ? 2 - pad_h : pad_h; g.pad_w = mode ? 2 - pad_w : pad_w;
@@ -494,13 +569,39 @@ int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, c
   const int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cl2::SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cl2::SMEM);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cl2::SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  cl2::conv_cl2_kernel<<<dim3((unsigned)grid), cl2::NT, cl2::SMEM, (hipStream_t)stream>>>(g);
+  if (fga) cl2::conv_cl2_kernel<true><<<dim3((unsigned)grid), cl2::NT, cl2::SMEM, (hipStream_t)stream>>>(g);
+  else cl2::conv_cl2_kernel<false><<<dim3((unsigned)grid), cl2::NT, cl2::SMEM, (hipStream_t)stream>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
+}
+
+// Same arguments and semantics as cplxamd_conv2d_cl (weights packed by cplxamd_conv2d_cl_pack); built for KH = KW = 3,
+// dilation 1, C % 32 == 0, N % 64 == 0 -- CPLXAMD_ESHAPE otherwise (the caller then takes cplxamd_conv2d_cl).
+int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                       void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                       int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream) {
+  return launch_cl2(x_r, x_i, w_packed, bias_r, bias_i, nullptr, nullptr, nullptr, y_r, y_i, B, H, W, C, N, KH, KW, dil_h,
+                    dil_w, pad_h, pad_w, mode, ws, ws_bytes, stream);
+}
+
+// Input gradient of the local-reparameterization convolutions (CplxConv2dVD / ARD, cplxmodule/nn/relevance/complex.py
+// :157-190 differentiated) in one launch: dx = dgrad(g; w) + 2 x (*) ga per plane, where dgrad is cplxamd_conv2d_cl2
+// with mode 1 (w packed with swap = 1: flipped, conjugated, channel-swapped) and ga [B][H][W][N] is the variance path's
+// data gradient (cplxamd_conv2d_clr, mode 1).  g_r / g_i: [B][H + 2 pad - 2][W + 2 pad - 2][C] output gradients;
+// x_r / x_i / ga / dx_r / dx_i: [B][H][W][N].  Bit-identical to cplxamd_conv2d_cl2 followed by cplxamd_lrt_dx_accum.
+// Same shape constraints as cplxamd_conv2d_cl2 (CPLXAMD_ESHAPE otherwise: the caller takes the two launches).
+int cplxamd_conv2d_cl2_lrt_dx(const void* g_r, const void* g_i, const void* w_packed, const void* x_r, const void* x_i,
+                              const void* ga, void* dx_r, void* dx_i, int64_t B, int H, int W, int C, int N, int pad_h,
+                              int pad_w, void* ws, int64_t ws_bytes, void* stream) {
+  if (!x_r || !x_i || !ga) return CPLXAMD_EINVAL;
+  return launch_cl2(g_r, g_i, w_packed, nullptr, nullptr, x_r, x_i, ga, dx_r, dx_i, B, H, W, C, N, 3, 3, 1, 1, pad_h, pad_w, 1,
+                    ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 14
+#define CPLXAMD_ABI_VERSION 15
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -423,6 +423,17 @@ int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, co
 int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
                        void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
                        int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream);
+/* Input gradient of the local-reparameterization convolutions (CplxConv2dVD / CplxConv2dARD: the layer of
+ * cplxmodule/nn/relevance/complex.py:157-190, differentiated) in ONE launch:
+ *     dx = dgrad(g; w) + 2 x (*) ga      per plane,
+ * dgrad = cplxamd_conv2d_cl2 with mode 1 (w_packed from cplxamd_conv2d_cl_pack with dgrad = 1) and ga the variance
+ * path's data gradient (cplxamd_conv2d_clr, mode 1).  g_r / g_i: [B][H + 2 pad - 2][W + 2 pad - 2][C] output gradients;
+ * x_r / x_i / ga / dx_r / dx_i: [B][H][W][N], all bf16 channels-last.  Bit-identical to cplxamd_conv2d_cl2 followed by
+ * cplxamd_lrt_dx_accum (the sum is formed on the bf16-rounded convolution result), minus one read-modify-write pass
+ * over dx.  Shapes as cplxamd_conv2d_cl2 (CPLXAMD_ESHAPE otherwise: take the two launches). */
+int cplxamd_conv2d_cl2_lrt_dx(const void* g_r, const void* g_i, const void* w_packed, const void* x_r, const void* x_i,
+                              const void* ga, void* dx_r, void* dx_i, int64_t B, int H, int W, int C, int N, int pad_h,
+                              int pad_w, void* ws, int64_t ws_bytes, void* stream);
 int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co);
 int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                             float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,

@@ -1,5 +1,5 @@
 """CplxConv2dVD(64, 64, 3, padding 1) on 256 x 256 bf16 images, training-mode forward (mean conv + variance conv + noise
-injection) + KL + backward: channels-last kernels vs the planar (round-1) path.   python scripts/lrt_conv_bench.py [B=32]"""
+injection) + KL + backward: channels-last kernels vs the planar (round-1) path.   python scripts/lrt_conv_bench.py [B=32] [cl]"""
 import os
 import sys
 import time
@@ -32,13 +32,14 @@ def run(cl):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(8):
+    for _ in range(20):
         step()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 8
+    return (time.perf_counter() - t0) / 20
 
 
-for cl in (True, False):
+modes = (True,) if len(sys.argv) > 2 and sys.argv[2] == "cl" else (True, False)
+for cl in modes:
     t = run(cl)
     flop = (8.0 + 2.0) * B * 256 * 256 * 64 * 64 * 9 * 3
     print(f"{'channels-last kernels' if cl else 'planar (r01) kernels '}: {t * 1e3:8.3f} ms per step, {B / t:9.1f} images/s, "

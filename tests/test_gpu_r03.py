@@ -359,3 +359,55 @@ def test_bucket_all_reduce_runs_beside_the_gemms():
     r = subprocess.run([sys.executable, os.path.join(here, "dp_overlap_check.py")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "overlap OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 64, 64, 64, 64, 1), (3, 64, 128, 50, 70, 1), (2, 128, 64, 33, 37, 0), (5, 64, 96, 16, 32, 1)])
+def test_fused_lrt_conv_input_gradient_is_bit_identical(shape):
+    """cplxamd_conv2d_cl2_lrt_dx: dx = dgrad(g; w) + 2 x (*) ga in the epilogue of the 2-d-patch data-gradient kernel ==
+    cplxamd_conv2d_cl2 (mode 1) followed by cplxamd_lrt_dx_accum, bit for bit -- full tiles, ragged right / bottom
+    edges (pixels beyond the image go to the dump buffer), `valid` padding; and through CplxConv2dVD's backward."""
+    from cplxmodule_amd import Cplx, conv, ops
+    from cplxmodule_amd.nn import relevance as rel
+    from cplxmodule_amd.nn.relevance.noise import noise
+    B, Ci, Co, H, W, pad = shape
+    dev, bf = "cuda", torch.bfloat16
+    torch.manual_seed(H * W)
+    cl = lambda *s, k=1.0: torch.randn(*s, device=dev).mul(k).to(bf).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    gr, gi = cl(B, Co, Ho, Wo), cl(B, Co, Ho, Wo)
+    xr, xi, ga = cl(B, Ci, H, W), cl(B, Ci, H, W), cl(B, Ci, H, W, k=0.3)
+    wr, wi = (torch.randn(Co, Ci, 3, 3, device=dev).mul(0.05).to(bf) for _ in range(2))
+    geom = (B, Ci, Co, H, W, 3, 3, 1, 1, pad, pad, 1, 1, 1)
+    assert conv._LRT_DX_FUSE and conv._CL_PATCH
+    dxr, dxi = conv.cl_conv_lrt_dx(gr, gi, wr, wi, geom, xr, xi, ga)
+    rr, ri = conv.cl_conv(gr, gi, wr, wi, None, None, geom, dgrad=True)
+    plain_r, plain_i = rr.clone(), ri.clone()
+    ops.lrt_dx_accum(rr, ri, xr, xi, ga)
+    assert torch.equal(dxr, rr) and torch.equal(dxi, ri)
+    assert not torch.equal(dxr, plain_r)                     # (the elementwise term is there)
+    # the whole layer: fused and two-launch backward give the same input gradient
+    torch.manual_seed(1)
+    layer = rel.CplxConv2dVD(Ci, Co, 3, padding=pad).to(dev)
+    x = Cplx(xr.clone().requires_grad_(True), xi.clone().requires_grad_(True))
+
+    def grads(fuse):
+        conv._LRT_DX_FUSE = fuse
+        try:
+            x.real.grad = x.imag.grad = None
+            noise.manual_seed(11)
+            y = layer(x)
+            torch.autograd.backward((y.real, y.imag), (gr, gi))
+            return x.real.grad.clone(), x.imag.grad.clone()
+        finally:
+            conv._LRT_DX_FUSE = True
+    old = conv._CL_FORCE
+    conv._CL_FORCE = True
+    try:
+        if conv._cl_layer_ok(geom, xr):
+            a, b = grads(True), grads(False)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        else:
+            assert Ci % 64 or Co % 64                        # (the weight-gradient kernel wants 64-channel multiples)
+    finally:
+        conv._CL_FORCE = old
