@@ -20,11 +20,32 @@ namespace cplxamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CBM = 64, CBN = 64, CBK = 16, CLD = CBM + 1;
+constexpr int CBM = 64, CBN = 64, CBK = 16;
+
+// Division by a launch-constant divisor of indices below 2^31: q = (x * mul) >> (31 + s), s = ceil(log2 d),
+// mul = floor(2^(31 + s) / d) + 1 (Granlund-Montgomery round-up multiplier, exact for x < 2^31); d = 1 passes x through.
+// The gathers below split pixel / tap indices with these instead of 64-bit divisions (which were 3/4 of the
+// kernel's instructions: every operand element paid two of them).
+struct FastDiv { uint32_t mul, sh, d; };
+
+static FastDiv make_fastdiv(int64_t d64) {
+  FastDiv f{0u, 0u, (uint32_t)d64};
+  if (d64 <= 1) { f.d = 1; return f; }
+  uint32_t s = 0;
+  while ((1ull << s) < (uint64_t)d64) ++s;
+  f.mul = (uint32_t)(((1ull << (31 + s)) / (uint64_t)d64) + 1);
+  f.sh = s - 1;
+  return f;
+}
+
+__device__ __forceinline__ int fdiv(int x, const FastDiv& f) {      // x >= 0
+  return f.d == 1 ? x : (int)(__umulhi((uint32_t)x, f.mul) >> f.sh);
+}
 
 struct ConvP {
   int B, Ci, Co, H, W, KH, KW, Ho, Wo, sh, sw, ph, pw, dh, dw, G;
   int Cg, Cog;   // channels per group (in / out)
+  FastDiv f_khw, f_kw, f_howo, f_wo, f_hw, f_w, f_sh, f_sw;
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
@@ -35,9 +56,9 @@ struct ConvArgs {
   const float* bias_r; const float* bias_i;
   void* yr; void* yi;                 // output (WGRAD: fp32 partial slabs [splits][Co*Cg*KH*KW])
   ConvP p;
-  int64_t M, N, K;                    // GEMM dims per group
+  int M, N, K;                        // GEMM dims per group (all below 2^31: checked at launch)
   int splits;                         // WGRAD split-K factor (1 otherwise)
-  int64_t kchunk;                     // K elements per split
+  int kchunk;                         // K elements per split
 };
 
 template <typename T>
@@ -45,166 +66,223 @@ __device__ __forceinline__ float ldv(const void* p, int64_t off) {
   return io<T>::ld(reinterpret_cast<const T*>(p) + off);
 }
 
-// ---- operand fetchers: return the plane offset of element (row, k) or -1 if it is padding --
-template <int MODE>
-__device__ __forceinline__ int64_t a_offset(const ConvP& p, int g, int64_t m, int64_t k) {
-  if (MODE == MODE_FWD) {          // W[(g*Cog+m), k]
-    return ((int64_t)g * p.Cog + m) * ((int64_t)p.Cg * p.KH * p.KW) + k;
-  } else if (MODE == MODE_DGRAD) { // W[(g*Cog+co), ci=m, kh, kw], k = (co, kh, kw)
-    const int khw = p.KH * p.KW;
-    const int co = (int)(k / khw), r = (int)(k - (int64_t)co * khw);
-    return (((int64_t)g * p.Cog + co) * p.Cg + m) * khw + r;
-  } else {                         // G[b, g*Cog+m, oh, ow], k = (b, oh, ow)
-    const int64_t hw = (int64_t)p.Ho * p.Wo;
-    const int64_t b = k / hw, r = k - b * hw;
-    return ((b * p.Co + (int64_t)g * p.Cog + m) * hw) + r;
-  }
-}
-
-template <int MODE>
-__device__ __forceinline__ int64_t b_offset(const ConvP& p, int g, int64_t n, int64_t k) {
-  if (MODE == MODE_FWD) {          // n = (b, oh, ow), k = (ci, kh, kw) -> X
-    const int64_t hw = (int64_t)p.Ho * p.Wo;
-    const int64_t b = n / hw;
-    const int r = (int)(n - b * hw);
-    const int oh = r / p.Wo, ow = r - oh * p.Wo;
-    const int khw = p.KH * p.KW;
-    const int ci = (int)(k / khw), rk = (int)(k - (int64_t)ci * khw);
-    const int kh = rk / p.KW, kw = rk - kh * p.KW;
-    const int ih = oh * p.sh - p.ph + kh * p.dh, iw = ow * p.sw - p.pw + kw * p.dw;
-    if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return -1;
-    return ((b * p.Ci + (int64_t)g * p.Cg + ci) * p.H + ih) * p.W + iw;
-  } else if (MODE == MODE_DGRAD) { // n = (b, ih, iw), k = (co, kh, kw) -> G
-    const int64_t hw = (int64_t)p.H * p.W;
-    const int64_t b = n / hw;
-    const int r = (int)(n - b * hw);
-    const int ih = r / p.W, iw = r - ih * p.W;
-    const int khw = p.KH * p.KW;
-    const int co = (int)(k / khw), rk = (int)(k - (int64_t)co * khw);
-    const int kh = rk / p.KW, kw = rk - kh * p.KW;
-    const int th = ih + p.ph - kh * p.dh, tw = iw + p.pw - kw * p.dw;
-    if (th < 0 || tw < 0 || th % p.sh || tw % p.sw) return -1;
-    const int oh = th / p.sh, ow = tw / p.sw;
-    if (oh >= p.Ho || ow >= p.Wo) return -1;
-    return ((b * p.Co + (int64_t)g * p.Cog + co) * p.Ho + oh) * p.Wo + ow;
-  } else {                         // n = (ci, kh, kw), k = (b, oh, ow) -> X
-    const int khw = p.KH * p.KW;
-    const int ci = (int)(n / khw), rk = (int)(n - (int64_t)ci * khw);
-    const int kh = rk / p.KW, kw = rk - kh * p.KW;
-    const int64_t hw = (int64_t)p.Ho * p.Wo;
-    const int64_t b = k / hw;
-    const int r = (int)(k - b * hw);
-    const int oh = r / p.Wo, ow = r - oh * p.Wo;
-    const int ih = oh * p.sh - p.ph + kh * p.dh, iw = ow * p.sw - p.pw + kw * p.dw;
-    if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return -1;
-    return ((b * p.Ci + (int64_t)g * p.Cg + ci) * p.H + ih) * p.W + iw;
-  }
-}
-
-// One thread's 4 elements of a [64 x CBK] operand tile: gather global -> registers (fetch), then
-// registers -> LDS as d[k][r] (commit).  Split so that the gathers of tile t+1 are in flight while
-// the MFMAs of tile t run (the K loop is double-buffered in LDS).
-struct ConvRegs { float r[4], i[4]; };
-
-template <typename T, bool CPLX, int MODE, bool IS_A, bool KFAST>
-__device__ __forceinline__ ConvRegs fetch(const void* sr, const void* si, const ConvP& p, int g,
-                                          int64_t row0, int64_t rows, int64_t k0, int64_t kend) {
-  const int t = threadIdx.x;
-  ConvRegs o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int r, k;
-    if (KFAST) { k = t & 15; r = (t >> 4) + 16 * j; }
-    else { r = t & 63; k = (t >> 6) + 4 * j; }
-    const int64_t gr = row0 + r, gk = k0 + k;
-    float vr = 0.f, vi = 0.f;
-    if (gr < rows && gk < kend) {
-      const int64_t off = IS_A ? a_offset<MODE>(p, g, gr, gk) : b_offset<MODE>(p, g, gr, gk);
-      if (off >= 0) {
-        vr = ldv<T>(sr, off);
-        if (CPLX) vi = ldv<T>(si, off);
-      }
-    }
-    o.r[j] = vr;
-    o.i[j] = vi;
-  }
-  return o;
-}
-
-template <bool CPLX, bool KFAST>
-__device__ __forceinline__ void commit(float (*dr)[CLD], float (*di)[CLD], const ConvRegs& o) {
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int r, k;
-    if (KFAST) { k = t & 15; r = (t >> 4) + 16 * j; }
-    else { r = t & 63; k = (t >> 6) + 4 * j; }
-    dr[k][r] = o.r[j];
-    if (CPLX) di[k][r] = o.i[j];
-  }
-}
-
-// T: element type of the activations / gradients; TW: element type of the weight operand
-template <typename T, bool CPLX, int MODE>
+// Implicit-GEMM tile: TM x 64 outputs per workgroup of 4 waves, K in steps of 16, double-buffered in LDS; the gathers
+// of tile t + 1 are in flight while the MFMAs of tile t run.
+//   TM = 64: waves 2 (M) x 2 (N), each a 32 x 32 MFMA block over the whole K step.
+//   TM = 32 (M <= 32: narrow layers): waves 2 (N) x 2 (K halves of each step), partial sums joined through LDS at the
+//            end -- twice the workgroups and half the MFMA chain per wave of a 32 x 128 tile.
+// Operand elements per thread and K step: A (TM x 16): k = t & 15 fixed, rows (t >> 4) + 16 j; B (64 x 16): pixels fastest
+// (FWD, DGRAD: row t & 63 fixed, k = (t >> 6) + 4 j) or k fastest (WGRAD: k = t & 15 fixed, rows (t >> 4) + 16 j).
+// Whatever is fixed per thread is decomposed ONCE in front of the K loop.
+template <typename T, bool CPLX, int MODE, int TM>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
-  __shared__ float As_r[2][CBK][CLD], Bs_r[2][CBK][CLD];
-  __shared__ float As_i[CPLX ? 2 : 1][CPLX ? CBK : 1][CLD], Bs_i[CPLX ? 2 : 1][CPLX ? CBK : 1][CLD];
+  constexpr int ALD = TM + 1, BLD = CBN + 1, AJ = TM / 16;
+  constexpr bool KSPLIT = TM == 32;
+  __shared__ float As_r[2][CBK][ALD], Bs_r[2][CBK][BLD];
+  __shared__ float As_i[CPLX ? 2 : 1][CPLX ? CBK : 1][ALD], Bs_i[CPLX ? 2 : 1][CPLX ? CBK : 1][BLD];
+  __shared__ float red[KSPLIT ? 2 : 1][CPLX ? 2 : 1][KSPLIT ? 16 : 1][64];
   const ConvP& p = a.p;
+  const int t = threadIdx.x;
   const int g = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
-  const int64_t m0 = (int64_t)blockIdx.y * CBM, n0 = (int64_t)blockIdx.x * CBN;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32, l31 = lane & 31, lk = lane >> 5;
-  const int64_t kbeg = (int64_t)split * a.kchunk;
-  int64_t kend = kbeg + a.kchunk;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * CBN;
+  const int lane = t & 63, wid = t >> 6;
+  const int wm = KSPLIT ? 0 : (wid >> 1) * 32, wn = (wid & 1) * 32, l31 = lane & 31, lk = lane >> 5;
+  const int kq = KSPLIT ? (wid >> 1) : 0;
+  const int kbeg = split * a.kchunk;
+  int kend = kbeg + a.kchunk;
   if (kend > a.K) kend = a.K;
   // conjugation: DGRAD conj(W) is the A operand, WGRAD conj(X) is the B operand
   const float sa = (MODE == MODE_DGRAD) ? -1.f : 1.f, sb = (MODE == MODE_WGRAD) ? -1.f : 1.f;
-  constexpr bool BK_FAST = MODE == MODE_WGRAD;   // B: pixels fastest (FWD, DGRAD) or k (= pixels) fastest
+  const int khw = p.KH * p.KW, howo = p.Ho * p.Wo;
+  const void* a_r = MODE == MODE_WGRAD ? a.xr : a.wr;
+  const void* a_i = MODE == MODE_WGRAD ? a.xi : a.wi;
+  const void* b_r = MODE == MODE_WGRAD ? a.wr : a.xr;
+  const void* b_i = MODE == MODE_WGRAD ? a.wi : a.xi;
+
+  // ---- per-thread constants of the gathers
+  const int ka = t & 15, ra0 = t >> 4;                         // A: k lane, first row
+  const int rb = t & 63, kb0 = t >> 6;                         // B (pixels fastest): row, first k
+  // B row = output pixel (FWD) / input pixel (DGRAD): image, and the window origin
+  bool b_ok = false;
+  int b_h0 = 0, b_w0 = 0;
+  int64_t b_base = 0;
+  if (MODE != MODE_WGRAD) {
+    const int n = n0 + rb;
+    b_ok = n < a.N;
+    if (b_ok) {
+      if (MODE == MODE_FWD) {
+        const int b = fdiv(n, p.f_howo), r = n - b * howo;
+        const int oh = fdiv(r, p.f_wo), ow = r - oh * p.Wo;
+        b_h0 = oh * p.sh - p.ph; b_w0 = ow * p.sw - p.pw;
+        b_base = ((int64_t)b * p.Ci + (int64_t)g * p.Cg) * p.H * p.W;
+      } else {
+        const int b = fdiv(n, p.f_hw), r = n - b * (p.H * p.W);
+        const int ih = fdiv(r, p.f_w), iw = r - ih * p.W;
+        b_h0 = ih + p.ph; b_w0 = iw + p.pw;
+        b_base = ((int64_t)b * p.Co + (int64_t)g * p.Cog) * howo;
+      }
+    }
+  }
+  // WGRAD: B rows = (ci, kh, kw) taps
+  int w_ci[4], w_dh[4], w_dw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w_ci[j] = -1; w_dh[j] = w_dw[j] = 0;
+    if (MODE == MODE_WGRAD) {
+      const int n = n0 + ra0 + 16 * j;
+      if (n < a.N) {
+        const int ci = fdiv(n, p.f_khw), rk = n - ci * khw;
+        const int kh = fdiv(rk, p.f_kw), kw = rk - kh * p.KW;
+        w_ci[j] = ci; w_dh[j] = kh * p.dh - p.ph; w_dw[j] = kw * p.dw - p.pw;
+      }
+    }
+  }
+
+  float ar_[AJ], ai_[AJ], br_[4], bi_[4];
+  auto fetch_both = [&](int k0) __attribute__((always_inline)) {
+    // ---- A: weights (FWD: k contiguous; DGRAD: gathered) / grad-out (WGRAD: k = pixels contiguous)
+    const int gk = k0 + ka;
+    const bool kok = gk < kend;
+    int64_t abase = 0, astride = 0;                            // element (row m, this k) = abase + m * astride
+    int wb = 0, woh = 0, wow = 0;                              // WGRAD: pixel of this k
+    if (MODE == MODE_FWD) {
+      abase = (int64_t)g * p.Cog * a.K + gk; astride = a.K;
+    } else if (MODE == MODE_DGRAD) {
+      const int co = kok ? fdiv(gk, p.f_khw) : 0, r = gk - co * khw;
+      abase = ((int64_t)g * p.Cog + co) * p.Cg * khw + r; astride = khw;
+    } else {
+      wb = kok ? fdiv(gk, p.f_howo) : 0;
+      const int r = gk - wb * howo;
+      woh = kok ? fdiv(r, p.f_wo) : 0; wow = r - woh * p.Wo;
+      abase = ((int64_t)wb * p.Co + (int64_t)g * p.Cog) * howo + r; astride = howo;
+    }
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int m = m0 + ra0 + 16 * j;
+      float vr = 0.f, vi = 0.f;
+      if (kok && m < a.M) {
+        const int64_t off = abase + (int64_t)m * astride;
+        vr = ldv<T>(a_r, off);
+        if (CPLX) vi = ldv<T>(a_i, off);
+      }
+      ar_[j] = vr; ai_[j] = vi;
+    }
+    // ---- B
+    if (MODE == MODE_WGRAD) {
+      const int ihb = woh * p.sh, iwb = wow * p.sw;
+      const int64_t xb = ((int64_t)wb * p.Ci + (int64_t)g * p.Cg) * p.H * p.W;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float vr = 0.f, vi = 0.f;
+        const int ih = ihb + w_dh[j], iw = iwb + w_dw[j];
+        if (kok && w_ci[j] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+          const int64_t off = xb + ((int64_t)w_ci[j] * p.H + ih) * p.W + iw;
+          vr = ldv<T>(b_r, off);
+          if (CPLX) vi = ldv<T>(b_i, off);
+        }
+        br_[j] = vr; bi_[j] = vi;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + kb0 + 4 * j;
+        float vr = 0.f, vi = 0.f;
+        if (b_ok && k < kend) {
+          const int c = fdiv(k, p.f_khw), rk = k - c * khw;      // c: input channel (FWD) / output channel (DGRAD)
+          const int kh = fdiv(rk, p.f_kw), kw = rk - kh * p.KW;
+          if (MODE == MODE_FWD) {
+            const int ih = b_h0 + kh * p.dh, iw = b_w0 + kw * p.dw;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+              const int64_t off = b_base + ((int64_t)c * p.H + ih) * p.W + iw;
+              vr = ldv<T>(b_r, off);
+              if (CPLX) vi = ldv<T>(b_i, off);
+            }
+          } else {
+            const int th = b_h0 - kh * p.dh, tw = b_w0 - kw * p.dw;
+            if (th >= 0 && tw >= 0) {
+              const int oh = fdiv(th, p.f_sh), ow = fdiv(tw, p.f_sw);
+              if (oh * p.sh == th && ow * p.sw == tw && oh < p.Ho && ow < p.Wo) {
+                const int64_t off = b_base + ((int64_t)c * p.Ho + oh) * p.Wo + ow;
+                vr = ldv<T>(b_r, off);
+                if (CPLX) vi = ldv<T>(b_i, off);
+              }
+            }
+          }
+        }
+        br_[j] = vr; bi_[j] = vi;
+      }
+    }
+  };
+  auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      As_r[buf][ka][ra0 + 16 * j] = ar_[j];
+      if (CPLX) As_i[buf][ka][ra0 + 16 * j] = ai_[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (MODE == MODE_WGRAD) {
+        Bs_r[buf][ka][ra0 + 16 * j] = br_[j];
+        if (CPLX) Bs_i[buf][ka][ra0 + 16 * j] = bi_[j];
+      } else {
+        Bs_r[buf][kb0 + 4 * j][rb] = br_[j];
+        if (CPLX) Bs_i[buf][kb0 + 4 * j][rb] = bi_[j];
+      }
+    }
+  };
 
   f32x16 acc_r = {0}, acc_i = {0};
-  ConvRegs ra, rb;
-  auto fetch_both = [&](int64_t k0) {
-    // A: weights (FWD: k contiguous; DGRAD: gathered) / grad-out (WGRAD: k contiguous)
-    ra = fetch<T, CPLX, MODE, true, true>(MODE == MODE_WGRAD ? a.xr : a.wr, MODE == MODE_WGRAD ? a.xi : a.wi,
-                                          p, g, m0, a.M, k0, kend);
-    if (MODE == MODE_WGRAD) rb = fetch<T, CPLX, MODE, false, true>(a.wr, a.wi, p, g, n0, a.N, k0, kend);
-    else rb = fetch<T, CPLX, MODE, false, false>(a.xr, a.xi, p, g, n0, a.N, k0, kend);
-  };
   if (kbeg < kend) fetch_both(kbeg);
   int buf = 0;
-  for (int64_t k0 = kbeg; k0 < kend; k0 += CBK, buf ^= 1) {
-    commit<CPLX, true>(As_r[buf], As_i[CPLX ? buf : 0], ra);
-    commit<CPLX, BK_FAST>(Bs_r[buf], Bs_i[CPLX ? buf : 0], rb);
+  for (int k0 = kbeg; k0 < kend; k0 += CBK, buf ^= 1) {
+    commit(buf);
     __syncthreads();                         // tile visible; the other buffer is free again
     if (k0 + CBK < kend) fetch_both(k0 + CBK);
+    constexpr int KK0 = 0, KKN = KSPLIT ? CBK / 2 : CBK;
 #pragma unroll
-    for (int kk = 0; kk < CBK; kk += 2) {
-      const float ar = As_r[buf][kk + lk][wm + l31];
-      const float br = Bs_r[buf][kk + lk][wn + l31];
+    for (int kk = KK0; kk < KKN; kk += 2) {
+      const int kr = kq * (CBK / 2) + kk + lk;
+      const float ar = As_r[buf][kr][wm + l31];
+      const float br = Bs_r[buf][kr][wn + l31];
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, acc_r, 0, 0, 0);
       if (CPLX) {
-        const float ai = sa * As_i[buf][kk + lk][wm + l31];
-        const float bi = sb * Bs_i[buf][kk + lk][wn + l31];
+        const float ai = sa * As_i[buf][kr][wm + l31];
+        const float bi = sb * Bs_i[buf][kr][wn + l31];
         acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, acc_r, 0, 0, 0);
         acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, acc_i, 0, 0, 0);
         acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, acc_i, 0, 0, 0);
       }
     }
   }
+  if (KSPLIT) {                              // join the two K halves: waves 2, 3 hand theirs to waves 0, 1
+    if (kq == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red[wid & 1][0][r][lane] = acc_r[r];
+        if (CPLX) red[wid & 1][CPLX ? 1 : 0][r][lane] = acc_i[r];
+      }
+    }
+    __syncthreads();
+    if (kq == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc_r[r] += red[wid & 1][0][r][lane];
+      if (CPLX) acc_i[r] += red[wid & 1][CPLX ? 1 : 0][r][lane];
+    }
+  }
 
   // epilogue: col = lane & 31 runs along N, rows (M) across registers
-  const int64_t n = n0 + wn + l31;
+  const int n = n0 + wn + l31;
   if (n >= a.N) return;
   int64_t out_base, out_mstride;
   if (MODE == MODE_FWD) {
-    const int64_t hw = (int64_t)p.Ho * p.Wo;
-    const int64_t b = n / hw, r = n - b * hw;
-    out_base = (b * p.Co + (int64_t)g * p.Cog) * hw + r;
-    out_mstride = hw;
+    const int b = fdiv(n, p.f_howo), r = n - b * howo;
+    out_base = ((int64_t)b * p.Co + (int64_t)g * p.Cog) * howo + r;
+    out_mstride = howo;
   } else if (MODE == MODE_DGRAD) {
-    const int64_t hw = (int64_t)p.H * p.W;
-    const int64_t b = n / hw, r = n - b * hw;
-    out_base = (b * p.Ci + (int64_t)g * p.Cg) * hw + r;
+    const int hw = p.H * p.W;
+    const int b = fdiv(n, p.f_hw), r = n - b * hw;
+    out_base = ((int64_t)b * p.Ci + (int64_t)g * p.Cg) * hw + r;
     out_mstride = hw;
   } else {
     const int64_t wsz = (int64_t)p.Co * p.Cg * p.KH * p.KW;
@@ -213,9 +291,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
     if (m >= a.M) continue;
-    const int64_t o = out_base + m * out_mstride;
+    const int64_t o = out_base + (int64_t)m * out_mstride;
     float vr = acc_r[r], vi = acc_i[r];
     if (MODE == MODE_FWD && a.bias_r) {
       vr += a.bias_r[g * p.Cog + m];
@@ -299,13 +377,20 @@ static bool conv_geom_ok(const ConvP& p) {
          p.Wo > 0 && p.Cg == p.Ci / p.G && p.Cog == p.Co / p.G;
 }
 
+static int conv_tile_m(int64_t M) { return M <= 32 ? 32 : CBM; }
+
 template <typename T, int MODE>
 static int conv_launch(ConvArgs& a, bool cplx, hipStream_t st) {
-  dim3 grid((unsigned)((a.N + CBN - 1) / CBN), (unsigned)((a.M + CBM - 1) / CBM),
-            (unsigned)(a.p.G * a.splits));
+  const int tm = conv_tile_m(a.M);
+  dim3 grid((unsigned)((a.N + CBN - 1) / CBN), (unsigned)((a.M + tm - 1) / tm), (unsigned)(a.p.G * a.splits));
   if (grid.y > 65535 || grid.z > 65535) return CPLXAMD_ESHAPE;
-  if (cplx) conv_kernel<T, true, MODE><<<grid, 256, 0, st>>>(a);
-  else conv_kernel<T, false, MODE><<<grid, 256, 0, st>>>(a);
+  if (tm == 32) {
+    if (cplx) conv_kernel<T, true, MODE, 32><<<grid, 256, 0, st>>>(a);
+    else conv_kernel<T, false, MODE, 32><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (cplx) conv_kernel<T, true, MODE, 64><<<grid, 256, 0, st>>>(a);
+    else conv_kernel<T, false, MODE, 64><<<grid, 256, 0, st>>>(a);
+  }
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -324,7 +409,17 @@ static int fill_geom(const int* g, ConvP& p) {
   p.Ho = (p.H + 2 * p.ph - p.dh * (p.KH - 1) - 1) / p.sh + 1;
   p.Wo = (p.W + 2 * p.pw - p.dw * (p.KW - 1) - 1) / p.sw + 1;
   p.Cg = p.Ci / p.G; p.Cog = p.Co / p.G;
-  return conv_geom_ok(p) ? 0 : CPLXAMD_ESHAPE;
+  if (!conv_geom_ok(p)) return CPLXAMD_ESHAPE;
+  // the gathers index pixels and taps in 32 bits (offsets into the tensors stay 64-bit)
+  const int64_t lim = 0x7fe00000;   // (room for the split-K chunk rounding)
+  if ((int64_t)p.B * p.Ho * p.Wo > lim || (int64_t)p.B * p.H * p.W > lim || (int64_t)p.Cg * p.KH * p.KW > lim ||
+      (int64_t)p.Cog * p.KH * p.KW > lim)
+    return CPLXAMD_ESHAPE;
+  p.f_khw = make_fastdiv((int64_t)p.KH * p.KW); p.f_kw = make_fastdiv(p.KW);
+  p.f_howo = make_fastdiv((int64_t)p.Ho * p.Wo); p.f_wo = make_fastdiv(p.Wo);
+  p.f_hw = make_fastdiv((int64_t)p.H * p.W); p.f_w = make_fastdiv(p.W);
+  p.f_sh = make_fastdiv(p.sh); p.f_sw = make_fastdiv(p.sw);
+  return 0;
 }
 
 int cplxamd_conv2d_out_shape(const int* geom, int* ho, int* wo) {
@@ -347,7 +442,7 @@ int cplxamd_conv2d_fwd(const void* xr, const void* xi, const void* wr, const voi
   a.xr = xr; a.xi = xi; a.wr = wr; a.wi = wi; a.bias_r = bias_r; a.bias_i = bias_i;
   a.yr = yr; a.yi = yi;
   if (a.p.B == 0) return 0;                                   // empty batch: nothing to write
-  a.M = a.p.Cog; a.N = (int64_t)a.p.B * a.p.Ho * a.p.Wo; a.K = (int64_t)a.p.Cg * a.p.KH * a.p.KW;
+  a.M = a.p.Cog; a.N = a.p.B * a.p.Ho * a.p.Wo; a.K = a.p.Cg * a.p.KH * a.p.KW;
   a.splits = 1; a.kchunk = a.K;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32) return conv_launch<float, MODE_FWD>(a, cplx, st);
@@ -365,7 +460,7 @@ int cplxamd_conv2d_dgrad(const void* gr, const void* gi, const void* wr, const v
   if (rc) return rc;
   a.xr = gr; a.xi = gi; a.wr = wr; a.wi = wi; a.yr = dxr; a.yi = dxi;
   if (a.p.B == 0) return 0;
-  a.M = a.p.Cg; a.N = (int64_t)a.p.B * a.p.H * a.p.W; a.K = (int64_t)a.p.Cog * a.p.KH * a.p.KW;
+  a.M = a.p.Cg; a.N = a.p.B * a.p.H * a.p.W; a.K = a.p.Cog * a.p.KH * a.p.KW;
   a.splits = 1; a.kchunk = a.K;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32) return conv_launch<float, MODE_DGRAD>(a, cplx, st);
@@ -378,7 +473,8 @@ int cplxamd_conv2d_wgrad_splits(const int* geom) {
   ConvP p;
   if (fill_geom(geom, p)) return 0;
   const int64_t K = (int64_t)p.B * p.Ho * p.Wo;
-  const int64_t tiles = (int64_t)((p.Cog + CBM - 1) / CBM) * (((int64_t)p.Cg * p.KH * p.KW + CBN - 1) / CBN) * p.G;
+  const int tm = conv_tile_m(p.Cog);
+  const int64_t tiles = (int64_t)((p.Cog + tm - 1) / tm) * (((int64_t)p.Cg * p.KH * p.KW + CBN - 1) / CBN) * p.G;
   int64_t s = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU; more only adds slab traffic
   const int64_t maxs = (K + 4 * CBK - 1) / (4 * CBK);
   if (s > maxs) s = maxs;
@@ -413,8 +509,8 @@ int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const v
   a.splits = cplxamd_conv2d_wgrad_splits(geom);
   a.xr = gr; a.xi = gi; a.wr = xr; a.wi = xi;
   a.yr = ws; a.yi = (float*)ws + (int64_t)a.splits * wsz;
-  a.M = a.p.Cog; a.N = (int64_t)a.p.Cg * a.p.KH * a.p.KW; a.K = (int64_t)a.p.B * a.p.Ho * a.p.Wo;
-  a.kchunk = ((a.K + a.splits - 1) / a.splits + CBK - 1) / CBK * CBK;
+  a.M = a.p.Cog; a.N = a.p.Cg * a.p.KH * a.p.KW; a.K = a.p.B * a.p.Ho * a.p.Wo;
+  a.kchunk = (int)((((int64_t)a.K + a.splits - 1) / a.splits + CBK - 1) / CBK * CBK);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32) rc = conv_launch<float, MODE_WGRAD>(a, cplx, st);
   else if (dtype == CPLXAMD_BF16) rc = conv_launch<bf16_t, MODE_WGRAD>(a, cplx, st);
