@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -60,6 +60,7 @@ SIGNATURES = {
     "cplxamd_bilinear_reduce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_deinterleave": [_P, _P, _P, _L, _I, _P],
     "cplxamd_interleave": [_P, _P, _P, _L, _I, _P],
+    "cplxamd_split_relu": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "cplxamd_modrelu_fwd": [_P, _P, _P, _F, _I, _P, _P, _L, _I, _P],
     "cplxamd_modrelu_bwd": [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _L, _I, _P],
     "cplxamd_cplx_dropout": [_P, _P, _P, _P, _D, _U, _U, _P, _L, _I, _P],
@@ -83,6 +84,7 @@ SIGNATURES = {
     "cplxamd_conv2d_cl_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cplxamd_conv2d_cl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _P],
     "cplxamd_conv2d_cl2": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _P],
+    "cplxamd_chansum2": [_P, _P, _P, _P, _L, _I, _L, _I, _P, _P],
     "cplxamd_conv2d_cl2_lrt_dx": [_P] * 8 + [_L] + [_I] * 6 + [_P, _L, _P],
     "cplxamd_conv2d_cl_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
     "cplxamd_conv2d_cl_wgrad": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],

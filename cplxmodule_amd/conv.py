@@ -494,6 +494,18 @@ def chansum(g):
     return out
 
 
+def chansum2(gr, gi):
+    """The complex bias gradient: per-channel sums of both NCHW planes, both planes per launch -> float32 ([C], [C])."""
+    B, C = gr.shape[0], gr.shape[1]
+    if gr.numel() == 0:
+        return (torch.zeros(C, dtype=torch.float32, device=gr.device),) * 2
+    S = gr.numel() // (B * C)
+    out = torch.empty(2, C, dtype=torch.float32, device=gr.device)
+    ws = _scratch(gr.device, 2 * 64 * C * 8)
+    call("cplxamd_chansum2", ptr(gr), ptr(gi), ptr(out[0]), ptr(out[1]), B, C, S, dtype_code(gr), ptr(ws), stream_ptr())
+    return out[0], out[1]
+
+
 def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
     """Backward of the channels-last forward: xr / xi are the saved channels-last inputs."""
     need = ctx.needs_input_grad
@@ -567,7 +579,7 @@ class CplxConv2dFn(torch.autograd.Function):
             else:
                 dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape, gp=gp)
         if ctx.has_bias and (need[4] or need[5]):
-            dbr, dbi = chansum(gr), chansum(gi)
+            dbr, dbi = chansum2(gr, gi)
         return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
 
 
@@ -741,7 +753,7 @@ class CplxConv2dLRTFn(torch.autograd.Function):
         if need[2] or need[3]:
             dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape)
         if ctx.has_bias and (need[4] or need[5]):
-            dbr, dbi = chansum(gr), chansum(gi)
+            dbr, dbi = chansum2(gr, gi)
         if need[6]:
             dls2, _ = conv_wgrad(gs2, None, a, None, ctx.geom, ctx.wshape,
                                  emul=ops.exp(ls2.contiguous()))
@@ -960,7 +972,7 @@ class CplxConvTranspose2dFn(torch.autograd.Function):
             dwr, dvi = conv_wgrad(xr, xi, gr, gi, ctx.geom, ctx.wshape)
             dwi = -dvi
         if ctx.has_bias and (need[4] or need[5]):
-            dbr, dbi = chansum(gr), chansum(gi)
+            dbr, dbi = chansum2(gr, gi)
         return (dxr, dxi, dwr, dwi, dbr, dbi) + (None,) * 5
 
 

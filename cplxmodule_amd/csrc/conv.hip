@@ -20,7 +20,7 @@ namespace cplxamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CBM = 64, CBN = 64, CBK = 16;
+constexpr int CBM = 64, CBN = 64, CBK = 16, KH16 = CBK / 16;   // (K step 32 measured no faster on the narrow layers of cfg5: 1.32 vs 1.29 ms per step)
 
 // Division by a launch-constant divisor of indices below 2^31: q = (x * mul) >> (31 + s), s = ceil(log2 d),
 // mul = floor(2^(31 + s) / d) + 1 (Granlund-Montgomery round-up multiplier, exact for x < 2^31); d = 1 passes x through.
@@ -66,13 +66,13 @@ __device__ __forceinline__ float ldv(const void* p, int64_t off) {
   return io<T>::ld(reinterpret_cast<const T*>(p) + off);
 }
 
-// Implicit-GEMM tile: TM x 64 outputs per workgroup of 4 waves, K in steps of 16, double-buffered in LDS; the gathers
+// Implicit-GEMM tile: TM x 64 outputs per workgroup of 4 waves, K in steps of CBK = 16, double-buffered in LDS; the gathers
 // of tile t + 1 are in flight while the MFMAs of tile t run.
 //   TM = 64: waves 2 (M) x 2 (N), each a 32 x 32 MFMA block over the whole K step.
 //   TM = 32 (M <= 32: narrow layers): waves 2 (N) x 2 (K halves of each step), partial sums joined through LDS at the
 //            end -- twice the workgroups and half the MFMA chain per wave of a 32 x 128 tile.
-// Operand elements per thread and K step: A (TM x 16): k = t & 15 fixed, rows (t >> 4) + 16 j; B (64 x 16): pixels fastest
-// (FWD, DGRAD: row t & 63 fixed, k = (t >> 6) + 4 j) or k fastest (WGRAD: k = t & 15 fixed, rows (t >> 4) + 16 j).
+// Operand elements per thread and K step: A (TM x CBK): k = (t & 15) + 16 h, rows (t >> 4) + 16 j; B (64 x CBK): pixels fastest
+// (FWD, DGRAD: row t & 63 fixed, k = (t >> 6) + 4 j) or k fastest (WGRAD: k = (t & 15) + 16 h, rows (t >> 4) + 16 j).
 // Whatever is fixed per thread is decomposed ONCE in front of the K loop.
 template <typename T, bool CPLX, int MODE, int TM>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
@@ -138,53 +138,59 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
   }
 
-  float ar_[AJ], ai_[AJ], br_[4], bi_[4];
+  constexpr int BJ = CBK / 4;                                  // B elements per thread and K step (pixels fastest)
+  float ar_[KH16][AJ], ai_[KH16][AJ], br_[BJ], bi_[BJ];
   auto fetch_both = [&](int k0) __attribute__((always_inline)) {
-    // ---- A: weights (FWD: k contiguous; DGRAD: gathered) / grad-out (WGRAD: k = pixels contiguous)
-    const int gk = k0 + ka;
-    const bool kok = gk < kend;
-    int64_t abase = 0, astride = 0;                            // element (row m, this k) = abase + m * astride
-    int wb = 0, woh = 0, wow = 0;                              // WGRAD: pixel of this k
-    if (MODE == MODE_FWD) {
-      abase = (int64_t)g * p.Cog * a.K + gk; astride = a.K;
-    } else if (MODE == MODE_DGRAD) {
-      const int co = kok ? fdiv(gk, p.f_khw) : 0, r = gk - co * khw;
-      abase = ((int64_t)g * p.Cog + co) * p.Cg * khw + r; astride = khw;
-    } else {
-      wb = kok ? fdiv(gk, p.f_howo) : 0;
-      const int r = gk - wb * howo;
-      woh = kok ? fdiv(r, p.f_wo) : 0; wow = r - woh * p.Wo;
-      abase = ((int64_t)wb * p.Co + (int64_t)g * p.Cog) * howo + r; astride = howo;
-    }
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int m = m0 + ra0 + 16 * j;
-      float vr = 0.f, vi = 0.f;
-      if (kok && m < a.M) {
-        const int64_t off = abase + (int64_t)m * astride;
-        vr = ldv<T>(a_r, off);
-        if (CPLX) vi = ldv<T>(a_i, off);
+    for (int h = 0; h < KH16; ++h) {
+      // ---- A: weights (FWD: k contiguous; DGRAD: gathered) / grad-out (WGRAD: k = pixels contiguous)
+      const int gk = k0 + ka + 16 * h;
+      const bool kok = gk < kend;
+      int64_t abase = 0, astride = 0;                            // element (row m, this k) = abase + m * astride
+      int wb = 0, woh = 0, wow = 0;                              // WGRAD: pixel of this k
+      if (MODE == MODE_FWD) {
+        abase = (int64_t)g * p.Cog * a.K + gk; astride = a.K;
+      } else if (MODE == MODE_DGRAD) {
+        const int co = kok ? fdiv(gk, p.f_khw) : 0, r = gk - co * khw;
+        abase = ((int64_t)g * p.Cog + co) * p.Cg * khw + r; astride = khw;
+      } else {
+        wb = kok ? fdiv(gk, p.f_howo) : 0;
+        const int r = gk - wb * howo;
+        woh = kok ? fdiv(r, p.f_wo) : 0; wow = r - woh * p.Wo;
+        abase = ((int64_t)wb * p.Co + (int64_t)g * p.Cog) * howo + r; astride = howo;
       }
-      ar_[j] = vr; ai_[j] = vi;
-    }
-    // ---- B
-    if (MODE == MODE_WGRAD) {
-      const int ihb = woh * p.sh, iwb = wow * p.sw;
-      const int64_t xb = ((int64_t)wb * p.Ci + (int64_t)g * p.Cg) * p.H * p.W;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < AJ; ++j) {
+        const int m = m0 + ra0 + 16 * j;
         float vr = 0.f, vi = 0.f;
-        const int ih = ihb + w_dh[j], iw = iwb + w_dw[j];
-        if (kok && w_ci[j] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-          const int64_t off = xb + ((int64_t)w_ci[j] * p.H + ih) * p.W + iw;
-          vr = ldv<T>(b_r, off);
-          if (CPLX) vi = ldv<T>(b_i, off);
+        if (kok && m < a.M) {
+          const int64_t off = abase + (int64_t)m * astride;
+          vr = ldv<T>(a_r, off);
+          if (CPLX) vi = ldv<T>(a_i, off);
         }
-        br_[j] = vr; bi_[j] = vi;
+        ar_[h][j] = vr; ai_[h][j] = vi;
       }
-    } else {
+      // ---- B, k fastest (WGRAD): the same k, rows = taps
+      if (MODE == MODE_WGRAD) {
+        const int ihb = woh * p.sh, iwb = wow * p.sw;
+        const int64_t xb = ((int64_t)wb * p.Ci + (int64_t)g * p.Cg) * p.H * p.W;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {
+          float vr = 0.f, vi = 0.f;
+          const int ih = ihb + w_dh[j], iw = iwb + w_dw[j];
+          if (kok && w_ci[j] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+            const int64_t off = xb + ((int64_t)w_ci[j] * p.H + ih) * p.W + iw;
+            vr = ldv<T>(b_r, off);
+            if (CPLX) vi = ldv<T>(b_i, off);
+          }
+          br_[h * 4 + j] = vr; bi_[h * 4 + j] = vi;
+        }
+      }
+    }
+    // ---- B, pixels fastest (FWD, DGRAD)
+    if (MODE != MODE_WGRAD) {
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
         const int k = k0 + kb0 + 4 * j;
         float vr = 0.f, vi = 0.f;
         if (b_ok && k < kend) {
@@ -215,16 +221,23 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   };
   auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      As_r[buf][ka][ra0 + 16 * j] = ar_[j];
-      if (CPLX) As_i[buf][ka][ra0 + 16 * j] = ai_[j];
-    }
+    for (int h = 0; h < KH16; ++h)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (MODE == MODE_WGRAD) {
-        Bs_r[buf][ka][ra0 + 16 * j] = br_[j];
-        if (CPLX) Bs_i[buf][ka][ra0 + 16 * j] = bi_[j];
-      } else {
+      for (int j = 0; j < AJ; ++j) {
+        As_r[buf][ka + 16 * h][ra0 + 16 * j] = ar_[h][j];
+        if (CPLX) As_i[buf][ka + 16 * h][ra0 + 16 * j] = ai_[h][j];
+      }
+    if (MODE == MODE_WGRAD) {
+#pragma unroll
+      for (int h = 0; h < KH16; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Bs_r[buf][ka + 16 * h][ra0 + 16 * j] = br_[h * 4 + j];
+          if (CPLX) Bs_i[buf][ka + 16 * h][ra0 + 16 * j] = bi_[h * 4 + j];
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
         Bs_r[buf][kb0 + 4 * j][rb] = br_[j];
         if (CPLX) Bs_i[buf][kb0 + 4 * j][rb] = bi_[j];
       }
@@ -309,12 +322,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   }
 }
 
-// out[i] = (sum_s slab[s][i]) (* emul[i])
 // out[i] = (sum_s slab[s][i]) (* emul[i]).  Block = 64 consecutive elements x 16 split lanes (one wave
-// per split lane, coalesced 256-B reads, 4 loads in flight per thread), fixed summation order.
-__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* slabs, int splits, int64_t n,
-                                                        const float* emul, float* out) {
+// per split lane, coalesced 256-B reads, 4 loads in flight per thread), fixed summation order.  blockIdx.y = plane
+// (real / imaginary slabs and outputs; the multiplier applies to plane 0: the real-valued variance path).
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* slabs0, const float* slabs1, int splits, int64_t n,
+                                                        const float* emul, float* out0, float* out1) {
   __shared__ float red[16][64];
+  const float* slabs = blockIdx.y ? slabs1 : slabs0;
+  float* out = blockIdx.y ? out1 : out0;
+  if (blockIdx.y) emul = nullptr;
   const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -362,6 +378,39 @@ __global__ __launch_bounds__(256) void chansum_partial(const T* x, int64_t B, in
   const double t = block_sum<double, 256>(acc, red);
   if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * C + c] = t;
 }
+// both planes of a complex tensor per launch (the complex bias gradient): grid (C, chunks), partial[plane][chunk][c];
+// chansum_final then runs over 2 C "channels".  (Finishing in the same launch -- the last block of a channel to take a
+// ticket adds up the partials -- was measured SLOWER on this chip: device-scope visibility between the XCDs' L2s costs
+// more than the ~5 us of a second launch, 16 us against 2 x 4.9; with __threadfence() 78 us.)
+template <typename T>
+__global__ __launch_bounds__(256) void chansum2_partial(const T* xr, const T* xi, int64_t B, int C, int64_t S, double* partial) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, chunks = gridDim.y;
+  struct __attribute__((packed, aligned(sizeof(T)))) V8 { T v[8]; };
+  double acc[2] = {0.0, 0.0};
+  const int64_t S8 = S & ~(int64_t)7;
+  for (int64_t b = blockIdx.y; b < B; b += chunks) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const T* p = (pl ? xi : xr) + (b * C + c) * S;
+      for (int64_t s = (int64_t)threadIdx.x * 8; s < S8; s += 256 * 8) {
+        const V8 v = *reinterpret_cast<const V8*>(p + s);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += io<T>::ld(&v.v[e]);
+        acc[pl] += (double)q;
+      }
+      for (int64_t s = S8 + threadIdx.x; s < S; s += 256) acc[pl] += (double)io<T>::ld(p + s);
+    }
+  }
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    const double t = block_sum<double, 256>(acc[pl], red);
+    // laid out as chansum_final reads it for 2 C channels: [chunk][plane * C + c]
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * 2 * C + (int64_t)pl * C + c] = t;
+  }
+}
+
 // one wave per channel: lanes stride over the chunk partials, then a wave reduction
 __global__ __launch_bounds__(64) void chansum_final(const double* partial, int chunks, int C, float* out) {
   const int c = blockIdx.x;
@@ -517,12 +566,9 @@ int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const v
   else return CPLXAMD_EINVAL;
   if (rc) return rc;
   const int sgrid = (int)((wsz + 63) / 64);
-  slab_sum_kernel<<<sgrid, 1024, 0, st>>>((const float*)a.yr, a.splits, wsz, emul, dwr);
+  slab_sum_kernel<<<dim3(sgrid, cplx ? 2 : 1), 1024, 0, st>>>((const float*)a.yr, (const float*)a.yi, a.splits, wsz, emul,
+                                                              dwr, dwi);
   CPLXAMD_CHECK_LAUNCH();
-  if (cplx) {
-    slab_sum_kernel<<<sgrid, 1024, 0, st>>>((const float*)a.yi, a.splits, wsz, nullptr, dwi);
-    CPLXAMD_CHECK_LAUNCH();
-  }
   return 0;
 }
 
@@ -541,6 +587,27 @@ int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int 
     return CPLXAMD_EINVAL;
   CPLXAMD_CHECK_LAUNCH();
   chansum_final<<<C, 64, 0, st>>>((const double*)ws, chunks, C, out);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+/* Complex bias gradient, both planes per launch: out_r[c], out_i[c] = sums over (b, spatial) of the two NCHW planes.
+ * ws >= 2 * 64 * C doubles.  out_r and out_i must be the two halves of one [2][C] array (out_i == out_r + C). */
+int cplxamd_chansum2(const void* xr, const void* xi, float* out_r, float* out_i, int64_t B, int C, int64_t S, int dtype,
+                     void* ws, void* stream) {
+  if (!xr || !xi || !out_r || !out_i || !ws || B <= 0 || C <= 0 || S <= 0) return CPLXAMD_EINVAL;
+  if (out_i != out_r + C) return CPLXAMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = (int)(B < 64 ? B : 64);
+  dim3 grid(C, chunks);
+  if (dtype == CPLXAMD_F32)
+    chansum2_partial<float><<<grid, 256, 0, st>>>((const float*)xr, (const float*)xi, B, C, S, (double*)ws);
+  else if (dtype == CPLXAMD_BF16)
+    chansum2_partial<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)xr, (const bf16_t*)xi, B, C, S, (double*)ws);
+  else
+    return CPLXAMD_EINVAL;
+  CPLXAMD_CHECK_LAUNCH();
+  chansum_final<<<2 * C, 64, 0, st>>>((const double*)ws, chunks, 2 * C, out_r);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }

@@ -43,6 +43,35 @@ __global__ __launch_bounds__(kLT) void interleave_kernel(const T* re, const T* i
   }
 }
 
+// ReLU on both planes of a complex tensor (CplxToCplx[torch.nn.ReLU], cplxmodule/nn/modules/base.py:167-199) in one
+// launch, forward and backward: torch's semantics (NaN passes; the backward masks on the saved OUTPUT, y <= 0 -> 0).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(kLT) void split_relu_kernel(const T* ar, const T* ai, const T* gr, const T* gi, T* or_, T* oi,
+                                                         int64_t n) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * kLT;
+  auto f = [](float a, float g) __attribute__((always_inline)) -> float {
+    if (BWD) return a <= 0.f ? 0.f : g;
+    return (a > 0.f || a != a) ? a : 0.f;
+  };
+  for (int64_t i = (int64_t)blockIdx.x * kLT + threadIdx.x; i < n4; i += stride) {
+    const f4 a = ld4(ar + 4 * i), b = ld4(ai + 4 * i);
+    f4 u = a, v = b, x, y;
+    if (BWD) { u = ld4(gr + 4 * i); v = ld4(gi + 4 * i); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x.v[j] = f(a.v[j], u.v[j]); y.v[j] = f(b.v[j], v.v[j]); }
+    st4(or_ + 4 * i, x);
+    st4(oi + 4 * i, y);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      const float a = io<T>::ld(ar + e), b = io<T>::ld(ai + e);
+      io<T>::st(or_ + e, f(a, BWD ? io<T>::ld(gr + e) : a));
+      io<T>::st(oi + e, f(b, BWD ? io<T>::ld(gi + e) : b));
+    }
+  }
+}
+
 // modReLU with the reference's op order: m = max(|z|, 1e-5) (|z| = sqrt(fma(zi, zi, zr zr)), the CPU
 // kernel's form), s = max(1 - tau / m, 0), y = z s.  tau: scalar value, or a tensor of n elements.
 struct ModRelu {
@@ -204,6 +233,23 @@ int cplxamd_interleave(const void* re, const void* im, void* out, int64_t n, int
   if (dtype == CPLXAMD_F32) interleave_kernel<float><<<grid, kLT, 0, st>>>((const float*)re, (const float*)im, (float*)out, n);
   else if (dtype == CPLXAMD_BF16) interleave_kernel<bf16_t><<<grid, kLT, 0, st>>>((const bf16_t*)re, (const bf16_t*)im, (bf16_t*)out, n);
   else return CPLXAMD_EINVAL;
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+/* y = relu(x) on both planes (bwd == 0), or dx = (y <= 0 ? 0 : g) from the saved outputs (bwd != 0: a_* = y, g_* = g). */
+int cplxamd_split_relu(const void* a_r, const void* a_i, const void* g_r, const void* g_i, void* o_r, void* o_i, int64_t n,
+                       int bwd, int dtype, void* stream) {
+  if (!a_r || !a_i || !o_r || !o_i || n < 0 || (bwd && (!g_r || !g_i))) return CPLXAMD_EINVAL;
+  if (!al16(a_r) || !al16(a_i) || !al16(o_r) || !al16(o_i) || (bwd && (!al16(g_r) || !al16(g_i)))) return CPLXAMD_EALIGN;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid((n >> 2) + 1, kLT);
+#define SR(T, B) split_relu_kernel<T, B><<<grid, kLT, 0, st>>>((const T*)a_r, (const T*)a_i, (const T*)g_r, (const T*)g_i, (T*)o_r, (T*)o_i, n)
+  if (dtype == CPLXAMD_F32) { if (bwd) SR(float, true); else SR(float, false); }
+  else if (dtype == CPLXAMD_BF16) { if (bwd) SR(bf16_t, true); else SR(bf16_t, false); }
+  else return CPLXAMD_EINVAL;
+#undef SR
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }

@@ -98,6 +98,18 @@ def _split_from_module(Module):
         def forward(self, input):
             return input.apply(super().forward)
 
+    if Module is torch.nn.ReLU:
+        # the split activation of the Deep-Complex-Net style models: both planes in ONE launch each way (4 -> 2 launches
+        # per layer and step); in-place modules, CPU tensors and other dtypes keep torch's kernels
+        def forward(self, input):
+            re, im = input.real, input.imag
+            if (self.inplace or not re.is_cuda or re.dtype not in (torch.float32, torch.bfloat16) or re.dtype != im.dtype
+                    or re.shape != im.shape):
+                return input.apply(torch.nn.ReLU.forward.__get__(self))
+            from ... import ops
+            return Cplx(*ops.split_relu(re, im))
+        SplitLayer.forward = forward
+
     SplitLayer.__name__ = f"CplxSplitLayer{Module.__name__}"
     return SplitLayer
 

@@ -1288,6 +1288,34 @@ class ModReluFn(torch.autograd.Function):
         return dzr, dzi, dtau
 
 
+class SplitReluFn(torch.autograd.Function):
+    """torch.nn.ReLU on both planes (CplxToCplx[torch.nn.ReLU], cplxmodule/nn/modules/base.py:167-199): one launch
+    forward, one backward (the mask is read off the saved outputs, as aten's threshold_backward does)."""
+
+    @staticmethod
+    def forward(ctx, xr, xi):
+        require_device(xr, xi)
+        ctx.fmt = fmt = _layout_of(xr)
+        xr, xi = _al16(_cf(xr, fmt)), _al16(_cf(xi, fmt))
+        yr, yi = torch.empty_like(xr), torch.empty_like(xi)
+        call("cplxamd_split_relu", ptr(xr), ptr(xi), None, None, ptr(yr), ptr(yi), xr.numel(), 0, dtype_code(xr), stream_ptr())
+        ctx.save_for_backward(yr, yi)
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        yr, yi = ctx.saved_tensors
+        gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
+        dxr, dxi = torch.empty_like(yr), torch.empty_like(yi)
+        call("cplxamd_split_relu", ptr(yr), ptr(yi), ptr(gr), ptr(gi), ptr(dxr), ptr(dxi), yr.numel(), 1, dtype_code(yr),
+             stream_ptr())
+        return dxr, dxi
+
+
+def split_relu(xr, xi):
+    return SplitReluFn.apply(xr, xi)
+
+
 class CplxDropoutFn(torch.autograd.Function):
     """One keep / drop decision per complex element (nn/modules/extra.py:7-25); the mask is a
     function of (seed, offset) and is regenerated in backward."""

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 15
+#define CPLXAMD_ABI_VERSION 16
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -456,6 +456,11 @@ int cplxamd_conv2d_clr_wgrad(const void* g, const void* x, const float* emul, in
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);
+/* The complex bias gradient: out_r[c], out_i[c] (one [2][C] array: out_i == out_r + C) = the same sums of the two
+ * planes, both planes per launch (2 launches instead of 4: small models are bound by the NUMBER of dependent
+ * launches).  ws >= 2*64*C*8 bytes. */
+int cplxamd_chansum2(const void* x_r, const void* x_i, float* out_r, float* out_i, int64_t B, int C, int64_t S, int dtype,
+                     void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K3  complex batch normalisation (2x2 whitening + 2x2 affine), forward and backward.
@@ -509,6 +514,11 @@ int cplxamd_bn_bwd_sync(const void* gr, const void* gi, const void* xr, const vo
                         float* dbias, int dtype, float* dx_sums, const double* moments, const double* local_moments,
                         const double* count, void* ws, int64_t ws_bytes, void* stream);
 
+/* ReLU applied to the real and the imaginary plane (CplxToCplx[torch.nn.ReLU], nn/modules/base.py:167-199) in one launch.
+ * bwd == 0: o = relu(a) (NaN passes, as torch).  bwd != 0: a = the saved OUTPUTS, o = (a <= 0 ? 0 : g)
+ * (= aten::threshold_backward on the result).  16-byte aligned planes of n elements. */
+int cplxamd_split_relu(const void* a_r, const void* a_i, const void* g_r, const void* g_i, void* o_r, void* o_i, int64_t n,
+                       int bwd, int dtype, void* stream);
 /* ------------------------------------------------------------------------------------
  * layout converters and the non-GEMM layers either side of the path.
  *   cplxamd_deinterleave / _interleave : x[2n] <-> (re[n], im[n])   cplx.py:451-470

@@ -411,3 +411,45 @@ def test_fused_lrt_conv_input_gradient_is_bit_identical(shape):
             assert Ci % 64 or Co % 64                        # (the weight-gradient kernel wants 64-channel multiples)
     finally:
         conv._CL_FORCE = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_split_relu_one_launch_matches_torch(dtype):
+    """CplxToCplx[torch.nn.ReLU] on device tensors = ONE launch for both planes each way (cplxamd_split_relu), with
+    torch's semantics: NaN passes, the backward masks on the output; in-place modules keep torch's kernels."""
+    from cplxmodule_amd import Cplx, nn
+    dev = "cuda"
+    torch.manual_seed(3)
+    xr = torch.randn(5, 7, 9, 11, device=dev).to(dtype)
+    xi = torch.randn(5, 7, 9, 11, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    xr.view(-1)[:4] = torch.tensor([float("nan"), -0.0, 0.0, float("inf")], device=dev, dtype=dtype)
+    xr.requires_grad_(True); xi.requires_grad_(True)
+    gr, gi = torch.randn_like(xr), torch.randn_like(xi)
+    act = nn.CplxToCplx[torch.nn.ReLU]()
+    y = act(Cplx(xr, xi))
+    torch.autograd.backward((y.real, y.imag), (gr, gi))
+    got = (y.real.detach(), y.imag.detach(), xr.grad.clone(), xi.grad.clone())
+    xr.grad = xi.grad = None
+    rr, ri = torch.relu(xr), torch.relu(xi)
+    torch.autograd.backward((rr, ri), (gr, gi))
+    for a, b in zip(got, (rr.detach(), ri.detach(), xr.grad, xi.grad)):
+        assert torch.equal(torch.nan_to_num(a.float(), nan=7.0), torch.nan_to_num(b.float(), nan=7.0))
+    assert type(y.real.grad_fn).__name__.startswith("SplitReluFn")
+    z = nn.CplxToCplx[torch.nn.ReLU](inplace=True)(Cplx(xr.detach().clone(), xi.detach().clone()))
+    assert torch.equal(torch.nan_to_num(z.real.float(), nan=7.0), torch.nan_to_num(rr.detach().float(), nan=7.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 8, 28, 28), (3, 5, 7, 9), (70, 33, 1, 13), (1, 1, 1, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_complex_bias_gradient_both_planes_per_launch(shape, dtype):
+    """cplxamd_chansum2 (both planes in each of its two launches) == two cplxamd_chansum calls, bit for bit."""
+    from cplxmodule_amd import conv
+    dev = "cuda"
+    torch.manual_seed(sum(shape))
+    gr, gi = (torch.randn(*shape, device=dev).to(dtype) for _ in range(2))
+    a, b = conv.chansum2(gr, gi)
+    assert torch.equal(a, conv.chansum(gr)) and torch.equal(b, conv.chansum(gi))
+    ref = gr.double().sum(dim=(0, 2, 3))
+    assert (a.double() - ref).abs().max() <= 1e-6 * gr.double().abs().sum(dim=(0, 2, 3)).max() + 1e-30
