@@ -71,7 +71,7 @@ def test_batchnorm_functional_and_cma(golden):
         nn.CplxBatchNorm2d(3).to("cuda")(Cplx(xr, xi))
 
 
-@pytest.mark.parametrize("shape", [(8, 16, 33, 20), (3, 5, 7, 9), (512, 24), (2, 64, 128, 128)])
+@pytest.mark.parametrize("shape", [(8, 16, 33, 20), (3, 5, 7, 9), (512, 24), (2, 64, 128, 128), (256, 8, 28, 28), (70, 32, 7, 7)])
 def test_batchnorm_vs_oracle_shapes(shape):
     """Shapes that exercise the vector / scalar paths, plane segmentation and the [B,F] kernel;
     output moments must come out as (0, I): whitening property, size independent."""
