@@ -69,25 +69,41 @@ __device__ __forceinline__ float ldv(const void* p, int64_t off) {
 // Implicit-GEMM tile: TM x 64 outputs per workgroup of 4 waves, K in steps of CBK = 16, double-buffered in LDS; the gathers
 // of tile t + 1 are in flight while the MFMAs of tile t run.
 //   TM = 64: waves 2 (M) x 2 (N), each a 32 x 32 MFMA block over the whole K step.
-//   TM = 32 (M <= 32: narrow layers): waves 2 (N) x 2 (K halves of each step), partial sums joined through LDS at the
-//            end -- twice the workgroups and half the MFMA chain per wave of a 32 x 128 tile.
-// Operand elements per thread and K step: A (TM x CBK): k = (t & 15) + 16 h, rows (t >> 4) + 16 j; B (64 x CBK): pixels fastest
-// (FWD, DGRAD: row t & 63 fixed, k = (t >> 6) + 4 j) or k fastest (WGRAD: k = (t & 15) + 16 h, rows (t >> 4) + 16 j).
-// Whatever is fixed per thread is decomposed ONCE in front of the K loop.
-template <typename T, bool CPLX, int MODE, int TM>
+//   TM = 32 (M <= 32: narrow layers), TN = 64: waves 2 (N) x 2 (K halves of each step), partial sums joined through LDS
+//            at the end -- twice the workgroups and half the MFMA chain per wave of a 32 x 128 tile.
+//   TM = 32, TN = 32 (narrow layers with few pixels: fewer than two 32 x 64 tiles per CU): the four waves take a quarter
+//            of each K step -- with one workgroup per CU a wave has its SIMD to itself, and its gather arithmetic, LDS
+//            traffic and MFMAs simply add up (PMC: VALU 9 %, MFMA 10 % busy on cfg5's 7 x 7 layers); half the tile is half
+//            of all three per wave, on twice the workgroups.
+// Operand elements per thread and K step: A (TM x CBK): k = (t & 15) + 16 h, rows (t >> 4) + 16 j; B (TN x CBK): pixels
+// fastest (FWD, DGRAD: row t % TN fixed, k = t / TN + (256 / TN) j) or k fastest (WGRAD: k = (t & 15) + 16 h, rows
+// (t >> 4) + 16 j).  Whatever is fixed per thread is decomposed ONCE in front of the K loop.
+template <typename T, bool CPLX, int MODE, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
-  constexpr int ALD = TM + 1, BLD = CBN + 1, AJ = TM / 16;
-  constexpr bool KSPLIT = TM == 32;
+  static_assert((TM == 64 && TN == 64) || (TM == 32 && (TN == 64 || TN == 32)), "tile shapes");
+  constexpr int ALD = TM + 1, BLD = TN + 1, AJ = TM / 16;
+  constexpr int WN = TN / 32, KS = 4 / ((TM / 32) * WN);       // waves along N; K parts of a step (1, 2 or 4)
+  constexpr bool KSPLIT = KS > 1;
+  constexpr int KBS = 256 / TN, BJ = CBK / KBS, WJ = TN / 16;  // B: k stride / elements per thread (pixels fastest); rows (k fastest)
+  // LDS: operand rings (statically addressed: the MFMA loop's reads fold their offsets into the instructions); the
+  // K-split's hand-over buffers (2 waves x 16 x 64 floats per plane) reuse the B rings once the K loop is done -- 25 KiB
+  // per workgroup instead of 41: more workgroups per CU, which is what hides the load latencies of the short (1-5 K step)
+  // workgroups of wide, shallow layers
+  constexpr int NPL = CPLX ? 2 : 1;
   __shared__ float As_r[2][CBK][ALD], Bs_r[2][CBK][BLD];
   __shared__ float As_i[CPLX ? 2 : 1][CPLX ? CBK : 1][ALD], Bs_i[CPLX ? 2 : 1][CPLX ? CBK : 1][BLD];
-  __shared__ float red[KSPLIT ? 2 : 1][CPLX ? 2 : 1][KSPLIT ? 16 : 1][64];
+  __shared__ float sbias[2][64];                               // this tile's bias (FWD)
+  static_assert(KS != 2 || 2 * 16 * 64 <= 2 * CBK * BLD, "hand-over buffer must fit in a B ring");
+  __shared__ float red4[KS == 4 ? 3 * NPL * 16 * 64 : 1];     // (three handing waves: does not fit in the 32-wide rings)
+  float (*red_r)[16][64] = reinterpret_cast<float (*)[16][64]>(KS == 4 ? &red4[0] : &Bs_r[0][0][0]);
+  float (*red_i)[16][64] = reinterpret_cast<float (*)[16][64]>(KS == 4 ? &red4[CPLX ? 3 * 16 * 64 : 0] : &Bs_i[0][0][0]);
   const ConvP& p = a.p;
   const int t = threadIdx.x;
   const int g = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * CBN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int lane = t & 63, wid = t >> 6;
-  const int wm = KSPLIT ? 0 : (wid >> 1) * 32, wn = (wid & 1) * 32, l31 = lane & 31, lk = lane >> 5;
-  const int kq = KSPLIT ? (wid >> 1) : 0;
+  const int wm = KSPLIT ? 0 : (wid >> 1) * 32, wn = (wid % WN) * 32, l31 = lane & 31, lk = lane >> 5;
+  const int kq = KSPLIT ? wid / WN : 0;                        // which K part of each step
   const int kbeg = split * a.kchunk;
   int kend = kbeg + a.kchunk;
   if (kend > a.K) kend = a.K;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 
   // ---- per-thread constants of the gathers
   const int ka = t & 15, ra0 = t >> 4;                         // A: k lane, first row
-  const int rb = t & 63, kb0 = t >> 6;                         // B (pixels fastest): row, first k
+  const int rb = t % TN, kb0 = t / TN;                         // B (pixels fastest): row, first k
   // B row = output pixel (FWD) / input pixel (DGRAD): image, and the window origin
   bool b_ok = false;
   int b_h0 = 0, b_w0 = 0;
@@ -124,9 +140,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
   }
   // WGRAD: B rows = (ci, kh, kw) taps
-  int w_ci[4], w_dh[4], w_dw[4];
+  int w_ci[WJ], w_dh[WJ], w_dw[WJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < WJ; ++j) {
     w_ci[j] = -1; w_dh[j] = w_dw[j] = 0;
     if (MODE == MODE_WGRAD) {
       const int n = n0 + ra0 + 16 * j;
@@ -138,8 +154,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
   }
 
-  constexpr int BJ = CBK / 4;                                  // B elements per thread and K step (pixels fastest)
-  float ar_[KH16][AJ], ai_[KH16][AJ], br_[BJ], bi_[BJ];
+  constexpr int NB = MODE == MODE_WGRAD ? KH16 * WJ : BJ;      // B elements per thread and K step
+  float ar_[KH16][AJ], ai_[KH16][AJ], br_[NB], bi_[NB];
   auto fetch_both = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < KH16; ++h) {
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         const int ihb = woh * p.sh, iwb = wow * p.sw;
         const int64_t xb = ((int64_t)wb * p.Ci + (int64_t)g * p.Cg) * p.H * p.W;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WJ; ++j) {
           float vr = 0.f, vi = 0.f;
           const int ih = ihb + w_dh[j], iw = iwb + w_dw[j];
           if (kok && w_ci[j] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
             vr = ldv<T>(b_r, off);
             if (CPLX) vi = ldv<T>(b_i, off);
           }
-          br_[h * 4 + j] = vr; bi_[h * 4 + j] = vi;
+          br_[h * WJ + j] = vr; bi_[h * WJ + j] = vi;
         }
       }
     }
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     if (MODE != MODE_WGRAD) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
-        const int k = k0 + kb0 + 4 * j;
+        const int k = k0 + kb0 + KBS * j;
         float vr = 0.f, vi = 0.f;
         if (b_ok && k < kend) {
           const int c = fdiv(k, p.f_khw), rk = k - c * khw;      // c: input channel (FWD) / output channel (DGRAD)
@@ -231,30 +247,34 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 #pragma unroll
       for (int h = 0; h < KH16; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          Bs_r[buf][ka + 16 * h][ra0 + 16 * j] = br_[h * 4 + j];
-          if (CPLX) Bs_i[buf][ka + 16 * h][ra0 + 16 * j] = bi_[h * 4 + j];
+        for (int j = 0; j < WJ; ++j) {
+          Bs_r[buf][ka + 16 * h][ra0 + 16 * j] = br_[h * WJ + j];
+          if (CPLX) Bs_i[buf][ka + 16 * h][ra0 + 16 * j] = bi_[h * WJ + j];
         }
     } else {
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
-        Bs_r[buf][kb0 + 4 * j][rb] = br_[j];
-        if (CPLX) Bs_i[buf][kb0 + 4 * j][rb] = bi_[j];
+        Bs_r[buf][kb0 + KBS * j][rb] = br_[j];
+        if (CPLX) Bs_i[buf][kb0 + KBS * j][rb] = bi_[j];
       }
     }
   };
 
   f32x16 acc_r = {0}, acc_i = {0};
+  if (MODE == MODE_FWD && a.bias_r && t < 2 * TM) {            // the tile's bias -> LDS now, not a dependent load in the epilogue
+    const int pl = t / TM, m = m0 + (t - pl * TM);
+    if (pl == 0 || CPLX) sbias[pl][t - pl * TM] = m < a.M ? (pl ? a.bias_i : a.bias_r)[g * p.Cog + m] : 0.f;
+  }
   if (kbeg < kend) fetch_both(kbeg);
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += CBK, buf ^= 1) {
     commit(buf);
     __syncthreads();                         // tile visible; the other buffer is free again
     if (k0 + CBK < kend) fetch_both(k0 + CBK);
-    constexpr int KK0 = 0, KKN = KSPLIT ? CBK / 2 : CBK;
+    constexpr int KKN = CBK / KS;
 #pragma unroll
-    for (int kk = KK0; kk < KKN; kk += 2) {
-      const int kr = kq * (CBK / 2) + kk + lk;
+    for (int kk = 0; kk < KKN; kk += 2) {
+      const int kr = kq * KKN + kk + lk;
       const float ar = As_r[buf][kr][wm + l31];
       const float br = Bs_r[buf][kr][wn + l31];
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, acc_r, 0, 0, 0);
@@ -267,21 +287,25 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
       }
     }
   }
-  if (KSPLIT) {                              // join the two K halves: waves 2, 3 hand theirs to waves 0, 1
-    if (kq == 1) {
+  if (KSPLIT) {                              // join the K parts: the waves with kq > 0 hand theirs to the kq == 0 waves
+    __syncthreads();                         // (every wave is done with the B rings the hand-over buffer may live in)
+    if (kq > 0) {
+      const int slot = (kq - 1) * WN + (wid % WN);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        red[wid & 1][0][r][lane] = acc_r[r];
-        if (CPLX) red[wid & 1][CPLX ? 1 : 0][r][lane] = acc_i[r];
+        red_r[slot][r][lane] = acc_r[r];
+        if (CPLX) red_i[slot][r][lane] = acc_i[r];
       }
     }
     __syncthreads();
-    if (kq == 1) return;
+    if (kq > 0) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc_r[r] += red[wid & 1][0][r][lane];
-      if (CPLX) acc_i[r] += red[wid & 1][CPLX ? 1 : 0][r][lane];
-    }
+    for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc_r[r] += red_r[q * WN + (wid % WN)][r][lane];
+        if (CPLX) acc_i[r] += red_i[q * WN + (wid % WN)][r][lane];
+      }
   }
 
   // epilogue: col = lane & 31 runs along N, rows (M) across registers
@@ -309,8 +333,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     const int64_t o = out_base + (int64_t)m * out_mstride;
     float vr = acc_r[r], vi = acc_i[r];
     if (MODE == MODE_FWD && a.bias_r) {
-      vr += a.bias_r[g * p.Cog + m];
-      if (CPLX) vi += a.bias_i[g * p.Cog + m];
+      vr += sbias[0][m - m0];
+      if (CPLX) vi += sbias[1][m - m0];
     }
     if (MODE == MODE_WGRAD) {
       reinterpret_cast<float*>(a.yr)[o] = vr;
@@ -427,19 +451,25 @@ static bool conv_geom_ok(const ConvP& p) {
 }
 
 static int conv_tile_m(int64_t M) { return M <= 32 ? 32 : CBM; }
+// narrow layers with few pixels: 32-pixel tiles when 64-pixel ones would leave the chip with fewer than two per CU
+static int conv_tile_n(int64_t M, int64_t N, int64_t zdim) {
+  return (M <= 32 && ((N + CBN - 1) / CBN) * ((M + 31) / 32) * zdim < 512) ? 32 : CBN;
+}
 
 template <typename T, int MODE>
 static int conv_launch(ConvArgs& a, bool cplx, hipStream_t st) {
-  const int tm = conv_tile_m(a.M);
-  dim3 grid((unsigned)((a.N + CBN - 1) / CBN), (unsigned)((a.M + tm - 1) / tm), (unsigned)(a.p.G * a.splits));
+  const int tm = conv_tile_m(a.M), tn = conv_tile_n(a.M, a.N, (int64_t)a.p.G * a.splits);
+  dim3 grid((unsigned)((a.N + tn - 1) / tn), (unsigned)((a.M + tm - 1) / tm), (unsigned)(a.p.G * a.splits));
   if (grid.y > 65535 || grid.z > 65535) return CPLXAMD_ESHAPE;
-  if (tm == 32) {
-    if (cplx) conv_kernel<T, true, MODE, 32><<<grid, 256, 0, st>>>(a);
-    else conv_kernel<T, false, MODE, 32><<<grid, 256, 0, st>>>(a);
-  } else {
-    if (cplx) conv_kernel<T, true, MODE, 64><<<grid, 256, 0, st>>>(a);
-    else conv_kernel<T, false, MODE, 64><<<grid, 256, 0, st>>>(a);
-  }
+#define CONV_GO(TM_, TN_)                                                                   \
+  do {                                                                                      \
+    if (cplx) conv_kernel<T, true, MODE, TM_, TN_><<<grid, 256, 0, st>>>(a);                \
+    else conv_kernel<T, false, MODE, TM_, TN_><<<grid, 256, 0, st>>>(a);                    \
+  } while (0)
+  if (tm == 64) CONV_GO(64, 64);
+  else if (tn == 64) CONV_GO(32, 64);
+  else CONV_GO(32, 32);
+#undef CONV_GO
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -523,7 +553,7 @@ int cplxamd_conv2d_wgrad_splits(const int* geom) {
   if (fill_geom(geom, p)) return 0;
   const int64_t K = (int64_t)p.B * p.Ho * p.Wo;
   const int tm = conv_tile_m(p.Cog);
-  const int64_t tiles = (int64_t)((p.Cog + tm - 1) / tm) * (((int64_t)p.Cg * p.KH * p.KW + CBN - 1) / CBN) * p.G;
+  const int64_t tiles = (int64_t)((p.Cog + tm - 1) / tm) * (((int64_t)p.Cg * p.KH * p.KW + CBN - 1) / CBN) * p.G;   // (64-wide: the split plan comes first)
   int64_t s = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU; more only adds slab traffic
   const int64_t maxs = (K + 4 * CBK - 1) / (4 * CBK);
   if (s > maxs) s = maxs;
