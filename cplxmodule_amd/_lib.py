@@ -102,6 +102,7 @@ SIGNATURES = {
     "cplxamd_conv2d_wgrad_splits": [_P],
     "cplxamd_conv2d_wgrad_ws_bytes": [_P, _I],
     "cplxamd_conv2d_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
+    "cplxamd_conv2d_wgrad_bias": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
     "cplxamd_conv2d_out_shape": [_P, _P, _P],
     "cplxamd_conv2d_ktab_size": [_P, _I],
     "cplxamd_conv2d_ktab_fill": [_P, _I, _P],
@@ -112,6 +113,7 @@ SIGNATURES = {
     "cplxamd_chansum": [_P, _P, _L, _I, _L, _I, _P, _P],
     "cplxamd_bn_ws_bytes": [_I],
     "cplxamd_bn_fwd": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _L, _P],
+    "cplxamd_bn_fwd_ex": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _L, _P],
     "cplxamd_bn_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _L, _P],
     "cplxamd_bn_bwd_sums": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _P, _L, _P],
     "cplxamd_bn_rows_path": [_L, _I, _L],

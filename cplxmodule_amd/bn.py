@@ -70,7 +70,8 @@ class CplxBatchNormFn(torch.autograd.Function):
     of weight / bias stay local sums (the data-parallel exchange averages them like any other parameter)."""
 
     @staticmethod
-    def forward(ctx, xr, xi, weight, bias, running_mean, running_var, training, momentum, eps, process_group=None):
+    def forward(ctx, xr, xi, weight, bias, running_mean, running_var, training, momentum, eps, process_group=None,
+                tracked=None):
         require_device(xr, xi, weight, bias, running_mean, running_var)
         if not training and running_mean is None:
             raise ValueError("evaluation mode requires running statistics")
@@ -92,9 +93,10 @@ class CplxBatchNormFn(torch.autograd.Function):
                  ptr(running_mean), ptr(running_var), ptr(saved), dtype_code(xr), momentum, eps, ptr(m),
                  ptr(ctx.count), ptr(ws), ws.numel(), stream_ptr())
         else:
-            call("cplxamd_bn_fwd", ptr(xr), ptr(xi), ptr(yr), ptr(yi), B, F, S, ptr(w), ptr(b),
+            # tracked: the module's num_batches_tracked, incremented by the finalize launch (one launch less per layer)
+            call("cplxamd_bn_fwd_ex", ptr(xr), ptr(xi), ptr(yr), ptr(yi), B, F, S, ptr(w), ptr(b),
                  ptr(running_mean), ptr(running_var), ptr(saved), int(training), dtype_code(xr),
-                 momentum, eps, ptr(ws), ws.numel(), stream_ptr())
+                 momentum, eps, ptr(tracked), ptr(ws), ws.numel(), stream_ptr())
         ctx.save_for_backward(xr, xi, w, saved)
         ctx.training, ctx.affine = training, weight is not None
         return yr, yi
@@ -136,4 +138,4 @@ class CplxBatchNormFn(torch.autograd.Function):
         if sums is not None:
             ops.attach_colsum(dxr, sums[0])
             ops.attach_colsum(dxi, sums[1])
-        return dxr, dxi, dw, db, None, None, None, None, None, None
+        return dxr, dxi, dw, db, None, None, None, None, None, None, None

@@ -440,8 +440,10 @@ def _wgrad_rows(gp, xp, geom, w_shape, emul):
     return None
 
 
-def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None, xp=None, gp=None):
-    """xr / xi may be None when xp (input_grid) is given; gp: a grad_grid shared with conv_dgrad."""
+def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None, xp=None, gp=None, bias_out=None):
+    """xr / xi may be None when xp (input_grid) is given; gp: a grad_grid shared with conv_dgrad.
+    bias_out: a list the BIAS gradient (per-channel sums of gr [, gi], float32) is appended to when the kernel that runs
+    produces it on the way (the generic kernel: one more GEMM column); left empty otherwise -- the caller then sums."""
     lib = _lib.load()
     cplx = gi is not None
     if geom[0] == 0:                       # empty batch: the gradient is zero
@@ -468,8 +470,12 @@ def conv_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None, xp=None, gp=None):
     ws = _scratch(gr.device, nbytes)
     dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)
     dwi = torch.empty_like(dwr) if cplx else None
-    call("cplxamd_conv2d_wgrad", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul), ptr(dwr), ptr(dwi),
-         geom, dtype_code(gr), ptr(ws), ws.numel(), stream_ptr())
+    db = None
+    if bias_out is not None:
+        db = torch.empty((2 if cplx else 1), geom[2], dtype=torch.float32, device=gr.device)
+        bias_out.extend(db[i] for i in range(db.shape[0]))
+    call("cplxamd_conv2d_wgrad_bias", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul), ptr(dwr), ptr(dwi), ptr(db),
+         ptr(db[1]) if (db is not None and cplx) else None, geom, dtype_code(gr), ptr(ws), ws.numel(), stream_ptr())
     return dwr, dwi
 
 
@@ -573,13 +579,15 @@ class CplxConv2dFn(torch.autograd.Function):
         gp = _shared_grad_grid(gr, gi, ctx.geom, need[0] or need[1], need[2] or need[3])
         if need[0] or need[1]:
             dxr, dxi = conv_dgrad(gr, gi, wcr, wci, ctx.geom, ctx.xshape, gp=gp)
+        want_b = ctx.has_bias and (need[4] or need[5])
+        bsum = [] if want_b else None                 # filled by the weight-gradient kernel when it can carry the sums
         if need[2] or need[3]:
             if ctx.grid:
-                dwr, dwi = conv_wgrad(gr, gi, None, None, ctx.geom, ctx.wshape, xp=(xr, xi), gp=gp)
+                dwr, dwi = conv_wgrad(gr, gi, None, None, ctx.geom, ctx.wshape, xp=(xr, xi), gp=gp, bias_out=bsum)
             else:
-                dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape, gp=gp)
-        if ctx.has_bias and (need[4] or need[5]):
-            dbr, dbi = chansum2(gr, gi)
+                dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape, gp=gp, bias_out=bsum)
+        if want_b:
+            dbr, dbi = bsum if bsum else chansum2(gr, gi)
         return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
 
 
@@ -628,13 +636,15 @@ class RealConv2dFn(torch.autograd.Function):
         gp = _shared_grad_grid(g, None, ctx.geom, need[0], need[1])
         if need[0]:
             dx, _ = conv_dgrad(g, None, wc, None, ctx.geom, ctx.xshape, gp=gp)
+        want_b = ctx.has_bias and need[2]
+        bsum = [] if want_b else None
         if need[1]:
             if ctx.grid:
-                dw, _ = conv_wgrad(g, None, None, None, ctx.geom, ctx.wshape, xp=(x, None), gp=gp)
+                dw, _ = conv_wgrad(g, None, None, None, ctx.geom, ctx.wshape, xp=(x, None), gp=gp, bias_out=bsum)
             else:
-                dw, _ = conv_wgrad(g, None, x, None, ctx.geom, ctx.wshape, gp=gp)
-        if ctx.has_bias and need[2]:
-            db = chansum(g)
+                dw, _ = conv_wgrad(g, None, x, None, ctx.geom, ctx.wshape, gp=gp, bias_out=bsum)
+        if want_b:
+            db = bsum[0] if bsum else chansum(g)
         return dx, dw, db, None, None, None, None
 
 

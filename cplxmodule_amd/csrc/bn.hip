@@ -337,6 +337,7 @@ __device__ __forceinline__ Whiten inv_sqrt_2x2(double a, double b, double d) {
 // (`local_in`; the data-parallel gradient exchange averages them like every other parameter gradient), the input
 // gradient uses the totals of all ranks.
 struct BnSync {
+  long long* tracked_inc = nullptr;      // forward: *tracked_inc += 1 in the finalize launch (num_batches_tracked)
   double* moments_out = nullptr;
   const double* moments_in = nullptr;
   const double* local_in = nullptr;
@@ -360,8 +361,9 @@ __global__ __launch_bounds__(64) void bn_collapse(const double* partial, int chu
 __global__ __launch_bounds__(64) void bn_fwd_finalize(const double* partial, int chunks, int F, double count,
                                 const float* weight, const float* bias, float* running_mean,
                                 float* running_var, int training, float momentum, float eps,
-                                float* saved, float* coef, const double* count_dev) {
+                                float* saved, float* coef, const double* count_dev, long long* tracked_inc) {
   const int f = blockIdx.x;
+  if (tracked_inc && f == 0 && threadIdx.x == 0) *tracked_inc += 1;
   if (count_dev) count = *count_dev;
   double mu, mv, vuu, vuv, vvv;
   double s[5] = {0, 0, 0, 0, 0};
@@ -597,7 +599,7 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
   const int tchunks = sync.moments_in ? 1 : chunks;
   if (!BWD)
     bn_fwd_finalize<<<F, 64, 0, st>>>(totals, tchunks, F, count, weight, bias, running_mean,
-                                        running_var, training, momentum, eps, saved, coef, sync.count_dev);
+                                        running_var, training, momentum, eps, saved, coef, sync.count_dev, sync.tracked_inc);
   else
     bn_bwd_finalize<<<F, 64, 0, st>>>(totals, tchunks, F, count, weight, saved, training,
                                         dweight, dbias, coef, sync.local_in, sync.count_dev);
@@ -651,25 +653,35 @@ extern "C" {
 
 int64_t cplxamd_bn_ws_bytes(int F) { return bn_ws_bytes(F); }
 
-int cplxamd_bn_fwd(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F,
-                   int64_t S, const float* weight, const float* bias, float* running_mean,
-                   float* running_var, float* saved, int training, int dtype, float momentum,
-                   float eps, void* ws, int64_t ws_bytes, void* stream) {
+int cplxamd_bn_fwd_ex(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F,
+                      int64_t S, const float* weight, const float* bias, float* running_mean,
+                      float* running_var, float* saved, int training, int dtype, float momentum,
+                      float eps, int64_t* tracked_inc, void* ws, int64_t ws_bytes, void* stream) {
   if (!xr || !xi || !yr || !yi || !saved || !ws || B <= 0 || F <= 0 || S <= 0) return CPLXAMD_EINVAL;
   if ((weight == nullptr) != (bias == nullptr)) return CPLXAMD_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return CPLXAMD_EINVAL;
   if (!training && !running_mean) return CPLXAMD_EINVAL;
   if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
   hipStream_t st = (hipStream_t)stream;
+  BnSync extra;
+  extra.tracked_inc = reinterpret_cast<long long*>(tracked_inc);
   if (dtype == CPLXAMD_F32)
     return bn_run<float, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias,
                                 running_mean, running_var, saved, nullptr, nullptr, training,
-                                momentum, eps, ws, st);
+                                momentum, eps, ws, st, nullptr, extra);
   if (dtype == CPLXAMD_BF16)
     return bn_run<bf16_t, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias,
                                  running_mean, running_var, saved, nullptr, nullptr, training,
-                                 momentum, eps, ws, st);
+                                 momentum, eps, ws, st, nullptr, extra);
   return CPLXAMD_EINVAL;
+}
+
+int cplxamd_bn_fwd(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F,
+                   int64_t S, const float* weight, const float* bias, float* running_mean,
+                   float* running_var, float* saved, int training, int dtype, float momentum,
+                   float eps, void* ws, int64_t ws_bytes, void* stream) {
+  return cplxamd_bn_fwd_ex(xr, xi, yr, yi, B, F, S, weight, bias, running_mean, running_var, saved, training, dtype, momentum,
+                           eps, nullptr, ws, ws_bytes, stream);
 }
 
 int cplxamd_bn_rows_path(int64_t B, int F, int64_t S) { return bn_rows_ok(B, F, S) ? 1 : 0; }

@@ -59,6 +59,9 @@ struct ConvArgs {
   int M, N, K;                        // GEMM dims per group (all below 2^31: checked at launch)
   int splits;                         // WGRAD split-K factor (1 otherwise)
   int kchunk;                         // K elements per split
+  int bias_col;                       // WGRAD: 1 = one more GEMM column n == N whose B entries are (1, 0): its outputs are
+                                      // the row sums of the A operand = the BIAS gradient (sum of G over batch and pixels),
+                                      // written behind the weight slab of each split (slab stride wsz + Co)
 };
 
 template <typename T>
@@ -150,6 +153,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         const int ci = fdiv(n, p.f_khw), rk = n - ci * khw;
         const int kh = fdiv(rk, p.f_kw), kw = rk - kh * p.KW;
         w_ci[j] = ci; w_dh[j] = kh * p.dh - p.ph; w_dw[j] = kw * p.dw - p.pw;
+      } else if (n == a.N && a.bias_col) {
+        w_ci[j] = -2;                                            // the ones column
       }
     }
   }
@@ -198,6 +203,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
             const int64_t off = xb + ((int64_t)w_ci[j] * p.H + ih) * p.W + iw;
             vr = ldv<T>(b_r, off);
             if (CPLX) vi = ldv<T>(b_i, off);
+          } else if (kok && w_ci[j] == -2) {
+            vr = 1.f;
           }
           br_[h * WJ + j] = vr; bi_[h * WJ + j] = vi;
         }
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 
   // epilogue: col = lane & 31 runs along N, rows (M) across registers
   const int n = n0 + wn + l31;
-  if (n >= a.N) return;
+  if (n >= a.N + (MODE == MODE_WGRAD ? a.bias_col : 0)) return;
   int64_t out_base, out_mstride;
   if (MODE == MODE_FWD) {
     const int b = fdiv(n, p.f_howo), r = n - b * howo;
@@ -322,9 +329,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     out_base = ((int64_t)b * p.Ci + (int64_t)g * p.Cg) * hw + r;
     out_mstride = hw;
   } else {
-    const int64_t wsz = (int64_t)p.Co * p.Cg * p.KH * p.KW;
-    out_base = (int64_t)split * wsz + (int64_t)g * p.Cog * a.N + n;
-    out_mstride = a.N;
+    const int64_t wsz = (int64_t)p.Co * p.Cg * p.KH * p.KW, slab = wsz + (a.bias_col ? p.Co : 0);
+    if (n < a.N) { out_base = (int64_t)split * slab + (int64_t)g * p.Cog * a.N + n; out_mstride = a.N; }
+    else { out_base = (int64_t)split * slab + wsz + (int64_t)g * p.Cog; out_mstride = 1; }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -350,10 +357,13 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 // per split lane, coalesced 256-B reads, 4 loads in flight per thread), fixed summation order.  blockIdx.y = plane
 // (real / imaginary slabs and outputs; the multiplier applies to plane 0: the real-valued variance path).
 __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* slabs0, const float* slabs1, int splits, int64_t n,
-                                                        const float* emul, float* out0, float* out1) {
+                                                        const float* emul, float* out0, float* out1, int64_t nw,
+                                                        float* outb0, float* outb1) {
+  // elements [0, nw) of a slab -> out (weights), [nw, n) -> outb (the fused bias-gradient column, conv_kernel WGRAD)
   __shared__ float red[16][64];
   const float* slabs = blockIdx.y ? slabs1 : slabs0;
   float* out = blockIdx.y ? out1 : out0;
+  float* outb = blockIdx.y ? outb1 : outb0;
   if (blockIdx.y) emul = nullptr;
   const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -372,7 +382,8 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* slabs0, con
     float acc = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) acc += red[w][lane];
-    out[i] = emul ? acc * emul[i] : acc;
+    if (i < nw) out[i] = emul ? acc * emul[i] : acc;
+    else outb[i - nw] = acc;
   }
 }
 
@@ -459,7 +470,7 @@ static int conv_tile_n(int64_t M, int64_t N, int64_t zdim) {
 template <typename T, int MODE>
 static int conv_launch(ConvArgs& a, bool cplx, hipStream_t st) {
   const int tm = conv_tile_m(a.M), tn = conv_tile_n(a.M, a.N, (int64_t)a.p.G * a.splits);
-  dim3 grid((unsigned)((a.N + tn - 1) / tn), (unsigned)((a.M + tm - 1) / tm), (unsigned)(a.p.G * a.splits));
+  dim3 grid((unsigned)((a.N + a.bias_col + tn - 1) / tn), (unsigned)((a.M + tm - 1) / tm), (unsigned)(a.p.G * a.splits));
   if (grid.y > 65535 || grid.z > 65535) return CPLXAMD_ESHAPE;
 #define CONV_GO(TM_, TN_)                                                                   \
   do {                                                                                      \
@@ -566,15 +577,23 @@ int64_t cplxamd_conv2d_wgrad_ws_bytes(const int* geom, int cplx) {
   ConvP p;
   if (fill_geom(geom, p)) return -1;
   const int64_t wsz = (int64_t)p.Co * p.Cg * p.KH * p.KW;
-  return (int64_t)cplxamd_conv2d_wgrad_splits(geom) * wsz * sizeof(float) * (cplx ? 2 : 1);
+  // [splits][planes] slabs of wsz + Co floats (the fused bias-gradient column), then the bias fallback's partial sums
+  return ((int64_t)cplxamd_conv2d_wgrad_splits(geom) * (wsz + p.Co) * sizeof(float) * (cplx ? 2 : 1) + 255) / 256 * 256 +
+         (int64_t)2 * 64 * p.Co * sizeof(double);
 }
 
-int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const void* xi,
-                         const float* emul, float* dwr, float* dwi, const int* geom, int dtype,
-                         void* ws, int64_t ws_bytes, void* stream) {
+int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws, void* stream);
+int cplxamd_chansum2(const void* xr, const void* xi, float* out_r, float* out_i, int64_t B, int C, int64_t S, int dtype,
+                     void* ws, void* stream);
+
+int cplxamd_conv2d_wgrad_bias(const void* gr, const void* gi, const void* xr, const void* xi,
+                              const float* emul, float* dwr, float* dwi, float* dbr, float* dbi, const int* geom,
+                              int dtype, void* ws, int64_t ws_bytes, void* stream) {
   if (!gr || !xr || !dwr || !geom || !ws) return CPLXAMD_EINVAL;
   const bool cplx = gi != nullptr;
   if (cplx && (!xi || !dwi)) return CPLXAMD_EINVAL;
+  const bool want_b = dbr != nullptr;
+  if (want_b && cplx && dbi != dbr + geom[2]) return CPLXAMD_EINVAL;       // one [2][Co] array
   ConvArgs a{};
   int rc = fill_geom(geom, a.p);
   if (rc) return rc;
@@ -582,24 +601,41 @@ int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const v
   if (a.p.B == 0) {                                            // empty batch: the gradient is zero
     hipError_t e = hipMemsetAsync(dwr, 0, wsz * sizeof(float), (hipStream_t)stream);
     if (e == hipSuccess && cplx) e = hipMemsetAsync(dwi, 0, wsz * sizeof(float), (hipStream_t)stream);
+    if (e == hipSuccess && want_b) e = hipMemsetAsync(dbr, 0, (cplx ? 2 : 1) * a.p.Co * sizeof(float), (hipStream_t)stream);
     return (int)e;
   }
   if (ws_bytes < cplxamd_conv2d_wgrad_ws_bytes(geom, cplx)) return CPLXAMD_EWS;
   a.splits = cplxamd_conv2d_wgrad_splits(geom);
-  a.xr = gr; a.xi = gi; a.wr = xr; a.wi = xi;
-  a.yr = ws; a.yi = (float*)ws + (int64_t)a.splits * wsz;
   a.M = a.p.Cog; a.N = a.p.Cg * a.p.KH * a.p.KW; a.K = a.p.B * a.p.Ho * a.p.Wo;
+  // the bias gradient rides as one more column of the GEMM where that column does not start a tile of its own
+  const int tn = conv_tile_n(a.M, a.N, (int64_t)a.p.G * a.splits);
+  a.bias_col = (want_b && a.N % tn != 0) ? 1 : 0;
+  const int64_t slab = wsz + (a.bias_col ? a.p.Co : 0);
+  a.xr = gr; a.xi = gi; a.wr = xr; a.wi = xi;
+  a.yr = ws; a.yi = (float*)ws + (int64_t)a.splits * slab;
   a.kchunk = (int)((((int64_t)a.K + a.splits - 1) / a.splits + CBK - 1) / CBK * CBK);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32) rc = conv_launch<float, MODE_WGRAD>(a, cplx, st);
   else if (dtype == CPLXAMD_BF16) rc = conv_launch<bf16_t, MODE_WGRAD>(a, cplx, st);
   else return CPLXAMD_EINVAL;
   if (rc) return rc;
-  const int sgrid = (int)((wsz + 63) / 64);
-  slab_sum_kernel<<<dim3(sgrid, cplx ? 2 : 1), 1024, 0, st>>>((const float*)a.yr, (const float*)a.yi, a.splits, wsz, emul,
-                                                              dwr, dwi);
+  const int sgrid = (int)((slab + 63) / 64);
+  slab_sum_kernel<<<dim3(sgrid, cplx ? 2 : 1), 1024, 0, st>>>((const float*)a.yr, (const float*)a.yi, a.splits, slab, emul,
+                                                              dwr, dwi, wsz, dbr, dbi);
   CPLXAMD_CHECK_LAUNCH();
+  if (want_b && !a.bias_col) {                                 // (the column would have cost a tile column: two small launches)
+    void* cws = (char*)ws + ((int64_t)a.splits * (wsz + a.p.Co) * sizeof(float) * (cplx ? 2 : 1) + 255) / 256 * 256;
+    const int64_t S = (int64_t)a.p.Ho * a.p.Wo;
+    return cplx ? cplxamd_chansum2(gr, gi, dbr, dbi, a.p.B, a.p.Co, S, dtype, cws, stream)
+                : cplxamd_chansum(gr, dbr, a.p.B, a.p.Co, S, dtype, cws, stream);
+  }
   return 0;
+}
+
+int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const void* xi,
+                         const float* emul, float* dwr, float* dwi, const int* geom, int dtype,
+                         void* ws, int64_t ws_bytes, void* stream) {
+  return cplxamd_conv2d_wgrad_bias(gr, gi, xr, xi, emul, dwr, dwi, nullptr, nullptr, geom, dtype, ws, ws_bytes, stream);
 }
 
 /* out[c] = sum over (b, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C doubles */

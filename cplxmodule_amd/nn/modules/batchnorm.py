@@ -12,15 +12,16 @@ from ... import cplx
 
 
 def cplx_batch_norm(input, running_mean, running_var, weight=None, bias=None, training=True,
-                    momentum=0.1, eps=1e-5, *, process_group=None):
+                    momentum=0.1, eps=1e-5, *, process_group=None, _tracked=None):
     """Functional form (batchnorm.py:189-278).  Running statistics are updated in place.
     process_group (not in the reference; None = its behaviour): share the training-mode batch statistics between
-    the ranks of that torch.distributed group (True = the default group), see bn.CplxBatchNormFn."""
+    the ranks of that torch.distributed group (True = the default group), see bn.CplxBatchNormFn.
+    _tracked (module-internal): an int64 device scalar the forward adds 1 to in its finalize launch."""
     assert (running_mean is None) == (running_var is None)
     assert (weight is None) == (bias is None)
     from ... import bn
     yr, yi = bn.CplxBatchNormFn.apply(input.real, input.imag, weight, bias, running_mean,
-                                      running_var, bool(training), float(momentum), float(eps), process_group)
+                                      running_var, bool(training), float(momentum), float(eps), process_group, _tracked)
     return cplx.Cplx(yr, yi)
 
 
@@ -72,13 +73,18 @@ class _CplxBatchNorm(CplxToCplx):
     def forward(self, input):
         self._check_input_dim(input)
         factor = 0.0 if self.momentum is None else self.momentum
+        tracked = None
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked += 1
+            if (self.momentum is not None and self.process_group is None and self.num_batches_tracked.is_cuda
+                    and self.num_batches_tracked.device == input.real.device):
+                tracked = self.num_batches_tracked       # the counter is bumped by the forward's finalize launch
+            else:
+                self.num_batches_tracked += 1
             if self.momentum is None:
                 factor = 1.0 / float(self.num_batches_tracked)
         return cplx_batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias,
                                self.training or not self.track_running_stats, factor, self.eps,
-                               process_group=self.process_group)
+                               process_group=self.process_group, _tracked=tracked)
 
     def extra_repr(self):
         return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, "

@@ -316,6 +316,13 @@ int64_t cplxamd_conv2d_wgrad_ws_bytes(const int* geom, int cplx);
 int cplxamd_conv2d_wgrad(const void* gr, const void* gi, const void* xr, const void* xi,
                          const float* emul, float* dwr, float* dwi, const int* geom, int dtype,
                          void* ws, int64_t ws_bytes, void* stream);
+/* cplxamd_conv2d_wgrad that also returns the bias gradient dbr / dbi [Co] (float32; complex: one [2][Co] array, dbi ==
+ * dbr + Co; NULL = not wanted): the sum of G over batch and pixels rides as one more column of the weight-gradient GEMM
+ * (its B entries are (1, 0)) and through the same slab sum -- no launches of its own -- unless that column would start a
+ * tile of its own, in which case the library runs cplxamd_chansum2 / cplxamd_chansum.  Same workspace. */
+int cplxamd_conv2d_wgrad_bias(const void* gr, const void* gi, const void* xr, const void* xi,
+                              const float* emul, float* dwr, float* dwi, float* dbr, float* dbi, const int* geom,
+                              int dtype, void* ws, int64_t ws_bytes, void* stream);
 /* bf16 fast path of the same three operations (bf16 MFMA, register-gathered operand tiles).
  * ktab: device copy of the int[3*T] table written by cplxamd_conv2d_ktab_fill (a host-side
  * helper; mode 0 = fwd / wgrad table over (ci, kh, kw), 1 = dgrad table over (co, kh, kw)).
@@ -477,6 +484,12 @@ int cplxamd_bn_fwd(const void* xr, const void* xi, void* yr, void* yi, int64_t B
                    int64_t S, const float* weight, const float* bias, float* running_mean,
                    float* running_var, float* saved, int training, int dtype, float momentum,
                    float eps, void* ws, int64_t ws_bytes, void* stream);
+/* cplxamd_bn_fwd that also adds 1 to *tracked_inc (the module's int64 num_batches_tracked; may be NULL) in its finalize
+ * launch: one launch less per layer and step than an elementwise add of its own. */
+int cplxamd_bn_fwd_ex(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F,
+                      int64_t S, const float* weight, const float* bias, float* running_mean,
+                      float* running_var, float* saved, int training, int dtype, float momentum,
+                      float eps, int64_t* tracked_inc, void* ws, int64_t ws_bytes, void* stream);
 int cplxamd_bn_bwd(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr,
                    void* dxi, int64_t B, int F, int64_t S, const float* weight,
                    const float* saved, float* dweight, float* dbias, int training, int dtype,

@@ -453,3 +453,30 @@ def test_complex_bias_gradient_both_planes_per_launch(shape, dtype):
     assert torch.equal(a, conv.chansum(gr)) and torch.equal(b, conv.chansum(gi))
     ref = gr.double().sum(dim=(0, 2, 3))
     assert (a.double() - ref).abs().max() <= 1e-6 * gr.double().abs().sum(dim=(0, 2, 3)).max() + 1e-30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(32, 8, 8, 28, 28, 2, 1, True),      # N = 72: the sums ride as GEMM column 72
+                                 (16, 64, 32, 9, 9, 1, 1, True),      # N = 576 = 9 x 64: own tile -> the library sums apart
+                                 (8, 6, 10, 11, 13, 1, 2, True),      # groups = 2
+                                 (8, 5, 7, 12, 10, 1, 1, False)])     # real-valued
+def test_bias_gradient_from_the_weight_gradient_gemm(cfg):
+    """cplxamd_conv2d_wgrad_bias: the bias gradient (sums of G over batch and pixels) as one more column of the generic
+    weight-gradient GEMM == float64 sums; the weight gradient itself is bit-identical to cplxamd_conv2d_wgrad's."""
+    from cplxmodule_amd import conv
+    B, Ci, Co, H, W, stride, groups, cplx = cfg
+    dev = "cuda"
+    torch.manual_seed(Ci * Co)
+    x = [torch.randn(B, Ci, H, W, device=dev) for _ in range(2 if cplx else 1)]
+    wshape = (Co, Ci // groups, 3, 3)
+    geom, oshape = conv._geom(x[0].shape, wshape, (stride, stride), (1, 1), (1, 1), groups)
+    g = [torch.randn(oshape, device=dev) for _ in range(2 if cplx else 1)]
+    gi, xi = (g[1], x[1]) if cplx else (None, None)
+    bsum = []
+    dwr, dwi = conv.conv_wgrad(g[0], gi, x[0], xi, geom, wshape, bias_out=bsum)
+    pr, pi = conv.conv_wgrad(g[0], gi, x[0], xi, geom, wshape)
+    assert torch.equal(dwr, pr) and (not cplx or torch.equal(dwi, pi))
+    assert len(bsum) == (2 if cplx else 1)
+    for got, t in zip(bsum, g):
+        ref = t.double().sum(dim=(0, 2, 3))
+        assert (got.double() - ref).abs().max() <= 2e-6 * t.double().abs().sum(dim=(0, 2, 3)).max()
