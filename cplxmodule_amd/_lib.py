@@ -96,6 +96,7 @@ SIGNATURES = {
     "cplxamd_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "cplxamd_colsum_ws_bytes": [_I],
     "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P, _P],
+    "cplxamd_colsum2": [_P, _P, _L, _P, _P, _I, _I, _I, _P, _P],
     "cplxamd_lrt_dx_accum": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "cplxamd_conv2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "cplxamd_conv2d_dgrad": [_P, _P, _P, _P, _P, _P, _P, _I, _P],

@@ -240,8 +240,14 @@ __global__ __launch_bounds__(256) void generic_slab_reduce_kernel(const float* s
   const float beta = (accumulate && beta_p) ? *beta_p : 1.0f;
   const int64_t n = (int64_t)M * N, stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    float acc = 0.f;
-    for (int s = 0; s < splits; ++s) acc += slabs[(int64_t)s * slab_stride + i];
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};        // four loads in flight (a head's 49 splits were 49 dependent round trips)
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a4[u] += slabs[(int64_t)(s + u) * slab_stride + i];
+    }
+    for (; s < splits; ++s) a4[0] += slabs[(int64_t)s * slab_stride + i];
+    float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
     const int64_t o = (int64_t)row * ldc + col;
     if (bias) acc += bias[col];

@@ -177,19 +177,33 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const T* in, float* pa
   }
 }
 
+// few rows (a head's [batch, outputs] gradient): 64 columns x 16 row lanes per block, 4 loads in flight per thread;
+// blockIdx.y = plane (the two planes of a complex bias gradient in one launch)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* in, int64_t ld, float* out, int rows,
-                                                     int cols) {
-  __shared__ float part[4][64];
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* in0, const T* in1, int64_t ld, float* out0, float* out1,
+                                                      int rows, int cols) {
+  __shared__ float part[16][64];
+  const T* in = blockIdx.y ? in1 : in0;
+  float* out = blockIdx.y ? out1 : out0;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int ty = threadIdx.x >> 6;
-  float acc = 0.0f;
-  if (c < cols)
-    for (int r = ty; r < rows; r += 4) acc += io<T>::ld(in + (int64_t)r * ld + c);
-  part[ty][threadIdx.x & 63] = acc;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    int r = ty;
+    for (; r + 48 < rows; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += io<T>::ld(in + (int64_t)(r + 16 * u) * ld + c);
+    }
+    for (; r < rows; r += 16) a[0] += io<T>::ld(in + (int64_t)r * ld + c);
+  }
+  part[ty][threadIdx.x & 63] = (a[0] + a[1]) + (a[2] + a[3]);
   __syncthreads();
-  if (ty == 0 && c < cols)
-    out[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  if (ty == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][threadIdx.x];
+    out[c] = t;
+  }
 }
 
 template <typename T, typename TG, bool CPLX>
@@ -408,9 +422,33 @@ int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, i
   }
   const int grid = (cols + 63) / 64;
   if (dtype == CPLXAMD_F32)
-    colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)in, ld, out, rows, cols);
+    colsum_kernel<float><<<grid, 1024, 0, st>>>((const float*)in, nullptr, ld, out, nullptr, rows, cols);
   else if (dtype == CPLXAMD_BF16)
-    colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)in, ld, out, rows, cols);
+    colsum_kernel<bf16_t><<<grid, 1024, 0, st>>>((const bf16_t*)in, nullptr, ld, out, nullptr, rows, cols);
+  else
+    return CPLXAMD_EINVAL;
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+/* Column sums of the two planes of a complex [rows, cols] tensor (the complex bias gradient of a linear layer): one
+ * launch where cplxamd_colsum takes its few-rows kernel, else two cplxamd_colsum passes (ws: as for cplxamd_colsum). */
+int cplxamd_colsum2(const void* in_r, const void* in_i, int64_t ld, float* out_r, float* out_i, int rows, int cols,
+                    int dtype, void* ws, void* stream) {
+  if (!in_r || !in_i || !out_r || !out_i || rows < 0 || cols < 0) return CPLXAMD_EINVAL;
+  if (cols == 0) return 0;
+  const bool vec = ws && (cols % 4 == 0) && (ld % 4 == 0) && rows >= 64 && ((reinterpret_cast<uintptr_t>(in_r) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(in_i) & 15) == 0);
+  if (vec) {
+    const int rc = cplxamd_colsum(in_r, ld, out_r, rows, cols, dtype, ws, stream);
+    return rc ? rc : cplxamd_colsum(in_i, ld, out_i, rows, cols, dtype, ws, stream);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((cols + 63) / 64, 2);
+  if (dtype == CPLXAMD_F32)
+    colsum_kernel<float><<<grid, 1024, 0, st>>>((const float*)in_r, (const float*)in_i, ld, out_r, out_i, rows, cols);
+  else if (dtype == CPLXAMD_BF16)
+    colsum_kernel<bf16_t><<<grid, 1024, 0, st>>>((const bf16_t*)in_r, (const bf16_t*)in_i, ld, out_r, out_i, rows, cols);
   else
     return CPLXAMD_EINVAL;
   CPLXAMD_CHECK_LAUNCH();

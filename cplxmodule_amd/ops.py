@@ -101,6 +101,14 @@ def colsum_hint(t):
 
 def colsum2(tr, ti, out=None):
     """Column sums of two planes (the complex bias gradient) -> float32 ([C], [C])."""
+    if out is None and tr.dim() == 2 and tr.shape == ti.shape and tr.dtype == ti.dtype:
+        require_device(tr, ti)
+        tr, ti = tr.contiguous(), ti.contiguous()
+        R, C = tr.shape
+        o = torch.empty(2, C, dtype=torch.float32, device=tr.device)
+        ws = torch.empty(int(_lib.load().cplxamd_colsum_ws_bytes(C)), dtype=torch.uint8, device=tr.device)
+        call("cplxamd_colsum2", ptr(tr), ptr(ti), C, ptr(o[0]), ptr(o[1]), R, C, dtype_code(tr), ptr(ws), stream_ptr())
+        return o[0], o[1]
     return colsum(tr, None if out is None else out[0]), colsum(ti, None if out is None else out[1])
 
 

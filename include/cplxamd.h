@@ -289,6 +289,10 @@ int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, 
 int64_t cplxamd_colsum_ws_bytes(int cols);
 int cplxamd_colsum(const void* in, int64_t ld, float* out, int rows, int cols, int dtype,
                    void* ws, void* stream);
+/* Column sums of both planes of a complex [rows, cols] tensor (a linear layer's complex bias gradient): one launch on
+ * cplxamd_colsum's few-rows path, else two cplxamd_colsum passes.  ws as for cplxamd_colsum. */
+int cplxamd_colsum2(const void* in_r, const void* in_i, int64_t ld, float* out_r, float* out_i, int rows, int cols,
+                    int dtype, void* ws, void* stream);
 /* dxr += 2 xr ga ; dxi += 2 xi ga   (LRT backward; xi/dxi NULL for real) */
 int cplxamd_lrt_dx_accum(void* dxr, void* dxi, const void* xr, const void* xi, const void* ga,
                          int64_t n, int dtype, int ga_dtype, void* stream);
