@@ -19,6 +19,7 @@
 namespace cplxamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CBM = 64, CBN = 64, CBK = 16, KH16 = CBK / 16;   // (K step 32 measured no faster on the narrow layers of cfg5: 1.32 vs 1.29 ms per step)
 
@@ -81,9 +82,16 @@ __device__ __forceinline__ float ldv(const void* p, int64_t off) {
 // Operand elements per thread and K step: A (TM x CBK): k = (t & 15) + 16 h, rows (t >> 4) + 16 j; B (TN x CBK): pixels
 // fastest (FWD, DGRAD: row t % TN fixed, k = t / TN + (256 / TN) j) or k fastest (WGRAD: k = (t & 15) + 16 h, rows
 // (t >> 4) + 16 j).  Whatever is fixed per thread is decomposed ONCE in front of the K loop.
-template <typename T, bool CPLX, int MODE, int TM, int TN>
+// NARROW = 1 / 2 (TM = 32, M <= 8 / M <= 16: the first layers of small-width models, and every data gradient into them):
+//   the products run on v_mfma_f32_4x4x1_16b_f32 -- 16 independent 4 x 4 blocks per instruction, here 8 pixel quads x 2
+//   channel quads, i.e. 32 pixels x 8 channels x 1 k in 8 cycles -- once per 8-channel group, instead of on 32 x 32 x 2
+//   tiles whose 32 rows an 8-channel operand fills to a quarter (PMC / ablation: the MFMAs were 34 of the 61 us of cfg5's
+//   layer-2 data gradient).  Lane l: A = channel 4 (l >> 5) + (l & 3), B = pixel 4 ((l >> 2) & 7) + (l & 3), D register r =
+//   channel 4 (l >> 5) + r of that pixel.
+template <typename T, bool CPLX, int MODE, int TM, int TN, int NARROW>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   static_assert((TM == 64 && TN == 64) || (TM == 32 && (TN == 64 || TN == 32)), "tile shapes");
+  static_assert(NARROW == 0 || (TM == 32 && NARROW <= 2), "4 x 4 x 1 path: one or two 8-channel groups of a 32-row tile");
   constexpr int ALD = TM + 1, BLD = TN + 1, AJ = TM / 16;
   constexpr int WN = TN / 32, KS = 4 / ((TM / 32) * WN);       // waves along N; K parts of a step (1, 2 or 4)
   constexpr bool KSPLIT = KS > 1;
@@ -268,6 +276,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   };
 
   f32x16 acc_r = {0}, acc_i = {0};
+  constexpr int NCG = NARROW ? NARROW : 1;
+  f32x4 nr[NCG], ni[NCG];
+#pragma unroll
+  for (int c = 0; c < NCG; ++c) { nr[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ni[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int chl = (lane >> 5) * 4 + (lane & 3), pxl = ((lane >> 2) & 7) * 4 + (lane & 3);   // NARROW: this lane's channel / pixel
   if (MODE == MODE_FWD && a.bias_r && t < 2 * TM) {            // the tile's bias -> LDS now, not a dependent load in the epilogue
     const int pl = t / TM, m = m0 + (t - pl * TM);
     if (pl == 0 || CPLX) sbias[pl][t - pl * TM] = m < a.M ? (pl ? a.bias_i : a.bias_r)[g * p.Cog + m] : 0.f;
@@ -279,6 +292,26 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     __syncthreads();                         // tile visible; the other buffer is free again
     if (k0 + CBK < kend) fetch_both(k0 + CBK);
     constexpr int KKN = CBK / KS;
+    if (NARROW) {
+#pragma unroll
+      for (int kk = 0; kk < KKN; ++kk) {
+        const int kr = kq * KKN + kk;
+        const float br = Bs_r[buf][kr][wn + pxl];
+        const float bi = CPLX ? sb * Bs_i[buf][kr][wn + pxl] : 0.f;
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) {
+          const float ar = As_r[buf][kr][c * 8 + chl];
+          nr[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar, br, nr[c], 0, 0, 0);
+          if (CPLX) {
+            const float ai = sa * As_i[buf][kr][c * 8 + chl];
+            nr[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(-ai, bi, nr[c], 0, 0, 0);
+            ni[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar, bi, ni[c], 0, 0, 0);
+            ni[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(ai, br, ni[c], 0, 0, 0);
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < KKN; kk += 2) {
       const int kr = kq * KKN + kk + lk;
@@ -294,12 +327,19 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
       }
     }
   }
+  constexpr int NR = NARROW ? 4 * NARROW : 16;                 // result registers per lane and plane
+  if (NARROW) {
+#pragma unroll
+    for (int c = 0; c < NCG; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc_r[c * 4 + r] = nr[c][r]; acc_i[c * 4 + r] = ni[c][r]; }
+  }
   if (KSPLIT) {                              // join the K parts: the waves with kq > 0 hand theirs to the kq == 0 waves
     __syncthreads();                         // (every wave is done with the B rings the hand-over buffer may live in)
     if (kq > 0) {
       const int slot = (kq - 1) * WN + (wid % WN);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < NR; ++r) {
         red_r[slot][r][lane] = acc_r[r];
         if (CPLX) red_i[slot][r][lane] = acc_i[r];
       }
@@ -309,14 +349,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 #pragma unroll
     for (int q = 0; q < KS - 1; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < NR; ++r) {
         acc_r[r] += red_r[q * WN + (wid % WN)][r][lane];
         if (CPLX) acc_i[r] += red_i[q * WN + (wid % WN)][r][lane];
       }
   }
 
-  // epilogue: col = lane & 31 runs along N, rows (M) across registers
-  const int n = n0 + wn + l31;
+  // epilogue: col = lane & 31 (NARROW: the lane's pixel) runs along N, rows (M) across registers
+  const int n = n0 + wn + (NARROW ? pxl : l31);
   if (n >= a.N + (MODE == MODE_WGRAD ? a.bias_col : 0)) return;
   int64_t out_base, out_mstride;
   if (MODE == MODE_FWD) {
@@ -334,8 +374,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     else { out_base = (int64_t)split * slab + wsz + (int64_t)g * p.Cog; out_mstride = 1; }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+  for (int r = 0; r < NR; ++r) {
+    const int m = NARROW ? m0 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3) : m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
     if (m >= a.M) continue;
     const int64_t o = out_base + (int64_t)m * out_mstride;
     float vr = acc_r[r], vi = acc_i[r];
@@ -472,14 +512,15 @@ static int conv_launch(ConvArgs& a, bool cplx, hipStream_t st) {
   const int tm = conv_tile_m(a.M), tn = conv_tile_n(a.M, a.N, (int64_t)a.p.G * a.splits);
   dim3 grid((unsigned)((a.N + a.bias_col + tn - 1) / tn), (unsigned)((a.M + tm - 1) / tm), (unsigned)(a.p.G * a.splits));
   if (grid.y > 65535 || grid.z > 65535) return CPLXAMD_ESHAPE;
-#define CONV_GO(TM_, TN_)                                                                   \
+#define CONV_GO(TM_, TN_, NW_)                                                              \
   do {                                                                                      \
-    if (cplx) conv_kernel<T, true, MODE, TM_, TN_><<<grid, 256, 0, st>>>(a);                \
-    else conv_kernel<T, false, MODE, TM_, TN_><<<grid, 256, 0, st>>>(a);                    \
+    if (cplx) conv_kernel<T, true, MODE, TM_, TN_, NW_><<<grid, 256, 0, st>>>(a);           \
+    else conv_kernel<T, false, MODE, TM_, TN_, NW_><<<grid, 256, 0, st>>>(a);               \
   } while (0)
-  if (tm == 64) CONV_GO(64, 64);
-  else if (tn == 64) CONV_GO(32, 64);
-  else CONV_GO(32, 32);
+  const int nw = a.M <= 8 ? 1 : (a.M <= 16 ? 2 : 0);           // 8-channel groups on the 4 x 4 x 1 path
+  if (tm == 64) CONV_GO(64, 64, 0);
+  else if (tn == 64) { if (nw == 1) CONV_GO(32, 64, 1); else if (nw == 2) CONV_GO(32, 64, 2); else CONV_GO(32, 64, 0); }
+  else { if (nw == 1) CONV_GO(32, 32, 1); else if (nw == 2) CONV_GO(32, 32, 2); else CONV_GO(32, 32, 0); }
 #undef CONV_GO
   CPLXAMD_CHECK_LAUNCH();
   return 0;

@@ -10,7 +10,7 @@ python - <<'PY' | tee gpurun_out/r03/conv_pmc.txt
 import csv, glob, collections, re
 val = collections.defaultdict(list); dur = collections.defaultdict(list)
 def key(r):
-    m = re.search(r"conv_kernel<float, true, (\d), (\d+)>", r["Kernel_Name"])
+    m = re.search(r"conv_kernel<float, true, (\d), (\d+)", r["Kernel_Name"])
     if not m: return None
     if "Grid_Size" in r:
         return (int(m.group(1)), int(r["Grid_Size"]) // int(r["Workgroup_Size"]))

@@ -480,3 +480,36 @@ def test_bias_gradient_from_the_weight_gradient_gemm(cfg):
     for got, t in zip(bsum, g):
         ref = t.double().sum(dim=(0, 2, 3))
         assert (got.double() - ref).abs().max() <= 2e-6 * t.double().abs().sum(dim=(0, 2, 3)).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(5, 8, 8, 28, 28, 2, 1, 1),      # 4 x 4 x 1 path, one channel group (cfg5 layer 2)
+                                 (4, 8, 16, 14, 14, 1, 1, 1),     # two groups forward / weight gradient, one for the data gradient
+                                 (3, 12, 10, 9, 11, 2, 2, 1),     # ragged channel counts, stride 2, dilation 2
+                                 (2, 24, 32, 7, 7, 1, 1, 2),      # groups = 2: 12 / 16 channels per group
+                                 (70, 16, 32, 7, 7, 1, 1, 1)])    # 32 x 32 tiles (few pixels), 32 rows: the 32 x 32 x 2 path
+def test_generic_conv_narrow_layers_vs_float64(cfg):
+    """The generic fp32 conv kernels on narrow layers (v_mfma_f32_4x4x1 for <= 16 output rows, 32 x 32 tiles with a 4-way K
+    split for few pixels): forward, data gradient, weight and bias gradient against torch's float64 convolution."""
+    from cplxmodule_amd import conv
+    B, Ci, Co, H, W, stride, dil, groups = cfg
+    dev = "cuda"
+    torch.manual_seed(Ci + Co)
+    xr, xi = (torch.randn(B, Ci, H, W, device=dev) for _ in range(2))
+    wr, wi = (torch.randn(Co, Ci // groups, 3, 3, device=dev) * 0.2 for _ in range(2))
+    br, bi = torch.randn(Co, device=dev), torch.randn(Co, device=dev)
+    geom, oshape = conv._geom(xr.shape, wr.shape, (stride, stride), (dil, dil), (dil, dil), groups)
+    gr, gi = (torch.randn(oshape, device=dev) for _ in range(2))
+    yr, yi = conv.conv_fwd(xr, xi, wr, wi, br, bi, geom, oshape)
+    dxr, dxi = conv.conv_dgrad(gr, gi, wr, wi, geom, xr.shape)
+    bsum = []
+    dwr, dwi = conv.conv_wgrad(gr, gi, xr, xi, geom, wr.shape, bias_out=bsum)
+    d = lambda t: t.double().cpu().requires_grad_(True)  # noqa: E731
+    Xr, Xi, Wr, Wi = d(xr), d(xi), d(wr), d(wi)
+    c = lambda x, w: torch.nn.functional.conv2d(x, w, None, stride, dil, dil, groups)  # noqa: E731
+    Yr = c(Xr, Wr) - c(Xi, Wi) + br.double().cpu()[None, :, None, None]
+    Yi = c(Xr, Wi) + c(Xi, Wr) + bi.double().cpu()[None, :, None, None]
+    torch.autograd.backward((Yr, Yi), (gr.double().cpu(), gi.double().cpu()))
+    for got, ref in ((yr, Yr.detach()), (yi, Yi.detach()), (dxr, Xr.grad), (dxi, Xi.grad), (dwr, Wr.grad), (dwi, Wi.grad),
+                     (bsum[0], gr.double().cpu().sum((0, 2, 3))), (bsum[1], gi.double().cpu().sum((0, 2, 3)))):
+        assert (got.double().cpu() - ref).abs().max() <= 2e-6 * ref.abs().max() * max(1.0, (B * oshape[2] * oshape[3]) ** 0.5 / 30)
