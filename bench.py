@@ -266,6 +266,54 @@ def cfg4_point(dev, log2_batch=20):
         return {"error": str(e)[:200]}
 
 
+def cfg5_point(dev, batch=256, width=8, steps=100):
+    """BASELINE configs[4] (rank 0, N = 1, outside the timed region): the Deep-Complex-Net style model of
+    examples/train_sparsify.py -- 6 x (CplxConv2d + CplxBatchNorm2d + split ReLU) + CplxLinearARD head, float32 -- on
+    synthetic complex MNIST, one train step = forward + cross-entropy + KL + backward + fused Adam, replayed as ONE
+    hipGraph per step (a launch-bound model: ~130 kernels of a few microseconds)."""
+    import importlib.util
+    from cplxmodule_amd.nn import relevance as rel
+    from cplxmodule_amd.nn.relevance.noise import noise
+    from cplxmodule_amd.utils.graphs import GraphedStep
+    old_mode = noise.mode
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        spec = importlib.util.spec_from_file_location("train_sparsify", os.path.join(here, "examples", "train_sparsify.py"))
+        ts = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ts)
+        torch.manual_seed(0)
+        net = ts.Net(rel.CplxLinearARD, width).to(dev)
+        x, y = ts.synthetic_complex_mnist(batch, dev, seed=100)
+        noise.set_mode("philox-device")
+        opt = torch.optim.Adam(net.parameters(), lr=2e-3, capturable=True, fused=True)
+        net.train()
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(net(x), y)
+            kl = sum(rel.penalties(net), torch.zeros((), device=dev))
+            (loss + 2e-3 * kl).backward()
+            opt.step()
+            return loss.detach(), kl.detach()
+
+        g = GraphedStep(step, modules=[net], warmup=5)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {"workload": f"6 x (CplxConv2d + CplxBatchNorm2d + ReLU) + CplxLinearARD, width {width}, complex MNIST 28x28, "
+                            f"batch {batch}, float32, fwd + loss + KL + bwd + fused Adam, one hipGraph replay per step",
+                "ms_per_step": round(dt * 1e3, 4), "images_per_s": round(batch / dt, 1),
+                "loss": round(float(g.outputs[0]), 4)}
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)[:200]}
+    finally:
+        noise.set_mode(old_mode)
+
+
 def cfg2_point(dev):
     """BASELINE configs[1] as written (rank 0, N = 1, outside the timed region): plain CplxLinear(4096, 4096), bf16,
     batch 8192, forward + backward with the 4-GEMM kernel (`cplx.linear`, one fused 4M launch per pass) and with
@@ -482,6 +530,7 @@ def main():
             line["cfg2_linear"] = cfg2_point(dev)
             line["conv_cfg3"] = conv_point(dev)
             line["cfg4_lrt"] = cfg4_point(dev)
+            line["cfg5_train_step"] = cfg5_point(dev)
             line["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(line), flush=True)
     if grouped:

@@ -10,5 +10,7 @@ python scripts/r03/bench_graph.py 2>/dev/null | tail -1 > $O/graph_replay.txt
 python scripts/r03/bench_graph.py --rccl1 2>/dev/null | grep "^rccl1" >> $O/graph_replay.txt
 python scripts/r03/cfg5_graph.py 2>/dev/null | grep "^plain" >> $O/graph_replay.txt
 python scripts/r03/cfg5_graph.py --rccl1 2>/dev/null | grep "^rccl1" >> $O/graph_replay.txt
+bash scripts/r03/cfg5_steps_prof.sh > /dev/null 2>&1      # -> cfg5_steps_kernel_stats.txt (100 graph replays)
+bash scripts/r03/cfg5_timeline.sh 140 > /dev/null 2>&1    # -> cfg5_timeline.txt (the kernels of one step, in order)
 for f in 1 0; do CPLXAMD_LRT_DX_FUSE=$f python bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('lrt_dx_fuse=$f', d['ms_per_step'], d['step_ms'], d['roofline']['launch_ms'])"; done > $O/lrt_dx_fuse_ab.txt
 cat $O/graph_replay.txt $O/lrt_dx_fuse_ab.txt; head -c 300 $O/bench_n1.json; echo; cat $O/other_configs.jsonl | cut -c1-250
