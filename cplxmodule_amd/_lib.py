@@ -60,6 +60,7 @@ SIGNATURES = {
     "cplxamd_bilinear_reduce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_deinterleave": [_P, _P, _P, _L, _I, _P],
     "cplxamd_interleave": [_P, _P, _P, _L, _I, _P],
+    "cplxamd_cplx_mul": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_split_relu": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "cplxamd_modrelu_fwd": [_P, _P, _P, _F, _I, _P, _P, _L, _I, _P],
     "cplxamd_modrelu_bwd": [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _L, _I, _P],

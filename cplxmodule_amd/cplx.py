@@ -211,6 +211,8 @@ class Cplx:
         return -self + other
 
     def __mul__(self, other):
+        if isinstance(other, Cplx) and ops.cplx_mul_ok(self._re, self._im, other._re, other._im):
+            return type(self)(*ops.cplx_mul(self._re, self._im, other._re, other._im))      # one launch, same bits
         if isinstance(other, (Cplx, complex)):
             return type(self)(self._re * other.real - self._im * other.imag,
                               self._im * other.real + self._re * other.imag)
@@ -219,6 +221,8 @@ class Cplx:
     __rmul__ = __imul__ = __mul__
 
     def __truediv__(self, other):
+        if isinstance(other, Cplx) and ops.cplx_mul_ok(self._re, self._im, other._re, other._im):
+            return type(self)(*ops.cplx_mul(self._re, self._im, other._re, other._im, div=True))
         if isinstance(other, (Cplx, complex)):
             other = Cplx(other) if isinstance(other, complex) else other
             den = other.real * other.real + other.imag * other.imag

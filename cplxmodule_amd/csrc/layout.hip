@@ -43,6 +43,45 @@ __global__ __launch_bounds__(kLT) void interleave_kernel(const T* re, const T* i
   }
 }
 
+// Elementwise complex product / quotient (Cplx.__mul__ / __truediv__, cplxmodule/cplx.py:135-165) in ONE launch, with the
+// reference's operation order (every product, sum and quotient rounded on its own: no fused multiply-add), so values
+// are bit-identical to its 6 / 12 elementwise torch kernels:
+//   mul:  re = a c - b d;  im = b c + a d                       (conj_b: d -> -d)
+//   div:  den = c c + d d;  p = c / den, q = -d / den;  re = a p - b q;  im = b p + a q      (conj_b: d -> -d)
+// `neg` negates the result (the quotient's gradient with respect to the divisor).  (fp contraction is off file-wide.)
+template <typename T, bool DIV>
+__global__ __launch_bounds__(kLT) void cplx_mul_kernel(const T* ar, const T* ai, const T* br, const T* bi, T* or_, T* oi,
+                                                       int64_t n, float sd, float sg) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * kLT;
+  auto f = [&](float a, float b, float c, float d, float& re, float& im) __attribute__((always_inline)) {
+    d = sd * d;
+    if (DIV) {
+      const float den = c * c + d * d;
+      c = c / den;
+      d = -d / den;
+    }
+    const float t0 = a * c, t1 = b * d, t2 = b * c, t3 = a * d;
+    re = sg * (t0 - t1);
+    im = sg * (t2 + t3);
+  };
+  for (int64_t i = (int64_t)blockIdx.x * kLT + threadIdx.x; i < n4; i += stride) {
+    const f4 a = ld4(ar + 4 * i), b = ld4(ai + 4 * i), c = ld4(br + 4 * i), d = ld4(bi + 4 * i);
+    f4 x, y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f(a.v[j], b.v[j], c.v[j], d.v[j], x.v[j], y.v[j]);
+    st4(or_ + 4 * i, x);
+    st4(oi + 4 * i, y);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      float x, y;
+      f(io<T>::ld(ar + e), io<T>::ld(ai + e), io<T>::ld(br + e), io<T>::ld(bi + e), x, y);
+      io<T>::st(or_ + e, x);
+      io<T>::st(oi + e, y);
+    }
+  }
+}
 // ReLU on both planes of a complex tensor (CplxToCplx[torch.nn.ReLU], cplxmodule/nn/modules/base.py:167-199) in one
 // launch, forward and backward: torch's semantics (NaN passes; the backward masks on the saved OUTPUT, y <= 0 -> 0).
 template <typename T, bool BWD>
@@ -233,6 +272,25 @@ int cplxamd_interleave(const void* re, const void* im, void* out, int64_t n, int
   if (dtype == CPLXAMD_F32) interleave_kernel<float><<<grid, kLT, 0, st>>>((const float*)re, (const float*)im, (float*)out, n);
   else if (dtype == CPLXAMD_BF16) interleave_kernel<bf16_t><<<grid, kLT, 0, st>>>((const bf16_t*)re, (const bf16_t*)im, (bf16_t*)out, n);
   else return CPLXAMD_EINVAL;
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+/* o = a b (div == 0) or a / b (div != 0), b conjugated first when conj_b != 0, negated when neg != 0; planes of n elements,
+ * 16-byte aligned.  Operation order of cplxmodule/cplx.py:135-165 (bit-identical values). */
+int cplxamd_cplx_mul(const void* a_r, const void* a_i, const void* b_r, const void* b_i, void* o_r, void* o_i, int64_t n,
+                     int div, int conj_b, int neg, int dtype, void* stream) {
+  if (!a_r || !a_i || !b_r || !b_i || !o_r || !o_i || n < 0) return CPLXAMD_EINVAL;
+  if (!al16(a_r) || !al16(a_i) || !al16(b_r) || !al16(b_i) || !al16(o_r) || !al16(o_i)) return CPLXAMD_EALIGN;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid((n >> 2) + 1, kLT);
+  const float sd = conj_b ? -1.f : 1.f, sg = neg ? -1.f : 1.f;
+#define CM(T, D) cplx_mul_kernel<T, D><<<grid, kLT, 0, st>>>((const T*)a_r, (const T*)a_i, (const T*)b_r, (const T*)b_i, (T*)o_r, (T*)o_i, n, sd, sg)
+  if (dtype == CPLXAMD_F32) { if (div) CM(float, true); else CM(float, false); }
+  else if (dtype == CPLXAMD_BF16) { if (div) CM(bf16_t, true); else CM(bf16_t, false); }
+  else return CPLXAMD_EINVAL;
+#undef CM
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }

@@ -1296,6 +1296,60 @@ class ModReluFn(torch.autograd.Function):
         return dzr, dzi, dtau
 
 
+def _cplx_mul(ar, ai, br, bi, div=False, conj_b=False, neg=False):
+    outr, outi = torch.empty_like(ar), torch.empty_like(ai)
+    call("cplxamd_cplx_mul", ptr(ar), ptr(ai), ptr(br), ptr(bi), ptr(outr), ptr(outi), ar.numel(), int(div), int(conj_b),
+         int(neg), dtype_code(ar), stream_ptr())
+    return outr, outi
+
+
+def cplx_mul_ok(ar, ai, br, bi):
+    """Both operands planar complex device tensors of one shape / dtype (float32 or bf16): the one-launch kernel applies
+    (broadcasting products, scalars and CPU tensors keep torch's elementwise kernels)."""
+    return (ar.is_cuda and ar.dtype in (torch.float32, torch.bfloat16) and ar.numel() > 0
+            and all(t.shape == ar.shape and t.dtype == ar.dtype and t.device == ar.device for t in (ai, br, bi)))
+
+
+class CplxMulFn(torch.autograd.Function):
+    """Cplx * Cplx and Cplx / Cplx (cplxmodule/cplx.py:135-165) in one launch (the reference: 6 / 12 elementwise kernels,
+    same operation order -> same bits); gradients d(ab)/da = g conj(b), d(ab)/db = g conj(a), d(a/b)/da = g / conj(b),
+    d(a/b)/db = -(g conj(a/b)) / conj(b): one launch each (two for the last)."""
+
+    @staticmethod
+    def forward(ctx, ar, ai, br, bi, div):
+        require_device(ar, ai, br, bi)
+        ctx.fmt = fmt = _layout_of(ar)
+        ar, ai, br, bi = (_al16(_cf(t, fmt)) for t in (ar, ai, br, bi))
+        yr, yi = _cplx_mul(ar, ai, br, bi, div=div)
+        ctx.div = div
+        ctx.save_for_backward(*((br, bi, yr, yi) if div else (ar, ai, br, bi)))
+        return yr, yi
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
+        need_a, need_b = ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        da = db = (None, None)
+        if ctx.div:
+            br, bi, yr, yi = ctx.saved_tensors
+            if need_a:
+                da = _cplx_mul(gr, gi, br, bi, div=True, conj_b=True)
+            if need_b:
+                t = _cplx_mul(gr, gi, yr, yi, conj_b=True)
+                db = _cplx_mul(t[0], t[1], br, bi, div=True, conj_b=True, neg=True)
+        else:
+            ar, ai, br, bi = ctx.saved_tensors
+            if need_a:
+                da = _cplx_mul(gr, gi, br, bi, conj_b=True)
+            if need_b:
+                db = _cplx_mul(gr, gi, ar, ai, conj_b=True)
+        return da[0], da[1], db[0], db[1], None
+
+
+def cplx_mul(ar, ai, br, bi, div=False):
+    return CplxMulFn.apply(ar, ai, br, bi, bool(div))
+
+
 class SplitReluFn(torch.autograd.Function):
     """torch.nn.ReLU on both planes (CplxToCplx[torch.nn.ReLU], cplxmodule/nn/modules/base.py:167-199): one launch
     forward, one backward (the mask is read off the saved outputs, as aten's threshold_backward does)."""

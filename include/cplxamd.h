@@ -531,6 +531,13 @@ int cplxamd_bn_bwd_sync(const void* gr, const void* gi, const void* xr, const vo
                         float* dbias, int dtype, float* dx_sums, const double* moments, const double* local_moments,
                         const double* count, void* ws, int64_t ws_bytes, void* stream);
 
+/* Elementwise complex product (div == 0) or quotient (div != 0) of two planar complex tensors in one launch
+ * (Cplx.__mul__ / __truediv__, cplxmodule/cplx.py:135-165: 6 / 12 elementwise torch kernels), with the reference's
+ * operation order -- no fused multiply-add -- so float32 values are bit-identical.  conj_b: b is conjugated first;
+ * neg: the result is negated (together they give the gradients: d(ab)/da = g conj(b), d(a/b)/da = g / conj(b),
+ * d(a/b)/db = -(g conj(a/b)) / conj(b)).  16-byte aligned planes of n elements. */
+int cplxamd_cplx_mul(const void* a_r, const void* a_i, const void* b_r, const void* b_i, void* o_r, void* o_i, int64_t n,
+                     int div, int conj_b, int neg, int dtype, void* stream);
 /* ReLU applied to the real and the imaginary plane (CplxToCplx[torch.nn.ReLU], nn/modules/base.py:167-199) in one launch.
  * bwd == 0: o = relu(a) (NaN passes, as torch).  bwd != 0: a = the saved OUTPUTS, o = (a <= 0 ? 0 : g)
  * (= aten::threshold_backward on the result).  16-byte aligned planes of n elements. */

@@ -526,3 +526,37 @@ def test_generic_conv_narrow_layers_vs_float64(cfg, dtype):
         if dtype == torch.bfloat16 and got.dtype == torch.bfloat16:
             tol = 2.0 ** -8                                  # (float32 accumulation, outputs rounded to bf16)
         assert (got.double().cpu() - ref).abs().max() <= tol * ref.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("div", [False, True])
+@pytest.mark.parametrize("n", [(7, 33), (4, 16, 9, 9), (1,)])
+def test_cplx_product_and_quotient_in_one_launch(div, n):
+    """Cplx * Cplx and Cplx / Cplx on same-shape device tensors run cplxamd_cplx_mul: values bit-identical to the
+    reference's chain of elementwise torch kernels (cplxmodule/cplx.py:135-165: every product / sum / quotient rounded on
+    its own), gradients equal to autograd through that chain; broadcasting operands keep the chain."""
+    from cplxmodule_amd import Cplx
+    dev = "cuda"
+    torch.manual_seed(len(n) + int(div))
+    mk = lambda: torch.randn(*n, device=dev).requires_grad_(True)  # noqa: E731
+    ar, ai, br, bi = mk(), mk(), mk(), mk()
+    gr, gi = torch.randn(*n, device=dev), torch.randn(*n, device=dev)
+    z = Cplx(ar, ai) / Cplx(br, bi) if div else Cplx(ar, ai) * Cplx(br, bi)
+    assert type(z.real.grad_fn).__name__.startswith("CplxMulFn")
+    torch.autograd.backward((z.real, z.imag), (gr, gi))
+    got = [t.grad.clone() for t in (ar, ai, br, bi)]
+    for t in (ar, ai, br, bi):
+        t.grad = None
+    if div:                                                  # the reference's lines, op for op
+        den = br * br + bi * bi
+        cr, ci = br / den, (-bi) / den
+    else:
+        cr, ci = br, bi
+    rr, ri = ar * cr - ai * ci, ai * cr + ar * ci
+    assert torch.equal(z.real.detach(), rr.detach()) and torch.equal(z.imag.detach(), ri.detach())
+    torch.autograd.backward((rr, ri), (gr, gi))
+    for a, t in zip(got, (ar, ai, br, bi)):
+        assert (a - t.grad).abs().max() <= 4e-6 * t.grad.abs().max()
+    if n[0] > 1:
+        w = Cplx(ar, ai) * Cplx(br[:1], bi[:1])              # broadcast: torch's kernels
+        assert not type(w.real.grad_fn).__name__.startswith("CplxMulFn")
