@@ -51,6 +51,19 @@ struct ConvP {
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 
+// Strided data gradient by PHASES.  Input pixel (ih, iw) receives tap (kh, kw) only if (ih + ph - kh dh) is a multiple of
+// sh (and likewise in w): with stride 2 three taps of four multiply zeros in the plain implicit GEMM.  The input pixels
+// are therefore split into sh x sw classes by (ih + ph) mod sh, (iw + pw) mod sw; inside a class the valid taps are the same
+// for every pixel -- an arithmetic progression kh = kh0 + a khs, a < nh -- and the class is its own GEMM: N = pixels of the
+// class, K = Cout x nh x nw.  blockIdx.z carries the class.  (Strides up to 2 per dimension; larger ones take the plain path.)
+struct DgradPhase {
+  int ih0, iw0, Hp, Wp;               // first row / column of the class, rows / columns in it
+  int kh0, kw0, nh, nw;               // first valid tap and number of valid taps per dimension
+  int N, K;                           // GEMM dims of the class
+  FastDiv f_hpwp, f_wp, f_nhw, f_nw;
+};
+constexpr int kMaxPhases = 4;
+
 struct ConvArgs {
   const void* xr; const void* xi;     // FWD: input      DGRAD: grad out   WGRAD: grad out
   const void* wr; const void* wi;     // FWD: weight     DGRAD: weight     WGRAD: input
@@ -60,6 +73,9 @@ struct ConvArgs {
   int M, N, K;                        // GEMM dims per group (all below 2^31: checked at launch)
   int splits;                         // WGRAD split-K factor (1 otherwise)
   int kchunk;                         // K elements per split
+  int nph;                            // DGRAD: number of phases (0 = plain path)
+  int khs, kws;                       // DGRAD phases: tap steps
+  DgradPhase phase[kMaxPhases];
   int bias_col;                       // WGRAD: 1 = one more GEMM column n == N whose B entries are (1, 0): its outputs are
                                       // the row sums of the A operand = the BIAS gradient (sum of G over batch and pixels),
                                       // written behind the weight slab of each split (slab stride wsz + Co)
@@ -110,14 +126,20 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   float (*red_i)[16][64] = reinterpret_cast<float (*)[16][64]>(KS == 4 ? &red4[CPLX ? 3 * 16 * 64 : 0] : &Bs_i[0][0][0]);
   const ConvP& p = a.p;
   const int t = threadIdx.x;
-  const int g = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
+  const bool phased = MODE == MODE_DGRAD && a.nph > 0;
+  const int zz = phased ? blockIdx.z / a.nph : blockIdx.z;
+  const DgradPhase& P = a.phase[phased ? blockIdx.z % a.nph : 0];
+  const int g = zz / a.splits, split = zz % a.splits;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int Nn = phased ? P.N : a.N;                           // this launch's (class's) pixels
+  if (phased && n0 >= Nn) return;                              // (the grid is sized for the largest class)
   const int lane = t & 63, wid = t >> 6;
   const int wm = KSPLIT ? 0 : (wid >> 1) * 32, wn = (wid % WN) * 32, l31 = lane & 31, lk = lane >> 5;
   const int kq = KSPLIT ? wid / WN : 0;                        // which K part of each step
   const int kbeg = split * a.kchunk;
   int kend = kbeg + a.kchunk;
   if (kend > a.K) kend = a.K;
+  if (phased) kend = P.K;
   // conjugation: DGRAD conj(W) is the A operand, WGRAD conj(X) is the B operand
   const float sa = (MODE == MODE_DGRAD) ? -1.f : 1.f, sb = (MODE == MODE_WGRAD) ? -1.f : 1.f;
   const int khw = p.KH * p.KW, howo = p.Ho * p.Wo;
@@ -135,9 +157,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   int64_t b_base = 0;
   if (MODE != MODE_WGRAD) {
     const int n = n0 + rb;
-    b_ok = n < a.N;
+    b_ok = n < Nn;
     if (b_ok) {
-      if (MODE == MODE_FWD) {
+      if (phased) {
+        const int b = fdiv(n, P.f_hpwp), r = n - b * (P.Hp * P.Wp);
+        const int tq = fdiv(r, P.f_wp), uq = r - tq * P.Wp;
+        b_h0 = P.ih0 + tq * p.sh + p.ph; b_w0 = P.iw0 + uq * p.sw + p.pw;
+        b_base = ((int64_t)b * p.Co + (int64_t)g * p.Cog) * howo;
+      } else if (MODE == MODE_FWD) {
         const int b = fdiv(n, p.f_howo), r = n - b * howo;
         const int oh = fdiv(r, p.f_wo), ow = r - oh * p.Wo;
         b_h0 = oh * p.sh - p.ph; b_w0 = ow * p.sw - p.pw;
@@ -180,7 +207,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
       if (MODE == MODE_FWD) {
         abase = (int64_t)g * p.Cog * a.K + gk; astride = a.K;
       } else if (MODE == MODE_DGRAD) {
-        const int co = kok ? fdiv(gk, p.f_khw) : 0, r = gk - co * khw;
+        int co, r;
+        if (phased) {
+          co = kok ? fdiv(gk, P.f_nhw) : 0;
+          const int rk = gk - co * (P.nh * P.nw), ta = kok ? fdiv(rk, P.f_nw) : 0;
+          r = (P.kh0 + ta * a.khs) * p.KW + P.kw0 + (rk - ta * P.nw) * a.kws;
+        } else {
+          co = kok ? fdiv(gk, p.f_khw) : 0; r = gk - co * khw;
+        }
         abase = ((int64_t)g * p.Cog + co) * p.Cg * khw + r; astride = khw;
       } else {
         wb = kok ? fdiv(gk, p.f_howo) : 0;
@@ -225,8 +259,16 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         const int k = k0 + kb0 + KBS * j;
         float vr = 0.f, vi = 0.f;
         if (b_ok && k < kend) {
-          const int c = fdiv(k, p.f_khw), rk = k - c * khw;      // c: input channel (FWD) / output channel (DGRAD)
-          const int kh = fdiv(rk, p.f_kw), kw = rk - kh * p.KW;
+          int c, kh, kw;                                         // c: input channel (FWD) / output channel (DGRAD)
+          if (phased) {
+            c = fdiv(k, P.f_nhw);
+            const int rk = k - c * (P.nh * P.nw), ta = fdiv(rk, P.f_nw);
+            kh = P.kh0 + ta * a.khs; kw = P.kw0 + (rk - ta * P.nw) * a.kws;
+          } else {
+            c = fdiv(k, p.f_khw);
+            const int rk = k - c * khw;
+            kh = fdiv(rk, p.f_kw); kw = rk - kh * p.KW;
+          }
           if (MODE == MODE_FWD) {
             const int ih = b_h0 + kh * p.dh, iw = b_w0 + kw * p.dw;
             if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
@@ -357,7 +399,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 
   // epilogue: col = lane & 31 (NARROW: the lane's pixel) runs along N, rows (M) across registers
   const int n = n0 + wn + (NARROW ? pxl : l31);
-  if (n >= a.N + (MODE == MODE_WGRAD ? a.bias_col : 0)) return;
+  if (n >= Nn + (MODE == MODE_WGRAD ? a.bias_col : 0)) return;
   int64_t out_base, out_mstride;
   if (MODE == MODE_FWD) {
     const int b = fdiv(n, p.f_howo), r = n - b * howo;
@@ -365,7 +407,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     out_mstride = howo;
   } else if (MODE == MODE_DGRAD) {
     const int hw = p.H * p.W;
-    const int b = fdiv(n, p.f_hw), r = n - b * hw;
+    int b, r;
+    if (phased) {
+      b = fdiv(n, P.f_hpwp);
+      const int rr = n - b * (P.Hp * P.Wp), tq = fdiv(rr, P.f_wp);
+      r = (P.ih0 + tq * p.sh) * p.W + P.iw0 + (rr - tq * P.Wp) * p.sw;
+    } else {
+      b = fdiv(n, p.f_hw); r = n - b * hw;
+    }
     out_base = ((int64_t)b * p.Ci + (int64_t)g * p.Cg) * hw + r;
     out_mstride = hw;
   } else {
@@ -501,6 +550,37 @@ static bool conv_geom_ok(const ConvP& p) {
          p.Wo > 0 && p.Cg == p.Ci / p.G && p.Cog == p.Co / p.G;
 }
 
+static int gcd_i(int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; }
+
+// DGRAD: the phase plan (DgradPhase) for strides up to 2 per dimension; leaves a.nph = 0 (plain path) for unit stride,
+// larger strides, or when a phase's pixel count would not fit the 32-bit index math
+static void plan_dgrad_phases(ConvArgs& a) {
+  const ConvP& p = a.p;
+  a.nph = 0;
+  if ((p.sh == 1 && p.sw == 1) || p.sh > 2 || p.sw > 2) return;
+  a.khs = p.sh / gcd_i(p.dh, p.sh);
+  a.kws = p.sw / gcd_i(p.dw, p.sw);
+  int n = 0;
+  for (int rh = 0; rh < p.sh; ++rh)
+    for (int rw = 0; rw < p.sw; ++rw) {
+      DgradPhase& q = a.phase[n++];
+      q.ih0 = ((rh - p.ph) % p.sh + p.sh) % p.sh;
+      q.iw0 = ((rw - p.pw) % p.sw + p.sw) % p.sw;
+      q.Hp = q.ih0 < p.H ? (p.H - q.ih0 + p.sh - 1) / p.sh : 0;
+      q.Wp = q.iw0 < p.W ? (p.W - q.iw0 + p.sw - 1) / p.sw : 0;
+      q.kh0 = q.kw0 = 0; q.nh = q.nw = 0;
+      for (int kh = 0; kh < p.KH; ++kh)
+        if ((kh * p.dh) % p.sh == rh) { if (!q.nh) q.kh0 = kh; ++q.nh; }
+      for (int kw = 0; kw < p.KW; ++kw)
+        if ((kw * p.dw) % p.sw == rw) { if (!q.nw) q.kw0 = kw; ++q.nw; }
+      q.N = p.B * q.Hp * q.Wp;
+      q.K = p.Cog * q.nh * q.nw;
+      q.f_hpwp = make_fastdiv((int64_t)q.Hp * q.Wp); q.f_wp = make_fastdiv(q.Wp);
+      q.f_nhw = make_fastdiv((int64_t)q.nh * q.nw); q.f_nw = make_fastdiv(q.nw);
+    }
+  a.nph = n;
+}
+
 static int conv_tile_m(int64_t M) { return M <= 32 ? 32 : CBM; }
 // narrow layers with few pixels: 32-pixel tiles when 64-pixel ones would leave the chip with fewer than two per CU
 static int conv_tile_n(int64_t M, int64_t N, int64_t zdim) {
@@ -509,8 +589,15 @@ static int conv_tile_n(int64_t M, int64_t N, int64_t zdim) {
 
 template <typename T, int MODE>
 static int conv_launch(ConvArgs& a, bool cplx, hipStream_t st) {
-  const int tm = conv_tile_m(a.M), tn = conv_tile_n(a.M, a.N, (int64_t)a.p.G * a.splits);
-  dim3 grid((unsigned)((a.N + a.bias_col + tn - 1) / tn), (unsigned)((a.M + tm - 1) / tm), (unsigned)(a.p.G * a.splits));
+  int64_t nmax = a.N;                                          // DGRAD by phases: the largest class sizes the grid
+  if (MODE == MODE_DGRAD && a.nph > 0) {
+    nmax = 0;
+    for (int i = 0; i < a.nph; ++i) nmax = a.phase[i].N > nmax ? a.phase[i].N : nmax;
+  }
+  const int zmul = (MODE == MODE_DGRAD && a.nph > 0) ? a.nph : 1;
+  const int tm = conv_tile_m(a.M), tn = conv_tile_n(a.M, nmax, (int64_t)a.p.G * a.splits * zmul);
+  dim3 grid((unsigned)((nmax + a.bias_col + tn - 1) / tn), (unsigned)((a.M + tm - 1) / tm),
+            (unsigned)(a.p.G * a.splits * zmul));
   if (grid.y > 65535 || grid.z > 65535) return CPLXAMD_ESHAPE;
 #define CONV_GO(TM_, TN_, NW_)                                                              \
   do {                                                                                      \
@@ -593,6 +680,7 @@ int cplxamd_conv2d_dgrad(const void* gr, const void* gi, const void* wr, const v
   if (a.p.B == 0) return 0;
   a.M = a.p.Cg; a.N = a.p.B * a.p.H * a.p.W; a.K = a.p.Cog * a.p.KH * a.p.KW;
   a.splits = 1; a.kchunk = a.K;
+  plan_dgrad_phases(a);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CPLXAMD_F32) return conv_launch<float, MODE_DGRAD>(a, cplx, st);
   if (dtype == CPLXAMD_BF16) return conv_launch<bf16_t, MODE_DGRAD>(a, cplx, st);

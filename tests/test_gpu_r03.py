@@ -487,7 +487,10 @@ def test_bias_gradient_from_the_weight_gradient_gemm(cfg):
                                  (4, 8, 16, 14, 14, 1, 1, 1),     # two groups forward / weight gradient, one for the data gradient
                                  (3, 12, 10, 9, 11, 2, 2, 1),     # ragged channel counts, stride 2, dilation 2
                                  (2, 24, 32, 7, 7, 1, 1, 2),      # groups = 2: 12 / 16 channels per group
-                                 (70, 16, 32, 7, 7, 1, 1, 1)])    # 32 x 32 tiles (few pixels), 32 rows: the 32 x 32 x 2 path
+                                 (70, 16, 32, 7, 7, 1, 1, 1),     # 32 x 32 tiles (few pixels), 32 rows: the 32 x 32 x 2 path
+                                 (3, 16, 16, 13, 10, (2, 1), 1, 1),   # data gradient by stride phases: 2 x 1 classes
+                                 (2, 40, 48, 9, 12, (1, 2), (1, 2), 1),   # ... 1 x 2 classes, dilated taps, 64-row tiles
+                                 (2, 6, 5, 8, 8, 3, 1, 1)])       # stride 3: the plain data-gradient path
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_generic_conv_narrow_layers_vs_float64(cfg, dtype):
     """The generic fp32 conv kernels on narrow layers (v_mfma_f32_4x4x1 for <= 16 output rows, 32 x 32 tiles with a 4-way K
@@ -499,7 +502,8 @@ def test_generic_conv_narrow_layers_vs_float64(cfg, dtype):
     xr, xi = (torch.randn(B, Ci, H, W, device=dev).to(dtype) for _ in range(2))
     wr, wi = ((torch.randn(Co, Ci // groups, 3, 3, device=dev) * 0.2).to(dtype) for _ in range(2))
     br, bi = torch.randn(Co, device=dev), torch.randn(Co, device=dev)
-    geom, oshape = conv._geom(xr.shape, wr.shape, (stride, stride), (dil, dil), (dil, dil), groups)
+    stride, dil = conv._pair(stride), conv._pair(dil)
+    geom, oshape = conv._geom(xr.shape, wr.shape, stride, dil, dil, groups)
     gr, gi = (torch.randn(oshape, device=dev).to(dtype) for _ in range(2))
     lib, P, st = conv._lib.load(), conv.ptr, conv.stream_ptr
     code = conv.dtype_code(xr)
