@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBnT) void bn_reduce_planes(const T* xr, const T* x
 template <typename T, int NS, bool BWD>
 __global__ __launch_bounds__(kBnT) void bn_reduce_small(const T* xr, const T* xi, const T* gr, const T* gi,
                                                         const float* saved, int B, int F, int S, double* partial) {
-  __shared__ double red[kBnT / 64];
+  __shared__ double red[kBnT / 64][NS];
   const int f = blockIdx.x;
   float mu = 0.f, mv = 0.f;
   if (BWD) { mu = saved[f]; mv = saved[F + f]; }
@@ -145,10 +145,19 @@ __global__ __launch_bounds__(kBnT) void bn_reduce_small(const T* xr, const T* xi
     for (int r = 0; r < 4; ++r)
       if (i0 + r * stride < E) accum<NS, BWD>(a, u[r], v[r], p[r], q[r], mu, mv);
   }
+  // all NS moments through ONE barrier (six block_sum calls were twelve): waves reduce by shuffles, the first NS lanes of
+  // wave 0 add the kBnT / 64 wave sums in a fixed order
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
-    const double t = block_sum<double, kBnT>(a.v[j], red);
-    if (threadIdx.x == 0) partial[((int64_t)blockIdx.y * F + f) * NS + j] = t;
+    const double t = wave_sum(a.v[j]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBnT / 64; ++w) t += red[w][threadIdx.x];
+    partial[((int64_t)blockIdx.y * F + f) * NS + threadIdx.x] = t;
   }
 }
 
