@@ -348,9 +348,13 @@ def reparam_bwd(g_r, g_i, s2, eps=None, seed=0, offset=0, out_dtype=torch.float3
         if not fused:
             call("cplxamd_lrt_reparam_bwd_ex", ptr(g_r), ptr(g_i), ptr(s2), ptr(e_r), ptr(e_i), sd, of, st,
                  ptr(g_s2), g_r.numel(), dtype_code(g_r), dtype_code(g_s2), dtype_code(s2), stream_ptr())
-            colsum(_as_rows(g_r, rows, cols), out=sum_r)
-            if g_i is not None:
-                colsum(_as_rows(g_i, rows, cols), out=sum_i)
+            if g_i is not None:                  # both planes' bias sums in one launch
+                a_r, a_i = _as_rows(g_r, rows, cols).contiguous(), _as_rows(g_i, rows, cols).contiguous()
+                cws = torch.empty(int(_lib.load().cplxamd_colsum_ws_bytes(cols)), dtype=torch.uint8, device=g_r.device)
+                call("cplxamd_colsum2", ptr(a_r), ptr(a_i), cols, ptr(sum_r), ptr(sum_i), rows, cols, dtype_code(a_r), ptr(cws),
+                     stream_ptr())
+            else:
+                colsum(_as_rows(g_r, rows, cols), out=sum_r)
         for dst, src in zip(outs, (sum_r, sum_i)):
             if dst is not None and src is not None and dst is not src:
                 dst.copy_(src.view_as(dst))
