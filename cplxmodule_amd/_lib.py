@@ -49,6 +49,7 @@ SIGNATURES = {
     "cplxamd_rgemm_ex": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P],
     "cplxamd_vd_prep_kl": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "cplxamd_cgemm_lrt_dx": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
+    "cplxamd_rgemm_lrt_dx": [_P, _L, _L, _P, _L, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "cplxamd_cgemm_batched": [_P, _P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "cplxamd_rgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "cplxamd_gemm_ws_bytes": [_I, _I, _I, _I, _I, _I],

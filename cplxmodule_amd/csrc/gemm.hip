@@ -71,6 +71,18 @@ int cplxamd_cgemm_lrt_dx(const void* g_r, const void* g_i, int64_t g_rs, int64_t
   return launch_gemm_bf16<true>(g, CPLXAMD_BF16, (hipStream_t)stream);
 }
 
+int cplxamd_rgemm_lrt_dx(const void* gg, int64_t g_rs, int64_t g_cs, const void* w, int64_t w_rs, int64_t w_cs,
+                         const void* x, const void* ga, int64_t ldx, void* dx, int64_t ldc, int M, int N, int K, int dtype,
+                         void* stream) {
+  if (!gg || !w || !x || !ga || !dx) return CPLXAMD_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || ldc < N || ldx < N) return CPLXAMD_EINVAL;
+  if (dtype != CPLXAMD_BF16) return CPLXAMD_ESHAPE;
+  GemmArgs g{gg, nullptr, g_rs, g_cs, w, nullptr, w_rs, w_cs, nullptr, nullptr, nullptr,
+             dx, nullptr, ldc, M, N, K, 0, 0};
+  g.fx_r = x; g.fx_i = nullptr; g.fga = ga; g.fld = ldx;
+  return launch_gemm_bf16<false>(g, CPLXAMD_BF16, (hipStream_t)stream);
+}
+
 int cplxamd_cgemm_batched(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs, int64_t a_bs,
                           const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs, int64_t b_bs,
                           void* c_r, void* c_i, int64_t ldc, int64_t c_bs, int batch, int M, int N, int K,

@@ -725,8 +725,8 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   }
   const GemmArgs& g = g0;
   if (g.splits > 1 || g.g1 || g.emul || g.accumulate || (g.M % C::BM) || (g.N % C::BN) || g.K / BK < 12) return 0;
-  if (g.fga && (!(CPLX && CONJ && TB && sizeof(TOUT) == 2) || (g.fld & 7) || !aligned16(g.fga) || !aligned16(g.fx_r) ||
-                !aligned16(g.fx_i) || g.bias_r)) return 0;      // (the caller runs the two-kernel path)
+  if (g.fga && (!((CPLX ? CONJ : true) && TB && !TA && sizeof(TOUT) == 2) || (g.fld & 7) || !aligned16(g.fga) ||
+                !aligned16(g.fx_r) || (CPLX && !aligned16(g.fx_i)) || g.bias_r)) return 0;   // (the caller runs the two-kernel path)
   // instantiated for the layouts the layers launch with a plain epilogue: forward (N,N), input gradient (N,T)
   // -- the weight gradients carry the fused KL accumulate and stay on the one-tile kernel
   constexpr bool kBf16Out = sizeof(TOUT) == 2;
@@ -744,7 +744,7 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
   a.group_m = gm > 0 ? gm : 1;
   if constexpr (kInstantiated) {
-    constexpr bool kFusable = CPLX && CONJ && TB && kBf16Out;      // the LRT input gradient (gemm.h: fga)
+    constexpr bool kFusable = (CPLX ? CONJ : true) && TB && kBf16Out;   // the LRT input gradient, complex and real (gemm.h: fga)
     auto go = [&](auto RR) -> int {
       constexpr int R = decltype(RR)::value;
       if constexpr (kFusable) {

@@ -35,7 +35,7 @@ enum { PB_NORMAL = 0, PB_FIRST0 = 1, PB_FIRST1 = 2, PB_T3 = 3, PB_T2 = 4, PB_LAS
 
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, int R, bool FUSE = false>
 __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(GemmArgs g) {
-  static_assert(!FUSE || (CPLX && sizeof(TOUT) == 2), "the fused LRT input gradient is the complex bf16-out kernel");
+  static_assert(!FUSE || sizeof(TOUT) == 2, "the fused LRT input gradient is a bf16-out kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = Cfg<CPLX>;
   constexpr int NT = C::NT, BM = C::BM, BN = C::BN, IB = C::IB, JB = C::JB, L = C::LOADS;
@@ -309,13 +309,14 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(Gemm
           const int64_t u = (int64_t)(((uint64_t)uhi << 32) | ulo);
           lga[rd] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(fga) + u + loff);
           lxr[rd] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(fxr) + u + loff);
-          lxi[rd] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(fxi) + u + loff);
+          if constexpr (CPLX) lxi[rd] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(fxi) + u + loff);
+          else lxi[rd] = uint4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
           const int round = rbase + rd;
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
+          for (int pl = 0; pl < NPL; ++pl) {
             if (r8 == round) {
 #pragma unroll
               for (int j = 0; j < JB; ++j)

@@ -513,6 +513,22 @@ def _cplx_lrt_dx(g2r, g2i, wr, wi, x2r, x2i, ga):
     return dxr, dxi
 
 
+def _real_lrt_dx(g2, w, x2, ga):
+    """Input gradient of the real LRT layer, dX = G W + 2 X (*) ga: one launch (cplxamd_rgemm_lrt_dx) when the persistent
+    bf16 kernel takes the shape, else the GEMM and the accumulate pass (bit-identical)."""
+    B, O = g2.shape
+    I = w.shape[1]
+    if (_LRT_DX_FUSE and _is_bf16(g2) and _is_bf16(x2) and _is_bf16(ga) and _is_bf16(w) and I % 8 == 0 and O % 8 == 0
+            and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (g2, w, x2, ga))):
+        dx = torch.empty(B, I, dtype=torch.bfloat16, device=g2.device)
+        if try_call("cplxamd_rgemm_lrt_dx", ptr(g2), O, 1, ptr(w), 1, I, ptr(x2), ptr(ga), I, ptr(dx), I, B, I, O,
+                    dtype_code(g2), stream_ptr()):
+            return dx
+    dx = _real_linear_dx(g2, w, x2.dtype)
+    lrt_dx_accum(dx, None, x2, None, ga)
+    return dx
+
+
 def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0, accumulate=False, beta=None, emul=None):
     """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]; both operands
     are K-major as stored (the bf16 kernel reads them through ds_read_b64_tr_b16).
@@ -905,9 +921,8 @@ class RealLinearLRTFn(torch.autograd.Function):
             ctx.klg = None
         _announce(ls2 if dls2 is not None else None, w if dw is not None else None, b if db is not None else None)
         if need[0]:
-            dx = _real_linear_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), dt)
             ga = _real_linear_dx(gs2, ctx.S, dt)
-            lrt_dx_accum(dx, None, x2, None, ga)
+            dx = _real_lrt_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), x2, ga)
             dx = dx.view(*ctx.lead, I)
         return dx, dw, db, dls2, None, None, None, None
 

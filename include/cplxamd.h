@@ -235,6 +235,12 @@ int cplxamd_cgemm_lrt_dx(const void* g_r, const void* g_i, int64_t g_rs, int64_t
                          const void* w_r, const void* w_i, int64_t w_rs, int64_t w_cs,
                          const void* x_r, const void* x_i, const void* ga, int64_t ldx,
                          void* dx_r, void* dx_i, int64_t ldc, int M, int N, int K, int dtype, void* stream);
+/* The same for the REAL local-reparameterization layers (LinearVD / LinearARD, nn/relevance/real/base.py:43-49
+ * differentiated): dX = G W + 2 X (*) ga in the epilogue of the persistent real kernel; bit-identical to cplxamd_rgemm
+ * followed by cplxamd_lrt_dx_accum.  CPLXAMD_ESHAPE = run those two. */
+int cplxamd_rgemm_lrt_dx(const void* g, int64_t g_rs, int64_t g_cs, const void* w, int64_t w_rs, int64_t w_cs,
+                         const void* x, const void* ga, int64_t ldx, void* dx, int64_t ldc, int M, int N, int K, int dtype,
+                         void* stream);
 
 /* Batched complex GEMM (Cplx.__matmul__ on [..., M, K] @ [..., K, N], cplx.py:167-181): `batch`
  * independent products in ONE launch of the exact-f32 MFMA kernel (any strides, any dtype pair);

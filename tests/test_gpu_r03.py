@@ -564,3 +564,32 @@ def test_cplx_product_and_quotient_in_one_launch(div, n):
     if n[0] > 1:
         w = Cplx(ar, ai) * Cplx(br[:1], bi[:1])              # broadcast: torch's kernels
         assert not type(w.real.grad_fn).__name__.startswith("CplxMulFn")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("O", [4096, 4064, 4128])          # contraction over O: (O / 32) % 3 = 2, 1, 0 -> all three ring phases
+def test_fused_real_lrt_input_gradient_is_bit_identical(O):
+    """cplxamd_rgemm_lrt_dx (LinearVD / LinearARD): dX = G W + 2 X (*) ga in the epilogue of the persistent real (N,T)
+    kernel == cplxamd_rgemm followed by cplxamd_lrt_dx_accum, bit for bit; through the layer's backward as well."""
+    from cplxmodule_amd import ops
+    from cplxmodule_amd._lib import BF16, ptr, stream_ptr, try_call
+    dev, bf = "cuda", torch.bfloat16
+    B, I = 8192, 4096                                        # 32 x 16 = 512 tiles of 256 x 256: two rounds on 256 CUs
+    torch.manual_seed(O)
+    g = torch.randn(B, O, device=dev).to(bf)
+    w = torch.randn(O, I, device=dev).mul(0.02).to(bf)
+    x = torch.randn(B, I, device=dev).to(bf)
+    ga = torch.randn(B, I, device=dev).mul(0.3).to(bf)
+    dx = torch.empty(B, I, device=dev, dtype=bf)
+    assert try_call("cplxamd_rgemm_lrt_dx", ptr(g), O, 1, ptr(w), 1, I, ptr(x), ptr(ga), I, ptr(dx), I, B, I, O, BF16,
+                    stream_ptr()), "the persistent kernel must take this shape"
+    ref = ops._real_linear_dx(g, w, bf)
+    ops.lrt_dx_accum(ref, None, x, None, ga)
+    assert torch.equal(dx, ref)
+    assert torch.equal(ops._real_lrt_dx(g, w, x, ga), ref)
+    rows = torch.randint(0, B, (8,), device=dev)
+    f64 = g[rows].double() @ w.double() + 2 * x[rows].double() * ga[rows].double()
+    assert (dx[rows].double() - f64).abs().max() <= 1.2e-2 * f64.abs().max()
+    small = torch.empty(B - 8, I, device=dev, dtype=bf)      # partial tiles: declined, the wrapper runs the two calls
+    assert not try_call("cplxamd_rgemm_lrt_dx", ptr(g), O, 1, ptr(w), 1, I, ptr(x), ptr(ga), I, ptr(small), I, B - 8, I, O, BF16,
+                        stream_ptr())
