@@ -1,7 +1,8 @@
 // K2: complex / real 2-d convolution (cross-correlation, NCHW, groups, stride, padding,
 // dilation) forward, dgrad and wgrad as implicit GEMMs on the exact-f32 matrix cores:
 // operand tiles are gathered on the fly (im2col is never materialised) into LDS and
-// contracted with v_mfma_f32_32x32x2_f32; complex = 4 MFMA chains sharing one K-loop.
+// contracted with v_mfma_f32_32x32x2_f32 (v_mfma_f32_4x4x1_16b_f32 for layers of <= 16 output rows); complex = 4 MFMA
+// chains sharing one K-loop.
 //
 //   FWD    Y[b,co,oh,ow]  = sum_{ci,kh,kw} X[b,ci,oh*s-p+kh*d, ..] * W[co,ci,kh,kw] (+ bias)
 //          GEMM: M = Co/g, N = B*Ho*Wo (pixels, coalesced stores), K = Ci/g*KH*KW
@@ -13,7 +14,10 @@
 //
 // Reference: cplx.convnd / convnd_quick / convnd_naive, cplxmodule/cplx.py:717-800 (no conjugation
 // in the forward), and the LRT variance conv nn/relevance/complex/base.py:125-133.
-// This is the parity-first kernel (round 1); the bf16-MFMA tiling is the next step.
+// This is the parity path (exact float32) and the kernel of every geometry the channels-last bf16 kernels (conv_cl*.hip,
+// conv_nhwc*.hip) do not take -- strides, groups, odd channel counts, small layers.  Round 3 made it fast on small,
+// launch-bound models (BASELINE configs[4]): multiply-shift index math, narrow tiles, 4 x 4 x 1 MFMAs, stride phases for
+// the data gradient, the bias gradient as a column of the weight-gradient GEMM.
 #include "common.h"
 
 namespace cplxamd {
