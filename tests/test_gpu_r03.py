@@ -490,6 +490,7 @@ def test_bias_gradient_from_the_weight_gradient_gemm(cfg):
                                  (70, 16, 32, 7, 7, 1, 1, 1),     # 32 x 32 tiles (few pixels), 32 rows: the 32 x 32 x 2 path
                                  (3, 16, 16, 13, 10, (2, 1), 1, 1),   # data gradient by stride phases: 2 x 1 classes
                                  (2, 40, 48, 9, 12, (1, 2), (1, 2), 1),   # ... 1 x 2 classes, dilated taps, 64-row tiles
+                                 (2, 8, 12, 9, 11, 2, 1, 2),      # stride phases with groups = 2, odd image sizes
                                  (2, 6, 5, 8, 8, 3, 1, 1)])       # stride 3: the plain data-gradient path
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_generic_conv_narrow_layers_vs_float64(cfg, dtype):
