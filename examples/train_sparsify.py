@@ -51,6 +51,9 @@ class Net(torch.nn.Module):
         return abs(z)                       # logits = modulus of the 10 complex outputs
 
 
+REPLAY_MS = []          # per phase: ms per replayed step (train_graph)
+
+
 def train_graph(model, x, y, steps, klw, lr, wrap=False):
     """The whole step -- forward, loss + KL, backward [, gradient exchange], Adam -- captured once in a hipGraph
     (cplxmodule_amd.utils.graphs.GraphedStep) and replayed: the model is launch-bound (tens of small kernels per
@@ -77,9 +80,14 @@ def train_graph(model, x, y, steps, klw, lr, wrap=False):
         return loss.detach(), kl.detach()
 
     g = GraphedStep(step, modules=[model], warmup=3)       # warm-up: allocator, caches, Adam state (3 real steps)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(steps - 3):
         out = g.replay()
         hist.append((out[0].clone(), out[1].clone()))       # no host sync inside the loop
+    torch.cuda.synchronize()
+    REPLAY_MS.append((time.perf_counter() - t0) / max(steps - 3, 1) * 1e3)   # steady state, without warm-up / capture
     rel.noise.set_mode("philox")
     if par is not None:
         par.remove()
@@ -158,7 +166,9 @@ def main(argv=None):
               f"kept {int(masks['head.mask'].sum())}/{masks['head.mask'].numel()} head weights")
         if a.time:
             print(f"{4 * a.steps} steps in {elapsed:.2f} s = {1e3 * elapsed / (4 * a.steps):.2f} ms/step "
-                  f"({'hipGraph replay' if a.graph else 'eager'})")
+                  f"({'hipGraph replay, incl. three warm-ups + captures' if a.graph else 'eager'})")
+            if a.graph and REPLAY_MS:
+                print("replayed steps alone: " + " / ".join(f"{v:.3f}" for v in REPLAY_MS[-3:]) + " ms per step (dense / ARD / masked)")
     if world > 1:
         dist.destroy_process_group()
     return dict(dense=h1, ard=h2, masked=h3, sparsity=sp, acc=acc, masks=masks)
