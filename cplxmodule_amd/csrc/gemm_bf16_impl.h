@@ -476,7 +476,26 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
             if (row < g.M && col < g.N) {
               bf16_t* o = reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col;
               if (col + 7 < g.N) {
-                nt_store16(o, v);
+                if (g.fga) {
+                  // the LRT input gradient's elementwise term (gemm.h: fga) on the one-tile kernel -- the form the
+                  // data-parallel exchange and partial-tile shapes run; arithmetic of gemm_bf16_persist.h's FUSE
+                  // epilogue / util.hip dx_accum_kernel: bit-identical
+                  const int64_t fo = (int64_t)row * g.fld + col;
+                  const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.fga) + fo);
+                  const uint4 xv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(pl ? g.fx_i : g.fx_r) + fo);
+                  const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+                  uint32_t ow[4];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float d0 = __uint_as_float(vw[e] << 16), d1 = __uint_as_float(vw[e] & 0xffff0000u);
+                    const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+                    const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
+                    ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
+                  }
+                  nt_store16(o, uint4{ow[0], ow[1], ow[2], ow[3]});
+                } else {
+                  nt_store16(o, v);
+                }
               } else {
                 const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -788,7 +807,15 @@ static int launch_kernel(const GemmArgs& g, hipStream_t st) {
     const int rc = launch_persist<TOUT, CPLX, CONJ, TA, TB>(g, st, taken);
     if (rc || taken) return rc;
   }
-  if (g.fga) return CPLXAMD_ESHAPE;     // the fused epilogue exists in the persistent kernel only: never dropped silently
+  if (g.fga) {
+    // the one-tile kernel carries the fused term in its LDS-staged bf16 epilogue only: the launch must be one that takes
+    // that path with whole 16-byte column groups (same predicate as in the kernel), else decline -- never drop it silently
+    static const int ldsepi = env_int("CPLXAMD_GEMM_LDSEPI", 1);
+    const bool ok = sizeof(TOUT) == 2 && Cfg<CPLX>::JB == 2 && ldsepi && !g.g1 && !g.emul && !g.accumulate && g.splits <= 1 &&
+                    !g.bias_r && (g.ldc & 7) == 0 && (g.fld & 7) == 0 && (g.N & 7) == 0 && aligned16(g.c_r) &&
+                    (!CPLX || aligned16(g.c_i)) && aligned16(g.fga) && aligned16(g.fx_r) && (!CPLX || aligned16(g.fx_i));
+    if (!ok) return CPLXAMD_ESHAPE;
+  }
   return launch_kernel_r<TOUT, CPLX, CONJ, TA, TB>(g, st);
 }
 

@@ -229,8 +229,10 @@ int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int o
  * input and ga = d s2 . exp(log_sigma2) [M, N] (cplxamd_rgemm), all bf16, X / ga with row pitch ldx.  The elementwise
  * term rides in the epilogue of the persistent complex kernel (same arithmetic as cplxamd_cgemm followed by
  * cplxamd_lrt_dx_accum: bit-identical results), which saves the 7 plane passes of that second kernel.
- * CPLXAMD_ESHAPE when the persistent kernel does not take the launch (partial tiles, fewer tiles than CUs, unaligned
- * operands, cplxamd_gemm_set_persistent(0)): run the two calls instead -- nothing is dropped silently. */
+ * Launches the persistent kernel does not take (partial tiles, fewer tiles than CUs, cplxamd_gemm_set_persistent(0) = the
+ * data-parallel form) carry the term in the one-tile kernel's staged epilogue, same bits.  CPLXAMD_ESHAPE when neither
+ * epilogue applies (row pitches / N not multiples of 8 elements, unaligned operands): run the two calls instead --
+ * nothing is dropped silently. */
 int cplxamd_cgemm_lrt_dx(const void* g_r, const void* g_i, int64_t g_rs, int64_t g_cs,
                          const void* w_r, const void* w_i, int64_t w_rs, int64_t w_cs,
                          const void* x_r, const void* x_i, const void* ga, int64_t ldx,

@@ -306,9 +306,9 @@ def test_cfg5_data_parallel_step_as_one_graph_rccl():
 
 @pytest.mark.parametrize("O", [4096, 4064, 4128])          # contraction over O: (O / 32) % 3 = 2, 1, 0 -> all three ring phases
 def test_fused_lrt_input_gradient_is_bit_identical(O):
-    """cplxamd_cgemm_lrt_dx: dX = G conj(W) + 2 X (*) ga in the epilogue of the persistent complex (N,T) kernel ==
-    cplxamd_cgemm followed by cplxamd_lrt_dx_accum, bit for bit; shapes the persistent kernel does not take are
-    declined (CPLXAMD_ESHAPE), never computed without the elementwise term."""
+    """cplxamd_cgemm_lrt_dx: dX = G conj(W) + 2 X (*) ga in the epilogue of the complex (N,T) kernels (persistent, or one
+    workgroup per tile for partial tiles / the data-parallel form) == cplxamd_cgemm followed by cplxamd_lrt_dx_accum, bit
+    for bit; launches neither epilogue can take are declined (CPLXAMD_ESHAPE), never computed without the term."""
     from cplxmodule_amd import _lib, ops
     from cplxmodule_amd._lib import BF16, ptr, stream_ptr, try_call
     dev, bf = "cuda", torch.bfloat16
@@ -331,19 +331,27 @@ def test_fused_lrt_input_gradient_is_bit_identical(O):
     ref = G @ W.conj() + 2 * (xr[rows].double() + 1j * xi[rows].double()).cpu().numpy() * ga[rows].double().cpu().numpy()
     got = (dxr[rows].double() + 1j * dxi[rows].double()).cpu().numpy()
     assert np.abs(got - ref).max() <= 1.2e-2 * np.abs(ref).max()
-    # declined, not mis-computed: partial tiles / one workgroup per tile selected
-    small = torch.empty(8192 - 8, I, device=dev, dtype=bf)
-    assert not try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga), I,
-                        ptr(small), ptr(small), I, B - 8, I, O, BF16, stream_ptr())
+    # partial tiles and the data-parallel form (one workgroup per tile, cplxamd_gemm_set_persistent(0)): the one-tile
+    # kernel carries the term in its staged epilogue -- same bits
+    sr, si = torch.empty(B - 8, I, device=dev, dtype=bf), torch.empty(B - 8, I, device=dev, dtype=bf)
+    assert try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga), I,
+                    ptr(sr), ptr(si), I, B - 8, I, O, BF16, stream_ptr())
+    assert torch.equal(sr, rr[:B - 8]) and torch.equal(si, ri[:B - 8])
     lib = _lib.load()
     try:
         lib.cplxamd_gemm_set_persistent(0)
-        assert not try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga),
-                            I, ptr(dxr), ptr(dxi), I, B, I, O, BF16, stream_ptr())
-        a, b = ops._cplx_lrt_dx(gr, gi, wr, wi, xr, xi, ga)      # the host wrapper then runs the two calls
+        dxr.zero_(); dxi.zero_()
+        assert try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga),
+                        I, ptr(dxr), ptr(dxi), I, B, I, O, BF16, stream_ptr())
+        assert torch.equal(dxr, rr) and torch.equal(dxi, ri)
+        a, b = ops._cplx_lrt_dx(gr, gi, wr, wi, xr, xi, ga)
         assert torch.equal(a, rr) and torch.equal(b, ri)
     finally:
         lib.cplxamd_gemm_set_persistent(1)
+    # declined, not mis-computed: a row pitch the 16-byte epilogue accesses cannot take
+    odd = torch.empty(B, I + 4, device=dev, dtype=bf)
+    assert not try_call("cplxamd_cgemm_lrt_dx", ptr(gr), ptr(gi), O, 1, ptr(wr), ptr(wi), 1, I, ptr(xr), ptr(xi), ptr(ga), I,
+                        ptr(odd), ptr(odd), I + 4, B, I, O, BF16, stream_ptr())
 
 
 def test_bucket_all_reduce_runs_beside_the_gemms():
@@ -591,6 +599,7 @@ def test_fused_real_lrt_input_gradient_is_bit_identical(O):
     rows = torch.randint(0, B, (8,), device=dev)
     f64 = g[rows].double() @ w.double() + 2 * x[rows].double() * ga[rows].double()
     assert (dx[rows].double() - f64).abs().max() <= 1.2e-2 * f64.abs().max()
-    small = torch.empty(B - 8, I, device=dev, dtype=bf)      # partial tiles: declined, the wrapper runs the two calls
-    assert not try_call("cplxamd_rgemm_lrt_dx", ptr(g), O, 1, ptr(w), 1, I, ptr(x), ptr(ga), I, ptr(small), I, B - 8, I, O, BF16,
-                        stream_ptr())
+    small = torch.empty(B - 8, I, device=dev, dtype=bf)      # partial tiles: the one-tile kernel's staged epilogue, same bits
+    assert try_call("cplxamd_rgemm_lrt_dx", ptr(g), O, 1, ptr(w), 1, I, ptr(x), ptr(ga), I, ptr(small), I, B - 8, I, O, BF16,
+                    stream_ptr())
+    assert torch.equal(small, ref[:B - 8])
