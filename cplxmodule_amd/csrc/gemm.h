@@ -25,7 +25,7 @@ struct GemmArgs {
   // is a float on the DEVICE (nullptr: 1); emul_exp: the multiplier is exp(emul[m,n]) (emul = log_sigma2)
   const float* beta = nullptr; int emul_exp = 0;
   int emul_both = 0;   // complex GEMM: the (real) multiplier applies to both planes (masked layers' dW * mask)
-  // LRT input gradient fused into the epilogue (persistent complex bf16 kernel only): C = A op(B) + 2 X (*) ga with the
+  // LRT input gradient fused into the epilogue (bf16-out (N,T) kernels, complex and real, persistent and one-tile): C = A op(B) + 2 X (*) ga with the
   // layer input X = (fx_r, fx_i) [M, N] and ga = d|x|^2 [M, N] (all bf16, row pitch fld): the separate
   // cplxamd_lrt_dx_accum pass (7 plane passes over [B, I]) disappears.  Same arithmetic as the two-kernel path:
   // round(acc) to bf16 first, then fmaf(2 x, ga, that) rounded to bf16.
