@@ -25,7 +25,7 @@ for f in glob.glob("gpurun_out/r03/pmc_conv1/**/*kernel_trace.csv", recursive=Tr
         k = key(r)
         if k: dur[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 med = lambda x: sorted(x)[len(x) // 2] if x else float("nan")
-print("# conv_kernel<float, complex, MODE, 32> on cfg5's layers (MODE 0 fwd, 1 dgrad, 2 wgrad), rocprofv3 --pmc, medians per launch")
+print("# conv_kernel<float, complex, MODE, 32, TN, NARROW> on cfg5's layers (MODE 0 fwd, 1 dgrad, 2 wgrad), rocprofv3 --pmc, medians per launch")
 print(f"{'mode':>4s} {'wgs':>6s} {'us':>7s} {'GHz':>5s} {'VALU inst/wave':>15s} {'VALU busy':>10s} {'MFMA busy':>10s} {'wave wait':>10s}")
 for k in sorted(dur):
     g = med(val[(k, "GRBM_GUI_ACTIVE")]) / 8; us = med(dur[k])
