@@ -260,7 +260,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     if (MODE != MODE_WGRAD) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
-        const int k = k0 + kb0 + KBS * j;
+        // (64-pixel tiles: kb0 is the wave index, so k -- and its split into channel and tap -- is the same for the 64 lanes
+        //  and runs on the scalar unit; PMC: the vector ALUs are the busiest unit of the wide layers' launches)
+        const int k = TN == 64 ? __builtin_amdgcn_readfirstlane(k0 + kb0 + KBS * j) : k0 + kb0 + KBS * j;
         float vr = 0.f, vi = 0.f;
         if (b_ok && k < kend) {
           int c, kh, kw;                                         // c: input channel (FWD) / output channel (DGRAD)
