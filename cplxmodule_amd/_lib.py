@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -121,6 +121,7 @@ SIGNATURES = {
     "cplxamd_bn_bwd_sums": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _P, _L, _P],
     "cplxamd_bn_rows_path": [_L, _I, _L],
     "cplxamd_gemm_set_persistent": [_I],
+    "cplxamd_gemm_set_family": [_I],
     "cplxamd_bn_moments": [_P, _P, _P, _P, _P, _L, _I, _L, _I, _P, _P, _L, _P],
     "cplxamd_bn_fwd_sync": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _L, _P],
     "cplxamd_bn_bwd_sync": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P],

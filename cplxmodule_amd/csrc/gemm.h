@@ -46,6 +46,10 @@ int64_t gemm_generic_ws_bytes(int M, int N, int K, bool cplx);   // split-K scra
 template <bool CPLX>
 int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st);
 
+// one-wave-per-SIMD kernels (gemm_bf16_w4.hip): rc != 0 is an error; taken = false means "not a shape / epilogue this
+// family takes" and the caller goes on to the 8-wave kernels
+int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bool tb, hipStream_t st, bool& taken);
+
 // Gauss 3M (3 real MFMA GEMMs + fused combine) for dense bf16 operands; ESHAPE otherwise
 int launch_gemm_bf16_gauss(const GemmArgs& g, int out_dtype, hipStream_t st);
 int64_t gemm_bf16_gauss_ws_bytes(int M, int N, int K);
@@ -56,6 +60,8 @@ int64_t gemm_bf16_gauss_ws_bytes(int M, int N, int K);
 // takes twice as long.  One workgroup per tile degrades by the share of CUs taken instead: the data-parallel hook turns
 // the persistent form off while its collectives are in flight.
 extern int g_gemm_persistent;
+// kernel family switch (cplxamd_gemm_set_family): 1 = the one-wave-per-SIMD kernels where they apply
+extern int g_gemm_w4;
 
 // workspace the bf16 path wants for split-K at this shape (0: no split-K)
 int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx);

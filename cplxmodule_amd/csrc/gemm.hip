@@ -1,8 +1,12 @@
 // C-ABI dispatch for the complex / real GEMM entry points (include/cplxamd.h).
 #include "gemm.h"
 
+#include <stdlib.h>
+
 namespace cplxamd {
 int g_gemm_persistent = 1;
+static int env_w4() { const char* e = getenv("CPLXAMD_GEMM_W4"); return e ? (atoi(e) != 0) : 1; }
+int g_gemm_w4 = env_w4();
 }
 using namespace cplxamd;
 
@@ -11,6 +15,12 @@ extern "C" {
 int cplxamd_gemm_set_persistent(int on) {
   const int prev = g_gemm_persistent;
   g_gemm_persistent = on ? 1 : 0;
+  return prev;
+}
+
+int cplxamd_gemm_set_family(int w4) {
+  const int prev = g_gemm_w4;
+  g_gemm_w4 = w4 ? 1 : 0;
   return prev;
 }
 

@@ -803,6 +803,12 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 static int launch_kernel(const GemmArgs& g, hipStream_t st) {
   {
+    // round 4: the one-wave-per-SIMD family first (gemm_bf16_w4.hip; same bits)
+    bool taken = false;
+    const int rc = launch_gemm_bf16_w4(g, CPLX, sizeof(TOUT) == 2 ? CPLXAMD_BF16 : CPLXAMD_F32, TA, TB, st, taken);
+    if (rc || taken) return rc;
+  }
+  {
     bool taken = false;
     const int rc = launch_persist<TOUT, CPLX, CONJ, TA, TB>(g, st, taken);
     if (rc || taken) return rc;

@@ -1,0 +1,647 @@
+// One-wave-per-SIMD form of the bf16 complex / real MFMA GEMM (round 4): translation unit 3 of the bf16 GEMM family.
+//
+//   C[m,n] = sum_k A[m,k] * op(B[n,k]) (+ bias[n]),  planar re / im, fp32 accumulation, bf16 or fp32 output;
+//   same operand conventions as gemm_bf16_impl.h ("N" = K-contiguous rows, "T" = K-major as stored), same MFMA order per
+//   accumulator block and per K step, hence BIT-IDENTICAL results to the 8-wave kernels (tests/test_gpu_r04.py).
+//   Reference semantics: cplx.py:634-648 (linear_naive), nn/relevance/complex/base.py:43-56 (the LRT chain's GEMMs).
+//
+// Why another kernel (profiles/r03_gemm_pair_issue.txt, r02_gemm_ablation.md).  The 8-wave kernels are
+// bound by the REQUEST stream of their LDS-DMA staging: a 32-deep K tile asks for 64 bytes per operand row = half a cache
+// line, the other half a K tile (48 KiB of other lines) later: 2426 cycles per K tile against 2048 of MFMA issue.  Halves
+// requested back to back merge in flight (2026 cycles) -- but that needs the landing space of TWO K tiles free at once, and
+// a fourth 48-KiB LDS slot does not exist.  The register file does: at one wave per SIMD a wave owns 512 registers, the
+// 128 x 64 complex wave tile takes 256 of them as accumulators (the AGPR half), and 96 more hold a PAIR of K tiles in
+// flight.  So here
+//  * 4 waves (256 threads), one per SIMD, 2 x 2 over a 256 x 128 complex (256 x 256 real) tile: wave tile 128 x 64 complex
+//    = 16 blocks of 32 x 32 = 256 accumulators (real: 128 x 128);
+//  * operands go global -> VGPR (buffer_load_dwordx4) -> LDS (ds_write_b128): the loads of K tiles (t, t+1) are issued back
+//    to back, register pair by register pair, so that both halves of every 128-byte line are requested together;
+//  * LDS: ring of three 32-deep K-tile slots (144 KiB complex / 96 KiB real), images identical to the 8-wave kernels'
+//    (XOR-swizzled "N" rows read by ds_read_b128, "T" rows read by ds_read_b64_tr_b16), ONE s_barrier per K tile placed in
+//    the middle of the tile (rolling half-tile pipeline: fragments of the second K sub-step are already in registers);
+//  * the K loop is written slot by slot: after every MFMA a fixed list of "fillers" (one fragment read, one LDS write, one
+//    load pair, the sign XORs) pinned with sched_barrier -- at one wave per SIMD nothing else hides an instruction, the
+//    matrix pipe has room for <= 5 other issues per 32-cycle MFMA (MI355X_MICROARCH.md, constants table);
+//  * fragments double-buffered per K sub-step (104 VGPRs complex), negation for the (-Bi) products on the B fragment
+//    (8 XORs per sub-step instead of 16 on the A side; same products, same bits).
+// Schedule of K tile u (ring slot u % 3, parity u & 1; "sub" = K sub-step of 16):
+//   sub 0: MFMAs on F0 | read F1 <- (tile u, sub 1) | write half of the registers of tile u+2 into slot (u+2) % 3
+//   s_waitcnt (F1), s_barrier                       (every wave is done reading tile u-1 ... and has written tile u+1)
+//   sub 1: MFMAs on F1 | read F0 <- (tile u+1, sub 0) | write the other half | odd u: re-issue the register pairs with
+//          tiles (u+3, u+4) as they drain
+// Preconditions (the launcher declines otherwise and the 8-wave kernels run): full tiles, K % 64 == 0, K >= 128, no
+// split-K, no Gauss combine, 16-byte aligned operands / outputs.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm.h"
+
+namespace cplxamd {
+namespace w4 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef W4_DBG
+#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores
+#endif
+// where the two loads of a register pair go, in MFMA slots behind the pair's LDS write (experiments: scripts/r04/w4_build.sh)
+#ifndef W4_LDP
+#define W4_LDP 0
+#endif
+#ifndef W4_LDQ
+#define W4_LDQ 0
+#endif
+
+constexpr int BK = 32;
+
+template <bool CPLX>
+struct Cfg {
+  static constexpr int NT = 256;
+  static constexpr int IB = 4, JB = CPLX ? 2 : 4;               // 32 x 32 blocks per wave
+  static constexpr int WM = 2, WN = 2;
+  static constexpr int BM = 32 * IB * WM, BN = 32 * JB * WN;    // 256 x 128 (complex) / 256 x 256 (real)
+  static constexpr int NPL = CPLX ? 2 : 1;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  static constexpr int SLOT = NPL * (A_BYTES + B_BYTES);        // 48 / 32 KiB
+  static constexpr int SMEM = 3 * SLOT;
+  static constexpr int PA = BM * 4 / NT, PB = BN * 4 / NT;       // 16-byte pieces per lane, plane and K tile
+  static constexpr int NL = NPL * (PA + PB);                     // ... per K tile (12 / 8)
+  static constexpr int NFRAG = NPL * (IB + JB);                  // fragments per K sub-step (12 / 8)
+  static constexpr int NM = NPL * NPL * IB * JB;                 // MFMAs per K sub-step (32 / 16)
+};
+
+// ---- address maps (identical LDS images to gemm_bf16_impl.h: piece_voff / frag_n / frag_t) -------------------
+// piece j of a plane tile, chunk p = j * NT + tid:
+//  !T: (row = p >> 2, source chunk c = p & 3) of [rows][32 k]      -> LDS row * 64 + ((c ^ ((row >> 2) & 3)) << 4)
+//   T: (k = p / (ROWS/8), source chunk c = p % (ROWS/8)) of [32 k][ROWS] -> LDS k * ROWS*2 + ((c ^ ((k & 3) << 2)) << 4)
+template <int ROWS, bool T>
+__device__ __forceinline__ uint32_t src_voff(int64_t ld, int tid) {          // per-lane byte offset of piece 0
+  if (!T) return (uint32_t)((((int64_t)(tid >> 2)) * ld + (tid & 3) * 8) * 2);
+  constexpr int CPR = ROWS / 8;
+  return (uint32_t)((((int64_t)(tid / CPR)) * ld + (tid % CPR) * 8) * 2);
+}
+template <int ROWS, bool T>
+__device__ __forceinline__ uint32_t piece_stride(int64_t ld) {               // source bytes between pieces j and j + 1
+  constexpr int NT = 256;
+  if (!T) return (uint32_t)((NT / 4) * ld * 2);
+  return (uint32_t)((NT / (ROWS / 8)) * ld * 2);
+}
+template <int ROWS, bool T>
+__device__ __forceinline__ uint32_t dst_off(int tid) {                        // per-lane LDS byte offset of piece 0
+  if (!T) {
+    const int row = tid >> 2, c = tid & 3;
+    return (uint32_t)(row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+  }
+  constexpr int CPR = ROWS / 8;
+  const int k = tid / CPR, c = tid % CPR;
+  return (uint32_t)(k * (ROWS * 2) + ((c ^ ((k & 3) << 2)) << 4));
+}
+// (piece j adds j * 4096 bytes in every layout: 64 rows x 64 B, or (256 / CPR) k rows x ROWS * 2 B)
+
+// Fragment reads take this lane's LDS byte address (lane part + ring slot: ONE register per (slot, K sub-step) for an "N"
+// operand, per (slot, block) for a "T" operand, made opaque so that the compiler neither re-derives nor hoists variants of
+// it) plus a compile-time byte offset that fits the 16-bit offset field (plane, block row, K sub-step: < 48 KiB).
+typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
+typedef __attribute__((address_space(3))) s16x4* lds_tr_p;
+typedef __attribute__((address_space(3))) u32x4* lds_st_p;
+__device__ __forceinline__ bf16x8 lds_frag_n(uint32_t addr, int imm) { return *(lds_frag_p)(uintptr_t)(addr + (uint32_t)imm); }
+// "T" image [32 k][ROWS]: two hardware-transposed 4 x 16 reads, k and k + 4
+template <int ROWS>
+__device__ __forceinline__ bf16x8 lds_frag_t(uint32_t addr, int imm) {
+  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)(addr + (uint32_t)imm));
+  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)(addr + (uint32_t)(imm + 4 * ROWS * 2)));
+  const s16x8 both = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, both);
+}
+// lane parts.  "N": row * 64 + ((kc ^ ((row >> 2) & 3)) << 4) with row = (wave origin + lane & 31), kc = 2 ks + (lane >> 5);
+// "T": k * ROWS*2 + (((r >> 3) ^ ((k & 3) << 2)) << 4) + (r & 7) * 2 with k = 8 (lane >> 5) + (m >> 2), r = rb + 4 (m & 3),
+// rb = wave origin + 32 blk + 16 ((lane >> 4) & 1), m = lane & 15   (gemm_bf16_impl.h: frag_n / frag_t)
+__device__ __forceinline__ uint32_t lane_n(int worg, int lane, int ks) {
+  const int row = worg + (lane & 31), kc = ks * 2 + (lane >> 5);
+  return (uint32_t)(row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
+}
+template <int ROWS>
+__device__ __forceinline__ uint32_t lane_t(int worg, int lane, int blk) {
+  const int m = lane & 15, k = 8 * (lane >> 5) + (m >> 2);
+  const int r = worg + blk * 32 + 16 * ((lane >> 4) & 1) + 4 * (m & 3);
+  return (uint32_t)(k * (ROWS * 2) + (((r >> 3) ^ ((k & 3) << 2)) << 4) + (r & 7) * 2);
+}
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
+  uint4 u = __builtin_bit_cast(uint4, v);
+  u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ void store16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ void store16(float* p, const f4& a) { st4(p, a); }
+
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+
+// MFMA slot of the k-th LDS write of a K sub-step, and its inverse (-1: slot m - off carries no write)
+constexpr int write_slot(bool cplx, int k) { return cplx ? 6 + 4 * k : (k == 0 ? 6 : k == 1 ? 9 : k == 2 ? 11 : 14); }
+constexpr int slot_of_write(bool cplx, int nw, int m, int off) {
+  for (int k = 0; k < nw; ++k)
+    if (write_slot(cplx, k) + off == m) return k;
+  return -1;
+}
+
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using C = Cfg<CPLX>;
+  constexpr int NT = C::NT, BM = C::BM, BN = C::BN, IB = C::IB, JB = C::JB, NPL = C::NPL;
+  constexpr int PA = C::PA, PB = C::PB, NL = C::NL, NFRAG = C::NFRAG, NM = C::NM, SLOT = C::SLOT;
+
+  // ---- tile coordinates: XCD-contiguous grouped order (as gemm_bf16_kernel) ---------------------------------
+  const int tiles_m = g.M / BM, tiles_n = g.N / BN;
+  const int ntiles = tiles_m * tiles_n;
+  int bm, bn;
+  {
+    int lin = blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = lin & 7, idx = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective
+    const int GM = g.group_m;
+    const int per_group = GM * tiles_n;
+    const int grp = lin / per_group, in_grp = lin - grp * per_group;
+    const int first_m = grp * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    bm = first_m + in_grp % gm; bn = in_grp / gm;
+  }
+  const int m0 = __builtin_amdgcn_readfirstlane(bm * BM), n0 = __builtin_amdgcn_readfirstlane(bn * BN);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = (wid / C::WN) * (32 * IB), wn = (wid % C::WN) * (32 * JB);
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int l15 = lane & 15, lg = (lane >> 4) & 1;
+
+  const int64_t lda = TA ? g.a_cs : g.a_rs, ldb = TB ? g.b_cs : g.b_rs;
+  // plane base pointers of this tile (wave-uniform); a K tile pair advances them by `kstep` bytes
+  const char* pa[NPL]; const char* pb[NPL];
+  pa[0] = (const char*)g.a_r + (TA ? (int64_t)m0 : (int64_t)m0 * lda) * 2;
+  pb[0] = (const char*)g.b_r + (TB ? (int64_t)n0 : (int64_t)n0 * ldb) * 2;
+  if (CPLX) {
+    pa[NPL - 1] = (const char*)g.a_i + (TA ? (int64_t)m0 : (int64_t)m0 * lda) * 2;
+    pb[NPL - 1] = (const char*)g.b_i + (TB ? (int64_t)n0 : (int64_t)n0 * ldb) * 2;
+  }
+  const int64_t ka = TA ? lda * 2 : 2, kb = TB ? ldb * 2 : 2;       // bytes per k step
+  const uint32_t voa = src_voff<BM, TA>(lda, tid), vob = src_voff<BN, TB>(ldb, tid);
+  const uint32_t psa = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece_stride<BM, TA>(lda));
+  const uint32_t psb = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece_stride<BN, TB>(ldb));
+  // second K tile of a pair: + 32 k.  "N": 64 bytes further in the same line (immediate); "T": 32 rows further (scalar)
+  const uint32_t qa = TA ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(32 * ka)) : 0u;
+  const uint32_t qb = TB ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(32 * kb)) : 0u;
+  const uint32_t wra = dst_off<BM, TA>(tid), wrb = dst_off<BN, TB>(tid);
+
+  f32x16 acc_r[IB][JB], acc_i[CPLX ? IB : 1][JB];
+
+  // bias rides in the accumulators (see gemm_bf16_kernel)
+  const bool has_bias = g.bias_r != nullptr;
+  f4 bias_v[NPL][JB][4];
+  if (has_bias) {
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      const float* bias = pl ? g.bias_i : g.bias_r;
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_v[pl][j][q] = ld4(bias + n0 + wn + j * 32 + 8 * q + 4 * lk);
+    }
+  }
+
+  // ---- staging registers: [parity of the K tile][piece] ------------------------------------------------------
+  u32x4 st[2][NL];
+  // piece q: [0, PA) A re, [PA, PA+PB) B re, then A im, B im
+  auto load_piece = [&](auto PAR, auto Q, int kt) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value, q = decltype(Q)::value;
+    constexpr int pl = q / (PA + PB), r = q % (PA + PB);
+    constexpr bool isa = r < PA;
+    constexpr int j = isa ? r : r - PA;
+    // pair base = K tile (kt & ~1); the odd tile of the pair is +32 k
+    const int64_t kby = (int64_t)(kt & ~1) * BK * (isa ? ka : kb);
+    const char* base = (isa ? pa[pl] : pb[pl]) + kby;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffe, 0x00020000);
+    const uint32_t so = (uint32_t)j * (isa ? psa : psb) + (par ? (isa ? qa : qb) : 0u);
+    const uint32_t vo = (isa ? voa : vob) + ((par && !(isa ? TA : TB)) ? 64u : 0u);
+    st[par][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+  };
+  // LDS addresses: per ring slot one register per operand for the writes ...
+  const uint32_t smem_off = (uint32_t)(uintptr_t)smem;
+  uint32_t wa[3], wb[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    wa[s3] = opaque(smem_off + s3 * SLOT + wra);
+    wb[s3] = opaque(smem_off + s3 * SLOT + C::A_BYTES + wrb);
+  }
+  auto write_piece = [&](auto PAR, auto Q, auto WS) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value, q = decltype(Q)::value, ws = decltype(WS)::value;
+    constexpr int pl = q / (PA + PB), r = q % (PA + PB);
+    constexpr bool isa = r < PA;
+    constexpr int j = isa ? r : r - PA;
+    const uint32_t addr = (isa ? wa[ws] : wb[ws]) + (uint32_t)(pl * (C::A_BYTES + C::B_BYTES) + j * 4096);
+    *(lds_st_p)(uintptr_t)(addr) = st[par][q];
+  };
+  // ... and for the fragment reads one per K sub-step ("N") or per block ("T")
+  constexpr int NFA = TA ? IB : 2, NFB = TB ? JB : 2;
+  uint32_t fa[3][NFA], fb[3][NFB];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+    for (int x = 0; x < NFA; ++x)
+      fa[s3][x] = opaque(smem_off + s3 * SLOT + (TA ? lane_t<BM>(wm, lane, x) : lane_n(wm, lane, x)));
+#pragma unroll
+    for (int x = 0; x < NFB; ++x)
+      fb[s3][x] = opaque(smem_off + s3 * SLOT + C::A_BYTES + (TB ? lane_t<BN>(wn, lane, x) : lane_n(wn, lane, x)));
+  }
+  // fragment (plane pl, block, K sub-step ks) of ring slot S
+  auto a_frag = [&](auto S, auto PL, auto BLK, auto KS) __attribute__((always_inline)) -> bf16x8 {
+    constexpr int s3 = decltype(S)::value, pl = decltype(PL)::value, blk = decltype(BLK)::value, ks = decltype(KS)::value;
+    constexpr int po = pl * (C::A_BYTES + C::B_BYTES);
+    if constexpr (TA) return lds_frag_t<BM>(fa[s3][blk], po + ks * 16 * (BM * 2));
+    else return lds_frag_n(fa[s3][ks], po + blk * 2048);
+  };
+  auto b_frag = [&](auto S, auto PL, auto BLK, auto KS) __attribute__((always_inline)) -> bf16x8 {
+    constexpr int s3 = decltype(S)::value, pl = decltype(PL)::value, blk = decltype(BLK)::value, ks = decltype(KS)::value;
+    constexpr int po = pl * (C::A_BYTES + C::B_BYTES);
+    if constexpr (TB) return lds_frag_t<BN>(fb[s3][blk], po + ks * 16 * (BN * 2));
+    else return lds_frag_n(fb[s3][ks], po + blk * 2048);
+  };
+
+  // Fragment registers.  MFMA order inside a K sub-step is block row i outermost, so the A fragments of row i die after
+  // its 2 * NPL * JB MFMAs and the next sub-step's fragments of that row are read into the SAME registers (rows 0..2);
+  // row 3 (last used, first to be needed again too late) and all B fragments alternate between two sets.
+  bf16x8 ar[IB + 1], ai[CPLX ? IB + 1 : 1], br[2][JB], bi[2][CPLX ? JB : 1], nbi[CPLX ? JB : 1];
+  using PL0 = std::integral_constant<int, 0>; using PL1 = std::integral_constant<int, NPL - 1>;
+  auto rd_a = [&](auto F, auto I, auto S, auto KS) __attribute__((always_inline)) {   // row I of (slot S, sub-step KS) -> its register for set F
+    constexpr int f = decltype(F)::value, i = decltype(I)::value;
+    constexpr int d = i < IB - 1 ? i : IB - 1 + f;
+    ar[d] = a_frag(S, PL0{}, I, KS);
+  };
+  auto rd_ai = [&](auto F, auto I, auto S, auto KS) __attribute__((always_inline)) {
+    constexpr int f = decltype(F)::value, i = decltype(I)::value;
+    constexpr int d = i < IB - 1 ? i : IB - 1 + f;
+    if constexpr (CPLX) ai[d] = a_frag(S, PL1{}, I, KS);
+  };
+  auto rd_b = [&](auto F, auto J, auto S, auto KS) __attribute__((always_inline)) {
+    constexpr int f = decltype(F)::value;
+    br[f][decltype(J)::value] = b_frag(S, PL0{}, J, KS);
+  };
+  auto rd_bi = [&](auto F, auto J, auto S, auto KS) __attribute__((always_inline)) {
+    constexpr int f = decltype(F)::value;
+    if constexpr (CPLX) bi[f][decltype(J)::value] = b_frag(S, PL1{}, J, KS);
+  };
+
+  // MFMA m of a K sub-step on fragment set f.  Per accumulator the order is (br, then bi) per K sub-step as in
+  // gemm_bf16_kernel: bit-identical sums.  complex: m = i * 8 + ph * 4 + j * 2 + c;  real: m = i * JB + j
+  auto mfma = [&](auto F, auto MM) __attribute__((always_inline)) {
+    constexpr int f = decltype(F)::value, m = decltype(MM)::value;
+    if constexpr ((W4_DBG & 1) != 0) return;
+    if constexpr (CPLX) {
+      constexpr int i = m / 8, ph = (m % 8) / 4, j = (m % 4) / 2, c = m % 2;
+      constexpr int d = i < IB - 1 ? i : IB - 1 + f;
+      if constexpr (ph == 0) {
+        if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ar[d], acc_r[i][j], 0, 0, 0);
+        else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ai[d], acc_i[i][j], 0, 0, 0);
+      } else if constexpr (CONJ) {
+        if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[f][j], ai[d], acc_r[i][j], 0, 0, 0);
+        else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nbi[j], ar[d], acc_i[i][j], 0, 0, 0);
+      } else {
+        if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nbi[j], ai[d], acc_r[i][j], 0, 0, 0);
+        else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[f][j], ar[d], acc_i[i][j], 0, 0, 0);
+      }
+    } else {
+      constexpr int i = m / JB, j = m % JB;
+      constexpr int d = i < IB - 1 ? i : IB - 1 + f;
+      acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ar[d], acc_r[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nt = __builtin_amdgcn_readfirstlane(g.K / BK);
+
+  // One K sub-step: NM MFMA slots; behind slot m its fillers.  F = fragment set the MFMAs use (the reads fill the other
+  // one / the dead rows), PAR = parity of the K tile being computed (= parity of the registers being written), H = which
+  // half of the tile.  Slot table (G = MFMAs per block row = NM / IB):
+  //   0 .. 2 JB-1        next B fragments (other set);  0, 1 also: the sign XORs of THIS sub-step's Bi
+  //   2 JB, 2 JB + 1     next A row 3 (other set)          [real: JB]
+  //   (i+1) G, (i+1) G+1 next A row i = 0, 1, 2 (in place, behind the row's last MFMA)
+  //   the NL / 2 LDS writes (odd tiles: each followed by the register pair's two loads) on the free slots in between
+  auto sub = [&](auto F, auto PAR, auto H, auto RS, auto RKS, auto WS, int kt_next) __attribute__((always_inline)) {
+    constexpr int f = decltype(F)::value, par = decltype(PAR)::value, h = decltype(H)::value;
+    using I_F = std::integral_constant<int, f>;
+    using I_G = std::integral_constant<int, 1 - f>;
+    using I_P = std::integral_constant<int, par>;
+    constexpr int G = NM / IB;                                // 8 / 4
+    constexpr int NW = NL / 2;                                // writes per sub-step (6 / 4)
+    auto slot_fill = [&](auto MM) __attribute__((always_inline)) {
+      constexpr int m = decltype(MM)::value;
+      // --- fragment reads
+      if constexpr (m < NPL * JB) {
+        if constexpr (CPLX) {
+          if constexpr ((m & 1) == 0) rd_b(I_G{}, std::integral_constant<int, m / 2>{}, RS, RKS);
+          else rd_bi(I_G{}, std::integral_constant<int, m / 2>{}, RS, RKS);
+        } else {
+          rd_b(I_G{}, std::integral_constant<int, m>{}, RS, RKS);
+        }
+      }
+      if constexpr (CPLX && m < JB) nbi[m] = neg_frag(bi[f][m]);
+      if constexpr (m == NPL * JB) rd_a(I_G{}, std::integral_constant<int, IB - 1>{}, RS, RKS);
+      if constexpr (CPLX && m == NPL * JB + 1) rd_ai(I_G{}, std::integral_constant<int, IB - 1>{}, RS, RKS);
+      if constexpr (m >= G && m % G == 0 && m / G <= IB - 1) rd_a(I_G{}, std::integral_constant<int, m / G - 1>{}, RS, RKS);
+      if constexpr (CPLX && m >= G && m % G == 1 && m / G <= IB - 1) rd_ai(I_G{}, std::integral_constant<int, m / G - 1>{}, RS, RKS);
+      // --- LDS writes: complex slots 6 10 14 18 22 26 (never a read slot); real 6 9 11 14.  Odd tiles: the two loads that
+      // refill the register pair W4_LDP / W4_LDQ slots behind its write
+      constexpr int wi = slot_of_write(CPLX, NW, m, 0), lp = slot_of_write(CPLX, NW, m, W4_LDP), lq = slot_of_write(CPLX, NW, m, W4_LDQ);
+      if constexpr (wi >= 0 && (W4_DBG & 4) == 0) write_piece(I_P{}, std::integral_constant<int, h * NW + (wi >= 0 ? wi : 0)>{}, WS);
+      if constexpr (par == 1 && (W4_DBG & 2) == 0) {
+        if constexpr (lp >= 0) { W4_SB(); load_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, h * NW + (lp >= 0 ? lp : 0)>{}, kt_next); }
+        if constexpr (lq >= 0) { W4_SB(); load_piece(std::integral_constant<int, 1>{}, std::integral_constant<int, h * NW + (lq >= 0 ? lq : 0)>{}, kt_next); }
+      }
+    };
+    auto run = [&](auto self, auto MM) __attribute__((always_inline)) {
+      constexpr int m = decltype(MM)::value;
+      if constexpr (m < NM) {
+        mfma(I_F{}, MM);
+        W4_SB();
+        slot_fill(MM);
+        W4_SB();
+        self(self, std::integral_constant<int, m + 1>{});
+      }
+    };
+    run(run, std::integral_constant<int, 0>{});
+  };
+
+  // ---- prologue: K tiles 0, 1 through the registers into slots 0, 1; pair (2, 3) requested ------------------------
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  auto for_pieces = [&](auto fn) __attribute__((always_inline)) {
+    auto go = [&](auto self, auto Q) __attribute__((always_inline)) {
+      constexpr int q = decltype(Q)::value;
+      if constexpr (q < NL) { fn(Q); self(self, std::integral_constant<int, q + 1>{}); }
+    };
+    go(go, I0{});
+  };
+  for_pieces([&](auto Q) __attribute__((always_inline)) { load_piece(I0{}, Q, 0); load_piece(I1{}, Q, 0); });
+  // acc = bias[n] (or 0)
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc_r[i][j][4 * q + e] = has_bias ? bias_v[0][j][q].v[e] : 0.f;
+          if (CPLX) acc_i[i][j][4 * q + e] = has_bias ? bias_v[NPL - 1][j][q].v[e] : 0.f;
+        }
+  for_pieces([&](auto Q) __attribute__((always_inline)) {
+    write_piece(I0{}, Q, I0{});
+    write_piece(I1{}, Q, I1{});
+  });
+  {
+    const int kt = nt > 2 ? 2 : nt - 2;
+    for_pieces([&](auto Q) __attribute__((always_inline)) { load_piece(I0{}, Q, kt); load_piece(I1{}, Q, kt); });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    // fragments of (tile 0, sub 0) -> set 0
+    auto goa = [&](auto self, auto I) __attribute__((always_inline)) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (i < IB) { rd_a(I0{}, I, I0{}, I0{}); rd_ai(I0{}, I, I0{}, I0{}); self(self, std::integral_constant<int, i + 1>{}); }
+    };
+    auto gob = [&](auto self, auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (j < JB) { rd_b(I0{}, J, I0{}, I0{}); rd_bi(I0{}, J, I0{}, I0{}); self(self, std::integral_constant<int, j + 1>{}); }
+    };
+    gob(gob, I0{});
+    goa(goa, I0{});
+  }
+
+  // ---- K loop ---------------------------------------------------------------------------------------------------
+  // K tile t in ring slot S (compile time), parity P (compile time)
+  auto tile = [&](auto SS, auto PP, int t) __attribute__((always_inline)) {
+    constexpr int s = decltype(SS)::value;
+    using CUR = std::integral_constant<int, s>; using NXT = std::integral_constant<int, (s + 1) % 3>;
+    using WR = std::integral_constant<int, (s + 2) % 3>;
+    // odd tiles re-issue the register pairs with K tiles (t+3, t+4); past the end: the last pair again (unused)
+    const int ktn = (t + 3 < nt) ? t + 3 : nt - 2;
+    sub(I0{}, PP, I0{}, CUR{}, I1{}, WR{}, ktn);
+    // every wave: its F1 reads are complete (they are older than this sub-step's NL/2 LDS writes)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NL / 2) : "memory");
+    __builtin_amdgcn_s_barrier();
+    W4_SB();
+    sub(I1{}, PP, I1{}, NXT{}, I0{}, WR{}, ktn);
+  };
+  {
+    int t = 0;
+    for (; t + 6 <= nt; t += 6) {
+      tile(I0{}, I0{}, t);
+      tile(I1{}, I1{}, t + 1);
+      tile(I2{}, I0{}, t + 2);
+      tile(I0{}, I1{}, t + 3);
+      tile(I1{}, I0{}, t + 4);
+      tile(I2{}, I1{}, t + 5);
+    }
+    if (t < nt) {
+      tile(I0{}, I0{}, t);
+      tile(I1{}, I1{}, t + 1);
+      t += 2;
+      if (t < nt) {
+        tile(I2{}, I0{}, t);
+        tile(I0{}, I1{}, t + 1);
+      }
+    }
+  }
+
+  // ---- epilogue (the one-tile kernel's, for IB = 4 and JB / 2 column halves of 64) ------------------------------
+  TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
+  TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
+  const float beta = gemm_beta(g);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                    // every wave is done with the ring
+  if constexpr ((W4_DBG & 8) != 0) {
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        asm volatile("" ::"v"(acc_r[i][j]));
+        if (CPLX) asm volatile("" ::"v"(acc_i[i][j]));
+      }
+    return;
+  }
+  if constexpr (sizeof(TOUT) == 2) {
+    // bf16: the wave's tile goes through LDS so that a store instruction writes whole 128-byte lines
+    constexpr int PITCH = 144;                        // bytes per staged row (64 bf16 + 16 B pad)
+    char* reg = smem + wid * (64 * PITCH);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      TOUT* out = pl ? ci : cr;
+#pragma unroll
+      for (int jh = 0; jh < JB / 2; ++jh)
+#pragma unroll
+        for (int ih = 0; ih < IB / 2; ++ih) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int cl = jj * 32 + 8 * q + 4 * lk;
+                f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  v.v[e] = pl ? acc_i[CPLX ? ih * 2 + ii : 0][jh * 2 + jj][4 * q + e] : acc_r[ih * 2 + ii][jh * 2 + jj][4 * q + e];
+                st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
+              }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is in LDS (in-order LDS, own region)
+#pragma unroll
+          for (int pass = 0; pass < 8; ++pass) {
+            const int rl = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(reg + rl * PITCH + c8 * 2);
+            const int row = m0 + wm + ih * 64 + rl, col = n0 + wn + jh * 64 + c8;
+            bf16_t* o = reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col;
+            if (g.fga) {
+              // LRT input gradient's elementwise term (gemm.h: fga); arithmetic of util.hip dx_accum_kernel: bit-identical
+              const int64_t fo = (int64_t)row * g.fld + col;
+              const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.fga) + fo);
+              const uint4 xv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(pl ? g.fx_i : g.fx_r) + fo);
+              const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+              uint32_t ow[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float d0 = __uint_as_float(vw[e] << 16), d1 = __uint_as_float(vw[e] & 0xffff0000u);
+                const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+                const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
+                ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
+              }
+              store16(o, uint4{ow[0], ow[1], ow[2], ow[3]});
+            } else {
+              store16(o, v);
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
+        }
+    }
+  } else {
+    // float32: 32 rows x 64 columns per round; the elementwise multiplier (LRT log_sigma2 gradient, mask) and the
+    // accumulate operand are read row-major at the same point
+    constexpr int PITCH = 272;                        // bytes per staged row (64 floats + 16 B pad)
+    char* reg = smem + wid * (32 * PITCH);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      float* out = reinterpret_cast<float*>(pl ? ci : cr);
+#pragma unroll
+      for (int jh = 0; jh < JB / 2; ++jh)
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cl = jj * 32 + 8 * q + 4 * lk;
+              f4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v.v[e] = pl ? acc_i[CPLX ? i : 0][jh * 2 + jj][4 * q + e] : acc_r[i][jh * 2 + jj][4 * q + e];
+              st4(reinterpret_cast<float*>(reg + l31 * PITCH + cl * 4), v);
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int pass = 0; pass < 8; ++pass) {
+            const int rl = pass * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            f4 v = ld4(reinterpret_cast<const float*>(reg + rl * PITCH + c4 * 4));
+            const int row = m0 + wm + i * 32 + rl, col = n0 + wn + jh * 64 + c4;
+            const int64_t o = (int64_t)row * g.ldc + col;
+            if (g.emul && (!pl || g.emul_both)) {
+              const f4 m = ld4(g.emul + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v.v[e] *= gemm_emul(g, m.v[e]);
+            }
+            if (g.accumulate) {
+              const f4 p = ld4(out + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v.v[e] += beta * p.v[e];
+            }
+            store16(out + o, v);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+  }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+static int launch(const GemmArgs& g0, hipStream_t st) {
+  using C = Cfg<CPLX>;
+  GemmArgs g = g0;
+  static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
+  g.group_m = gm > 0 ? gm : 1;
+  const int64_t tiles = (int64_t)(g.M / C::BM) * (g.N / C::BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)tiles), C::NT, C::SMEM, st>>>(g);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename TOUT, bool CPLX, bool CONJ>
+static int launch_layout(const GemmArgs& g, bool ta, bool tb, hipStream_t st) {
+  if (ta) return tb ? launch<TOUT, CPLX, CONJ, true, true>(g, st) : CPLXAMD_ESHAPE;     // (T,N) is launched by nothing
+  return tb ? launch<TOUT, CPLX, CONJ, false, true>(g, st) : launch<TOUT, CPLX, CONJ, false, false>(g, st);
+}
+
+}  // namespace w4
+
+// 0 and taken = true: launched.  taken = false: the shape / epilogue is not one this kernel takes.
+int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bool tb, hipStream_t st, bool& taken) {
+  taken = false;
+  if (!g_gemm_w4) return 0;
+  const int bm = 256, bn = cplx ? 128 : 256;
+  if (g.splits > 1 || g.g1 || g.batch != 1) return 0;
+  if (ta && !tb) return 0;
+  if ((g.M % bm) || (g.N % bn) || (g.K % 64) || g.K < 128) return 0;
+  if ((int64_t)(g.M / bm) * (g.N / bn) > 0x7fffffff) return 0;
+  const int64_t lda = ta ? g.a_cs : g.a_rs, ldb = tb ? g.b_cs : g.b_rs;
+  if ((lda % 8) || (ldb % 8) || lda >= (1 << 22) || ldb >= (1 << 22)) return 0;      // 32-bit per-lane tile offsets
+  if (!w4::aligned16(g.a_r) || !w4::aligned16(g.b_r) || !w4::aligned16(g.c_r)) return 0;
+  if (cplx && (!w4::aligned16(g.a_i) || !w4::aligned16(g.b_i) || !w4::aligned16(g.c_i))) return 0;
+  if (g.bias_r && (!w4::aligned16(g.bias_r) || (cplx && !w4::aligned16(g.bias_i)))) return 0;
+  if (out_dtype == CPLXAMD_BF16) {
+    if ((g.ldc & 7) || g.emul || g.accumulate) return 0;
+    if (g.fga && ((g.fld & 7) || !w4::aligned16(g.fga) || !w4::aligned16(g.fx_r) || (cplx && !w4::aligned16(g.fx_i)) || g.bias_r))
+      return 0;
+  } else if (out_dtype == CPLXAMD_F32) {
+    if ((g.ldc & 3) || g.fga || (g.emul && !w4::aligned16(g.emul))) return 0;
+  } else {
+    return 0;
+  }
+  int rc;
+  const bool f32 = out_dtype == CPLXAMD_F32;
+  if (cplx) {
+    if (g.conj_b) rc = f32 ? w4::launch_layout<float, true, true>(g, ta, tb, st) : w4::launch_layout<bf16_t, true, true>(g, ta, tb, st);
+    else rc = f32 ? w4::launch_layout<float, true, false>(g, ta, tb, st) : w4::launch_layout<bf16_t, true, false>(g, ta, tb, st);
+  } else {
+    rc = f32 ? w4::launch_layout<float, false, false>(g, ta, tb, st) : w4::launch_layout<bf16_t, false, false>(g, ta, tb, st);
+  }
+  if (rc == CPLXAMD_ESHAPE) return 0;
+  if (rc) return rc;
+  taken = true;
+  return 0;
+}
+
+}  // namespace cplxamd

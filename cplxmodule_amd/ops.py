@@ -668,6 +668,10 @@ class CplxLinearLRTFn(torch.autograd.Function):
             # the (unscaled) KL gradients are written now -- into the parameters' data-parallel bucket
             # slices when there is one -- and the data gradients are added to them in backward
             ctx.klg = (grad_buffer(ls2), grad_buffer(wr), grad_buffer(wi))
+            # under a data-parallel hook these are views of the parameters' bucket slices: whatever a backward pass
+            # returns is copied into (or IS) that storage, so the pending KL gradients survive only the pass that
+            # consumes them (nll.backward(); (c * kl).backward() returned the data gradient as the KL one)
+            ctx.klg_shared = dp_hook is not None
         if _prep_ok(x2r, wrc, wic, ls2c):
             wcr, wci, S, kl, _ = prep_kl(kl_kind, wrc, wic, ls2c, kl_kind is not None, ctx.klg)
         else:
@@ -705,8 +709,10 @@ class CplxLinearLRTFn(torch.autograd.Function):
             if gkl is not None and ctx.kl_kind is not None:
                 if ctx.klg is None:          # the buffers hold totals by now: redo the KL part
                     wr, wi, ls2 = ctx.kl_params
-                    ctx.klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:]
+                    ctx.klg, ctx.klg_shared = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:], False
                 dls2, dwr, dwi = (_scaled(gkl, t) for t in ctx.klg)
+                if ctx.klg_shared:
+                    ctx.klg = None           # the hook overwrites the bucket slices with what this pass returns
             ctx.kl_only_ran = True
             return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
         x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi = _saved(ctx)
@@ -760,8 +766,8 @@ class CplxLinearLRTFn(torch.autograd.Function):
                 _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)  # (gs2^T a) * exp(ls2)
                 if klg is not None:
                     dls2.add_(klg[0] * gkl)
-        if fused:
-            ctx.klg = None                                   # consumed: the buffers hold totals now
+        if fused or getattr(ctx, "klg_shared", False):
+            ctx.klg = None                                   # consumed (or about to be overwritten by the hook's copy): the buffers hold totals now
         if not _EARLY_W:
             _announce(wr if dwr is not None else None, wi if dwi is not None else None)
         _announce(ls2 if dls2 is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
@@ -843,6 +849,7 @@ class RealLinearLRTFn(torch.autograd.Function):
         kl = ctx.klg = None
         if kl_kind is not None:
             ctx.klg = (grad_buffer(ls2), grad_buffer(w))
+            ctx.klg_shared = dp_hook is not None             # (see CplxLinearLRTFn.forward)
         if _prep_ok(x2, wc_, ls2c):
             wb, _, S, kl, _ = prep_kl(kl_kind, wc_, None, ls2c, kl_kind is not None,
                                       None if ctx.klg is None else (*ctx.klg, None))
@@ -873,8 +880,10 @@ class RealLinearLRTFn(torch.autograd.Function):
                 if ctx.klg is None:
                     w, ls2 = ctx.kl_params
                     r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
-                    ctx.klg = (r[1], r[2])
+                    ctx.klg, ctx.klg_shared = (r[1], r[2]), False
                 dls2, dw = _scaled(gkl, ctx.klg[0]), _scaled(gkl, ctx.klg[1])
+                if ctx.klg_shared:
+                    ctx.klg = None
             ctx.kl_only_ran = True
             return dx, dw, db, dls2, None, None, None, None
         x2, w, ls2, s2, a, eps, b = _saved(ctx)
@@ -917,7 +926,7 @@ class RealLinearLRTFn(torch.autograd.Function):
                 _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
                 if klg is not None:
                     dls2.add_(klg[0] * gkl)
-        if fused:
+        if fused or getattr(ctx, "klg_shared", False):
             ctx.klg = None
         _announce(ls2 if dls2 is not None else None, w if dw is not None else None, b if db is not None else None)
         if need[0]:

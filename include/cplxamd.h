@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 16
+#define CPLXAMD_ABI_VERSION 17
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -217,6 +217,15 @@ int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
  * RCCL all-reduce overlapping the backward pass -- and the GEMMs run one workgroup per tile, which shares CUs gracefully.
  * Results are bit-identical either way (tests/test_gpu_gemm_persist.py). */
 int cplxamd_gemm_set_persistent(int on);
+
+/* Process-wide choice of the bf16 GEMM kernel family (returns the previous setting):
+ *   1 (start value; env CPLXAMD_GEMM_W4=0 starts with 0)  the one-wave-per-SIMD kernels of round 4 (gemm_bf16_w4.hip:
+ *     4 waves, 128 x 64 complex wave tile in the accumulator half of the 512-register file, operands staged through
+ *     registers with both halves of every cache line requested together) wherever they take the launch (full 256 x 128
+ *     complex / 256 x 256 real tiles, K % 64 == 0), the 8-wave LDS-DMA kernels for everything else;
+ *   0  the 8-wave kernels only (rounds 1-3).
+ * Both families produce the same bits (same MFMA sequence per accumulator; tests/test_gpu_r04.py). */
+int cplxamd_gemm_set_family(int w4);
 
 /* Optional scratch for split-K (few output tiles, long K -- e.g. the weight gradient at batch
  * 2^20, or a 10-output head): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be NULL
