@@ -227,9 +227,33 @@ def conv_point(dev, batch=256):
         return {"error": str(e)[:200]}
 
 
-def cfg4_point(dev, log2_batch=20):
+# The reference itself (PyTorch CPU path of ivannz/cplxmodule) cannot travel to the GPU box; its numbers are the ones taken
+# in the build container (BASELINE.md section 2, rows 2 / 2' / 2'' / 4): context beside `cpu_baseline`, never a target.
+REFERENCE_CPU = {
+    "hardware": "8-core Intel Xeon 2.1 GHz, torch 2.10 CPU kernels (MKL / oneDNN), fp32, measured in the build container",
+    "source": "BASELINE.md section 2",
+    "cfg2_linear_4m(cplx.linear_naive, B=8192, 4096->4096, fwd+bwd)": {"ms_per_step": 6199, "samples_per_s": 1322},
+    "cfg2_linear_3m(cplx.linear_3m)": {"ms_per_step": 3966, "samples_per_s": 2065},
+    "cfg2_linear_cat(cplx.linear_cat)": {"ms_per_step": 4703, "samples_per_s": 1742},
+    "cfg4_lrt(CplxLinearVD 2048->2048 + exact KL, batch 2^14)": {"ms_per_step": 8723, "samples_per_s": 1878},
+}
+
+
+def gemm_launch_table(spans_mean, B, I, O):
+    """{launch: ms}, {launch: fraction of the bf16 MFMA peak} for the GEMM launches a KernelTimer saw (complex 8 B I O flop,
+    real 2 B I O; the LRT input gradient with its fused elementwise term is counted with the GEMM's flop only)."""
+    launches = {k: round(v, 4) for k, v in sorted(spans_mean.items()) if k[1:5] == "gemm" and v}
+    if "cgemm_NT" in launches:
+        launches.pop("cgemm_NT_fused_dx", None)      # fallback path: the wrapper timed GEMM + accumulate pass
+    cf, rf = 8.0 * B * I * O, 2.0 * B * I * O
+    frac = {k: round((cf if k[0] == "c" else rf) / (v * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4) for k, v in launches.items()}
+    return launches, frac
+
+
+def cfg4_point(dev, log2_batch=20, timer=None):
     """BASELINE configs[3] (rank 0, N = 1, outside the timed region): CplxLinearVD(2048, 2048), bf16 activations, batch
-    2^20, LRT forward + fused KL + full backward, loss = sum |y|^2 + 1e-3 KL; ms per step over 3 steps."""
+    2^20, LRT forward + fused KL + full backward, loss = sum |y|^2 + 1e-3 KL; ms per step over 3 steps; then one more
+    step with HIP events around every GEMM launch (K = 2048: half the K depth of the headline layer)."""
     try:
         from cplxmodule_amd import Cplx
         from cplxmodule_amd.nn import relevance as rel
@@ -258,10 +282,20 @@ def cfg4_point(dev, log2_batch=20):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
         flop = 3 * (8 + 2) * float(B) * F * F
-        return {"workload": f"CplxLinearVD(2048,2048), bf16, batch 2^{log2_batch}, LRT fwd + KL + full bwd",
-                "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1),
-                "tflops_whole_step": round(flop / dt / 1e12, 1),
-                "frac_of_mfma_peak_whole_step": round(flop / dt / 1e12 / BF16_PEAK_TFLOPS, 4)}
+        out = {"workload": f"CplxLinearVD(2048,2048), bf16, batch 2^{log2_batch}, LRT fwd + KL + full bwd",
+               "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1),
+               "tflops_whole_step": round(flop / dt / 1e12, 1),
+               "frac_of_mfma_peak_whole_step": round(flop / dt / 1e12 / BF16_PEAK_TFLOPS, 4)}
+        if timer is not None:
+            keep, timer.spans, timer.enabled = timer.spans, {}, True
+            step()
+            torch.cuda.synchronize()
+            timer.enabled = False
+            means = {k: timer.mean_ms(k) for k in timer.spans}
+            timer.spans = keep
+            out["launch_ms"], out["launch_frac"] = gemm_launch_table(means, B, F, F)
+            out["launch_ms_source"] = "one eager step, HIP events around the C-ABI calls (weight gradients: split-K launch + slab reduce)"
+        return out
     except Exception as e:  # pragma: no cover
         return {"error": str(e)[:200]}
 
@@ -481,9 +515,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        launches = {k: round(timer.mean_ms(k), 4) for k in sorted(timer.spans) if k[1:5] == "gemm"}
-        if "cgemm_NT" in launches:
-            launches.pop("cgemm_NT_fused_dx", None)      # fallback path: the wrapper timed GEMM + accumulate pass
+        launches, launch_frac = gemm_launch_table({k: timer.mean_ms(k) for k in timer.spans}, B, IN_F, OUT_F)
         cg = [v for k, v in launches.items() if k.startswith("cgemm")]
         gemm_ms = sum(cg) / len(cg) if cg else None
         traffic, traffic_per = gemm_traffic() if B == BATCH else (None, None)
@@ -514,9 +546,11 @@ def main():
                          # every GEMM launch of the step: forward NN, input gradient NT (with the LRT term 2 x ga fused into
                          # its epilogue: counted with the GEMM's 8 B I O flop only), weight gradient TT; complex (8 B I O
                          # flop) and the real variance GEMMs (2 B I O flop)
-                         "launch_ms": launches,
-                         "launch_frac": {k: round((flops if k[0] == "c" else real_flops) / (v * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4)
-                                         for k, v in launches.items()}},
+                         "launch_ms": launches, "launch_frac": launch_frac,
+                         # the headline is a graph replay, inside which HIP events cannot be recorded
+                         "launch_ms_source": ("ten eager steps right after the timed region (same process, same kernels)"
+                                              if graphed is not None else "the timed steps"),
+                         "traffic_source": "profiles/ PMC file of these kernels and shapes (bench.py: gemm_traffic), not this run"},
             "hbm_kernels_GBps": {
                 # in-step: operand prep + KL sum + KL gradients in one pass (12 B read, 6 + 12 B written)
                 "prep_kl_fused(30B/elt)": round(30 * nw / (pk * 1e-3) / 1e9, 1) if pk else None,
@@ -529,9 +563,10 @@ def main():
             line["hbm_kernels_GBps"].update(hbm_points(dev))
             line["cfg2_linear"] = cfg2_point(dev)
             line["conv_cfg3"] = conv_point(dev)
-            line["cfg4_lrt"] = cfg4_point(dev)
+            line["cfg4_lrt"] = cfg4_point(dev, timer=timer)
             line["cfg5_train_step"] = cfg5_point(dev)
             line["cpu_baseline"] = cpu_baseline(512)
+            line["reference_cpu"] = REFERENCE_CPU
         print(json.dumps(line), flush=True)
     if grouped:
         dist.destroy_process_group()

@@ -47,11 +47,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W4_DBG
-#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores
+#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores, 16 hot-source loads (always K tiles 0, 1)
 #endif
 // where the two loads of a register pair go, in MFMA slots behind the pair's LDS write (experiments: scripts/r04/w4_build.sh)
 #ifndef W4_LDP
 #define W4_LDP 0
+#endif
+#ifndef W4_WAIT1
+#define W4_WAIT1 0   // 1: ONE s_waitcnt lgkmcnt(1) at the head of every K sub-step covers all fragment reads of the previous one
 #endif
 #ifndef W4_LDQ
 #define W4_LDQ 0
@@ -137,18 +140,40 @@ __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
   u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
   return __builtin_bit_cast(bf16x8, u);
 }
-__device__ __forceinline__ void store16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
-__device__ __forceinline__ void store16(float* p, const f4& a) { st4(p, a); }
+__device__ __forceinline__ void store16(void* p, uint4 v) {
+  if ((W4_DBG & 8) == 0) *reinterpret_cast<uint4*>(p) = v;
+  else asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
+}
+__device__ __forceinline__ void store16(float* p, const f4& a) {
+  if ((W4_DBG & 8) == 0) st4(p, a);
+  else asm volatile("" ::"v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(p));
+}
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 
-// MFMA slot of the k-th LDS write of a K sub-step, and its inverse (-1: slot m - off carries no write)
-constexpr int write_slot(bool cplx, int k) { return cplx ? 6 + 4 * k : (k == 0 ? 6 : k == 1 ? 9 : k == 2 ? 11 : 14); }
-constexpr int slot_of_write(bool cplx, int nw, int m, int off) {
+// ---- where the LDS writes sit among the MFMA slots of a K sub-step ---------------------------------------------------
+// spread (W4_BURST 0): every sub-step writes half of ITS tile parity's registers (NL / 2 writes): tile u+2 is written over
+//   the whole of tile u; the pair (P_j, Q_j) is re-requested behind Q_j's write, so P has 2 sub-steps (~2048 cycles) from
+//   request to use, Q has 4.
+// burst (W4_BURST 1): both registers of a pair are written in the one window in which both of their ring slots are free --
+//   second sub-step of the even tile, first of the odd one -- and re-requested at once: 4 sub-steps (~4096 cycles) for every
+//   load, at the price of NL writes + NL loads in each of those two sub-steps and none in the other two.
+#ifndef W4_BURST
+#define W4_BURST 0
+#endif
+constexpr int write_slot(bool cplx, bool burst, int k) {
+  if (!burst) return cplx ? 6 + 4 * k : (k == 0 ? 6 : k == 1 ? 9 : k == 2 ? 11 : 14);
+  if (cplx) { constexpr int t[12] = {6, 7, 10, 11, 12, 13, 14, 15, 18, 19, 20, 21}; return t[k]; }
+  constexpr int t[8] = {5, 6, 7, 9, 10, 11, 13, 14};
+  return t[k];
+}
+constexpr int slot_of_write(bool cplx, bool burst, int nw, int m, int off) {
   for (int k = 0; k < nw; ++k)
-    if (write_slot(cplx, k) + off == m) return k;
+    if (write_slot(cplx, burst, k) + off == m) return k;
   return -1;
 }
+// LDS operations a sub-step issues behind its last fragment read (the counted wait in front of the barrier)
+constexpr int ops_after_last_read(bool cplx, bool burst, bool writes) { return !writes ? 0 : !burst ? 1 : cplx ? 0 : 2; }
 
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     constexpr bool isa = r < PA;
     constexpr int j = isa ? r : r - PA;
     // pair base = K tile (kt & ~1); the odd tile of the pair is +32 k
-    const int64_t kby = (int64_t)(kt & ~1) * BK * (isa ? ka : kb);
+    const int64_t kby = (W4_DBG & 16) ? 0 : (int64_t)(kt & ~1) * BK * (isa ? ka : kb);
     const char* base = (isa ? pa[pl] : pb[pl]) + kby;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffe, 0x00020000);
     const uint32_t so = (uint32_t)j * (isa ? psa : psb) + (par ? (isa ? qa : qb) : 0u);
@@ -330,11 +355,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   //   2 JB, 2 JB + 1     next A row 3 (other set)          [real: JB]
   //   (i+1) G, (i+1) G+1 next A row i = 0, 1, 2 (in place, behind the row's last MFMA)
   //   the NL / 2 LDS writes (odd tiles: each followed by the register pair's two loads) on the free slots in between
-  auto sub = [&](auto F, auto PAR, auto H, auto RS, auto RKS, auto WS, int kt_next) __attribute__((always_inline)) {
+  auto sub = [&](auto F, auto PAR, auto H, auto RS, auto RKS, auto WS, auto WS_P, auto WS_Q, int kt_next) __attribute__((always_inline)) {
     constexpr int f = decltype(F)::value, par = decltype(PAR)::value, h = decltype(H)::value;
     using I_F = std::integral_constant<int, f>;
     using I_G = std::integral_constant<int, 1 - f>;
     using I_P = std::integral_constant<int, par>;
+    using I0_ = std::integral_constant<int, 0>; using I1_ = std::integral_constant<int, 1>;
     constexpr int G = NM / IB;                                // 8 / 4
     constexpr int NW = NL / 2;                                // writes per sub-step (6 / 4)
     auto slot_fill = [&](auto MM) __attribute__((always_inline)) {
@@ -353,15 +379,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
       if constexpr (CPLX && m == NPL * JB + 1) rd_ai(I_G{}, std::integral_constant<int, IB - 1>{}, RS, RKS);
       if constexpr (m >= G && m % G == 0 && m / G <= IB - 1) rd_a(I_G{}, std::integral_constant<int, m / G - 1>{}, RS, RKS);
       if constexpr (CPLX && m >= G && m % G == 1 && m / G <= IB - 1) rd_ai(I_G{}, std::integral_constant<int, m / G - 1>{}, RS, RKS);
-      // --- LDS writes: complex slots 6 10 14 18 22 26 (never a read slot); real 6 9 11 14.  Odd tiles: the two loads that
-      // refill the register pair W4_LDP / W4_LDQ slots behind its write
-      constexpr int wi = slot_of_write(CPLX, NW, m, 0), lp = slot_of_write(CPLX, NW, m, W4_LDP), lq = slot_of_write(CPLX, NW, m, W4_LDQ);
-      if constexpr (wi >= 0 && (W4_DBG & 4) == 0) write_piece(I_P{}, std::integral_constant<int, h * NW + (wi >= 0 ? wi : 0)>{}, WS);
-      if constexpr (par == 1 && (W4_DBG & 2) == 0) {
-        if constexpr (lp >= 0) { W4_SB(); load_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, h * NW + (lp >= 0 ? lp : 0)>{}, kt_next); }
-        if constexpr (lq >= 0) { W4_SB(); load_piece(std::integral_constant<int, 1>{}, std::integral_constant<int, h * NW + (lq >= 0 ? lq : 0)>{}, kt_next); }
+      // --- LDS writes + the loads that refill the registers (see write_slot above)
+      if constexpr (!W4_BURST) {
+        constexpr int wi = slot_of_write(CPLX, false, NW, m, 0), lp = slot_of_write(CPLX, false, NW, m, W4_LDP),
+                      lq = slot_of_write(CPLX, false, NW, m, W4_LDQ);
+        if constexpr (wi >= 0 && (W4_DBG & 4) == 0) write_piece(I_P{}, std::integral_constant<int, h * NW + (wi >= 0 ? wi : 0)>{}, WS);
+        if constexpr (par == 1 && (W4_DBG & 2) == 0) {
+          if constexpr (lp >= 0) { W4_SB(); load_piece(I0_{}, std::integral_constant<int, h * NW + (lp >= 0 ? lp : 0)>{}, kt_next); }
+          if constexpr (lq >= 0) { W4_SB(); load_piece(I1_{}, std::integral_constant<int, h * NW + (lq >= 0 ? lq : 0)>{}, kt_next); }
+        }
+      } else if constexpr (par != h) {
+        // window sub-step: (even tile, second half) writes pairs 0 .. NW-1, (odd tile, first half) pairs NW .. NL-1;
+        // k-th write: pair k / 2, register k % 2 (P -> slot of tile u+2, Q -> slot of tile u+3 = the even tile's own slot)
+        constexpr int k = slot_of_write(CPLX, true, NL, m, 0);
+        if constexpr (k >= 0) {
+          constexpr int q = (par == 0 ? 0 : NW) + (k >= 0 ? k : 0) / 2, reg = (k >= 0 ? k : 0) % 2;
+          if constexpr ((W4_DBG & 4) == 0) {
+            if constexpr (reg == 0) write_piece(I0_{}, std::integral_constant<int, q>{}, WS_P);
+            else write_piece(I1_{}, std::integral_constant<int, q>{}, WS_Q);
+          }
+          if constexpr (reg == 1 && (W4_DBG & 2) == 0) {
+            W4_SB();
+            load_piece(I0_{}, std::integral_constant<int, q>{}, kt_next);
+            load_piece(I1_{}, std::integral_constant<int, q>{}, kt_next);
+          }
+        }
       }
     };
+    // every fragment read of the previous sub-step is older than its last LDS write: one counted wait instead of one in
+    // front of each fragment's first use (the builtin is visible to the compiler's own wait insertion)
+    if constexpr (W4_WAIT1 != 0) __builtin_amdgcn_s_waitcnt(0xC07F | (ops_after_last_read(CPLX, W4_BURST, !W4_BURST || par == h) << 8));
     auto run = [&](auto self, auto MM) __attribute__((always_inline)) {
       constexpr int m = decltype(MM)::value;
       if constexpr (m < NM) {
@@ -424,17 +471,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   // ---- K loop ---------------------------------------------------------------------------------------------------
   // K tile t in ring slot S (compile time), parity P (compile time)
   auto tile = [&](auto SS, auto PP, int t) __attribute__((always_inline)) {
-    constexpr int s = decltype(SS)::value;
+    constexpr int s = decltype(SS)::value, par = decltype(PP)::value;
     using CUR = std::integral_constant<int, s>; using NXT = std::integral_constant<int, (s + 1) % 3>;
     using WR = std::integral_constant<int, (s + 2) % 3>;
-    // odd tiles re-issue the register pairs with K tiles (t+3, t+4); past the end: the last pair again (unused)
-    const int ktn = (t + 3 < nt) ? t + 3 : nt - 2;
-    sub(I0{}, PP, I0{}, CUR{}, I1{}, WR{}, ktn);
-    // every wave: its F1 reads are complete (they are older than this sub-step's NL/2 LDS writes)
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NL / 2) : "memory");
+    // the register pairs are re-requested with the K tiles two pairs ahead; past the end: the last pair again (unused)
+    constexpr int ahead = (W4_BURST && par == 0) ? 4 : 3;
+    const int ktn = (t + ahead < nt) ? t + ahead : nt - 2;
+    // burst: P (tile u+2) -> even tile's WR slot = odd tile's NXT slot; Q (tile u+3) -> even tile's CUR = odd tile's WR
+    using WSP = std::conditional_t<par == 0, WR, NXT>;
+    using WSQ = std::conditional_t<par == 0, CUR, WR>;
+    sub(I0{}, PP, I0{}, CUR{}, I1{}, WR{}, WSP{}, WSQ{}, ktn);
+    // every wave: its F1 reads are complete (in-order LDS: all but the operations issued behind the last read)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ops_after_last_read(CPLX, W4_BURST, !W4_BURST || par == 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     W4_SB();
-    sub(I1{}, PP, I1{}, NXT{}, I0{}, WR{}, ktn);
+    sub(I1{}, PP, I1{}, NXT{}, I0{}, WR{}, WSP{}, WSQ{}, ktn);
   };
   {
     int t = 0;
@@ -461,31 +512,121 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
   TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
   const float beta = gemm_beta(g);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();                                    // every wave is done with the ring
-  if constexpr ((W4_DBG & 8) != 0) {
-#pragma unroll
-    for (int i = 0; i < IB; ++i)
-#pragma unroll
-      for (int j = 0; j < JB; ++j) {
-        asm volatile("" ::"v"(acc_r[i][j]));
-        if (CPLX) asm volatile("" ::"v"(acc_i[i][j]));
-      }
-    return;
-  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the surplus loads of the loop's tail target registers nothing reads: the compiler waits for them only where it reuses one)
+  __builtin_amdgcn_s_barrier();                       // every wave is done with the ring
+  // The epilogue's optional operands (fused LRT term; multiplier / accumulate operand) are tested ONCE, outside: a per-load
+  // "if (g.fga)" inside the unrolled passes makes the compiler branch around every load and wait for each one separately
+  // (cdna_hip_programming.md, "three .s-level traps" (c)) -- and at one wave per SIMD nothing else hides that latency.
+  // Global addresses: ONE per-lane 32-bit byte offset per operand kind (lane part of a staged round) + a wave-uniform
+  // offset per (round, pass) in a scalar register, through a buffer descriptor of the output tile -- sixteen 64-bit
+  // per-lane addresses per round cost more registers than the epilogue has beside the accumulators.
+  auto tile_rsrc = [&](const void* plane, int64_t ld, int esize) __attribute__((always_inline)) {
+    const char* base = (const char*)plane + ((int64_t)m0 * ld + n0) * esize;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffe, 0x00020000);
+  };
+  auto ldb128 = [](__amdgpu_buffer_rsrc_t r, uint32_t vo, uint32_t so) __attribute__((always_inline)) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+  };
+  auto stb128 = [](u32x4 v, __amdgpu_buffer_rsrc_t r, uint32_t vo, uint32_t so) __attribute__((always_inline)) {
+    if ((W4_DBG & 8) == 0) __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, 0);
+    else asm volatile("" ::"v"(v), "v"(vo));
+  };
   if constexpr (sizeof(TOUT) == 2) {
     // bf16: the wave's tile goes through LDS so that a store instruction writes whole 128-byte lines
-    constexpr int PITCH = 144;                        // bytes per staged row (64 bf16 + 16 B pad)
-    char* reg = smem + wid * (64 * PITCH);
+    auto epi16 = [&](auto FUSE) __attribute__((always_inline)) {
+      constexpr bool fuse = decltype(FUSE)::value;
+      constexpr int PITCH = 144;                        // bytes per staged row (64 bf16 + 16 B pad)
+      char* reg = smem + wid * (64 * PITCH);
+      // lane part: row (lane >> 3) of an 8-row pass, 16-byte column group (lane & 7); wave origin (wm, wn)
+      const uint32_t vo_c = (uint32_t)((((int64_t)(wm + (lane >> 3)) * g.ldc + wn + (lane & 7) * 8)) * 2);
+      const uint32_t vo_f = fuse ? (uint32_t)((((int64_t)(wm + (lane >> 3)) * g.fld + wn + (lane & 7) * 8)) * 2) : 0u;
+      const uint32_t p8c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(8 * g.ldc * 2));
+      const uint32_t p8f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(8 * g.fld * 2));
+      const __amdgpu_buffer_rsrc_t rga = tile_rsrc(fuse ? g.fga : g.c_r, fuse ? g.fld : g.ldc, 2);
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
-      TOUT* out = pl ? ci : cr;
+      for (int pl = 0; pl < NPL; ++pl) {
+        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? g.c_i : g.c_r, g.ldc, 2);
+        const __amdgpu_buffer_rsrc_t rx = tile_rsrc(fuse ? (pl ? g.fx_i : g.fx_r) : g.c_r, fuse ? g.fld : g.ldc, 2);
 #pragma unroll
-      for (int jh = 0; jh < JB / 2; ++jh)
+        for (int jh = 0; jh < JB / 2; ++jh)
 #pragma unroll
-        for (int ih = 0; ih < IB / 2; ++ih) {
+          for (int ih = 0; ih < IB / 2; ++ih) {
+            // the fused term's operands of this round (8 passes x (ga, x): 16 loads per lane) are requested FIRST and fly
+            // while the accumulators are converted and staged
+            u32x4 gv[fuse ? 8 : 1], xv[fuse ? 8 : 1];
+            if constexpr (fuse) {
 #pragma unroll
-          for (int ii = 0; ii < 2; ++ii)
+              for (int pass = 0; pass < 8; ++pass) {
+                const uint32_t so = (uint32_t)(ih * 8 + pass) * p8f + (uint32_t)(jh * 128);
+                gv[pass] = ldb128(rga, vo_f, so);
+                xv[pass] = ldb128(rx, vo_f, so);
+              }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int cl = jj * 32 + 8 * q + 4 * lk;
+                  f4 v;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    v.v[e] = pl ? acc_i[CPLX ? ih * 2 + ii : 0][jh * 2 + jj][4 * q + e] : acc_r[ih * 2 + ii][jh * 2 + jj][4 * q + e];
+                  st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is in LDS (in-order LDS, own region)
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+              const int rl = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+              const u32x4 v = *reinterpret_cast<const u32x4*>(reg + rl * PITCH + c8 * 2);
+              const uint32_t so = (uint32_t)(ih * 8 + pass) * p8c + (uint32_t)(jh * 128);
+              if constexpr (fuse) {
+                // LRT input gradient's elementwise term (gemm.h: fga); arithmetic of util.hip dx_accum_kernel: bit-identical
+                u32x4 ow;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float d0 = __uint_as_float(v[e] << 16), d1 = __uint_as_float(v[e] & 0xffff0000u);
+                  const float x0 = __uint_as_float(xv[pass][e] << 16), x1 = __uint_as_float(xv[pass][e] & 0xffff0000u);
+                  const float g0 = __uint_as_float(gv[pass][e] << 16), g1 = __uint_as_float(gv[pass][e] & 0xffff0000u);
+                  ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
+                }
+                stb128(ow, rout, vo_c, so);
+              } else {
+                stb128(v, rout, vo_c, so);
+              }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
+            W4_SB();                                             // (keeps the next rounds' operand loads out of this round: registers)
+          }
+      }
+    };
+    if (g.fga) epi16(std::true_type{}); else epi16(std::false_type{});
+  } else {
+    // float32: 32 rows x 64 columns per round; the elementwise multiplier (LRT log_sigma2 gradient, mask: both planes of a
+    // complex result -- the launcher declines a real-plane-only multiplier) and the accumulate operand are read row-major
+    auto epi32 = [&](auto HM, auto HACC) __attribute__((always_inline)) {
+      constexpr bool hm = decltype(HM)::value, hacc = decltype(HACC)::value;
+      constexpr int PITCH = 272;                        // bytes per staged row (64 floats + 16 B pad)
+      char* reg = smem + wid * (32 * PITCH);
+      const uint32_t vo = (uint32_t)((((int64_t)(wm + (lane >> 4)) * g.ldc + wn + (lane & 15) * 4)) * 4);
+      const uint32_t p4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(4 * g.ldc * 4));
+      const __amdgpu_buffer_rsrc_t rm = tile_rsrc(hm ? (const void*)g.emul : g.c_r, g.ldc, 4);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? g.c_i : g.c_r, g.ldc, 4);
+#pragma unroll
+        for (int jh = 0; jh < JB / 2; ++jh)
+#pragma unroll
+          for (int i = 0; i < IB; ++i) {
+            // multiplier / accumulate operands of this round first (see the bf16 path)
+            u32x4 mv[hm ? 8 : 1], pv[hacc ? 8 : 1];
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+              const uint32_t so = (uint32_t)(i * 8 + pass) * p4 + (uint32_t)(jh * 256);
+              if constexpr (hm) mv[pass] = ldb128(rm, vo, so);
+              if constexpr (hacc) pv[pass] = ldb128(rout, vo, so);
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -494,83 +635,38 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
                 f4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                  v.v[e] = pl ? acc_i[CPLX ? ih * 2 + ii : 0][jh * 2 + jj][4 * q + e] : acc_r[ih * 2 + ii][jh * 2 + jj][4 * q + e];
-                st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
+                  v.v[e] = pl ? acc_i[CPLX ? i : 0][jh * 2 + jj][4 * q + e] : acc_r[i][jh * 2 + jj][4 * q + e];
+                st4(reinterpret_cast<float*>(reg + l31 * PITCH + cl * 4), v);
               }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is in LDS (in-order LDS, own region)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int pass = 0; pass < 8; ++pass) {
-            const int rl = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-            const uint4 v = *reinterpret_cast<const uint4*>(reg + rl * PITCH + c8 * 2);
-            const int row = m0 + wm + ih * 64 + rl, col = n0 + wn + jh * 64 + c8;
-            bf16_t* o = reinterpret_cast<bf16_t*>(out) + (int64_t)row * g.ldc + col;
-            if (g.fga) {
-              // LRT input gradient's elementwise term (gemm.h: fga); arithmetic of util.hip dx_accum_kernel: bit-identical
-              const int64_t fo = (int64_t)row * g.fld + col;
-              const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.fga) + fo);
-              const uint4 xv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(pl ? g.fx_i : g.fx_r) + fo);
-              const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
-              uint32_t ow[4];
+            for (int pass = 0; pass < 8; ++pass) {
+              const int rl = pass * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+              f4 v = ld4(reinterpret_cast<const float*>(reg + rl * PITCH + c4 * 4));
+              const uint32_t so = (uint32_t)(i * 8 + pass) * p4 + (uint32_t)(jh * 256);
+              if constexpr (hm) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float d0 = __uint_as_float(vw[e] << 16), d1 = __uint_as_float(vw[e] & 0xffff0000u);
-                const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
-                const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
-                ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
+                for (int e = 0; e < 4; ++e) {
+                  v.v[e] *= gemm_emul(g, __uint_as_float(mv[pass][e]));
+                  // (rounded product: the 8-wave kernels apply the multiplier in a block of its own, so nothing there can
+                  //  contract it with the accumulate below; same bits here)
+                  asm volatile("" : "+v"(v.v[e]));
+                }
               }
-              store16(o, uint4{ow[0], ow[1], ow[2], ow[3]});
-            } else {
-              store16(o, v);
+              if constexpr (hacc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v.v[e] += beta * __uint_as_float(pv[pass][e]);
+              }
+              const u32x4 w = {__float_as_uint(v.v[0]), __float_as_uint(v.v[1]), __float_as_uint(v.v[2]), __float_as_uint(v.v[3])};
+              stb128(w, rout, vo, so);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_SB();
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
-        }
-    }
-  } else {
-    // float32: 32 rows x 64 columns per round; the elementwise multiplier (LRT log_sigma2 gradient, mask) and the
-    // accumulate operand are read row-major at the same point
-    constexpr int PITCH = 272;                        // bytes per staged row (64 floats + 16 B pad)
-    char* reg = smem + wid * (32 * PITCH);
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
-      float* out = reinterpret_cast<float*>(pl ? ci : cr);
-#pragma unroll
-      for (int jh = 0; jh < JB / 2; ++jh)
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int cl = jj * 32 + 8 * q + 4 * lk;
-              f4 v;
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                v.v[e] = pl ? acc_i[CPLX ? i : 0][jh * 2 + jj][4 * q + e] : acc_r[i][jh * 2 + jj][4 * q + e];
-              st4(reinterpret_cast<float*>(reg + l31 * PITCH + cl * 4), v);
-            }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int pass = 0; pass < 8; ++pass) {
-            const int rl = pass * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-            f4 v = ld4(reinterpret_cast<const float*>(reg + rl * PITCH + c4 * 4));
-            const int row = m0 + wm + i * 32 + rl, col = n0 + wn + jh * 64 + c4;
-            const int64_t o = (int64_t)row * g.ldc + col;
-            if (g.emul && (!pl || g.emul_both)) {
-              const f4 m = ld4(g.emul + o);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v.v[e] *= gemm_emul(g, m.v[e]);
-            }
-            if (g.accumulate) {
-              const f4 p = ld4(out + o);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v.v[e] += beta * p.v[e];
-            }
-            store16(out + o, v);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    }
+      }
+    };
+    if (g.emul) { if (g.accumulate) epi32(std::true_type{}, std::true_type{}); else epi32(std::true_type{}, std::false_type{}); }
+    else { if (g.accumulate) epi32(std::false_type{}, std::true_type{}); else epi32(std::false_type{}, std::false_type{}); }
   }
 }
 
@@ -610,7 +706,13 @@ static int launch_layout(const GemmArgs& g, bool ta, bool tb, hipStream_t st) {
 // 0 and taken = true: launched.  taken = false: the shape / epilogue is not one this kernel takes.
 int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bool tb, hipStream_t st, bool& taken) {
   taken = false;
-  if (!g_gemm_w4) return 0;
+  // which launches the family takes (cplxamd_gemm_set_family): bit 0 complex bf16-out, 1 complex bf16-out with the fused LRT
+  // term, 2 complex float32-out, 3 real bf16-out (4: with the fused term), 5 real float32-out
+  {
+    const bool f32o = out_dtype == CPLXAMD_F32;
+    const int bit = cplx ? (f32o ? 2 : g.fga ? 1 : 0) : (f32o ? 5 : g.fga ? 4 : 3);
+    if (!((g_gemm_w4 >> bit) & 1)) return 0;
+  }
   const int bm = 256, bn = cplx ? 128 : 256;
   if (g.splits > 1 || g.g1 || g.batch != 1) return 0;
   if (ta && !tb) return 0;
@@ -618,6 +720,7 @@ int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bo
   if ((int64_t)(g.M / bm) * (g.N / bn) > 0x7fffffff) return 0;
   const int64_t lda = ta ? g.a_cs : g.a_rs, ldb = tb ? g.b_cs : g.b_rs;
   if ((lda % 8) || (ldb % 8) || lda >= (1 << 22) || ldb >= (1 << 22)) return 0;      // 32-bit per-lane tile offsets
+  if (g.ldc >= (1 << 20) || g.fld >= (1 << 20)) return 0;                             // ... of the epilogue (256 rows x 4 bytes)
   if (!w4::aligned16(g.a_r) || !w4::aligned16(g.b_r) || !w4::aligned16(g.c_r)) return 0;
   if (cplx && (!w4::aligned16(g.a_i) || !w4::aligned16(g.b_i) || !w4::aligned16(g.c_i))) return 0;
   if (g.bias_r && (!w4::aligned16(g.bias_r) || (cplx && !w4::aligned16(g.bias_i)))) return 0;
@@ -627,6 +730,7 @@ int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bo
       return 0;
   } else if (out_dtype == CPLXAMD_F32) {
     if ((g.ldc & 3) || g.fga || (g.emul && !w4::aligned16(g.emul))) return 0;
+    if (cplx && g.emul && !g.emul_both) return 0;      // (a multiplier on the real plane only: nothing launches that)
   } else {
     return 0;
   }

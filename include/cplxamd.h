@@ -218,14 +218,16 @@ int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
  * Results are bit-identical either way (tests/test_gpu_gemm_persist.py). */
 int cplxamd_gemm_set_persistent(int on);
 
-/* Process-wide choice of the bf16 GEMM kernel family (returns the previous setting):
- *   1 (start value; env CPLXAMD_GEMM_W4=0 starts with 0)  the one-wave-per-SIMD kernels of round 4 (gemm_bf16_w4.hip:
- *     4 waves, 128 x 64 complex wave tile in the accumulator half of the 512-register file, operands staged through
- *     registers with both halves of every cache line requested together) wherever they take the launch (full 256 x 128
- *     complex / 256 x 256 real tiles, K % 64 == 0), the 8-wave LDS-DMA kernels for everything else;
- *   0  the 8-wave kernels only (rounds 1-3).
- * Both families produce the same bits (same MFMA sequence per accumulator; tests/test_gpu_r04.py). */
-int cplxamd_gemm_set_family(int w4);
+/* Process-wide choice of the bf16 GEMM kernel family per launch kind (returns the previous mask).  `mask` bits: which
+ * launches go to the one-wave-per-SIMD kernels of round 4 (gemm_bf16_w4.hip: 4 waves, 128 x 64 complex wave tile in the
+ * accumulator half of the 512-register file, operands staged through registers with both halves of every cache line
+ * requested together) wherever those take the shape (full 256 x 128 complex / 256 x 256 real tiles, K % 64 == 0):
+ *   bit 0 complex, bf16 out          bit 1 complex, bf16 out with the fused LRT input-gradient term     bit 2 complex, float32 out
+ *   bit 3 real, bf16 out             bit 4 real, bf16 out with the fused term                           bit 5 real, float32 out
+ * 0 = the 8-wave LDS-DMA kernels of rounds 1-3 everywhere, -1 = every bit.  Start value 0x09 (the launches the new family is
+ * faster on, profiles/r04_gemm_w4_ab.txt; env CPLXAMD_GEMM_W4=<mask> overrides).  Both families produce the same bits (same
+ * MFMA sequence per accumulator; tests/test_gpu_r04.py). */
+int cplxamd_gemm_set_family(int mask);
 
 /* Optional scratch for split-K (few output tiles, long K -- e.g. the weight gradient at batch
  * 2^20, or a 10-output head): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be NULL

@@ -106,7 +106,7 @@ def run(lib, tag, B, I, O, time_it=True):
     for s, (fn, _) in shapes.items():
         lib.cplxamd_gemm_set_family(0)
         ref = [t.clone() for t in fn()]
-        lib.cplxamd_gemm_set_family(1)
+        lib.cplxamd_gemm_set_family(-1)
         out = [t.clone() for t in fn()]
         torch.cuda.synchronize()
         same = all(torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32),
@@ -125,7 +125,7 @@ def run(lib, tag, B, I, O, time_it=True):
     fams = [("w8", 0), ("w4", 1)]
     times = {(n, s): [] for n, _ in fams for s in shapes}
     for n, f in fams:
-        lib.cplxamd_gemm_set_family(f)
+        lib.cplxamd_gemm_set_family(-1 if f else 0)
         for s, (fn, _) in shapes.items():
             for _ in range(3):
                 fn()
@@ -134,7 +134,7 @@ def run(lib, tag, B, I, O, time_it=True):
         for s, (fn, _) in shapes.items():
             order = fams if r % 2 == 0 else fams[::-1]
             for n, f in order:
-                lib.cplxamd_gemm_set_family(f)
+                lib.cplxamd_gemm_set_family(-1 if f else 0)
                 fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

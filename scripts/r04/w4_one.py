@@ -12,7 +12,7 @@ fam, shape = int(sys.argv[2]), sys.argv[3]
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 B, I, O = (int(v) for v in sys.argv[5:8]) if len(sys.argv) > 7 else (8192, 4096, 4096)
 fn = w4_ab.make(lib, B, I, O)[shape][0]
-lib.cplxamd_gemm_set_family(fam)
+lib.cplxamd_gemm_set_family(-1 if fam else 0)
 for _ in range(n):
     fn()
 torch.cuda.synchronize()

@@ -4,6 +4,7 @@
 #   usage: scripts/r04/w4_pmc.sh <tag> <lib.so> "<shapes>" "<families>"      -> gpurun_out/r04/pmc_<tag>.txt
 tag=$1; lib=$2; shapes=${3:-"c_fwd c_dgrad c_wgrad_kl r_fwd r_wgrad_kl"}; fams=${4:-"0 1"}
 R="${GRAFT_REPO_ROOT:-/root/repo}"
+case $lib in /*) ;; *) lib=$R/$lib;; esac
 out=$R/gpurun_out/r04; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for s in $shapes; do for f in $fams; do

@@ -100,9 +100,11 @@ def test_batchnorm_vs_oracle_shapes(shape):
     ((y.real * T(gr)).sum() + (y.imag * T(gi)).sum()).backward()
     bw = orc.cplx_batch_norm_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), None, None, W.astype(f), True, 1e-5)
     for n, t in dict(dxr=txr.grad, dxi=txi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
-        # dweight / dbias are sums of up to 10^6 products of mixed sign held against a float64 oracle: float32
-        # accumulation (ours and the reference's alike) leaves ~4e-5 of the largest entry; dX is elementwise
-        np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], 1e-4 if n in ("dweight", "dbias") else 4e-5), err_msg=n)
+        # norm-wise 1e-5 (atol = 1e-5 max|ref|) for the parameter gradients too: the per-feature sums are accumulated in
+        # float64 (bn.hip: accum<NS, true>), what is left is the float32 rounding of each product and of the saved
+        # statistics, ~1e-7.  (The 3.4-4.2e-5 that profiles/r03_parity_report.txt shows for this test is the whitening
+        # check further down: E|z|^2 = 1 - eps / V with eps = 1e-5 -- a property of the layer, not an error.)
+        np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], 1e-5), err_msg=n)
     # whitening property without affine
     bn2 = cls(F_, affine=False).to("cuda")
     z = bn2(Cplx(T(xr), T(xi)))

@@ -200,3 +200,145 @@ def test_cfg3_conv_bn_full_size_properties():
     assert torch.isfinite(g1).all()
     np.testing.assert_allclose(N(g2), 2 * N(g1), rtol=1e-6)      # split-K slabs: float32 sums, exact x2
     np.testing.assert_allclose(N(b2), 2 * N(b1), rtol=1e-6)
+
+
+# ---- round 4: the full-size BACKWARD legs, value-checked ------------------------------------------
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().double().numpy()
+
+
+def _cplx_noise_at(elems, seed, offset):
+    """The in-kernel noise of a complex layer at linear output indices `elems` (oracle/philox.py: element e is pair e & 1
+    of Philox group e >> 1, scaled by sqrt(1/2))."""
+    from oracle import philox
+    e = np.asarray(elems, dtype=np.uint64)
+    x = philox.philox4x32(e >> np.uint64(1), offset, seed)
+    u = philox._u01(x)
+    odd = (e & np.uint64(1)).astype(bool)
+    u0, u1 = np.where(odd, u[:, 2], u[:, 0]), np.where(odd, u[:, 3], u[:, 1])
+    r = np.sqrt(-2 * np.log(u0)) * np.sqrt(0.5)
+    return r * np.cos(2 * np.pi * u1), r * np.sin(2 * np.pi * u1)
+
+
+def test_cfg4_lrt_backward_values_at_full_size():
+    """configs[3] at its own batch 2^20: the input gradient (2^31 elements per plane -- the int32 boundary -- incl. the fused
+    2 x g_a term), dW and dlog_sigma2 against float64 on sampled rows / columns, the LAST rows included.  The noise of the
+    sampled outputs comes from the numpy statement of the Philox stream (reference: nn/relevance/complex/base.py:43-56
+    differentiated)."""
+    from cplxmodule_amd import Cplx
+    from cplxmodule_amd.nn import relevance as rel
+    B, F = 1 << 20, 2048
+    torch.manual_seed(0)
+    layer = rel.CplxLinearVD(F, F).to(DEV)
+    with torch.no_grad():
+        layer.log_sigma2.uniform_(-12, 4)
+    xr, xi = _bf(B, F, seed=11).requires_grad_(True), _bf(B, F, seed=12).requires_grad_(True)
+    rel.noise.manual_seed(9)
+    y = layer(Cplx(xr, xi))                          # (seed 9, offset 1)
+    gr, gi = y.real.detach().clone(), y.imag.detach().clone()     # upstream gradient of sum |y|^2 / 2
+    torch.autograd.backward((y.real, y.imag), (gr, gi))
+    dxr, dxi = xr.grad, xi.grad
+    assert dxr.shape == (B, F) and torch.isfinite(dxr.float()).all() and torch.isfinite(dxi.float()).all()
+    f = np.float64
+    w = layer.weight
+    Wr, Wi = N(w.real.bfloat16().float()).astype(f), N(w.imag.bfloat16().float()).astype(f)
+    ls2 = N(layer.log_sigma2).astype(f)
+    S16 = N(layer.log_sigma2.exp().bfloat16().float()).astype(f)                  # the variance GEMM's bf16 operand
+    # ---- (1) dX on sampled rows, first / middle / the very last ones (row index >= 2^20 - 8)
+    rows = np.array([0, 1, 4099, 524288, 777777] + list(range(B - 8, B)))
+    tr = torch.from_numpy(rows).to(DEV)
+    X_r, X_i = N(xr[tr].float()).astype(f), N(xi[tr].float()).astype(f)
+    G_r, G_i = N(gr[tr].float()).astype(f), N(gi[tr].float()).astype(f)
+    a = _bf16_round(X_r * X_r + X_i * X_i)
+    s2 = _bf16_round(a @ S16.T)
+    e_r, e_i = _cplx_noise_at((rows[:, None].astype(np.uint64) * np.uint64(F) + np.arange(F, dtype=np.uint64)[None]).ravel(), 9, 1)
+    e_r, e_i = e_r.reshape(len(rows), F), e_i.reshape(len(rows), F)
+    sd = np.sqrt(np.maximum(s2, 1e-8))
+    gs2 = _bf16_round(np.where(s2 >= 1e-8, (G_r * e_r + G_i * e_i) * 0.5 / sd, 0.0))
+    g_a = _bf16_round(gs2 @ S16)
+    ref_r = _bf16_round(G_r @ Wr + G_i @ Wi) + 2 * X_r * g_a
+    ref_i = _bf16_round(-G_r @ Wi + G_i @ Wr) + 2 * X_i * g_a
+    sc = np.abs(ref_r).max()
+    assert np.abs(2 * X_r * g_a).max() > 0.05 * sc            # the fused term is a visible part of what is checked
+    np.testing.assert_allclose(N(dxr[tr].float()), ref_r, rtol=2e-2, atol=2e-2 * sc)
+    np.testing.assert_allclose(N(dxi[tr].float()), ref_i, rtol=2e-2, atol=2e-2 * sc)
+    # ---- (2) dW = G^T conj(X) on three output rows, float64 over the full batch (chunked on the device)
+    o_rows = torch.tensor([0, 777, F - 1], device=DEV)
+    dWr = torch.zeros(3, F, dtype=torch.float64, device=DEV)
+    dWi = torch.zeros_like(dWr)
+    CH = 1 << 16
+    for c0 in range(0, B, CH):
+        sl = slice(c0, c0 + CH)
+        Gr, Gi = gr[sl][:, o_rows].double().t(), gi[sl][:, o_rows].double().t()
+        Xr, Xi = xr[sl].detach().double(), xi[sl].detach().double()
+        dWr += Gr @ Xr + Gi @ Xi
+        dWi += Gi @ Xr - Gr @ Xi
+    sw = float(dWr.abs().max())
+    np.testing.assert_allclose(N(layer.weight.real.grad[o_rows]), dWr.cpu().numpy(), rtol=1e-3, atol=1e-4 * sw)
+    np.testing.assert_allclose(N(layer.weight.imag.grad[o_rows]), dWi.cpu().numpy(), rtol=1e-3, atol=1e-4 * sw)
+    # ---- (3) dlog_sigma2 = (gs2^T |x|^2) exp(log_sigma2) on the same three rows: gs2 of those COLUMNS for every batch row
+    oc = o_rows.cpu().numpy()
+    elems = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(F) + oc[None].astype(np.uint64)).ravel()
+    er, ei = _cplx_noise_at(elems, 9, 1)
+    er, ei = torch.from_numpy(er.reshape(B, 3)).to(DEV), torch.from_numpy(ei.reshape(B, 3)).to(DEV)
+    S3 = layer.log_sigma2.exp().bfloat16().double()[o_rows]                        # [3, F]
+    acc = torch.zeros(3, F, dtype=torch.float64, device=DEV)
+    for c0 in range(0, B, CH):
+        sl = slice(c0, c0 + CH)
+        a_c = (xr[sl].detach().float() ** 2 + xi[sl].detach().float() ** 2).bfloat16().double()    # [CH, F]
+        s2_c = (a_c @ S3.t()).float().bfloat16().double()                                          # [CH, 3]
+        sd_c = s2_c.clamp_min(1e-8).sqrt()
+        gsd = gr[sl][:, o_rows].double() * er[sl] + gi[sl][:, o_rows].double() * ei[sl]
+        gs2_c = torch.where(s2_c >= 1e-8, gsd * 0.5 / sd_c, torch.zeros_like(gsd)).float().bfloat16().double()
+        acc += gs2_c.t() @ a_c
+    ref = (acc * layer.log_sigma2.detach().double()[o_rows].exp()).cpu().numpy()
+    got = N(layer.log_sigma2.grad[o_rows])
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=5e-3 * np.abs(ref).max())
+
+
+def test_cfg3_conv_backward_values_at_full_size():
+    """configs[2] at batch 256: the data gradient of the LAST image (highest addresses of the 2 x 2.1 GB gradient planes)
+    against the float64 oracle, sampled weight-gradient entries and the bias gradient against float64 sums over the whole
+    batch (reference: cplx.py:729-742 differentiated)."""
+    from cplxmodule_amd import Cplx, nn
+    B, C, H = 256, 64, 256
+    xr, xi = _bf(B, C, H, H, seed=21).requires_grad_(True), _bf(B, C, H, H, seed=22).requires_grad_(True)
+    torch.manual_seed(1)
+    conv = nn.CplxConv2d(C, C, 3).to(DEV)
+    y = conv(Cplx(xr, xi))
+    gr, gi = _bf(B, C, H - 2, H - 2, seed=23), _bf(B, C, H - 2, H - 2, seed=24)
+    torch.autograd.backward((y.real, y.imag), (gr, gi))
+    dxr, dxi = xr.grad, xi.grad
+    assert dxr.shape == xr.shape and torch.isfinite(dxr.float()).all()
+    f = np.float64
+    w = conv.weight
+    wr, wi = N(w.real.bfloat16().float()).astype(f), N(w.imag.bfloat16().float()).astype(f)
+    # (1) dX of the last image, a window of it (the oracle's im2col of a whole 64 x 256 x 256 image is 300 MB: crop the
+    # gradient to the rows that reach the window and place the result)
+    b = B - 1
+    h0, h1, w0, w1 = 100, 116, 230, 256                      # input window, touches the right border
+    g_sl = (slice(b, b + 1), slice(None), slice(h0 - 2, h1), slice(w0 - 2, H - 2))
+    Gr, Gi = N(gr[g_sl].float()).astype(f), N(gi[g_sl].float()).astype(f)
+    # dX[h, w] = sum_{kh, kw} G[h - kh, w - kw] conj(W[kh, kw]): a "full" correlation of the cropped gradient
+    hh, ww = Gr.shape[2] + 2, Gr.shape[3] + 2
+    zx = np.zeros((1, C, hh, ww))
+    bw = orc.cplx_conv2d_bwd(Gr, Gi, zx, zx, wr, wi, has_bias=False)
+    # rows / columns of that result whose every tap lies inside the crop: drop the first 2 rows / columns
+    ref_r, ref_i = bw["dxr"][0, :, 2:h1 - h0 + 2, 2:], bw["dxi"][0, :, 2:h1 - h0 + 2, 2:]
+    got_r, got_i = N(dxr[b, :, h0:h1, w0:w1].float()), N(dxi[b, :, h0:h1, w0:w1].float())
+    sc = np.abs(ref_r).max()
+    np.testing.assert_allclose(got_r, ref_r[:, :, :w1 - w0], rtol=1e-2, atol=1e-2 * sc)
+    np.testing.assert_allclose(got_i, ref_i[:, :, :w1 - w0], rtol=1e-2, atol=1e-2 * sc)
+    # (2) sampled weight-gradient entries: dW[co, ci, kh, kw] = sum_{b, h, w} G[b, co, h, w] conj(X[b, ci, h + kh, w + kw])
+    Ho = H - 2
+    for co, ci, kh, kw in [(0, 0, 0, 0), (63, 63, 2, 2), (17, 40, 1, 2), (5, 31, 2, 0)]:
+        Gr_, Gi_ = gr[:, co].double(), gi[:, co].double()
+        Xr_, Xi_ = xr[:, ci, kh:kh + Ho, kw:kw + Ho].detach().double(), xi[:, ci, kh:kh + Ho, kw:kw + Ho].detach().double()
+        want_r = float((Gr_ * Xr_ + Gi_ * Xi_).sum())
+        want_i = float((Gi_ * Xr_ - Gr_ * Xi_).sum())
+        norm = float((Gr_.abs() * Xr_.abs()).sum())           # size of the sum's terms: the float32 slab sums' error scale
+        assert abs(float(conv.weight.real.grad[co, ci, kh, kw]) - want_r) <= 1e-6 * norm + 1e-3 * abs(want_r)
+        assert abs(float(conv.weight.imag.grad[co, ci, kh, kw]) - want_i) <= 1e-6 * norm + 1e-3 * abs(want_i)
+    # (3) bias gradient = sum of G over batch and pixels
+    np.testing.assert_allclose(N(conv.bias.real.grad), gr.double().sum((0, 2, 3)).cpu().numpy(), rtol=1e-4, atol=2.0)
+    np.testing.assert_allclose(N(conv.bias.imag.grad), gi.double().sum((0, 2, 3)).cpu().numpy(), rtol=1e-4, atol=2.0)

@@ -1,0 +1,176 @@
+"""Round-4 GPU tests: the one-wave-per-SIMD GEMM family (csrc/gemm_bf16_w4.hip) against the 8-wave family and the
+float64 oracle, and the round-3 advisor finding about the two-call backward pattern under a data-parallel hook.
+Everything goes through libcplxamd.so (C ABI via ctypes)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle.cplx_oracle as orc
+from gpu_util import DEV, N
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, device=DEV, generator=g) * scale).bfloat16()
+
+
+@pytest.fixture
+def family():
+    """cplxamd_gemm_set_family, restored afterwards."""
+    from cplxmodule_amd import _lib
+    lib = _lib.load()
+    prev = lib.cplxamd_gemm_set_family(-1)
+    yield lib.cplxamd_gemm_set_family
+    lib.cplxamd_gemm_set_family(prev)
+
+
+# (B, I, O): K tile counts 4 (ring tail only), 12, 14 (6 + 6 + 2), 16, 20, 24 -- every entry / exit of the 6-tile ring loop;
+# 256-row / 128-column (complex) and 256-column (real) tiles, one and several per launch
+SHAPES = [(256, 128, 256), (512, 384, 512), (768, 448, 512), (1024, 640, 256), (512, 768, 768)]
+
+
+@pytest.mark.parametrize("B,I,O", SHAPES)
+def test_w4_family_is_bit_identical_to_w8(family, B, I, O):
+    """Same MFMA sequence per accumulator, same epilogue arithmetic: forward (N,N) with bias, input gradient (N,T) plain and
+    with the fused LRT term, weight gradient (T,T) float32 with the fused-KL accumulate; complex and real."""
+    from cplxmodule_amd import ops
+    bf = torch.bfloat16
+    xr, xi, gr, gi = _bf(B, I, seed=1), _bf(B, I, seed=2), _bf(B, O, seed=3), _bf(B, O, seed=4)
+    wr, wi = _bf(O, I, scale=0.05, seed=5), _bf(O, I, scale=0.05, seed=6)
+    bias = (torch.randn(O, device=DEV), torch.randn(O, device=DEV))
+    ga, a2, gs2 = _bf(B, I, seed=7), _bf(B, I, seed=8).abs(), _bf(B, O, seed=9)
+    S = torch.empty(O, I, device=DEV).uniform_(-12, 4).exp().to(bf)
+    ls2 = torch.empty(O, I, device=DEV).uniform_(-12, 4)
+    kl0 = [torch.randn(O, I, device=DEV) for _ in range(2)]
+    beta = torch.tensor(0.37, device=DEV)
+
+    def launches():
+        out = {}
+        out["c_fwd"] = ops.cgemm(xr, xi, (I, 1), wr, wi, (I, 1), B, O, I, bias=bias, out_dtype=bf)
+        out["c_dx"] = ops.cgemm(gr, gi, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=bf)
+        out["c_dx_lrt"] = ops._cplx_lrt_dx(gr, gi, wr, wi, xr, xi, ga)
+        dw = [t.clone() for t in kl0]
+        ops.cgemm(gr, gi, (1, O), xr, xi, (1, I), O, I, B, conj_b=True, out=dw, accumulate=True, beta=beta)
+        out["c_dw_kl"] = dw
+        out["c_dw"] = ops.cgemm(gr, gi, (1, O), xr, xi, (1, I), O, I, B, conj_b=True, out_dtype=torch.float32)
+        out["r_fwd"] = [ops.rgemm(a2, (I, 1), S, (I, 1), B, O, I, out_dtype=bf)]
+        out["r_fwd_f32"] = [ops.rgemm(a2, (I, 1), S, (I, 1), B, O, I, bias=bias[0], out_dtype=torch.float32)]
+        out["r_dx"] = [ops.rgemm(gs2, (O, 1), S, (1, I), B, I, O, out_dtype=bf)]
+        out["r_dx_lrt"] = [ops._real_lrt_dx(gs2, S, xr, ga)]
+        d = kl0[0].clone()
+        ops.rgemm(gs2, (1, O), a2, (1, I), O, I, B, emul=ls2, emul_exp=True, out=d, accumulate=True, beta=beta)
+        out["r_dw_kl"] = [d]
+        return out
+
+    family(0)
+    ref = launches()
+    family(-1)
+    got = launches()
+    for k in ref:
+        for a, b in zip(ref[k], got[k]):
+            assert a.dtype == b.dtype and torch.isfinite(b.float()).all(), k
+            assert torch.equal(a, b), f"{k}: {(a != b).sum().item()} of {a.numel()} elements differ"
+    # ... and the forward against the float64 oracle on a few rows (bf16 output rounding), so that "identical" is not
+    # "identically wrong"
+    rows = [0, 1, B // 2 + 3, B - 1]
+    f = np.float64
+    rr, ri = orc.cplx_linear(N(xr[rows].float()).astype(f), N(xi[rows].float()).astype(f), N(wr.float()).astype(f),
+                             N(wi.float()).astype(f), N(bias[0]).astype(f), N(bias[1]).astype(f))
+    sc = np.abs(rr).max()
+    np.testing.assert_allclose(N(got["c_fwd"][0][rows].float()), rr, rtol=8e-3, atol=8e-3 * sc)
+    np.testing.assert_allclose(N(got["c_fwd"][1][rows].float()), ri, rtol=8e-3, atol=8e-3 * sc)
+
+
+def test_w4_family_declines_what_it_does_not_take(family):
+    """Partial tiles, K not a multiple of 64, (T,N) layouts: the 8-wave / generic kernels run, the results stay right."""
+    from cplxmodule_amd import ops
+    bf = torch.bfloat16
+    family(-1)
+    for B, I, O in [(250, 128, 256), (256, 96, 256), (256, 128, 200)]:
+        xr, xi = _bf(B, I, seed=1), _bf(B, I, seed=2)
+        wr, wi = _bf(O, I, scale=0.05, seed=5), _bf(O, I, scale=0.05, seed=6)
+        yr, yi = ops.cgemm(xr, xi, (I, 1), wr, wi, (I, 1), B, O, I, out_dtype=bf)
+        f = np.float64
+        rr, ri = orc.cplx_linear(N(xr.float()).astype(f), N(xi.float()).astype(f), N(wr.float()).astype(f), N(wi.float()).astype(f))
+        sc = np.abs(rr).max()
+        np.testing.assert_allclose(N(yr.float()), rr, rtol=8e-3, atol=8e-3 * sc)
+        np.testing.assert_allclose(N(yi.float()), ri, rtol=8e-3, atol=8e-3 * sc)
+
+
+# ---- nll.backward(); (c * kl).backward() under a data-parallel hook --------------------------------
+class _CopyingBuckets:
+    """dp.BucketHook as ops sees it -- persistent float32 storage per parameter handed out as gradient buffers, an
+    announce call -- PLUS what its post-accumulate-grad hook does to that storage: the final .grad is copied into the
+    bucket slice (dp.py: BucketHook.on_grad)."""
+
+    def __init__(self, params):
+        self.store = {id(p): torch.zeros(p.shape, dtype=torch.float32, device=p.device) for p in params}
+        self.announced = []
+        self.handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+
+    def _on_grad(self, p):
+        t = self.store[id(p)]
+        if p.grad is not None and p.grad.data_ptr() != t.data_ptr():
+            t.copy_(p.grad)
+
+    def view_for(self, p):
+        t = self.store.get(id(p))
+        return None if t is None else t.view(t.shape)
+
+    def early_ready(self, *params):
+        self.announced += [p for p in params if p is not None]
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+
+
+@pytest.mark.parametrize("kind", ["cplx_vd", "real_ard"])
+@pytest.mark.parametrize("mode", ["nll_first", "kl_first", "one"])
+def test_two_call_backward_with_fused_kl_under_dp_hook(kind, mode):
+    """With the hook active the pending KL gradients live in the parameters' bucket slices -- the storage every backward
+    pass's result is copied into.  The data-only pass used to leave them pending, and the KL-only pass then returned the
+    (copied) data gradient scaled by c as the KL gradient.  No error, wrong numbers."""
+    from cplxmodule_amd import ops
+    from cplxmodule_amd.nn.relevance import penalties
+    from cplxmodule_amd.nn.relevance.noise import noise
+    from test_gpu_r03 import _grads, _make, _nll
+    layer, x, cplx_ = _make(kind)
+    c = 0.37
+
+    def run(m):
+        noise.manual_seed(11)
+        layer.zero_grad(set_to_none=True)
+        nll = _nll(layer(x), cplx_)
+        kl = sum(penalties(layer))
+        if m == "one":
+            (nll + c * kl).backward()
+        elif m == "nll_first":
+            nll.backward()
+            (c * kl).backward()
+        else:
+            (c * kl).backward(retain_graph=True)
+            nll.backward()
+        return _grads(layer)
+
+    run("one")                      # arms the fusion
+    ref = run("one")
+    assert layer._kl_fuse
+    hook = _CopyingBuckets(list(layer.parameters()))
+    ops.dp_hook = hook
+    try:
+        got = run(mode)
+    finally:
+        ops.dp_hook = None
+        hook.remove()
+    assert got.keys() == ref.keys()
+    for n in ref:
+        r = ref[n].float().cpu().numpy()
+        np.testing.assert_allclose(got[n].float().cpu().numpy(), r, rtol=2e-5, atol=2e-5 * np.abs(r).max(),
+                                   err_msg=f"{kind} {mode} {n}")
+        # the bucket slice holds the same total (it is what the all-reduce would average)
+        p = dict(layer.named_parameters())[n]
+        np.testing.assert_allclose(hook.store[id(p)].cpu().numpy(), r, rtol=2e-5, atol=2e-5 * np.abs(r).max(),
+                                   err_msg=f"bucket of {n}")
