@@ -5,9 +5,8 @@
 
 namespace cplxamd {
 int g_gemm_persistent = 1;
-// default: the launches the one-wave-per-SIMD family is faster on (profiles/r04_gemm_w4_ab.txt): bf16-out without a fused
-// elementwise operand, complex (bit 0) and real (bit 3)
-static int env_w4() { const char* e = getenv("CPLXAMD_GEMM_W4"); return e ? (int)strtol(e, nullptr, 0) : 0x09; }
+// default: every launch kind, subject to the K-depth rule of gemm_bf16_w4.hip (profiles/r04_gemm_w4_ab.txt)
+static int env_w4() { const char* e = getenv("CPLXAMD_GEMM_W4"); return e ? (int)strtol(e, nullptr, 0) : 0x3f; }
 int g_gemm_w4 = env_w4();
 }
 using namespace cplxamd;
@@ -22,7 +21,7 @@ int cplxamd_gemm_set_persistent(int on) {
 
 int cplxamd_gemm_set_family(int w4) {
   const int prev = g_gemm_w4;
-  g_gemm_w4 = w4 < 0 ? 0x3f : (w4 & 0x3f);
+  g_gemm_w4 = w4 < 0 ? 0x7f : (w4 & 0x7f);
   return prev;
 }
 

@@ -707,11 +707,18 @@ static int launch_layout(const GemmArgs& g, bool ta, bool tb, hipStream_t st) {
 int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bool tb, hipStream_t st, bool& taken) {
   taken = false;
   // which launches the family takes (cplxamd_gemm_set_family): bit 0 complex bf16-out, 1 complex bf16-out with the fused LRT
-  // term, 2 complex float32-out, 3 real bf16-out (4: with the fused term), 5 real float32-out
+  // term, 2 complex float32-out, 3 real bf16-out (4: with the fused term), 5 real float32-out; bit 6: regardless of K.
+  // Without bit 6 the K depth decides too (profiles/r04_gemm_w4_ab.txt): this family pays a full prologue / epilogue per
+  // output tile where the 8-wave (N,N) / (N,T) kernels run persistent, so it wins from K = 4096 on, at 1024 <= K < 4096 only
+  // on the (N,N) launches, below that nowhere.
   {
     const bool f32o = out_dtype == CPLXAMD_F32;
     const int bit = cplx ? (f32o ? 2 : g.fga ? 1 : 0) : (f32o ? 5 : g.fga ? 4 : 3);
     if (!((g_gemm_w4 >> bit) & 1)) return 0;
+    if (!((g_gemm_w4 >> 6) & 1)) {
+      if (g.K < 1024) return 0;
+      if (g.K < 4096 && (ta || tb || g.fga)) return 0;
+    }
   }
   const int bm = 256, bn = cplx ? 128 : 256;
   if (g.splits > 1 || g.g1 || g.batch != 1) return 0;

@@ -224,8 +224,10 @@ int cplxamd_gemm_set_persistent(int on);
  * requested together) wherever those take the shape (full 256 x 128 complex / 256 x 256 real tiles, K % 64 == 0):
  *   bit 0 complex, bf16 out          bit 1 complex, bf16 out with the fused LRT input-gradient term     bit 2 complex, float32 out
  *   bit 3 real, bf16 out             bit 4 real, bf16 out with the fused term                           bit 5 real, float32 out
- * 0 = the 8-wave LDS-DMA kernels of rounds 1-3 everywhere, -1 = every bit.  Start value 0x09 (the launches the new family is
- * faster on, profiles/r04_gemm_w4_ab.txt; env CPLXAMD_GEMM_W4=<mask> overrides).  Both families produce the same bits (same
+ *   bit 6 regardless of the K depth (without it: K >= 4096, or 1024 <= K < 4096 on (N,N) launches -- the family pays a
+ *         prologue and an epilogue per output tile where the 8-wave kernels run persistent; profiles/r04_gemm_w4_ab.txt)
+ * 0 = the 8-wave LDS-DMA kernels of rounds 1-3 everywhere, -1 = every bit.  Start value 0x3f (env CPLXAMD_GEMM_W4=<mask>
+ * overrides).  Both families produce the same bits (same
  * MFMA sequence per accumulator; tests/test_gpu_r04.py). */
 int cplxamd_gemm_set_family(int mask);
 

@@ -108,7 +108,13 @@ def run(lib, tag, B, I, O, time_it=True):
         ref = [t.clone() for t in fn()]
         lib.cplxamd_gemm_set_family(-1)
         out = [t.clone() for t in fn()]
+        lib.cplxamd_gemm_set_persistent(0)
+        out1 = [t.clone() for t in fn()]
+        lib.cplxamd_gemm_set_persistent(1)
         torch.cuda.synchronize()
+        if not all(torch.equal(a, b) for a, b in zip(out, out1)):
+            bad += 1
+            print(f"   {s:12s} MISMATCH between the persistent and the one-workgroup-per-tile launch", flush=True)
         same = all(torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32),
                                b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32)) for a, b in zip(ref, out))
         fin = all(torch.isfinite(b.float()).all().item() for b in out)
@@ -122,10 +128,12 @@ def run(lib, tag, B, I, O, time_it=True):
     if not time_it:
         return bad
     # ---- timing
-    fams = [("w8", 0), ("w4", 1)]
+    # w8: the 8-wave kernels (persistent where they have that form); w4: one wave per SIMD, persistent; w4o: one workgroup per tile
+    fams = [("w8", 0), ("w4", 1), ("w4o", 2)] if os.environ.get("W4O") else [("w8", 0), ("w4", 1)]
     times = {(n, s): [] for n, _ in fams for s in shapes}
     for n, f in fams:
         lib.cplxamd_gemm_set_family(-1 if f else 0)
+        lib.cplxamd_gemm_set_persistent(0 if f == 2 else 1)
         for s, (fn, _) in shapes.items():
             for _ in range(3):
                 fn()
@@ -135,6 +143,7 @@ def run(lib, tag, B, I, O, time_it=True):
             order = fams if r % 2 == 0 else fams[::-1]
             for n, f in order:
                 lib.cplxamd_gemm_set_family(-1 if f else 0)
+                lib.cplxamd_gemm_set_persistent(0 if f == 2 else 1)
                 fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -144,6 +153,7 @@ def run(lib, tag, B, I, O, time_it=True):
                 torch.cuda.synchronize()
                 times[(n, s)].append(e0.elapsed_time(e1) / PER)
     flop = B * I * O
+    lib.cplxamd_gemm_set_persistent(1)
     print(f"# {ROUNDS} interleaved rounds x {PER} launches; median ms (min ms) [TF/s at the median; 8MNK complex, 2MNK real]")
     print("family".ljust(8) + "".join(s.rjust(30) for s in shapes))
     for n, _ in fams:

@@ -281,7 +281,7 @@ def test_cfg4_lrt_backward_values_at_full_size():
     elems = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(F) + oc[None].astype(np.uint64)).ravel()
     er, ei = _cplx_noise_at(elems, 9, 1)
     er, ei = torch.from_numpy(er.reshape(B, 3)).to(DEV), torch.from_numpy(ei.reshape(B, 3)).to(DEV)
-    S3 = layer.log_sigma2.exp().bfloat16().double()[o_rows]                        # [3, F]
+    S3 = layer.log_sigma2.detach().exp().bfloat16().double()[o_rows]               # [3, F]
     acc = torch.zeros(3, F, dtype=torch.float64, device=DEV)
     for c0 in range(0, B, CH):
         sl = slice(c0, c0 + CH)
