@@ -212,7 +212,7 @@ class Cplx:
 
     def __mul__(self, other):
         if isinstance(other, Cplx) and ops.cplx_mul_ok(self._re, self._im, other._re, other._im):
-            return type(self)(*ops.cplx_mul(self._re, self._im, other._re, other._im))      # one launch, same bits
+            return type(self)(*ops.cplx_mul(self._re, self._im, other._re, other._im))      # one launch (float32: same bits as the reference's 6 kernels; bf16: float32 intermediates)
         if isinstance(other, (Cplx, complex)):
             return type(self)(self._re * other.real - self._im * other.imag,
                               self._im * other.real + self._re * other.imag)

@@ -185,9 +185,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   // ---- tile coordinates: XCD-contiguous grouped order (as gemm_bf16_kernel) ---------------------------------
   const int tiles_m = g.M / BM, tiles_n = g.N / BN;
   const int ntiles = tiles_m * tiles_n;
-  int bm, bn;
+  int bm, bn, split = 0;
   {
     int lin = blockIdx.x;
+    if (g.splits > 1) { split = lin / ntiles; lin -= split * ntiles; }     // split-K: block (split, tile), float32 slabs
     const int q = ntiles >> 3, r = ntiles & 7, xcd = lin & 7, idx = lin >> 3;
     lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective
     const int GM = g.group_m;
@@ -215,6 +216,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     pb[NPL - 1] = (const char*)g.b_i + (TB ? (int64_t)n0 : (int64_t)n0 * ldb) * 2;
   }
   const int64_t ka = TA ? lda * 2 : 2, kb = TB ? ldb * 2 : 2;       // bytes per k step
+  const int kbase = __builtin_amdgcn_readfirstlane(split * g.kchunk);
+  if (g.splits > 1) {
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) { pa[pl] += (int64_t)kbase * ka; pb[pl] += (int64_t)kbase * kb; }
+  }
   const uint32_t voa = src_voff<BM, TA>(lda, tid), vob = src_voff<BN, TB>(ldb, tid);
   const uint32_t psa = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece_stride<BM, TA>(lda));
   const uint32_t psb = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece_stride<BN, TB>(ldb));
@@ -346,7 +352,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     }
   };
 
-  const int nt = __builtin_amdgcn_readfirstlane(g.K / BK);
+  const int klen = g.splits > 1 ? ((g.K - kbase) < g.kchunk ? (g.K - kbase) : g.kchunk) : g.K;
+  const int nt = __builtin_amdgcn_readfirstlane(klen / BK);
 
   // One K sub-step: NM MFMA slots; behind slot m its fillers.  F = fragment set the MFMAs use (the reads fill the other
   // one / the dead rows), PAR = parity of the K tile being computed (= parity of the registers being written), H = which
@@ -509,8 +516,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   }
 
   // ---- epilogue (the one-tile kernel's, for IB = 4 and JB / 2 column halves of 64) ------------------------------
-  TOUT* cr = reinterpret_cast<TOUT*>(g.c_r);
-  TOUT* ci = reinterpret_cast<TOUT*>(g.c_i);
+  // output planes: C, or -- split-K -- this split's float32 slab pair [split][plane][M][ldc] of the workspace (dense, no
+  // bias / multiplier / accumulate: gemm_slab_reduce_kernel applies those)
+  void* out_r = g.c_r;
+  void* out_i = g.c_i;
+  if (g.splits > 1) {
+    const int64_t slab = (int64_t)g.M * g.ldc;
+    float* base = reinterpret_cast<float*>(g.ws) + (int64_t)split * NPL * slab;
+    out_r = base; out_i = base + slab;
+  }
   const float beta = gemm_beta(g);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the surplus loads of the loop's tail target registers nothing reads: the compiler waits for them only where it reuses one)
   __builtin_amdgcn_s_barrier();                       // every wave is done with the ring
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
       const __amdgpu_buffer_rsrc_t rga = tile_rsrc(fuse ? g.fga : g.c_r, fuse ? g.fld : g.ldc, 2);
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
-        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? g.c_i : g.c_r, g.ldc, 2);
+        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? out_i : out_r, g.ldc, 2);
         const __amdgpu_buffer_rsrc_t rx = tile_rsrc(fuse ? (pl ? g.fx_i : g.fx_r) : g.c_r, fuse ? g.fld : g.ldc, 2);
 #pragma unroll
         for (int jh = 0; jh < JB / 2; ++jh)
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
       const __amdgpu_buffer_rsrc_t rm = tile_rsrc(hm ? (const void*)g.emul : g.c_r, g.ldc, 4);
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
-        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? g.c_i : g.c_r, g.ldc, 4);
+        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? out_i : out_r, g.ldc, 4);
 #pragma unroll
         for (int jh = 0; jh < JB / 2; ++jh)
 #pragma unroll
@@ -690,7 +704,7 @@ static int launch(const GemmArgs& g0, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)tiles), C::NT, C::SMEM, st>>>(g);
+  gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -716,15 +730,23 @@ int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bo
     const int bit = cplx ? (f32o ? 2 : g.fga ? 1 : 0) : (f32o ? 5 : g.fga ? 4 : 3);
     if (!((g_gemm_w4 >> bit) & 1)) return 0;
     if (!((g_gemm_w4 >> 6) & 1)) {
-      if (g.K < 1024) return 0;
-      if (g.K < 4096 && (ta || tb || g.fga)) return 0;
+      const int keff = g.splits > 1 ? g.kchunk : g.K;      // K loop per output tile
+      if (keff < 1024) return 0;
+      if (keff < 4096 && (ta || tb || g.fga)) return 0;
     }
   }
   const int bm = 256, bn = cplx ? 128 : 256;
-  if (g.splits > 1 || g.g1 || g.batch != 1) return 0;
+  if (g.g1 || g.batch != 1) return 0;
+  if (g.splits > 1) {
+    // split-K slabs (float32, dense): every split's K range a multiple of 64 and at least 128 deep
+    const int last = g.K - (g.splits - 1) * g.kchunk;
+    if (out_dtype != CPLXAMD_F32 || !g.ws || (g.kchunk % 64) || last < 128 || (last % 64) || g.kchunk < 128) return 0;
+    if (g.bias_r || g.emul || g.accumulate || g.fga) return 0;
+    if (!cplx) return 0;       // (measured: complex slabs -2.4 %, real +2.8 % against the 8-wave kernel: profiles/r04_gemm_w4_ab.txt)
+  }
   if (ta && !tb) return 0;
   if ((g.M % bm) || (g.N % bn) || (g.K % 64) || g.K < 128) return 0;
-  if ((int64_t)(g.M / bm) * (g.N / bn) > 0x7fffffff) return 0;
+  if ((int64_t)(g.M / bm) * (g.N / bn) * g.splits > 0x7fffffff) return 0;
   const int64_t lda = ta ? g.a_cs : g.a_rs, ldb = tb ? g.b_cs : g.b_rs;
   if ((lda % 8) || (ldb % 8) || lda >= (1 << 22) || ldb >= (1 << 22)) return 0;      // 32-bit per-lane tile offsets
   if (g.ldc >= (1 << 20) || g.fld >= (1 << 20)) return 0;                             // ... of the epilogue (256 rows x 4 bytes)

@@ -242,7 +242,14 @@ class BucketHook:
             return
         b, off, numel, shape = e
         if b.launched:
-            # a second backward pass into an exchanged bucket (not supported: see the module docstring); sync() re-reduces
+            # a second backward pass into an exchanged bucket (see the module docstring): autograd has just accumulated into
+            # the bucket view on the compute stream while the asynchronous all-reduce may still be reading / writing
+            # b.flat.  Order the two: wait for the collective NOW (the accumulate is already queued behind nothing, so this
+            # only bounds the damage window to "before this hook"); sync() re-reduces the bucket.  Training loops that need
+            # several backward passes per exchange call zero_grad() / sync_gradients() between them.
+            for pb, work, _ in self.pending:
+                if pb is b and work is not None:
+                    work.wait()
             b.dirty = True
             return
         view = b.flat[off:off + numel].view(shape)

@@ -7,6 +7,7 @@ complex tensors are (real, imag) pairs of equal-shaped planes (cplxmodule/cplx.p
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import call, dtype_code, ptr, require_device, scratch_key, stream_ptr, try_call
@@ -697,6 +698,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
         ctx.lead, ctx.seed, ctx.offset = xr.shape[:-1], seed, offset
         ctx.kl_kind = kl_kind
         ctx.kl_params = (wr, wi, ls2) if kl_kind is not None else None    # (leaves: no cycle through ctx)
+        ctx.kl_versions = tuple(t._version for t in ctx.kl_params) if kl_kind is not None else None
         return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O), kl
 
     @staticmethod
@@ -709,6 +711,10 @@ class CplxLinearLRTFn(torch.autograd.Function):
             if gkl is not None and ctx.kl_kind is not None:
                 if ctx.klg is None:          # the buffers hold totals by now: redo the KL part
                     wr, wi, ls2 = ctx.kl_params
+                    if tuple(t._version for t in ctx.kl_params) != ctx.kl_versions:
+                        raise RuntimeError("a parameter of this layer was modified in place between its forward pass and a "
+                                           "backward pass that has to recompute the KL gradients (e.g. optimizer.step() "
+                                           "with a retained graph): the recomputation would use the NEW values")
                     ctx.klg, ctx.klg_shared = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:], False
                 dls2, dwr, dwi = (_scaled(gkl, t) for t in ctx.klg)
                 if ctx.klg_shared:
@@ -1340,7 +1346,8 @@ def cplx_mul_ok(ar, ai, br, bi):
 
 class CplxMulFn(torch.autograd.Function):
     """Cplx * Cplx and Cplx / Cplx (cplxmodule/cplx.py:135-165) in one launch (the reference: 6 / 12 elementwise kernels,
-    same operation order -> same bits); gradients d(ab)/da = g conj(b), d(ab)/db = g conj(a), d(a/b)/da = g / conj(b),
+    same operation order -> same bits for float32; bf16 planes keep float32 intermediates where the reference's chain of
+    torch ops rounds every product and sum to bf16: more accurate, not bit-identical); gradients d(ab)/da = g conj(b), d(ab)/db = g conj(a), d(a/b)/da = g / conj(b),
     d(a/b)/db = -(g conj(a/b)) / conj(b): one launch each (two for the last)."""
 
     @staticmethod
@@ -1354,6 +1361,7 @@ class CplxMulFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable      # raw kernels: a double backward (gradient penalties) raises instead of returning zeros
     def backward(ctx, gr, gi):
         gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
         need_a, need_b = ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
@@ -1393,6 +1401,7 @@ class SplitReluFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         yr, yi = ctx.saved_tensors
         gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))

@@ -56,6 +56,7 @@ class GraphedStep:
         self.stream = side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
+            out = None
             for _ in range(warmup):
                 out = fn(*self.static_inputs)
             del out

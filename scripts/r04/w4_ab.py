@@ -92,7 +92,25 @@ def make(lib, B, I, O, dev="cuda"):
                                  1, p(beta), None, 0, st))
         return dw_f[:1]
 
-    return {"c_fwd": (c_fwd, 8.0), "c_dgrad": (c_dgrad, 8.0), "c_dgrad_lrt": (c_dgrad_lrt, 8.0), "c_wgrad_kl": (c_wgrad_kl, 8.0),
+    lib.cplxamd_gemm_ws_bytes.argtypes = L.SIGNATURES["cplxamd_gemm_ws_bytes"]
+    lib.cplxamd_gemm_ws_bytes.restype = ctypes.c_int64
+    nws = max(int(lib.cplxamd_gemm_ws_bytes(O, I, B, 1, L.BF16, L.F32)), int(lib.cplxamd_gemm_ws_bytes(O, I, B, 0, L.BF16, L.F32)), 16)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+
+    def c_wgrad_ws():      # the weight gradient as the layers launch it: with the split-K workspace (used when few tiles + long K)
+        dw_f[0].copy_(kl0[0]); dw_f[1].copy_(kl0[1])
+        chk(lib.cplxamd_cgemm_ex(p(gr), p(gi), 1, O, p(xr), p(xi), 1, I, None, None, None, p(dw_f[0]), p(dw_f[1]), I,
+                                 O, I, B, 1, L.BF16, L.F32, 1, p(beta), 0, p(ws), nws, st))
+        return dw_f
+
+    def r_wgrad_ws():
+        dw_f[0].copy_(kl0[0])
+        chk(lib.cplxamd_rgemm_ex(p(gs2), 1, O, p(a2), 1, I, None, p(ls2), 1, p(dw_f[0]), I, O, I, B, L.BF16, L.F32,
+                                 1, p(beta), p(ws), nws, st))
+        return dw_f[:1]
+
+    extra = {"c_wgrad_ws": (c_wgrad_ws, 8.0), "r_wgrad_ws": (r_wgrad_ws, 2.0)} if os.environ.get("WS") else {}
+    return {**extra, "c_fwd": (c_fwd, 8.0), "c_dgrad": (c_dgrad, 8.0), "c_dgrad_lrt": (c_dgrad_lrt, 8.0), "c_wgrad_kl": (c_wgrad_kl, 8.0),
             "r_fwd": (r_fwd, 2.0), "r_dgrad": (r_dgrad, 2.0), "r_wgrad_kl": (r_wgrad_kl, 2.0)}
 
 
