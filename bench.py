@@ -45,6 +45,9 @@ def parse():
                     help="on (default): the step is captured ONCE in a hipGraph after the warm-up steps and every timed step is a "
                     "replay of it (same kernels, same work, fresh Philox noise per replay; with N > 1 the RCCL all-reduces "
                     "are graph nodes); off: eager launches.  A capture that fails falls back to eager.")
+    ap.add_argument("--rccl-channels", type=int, default=int(os.environ.get("CPLXAMD_RCCL_MAX_CHANNELS", "0")),
+                    help="cap RCCL at this many channels (= CUs its ring kernels hold while the GEMMs run; 0: RCCL's own choice); "
+                    "passed to dp.init_process_group(max_channels=...)")
     ap.add_argument("--force-collectives", action="store_true", help="world of one: initialise the process group and "
                     "issue every collective of the N > 1 path anyway (tests: RCCL calls on a single-GPU box)")
     return ap.parse_args()
@@ -417,6 +420,8 @@ def main():
         # RCCL's kernels must run NEXT TO the input-gradient GEMMs they are meant to overlap: a normal-priority stream can
         # share the compute stream's hardware queue and then runs in queue order (profiles/r03_dp_timeline.txt)
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        if args.rccl_channels > 0:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.rccl_channels))      # (dp.init_process_group: max_channels)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -441,7 +446,11 @@ def main():
     layer = rel.CplxLinearVD(IN_F, OUT_F).to(dev)
     with torch.no_grad():                      # mixed relevance so both Ei branches are exercised
         layer.log_sigma2.uniform_(-12, 4)
-    model = dp.DataParallel(layer)
+    # gloo (functional tests of the N > 1 path on one GPU) cannot be captured -- its collectives synchronise on the host --
+    # so with --graph on the COMPUTE of a step is the graph and the exchange runs behind each replay; every bucket is then
+    # reduced in sync_gradients() (overlap=False: the hooks' bookkeeping does not run during a replay)
+    split_exchange = grouped and args.backend != "nccl" and args.graph == "on"
+    model = dp.DataParallel(layer, overlap=not split_exchange)
     noise.manual_seed(1234 + rank)
     torch.manual_seed(1 + rank)                # per-rank synthetic shard
     B = args.batch
@@ -450,18 +459,37 @@ def main():
     klw = torch.tensor(KLW, device=dev)
     layer.train()
 
-    def step():
+    def compute():
         model.zero_grad()
         x.real.grad = x.imag.grad = None
         y = model(x)
         kl = sum(rel.penalties(layer, reduction="sum"))
         gy_r, gy_i = y.real.detach() * 2, y.imag.detach() * 2      # d(sum |y|^2)/dy
         torch.autograd.backward((y.real, y.imag, kl), (gy_r, gy_i, klw))
+        return kl
+
+    def exchange(kl):
         model.sync_gradients()
         return dp.all_reduce_scalar_mean(kl) if grouped else kl
 
+    def step():
+        return exchange(compute())
+
     graphed, mode = None, "eager"
-    if args.graph == "on" and (not grouped or args.backend == "nccl"):   # (gloo collectives synchronise on the host)
+    if split_exchange:
+        from cplxmodule_amd.utils.graphs import GraphedStep
+        noise.set_mode("philox-device")
+        inner = GraphedStep(compute, modules=[layer], warmup=max(args.warmup, 3))
+
+        class _ReplayThenExchange:          # same interface as GraphedStep for the timed loop below
+            @staticmethod
+            def replay():
+                model.hook.reset()          # (the buckets' bookkeeping of the previous step; .grad stays the bucket views)
+                return exchange(inner.replay())
+        graphed, mode = _ReplayThenExchange, "hipGraph replay of the compute + eager gloo exchange"
+        graphed.replay()
+        torch.cuda.synchronize()
+    elif args.graph == "on" and (not grouped or args.backend == "nccl"):
         # W eager warm-up steps on the capture stream, then ONE capture; the timed steps replay it.  (HIP events cannot be
         # recorded inside a replayed graph on ROCm -- "External events are disallowed" -- so the per-launch GEMM times of
         # `roofline` are taken with HIP events around the same launches in ten eager steps right after the timed region.)

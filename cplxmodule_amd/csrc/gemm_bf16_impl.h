@@ -32,9 +32,10 @@
 //    fragments in registers, so the MFMA pipe runs across the barrier and across the LDS latency
 //    of the next tile's first fragments (+2-4 % on N(0,1) data, +6 % on zero-filled operands).
 //  * few output tiles + long K (wgrad at batch 2^20): split-K into fp32 slabs + a reduce kernel.
-// Experiment variants of this file (compile-time ablation bits, the classic per-tile pipeline, one-wave-per-SIMD tiles,
-// alternative MFMA orders) live in scripts/gemm_experiments/ (scripts/ab_build.sh builds them); this header holds the
-// production kernels only.
+// The experiment variants of rounds 2-3 (compile-time ablation bits, the classic per-tile pipeline, alternative MFMA
+// orders) were working COPIES of this header; they are in the history only (git show 1a9fb01:scripts/gemm_experiments/),
+// their results in profiles/r02_gemm_ablation.md / r03_gemm_pair_issue.txt.  Round 4's family (gemm_bf16_w4.hip) keeps
+// its ablation switches in the production file behind W4_DBG / W4_BURST / ... (scripts/r04/w4_build.sh).
 #include <stdlib.h>
 
 #include <type_traits>

@@ -91,6 +91,23 @@ __device__ __forceinline__ float cplx_vd_value(float t) {
   return kEulerGamma + t + e1;
 }
 
+// 1 - exp(-x) for x = e^t >= 0 (the slope of the exact complex KL, complex/vd.py:95-99 differentiated): alternating series
+// below 1/4 (8 terms: the first omitted one is x^9 / 9! < 1e-11 x), 1 - expf(-x) above (absolute error of expf <= 6e-8 on
+// a result >= 0.22): relative error < 3e-7 everywhere, half the instructions of ocml's expm1f (the fused KL kernel is
+// co-limited by its ~140 lane-operations per element, profiles/r03_kl_pmc.txt).  Both arms are evaluated, one select.
+__device__ __forceinline__ float one_minus_exp_neg(float x) {
+  float s = -2.4801587e-5f;            // -1/8!
+  s = fmaf(s, x, 1.9841270e-4f);       // +1/7!
+  s = fmaf(s, x, -1.3888889e-3f);      // -1/6!
+  s = fmaf(s, x, 8.3333333e-3f);       // +1/5!
+  s = fmaf(s, x, -4.1666667e-2f);      // -1/4!
+  s = fmaf(s, x, 1.6666667e-1f);       // +1/3!
+  s = fmaf(s, x, -0.5f);
+  s = fmaf(s, x, 1.0f);
+  const float big = 1.0f - expf(-x);
+  return x < 0.25f ? s * x : big;
+}
+
 template <int KIND>
 __device__ __forceinline__ float kl_value(float t) {
   if (KIND == CPLXAMD_KL_REAL_VD)
@@ -120,12 +137,12 @@ __device__ __forceinline__ float kl_slope(float t) {
     return fmaf(0.5f, softplus_grad_f(t), kK1 * kK3 * su * (1.0f - su));
   }
   if (KIND == CPLXAMD_KL_REAL_ARD) return 0.5f * softplus_grad_f(t);
-  if (KIND == CPLXAMD_KL_CPLX_VD || KIND == CPLXAMD_KL_CPLX_VD_BOGUS) return -expm1f(-expf(t));  // 1 - exp(-e^t)
+  if (KIND == CPLXAMD_KL_CPLX_VD || KIND == CPLXAMD_KL_CPLX_VD_BOGUS) return one_minus_exp_neg(expf(t));  // 1 - exp(-e^t)
   if (KIND == CPLXAMD_KL_CPLX_VD_APPROX) {
     const float su = sigmoid_f(fmaf(1.36526f, t, -1.45926f));
     return fmaf(0.57810f * 1.36526f, su * (1.0f - su), softplus_grad_f(t));
   }
-  if (KIND == CPLXAMD_KL_CPLX_VD_SCALEFREE) return -0.5f * expm1f(-expf(t));
+  if (KIND == CPLXAMD_KL_CPLX_VD_SCALEFREE) return 0.5f * one_minus_exp_neg(expf(t));
   return softplus_grad_f(t);
 }
 
@@ -135,7 +152,8 @@ __device__ __forceinline__ void weight_grad(float fp, float wr, float wi, float 
   // d(-log_alpha)/dw = 2 w / (theta (theta + 1e-12)); 0 at theta == 0 (torch subgradient)
   if (theta > 0.0f) {
     if (CPLX) {
-      const float c = 2.0f * fp / (theta * (theta + 1e-12f));
+      // (one hardware reciprocal, 1 ulp, instead of the correctly rounded division's ~10 instructions)
+      const float c = 2.0f * fp * __builtin_amdgcn_rcpf(theta * (theta + 1e-12f));
       gwr = c * wr;
       gwi = c * wi;
     } else {

@@ -51,13 +51,25 @@ def is_initialized():
     return dist.is_available() and dist.is_initialized()
 
 
-def init_process_group(backend="nccl", device=None, **kwargs):
+def init_process_group(backend="nccl", device=None, max_channels=None, **kwargs):
     """torch.distributed.init_process_group with what the overlap of this module needs: RCCL's stream on a
     high-priority hardware queue (TORCH_NCCL_HIGH_PRIORITY=1, read when the process group is created; on the compute
     stream's queue its kernels run in queue order, i.e. not next to the GEMMs they are meant to overlap) and the
-    loop-back rendezvous address of a single node as the default."""
+    loop-back rendezvous address of a single node as the default.
+
+    max_channels (or env CPLXAMD_RCCL_MAX_CHANNELS): the CU split between the collectives and the GEMMs they overlap.
+    An RCCL ring / tree kernel holds one CU per channel for as long as it runs; while a bucket is in flight the GEMM
+    kernels launch one workgroup per tile (`cplxamd_gemm_set_persistent(0)`) and simply get the remaining CUs, so the
+    price of C channels is C / 256 of the matrix throughput for the duration of the exchange.  Eight ranks on xGMI are
+    link-bound long before they need 32+ CUs (7 links x ~153 GB/s per GPU against ~25 GB/s a CU can copy), so a cap of
+    8-16 is the value to try first when an 8-GPU run shows the input-gradient GEMMs starving; None (default) leaves
+    RCCL's own choice.  Sets NCCL_MAX_NCHANNELS before the communicator exists (it is read once, at creation)."""
     import os
     os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+    if max_channels is None and os.environ.get("CPLXAMD_RCCL_MAX_CHANNELS"):
+        max_channels = int(os.environ["CPLXAMD_RCCL_MAX_CHANNELS"])
+    if max_channels:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(max_channels)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend == "nccl" and device is not None:
         kwargs.setdefault("device_id", torch.device(device))

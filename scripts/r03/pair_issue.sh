@@ -4,7 +4,7 @@
 # the one-tile complex forward GEMM WITHOUT its MFMAs (CPLXAMD_GEMM_DBG_BUILD bit 2) with the request pattern varied:
 #   2 production half lines (the other half one K tile = 48 KiB later) | 130 whole lines in one instruction
 #   258 halves back to back | 770 halves three instructions apart
-# builds: scripts/ab_build.sh k<N> -DCPLXAMD_GEMM_DBG_BUILD=<N> -DCPLXAMD_GEMM_NO_PERSIST
+# builds (round-3 tree, git show 1a9fb01:scripts/ab_build.sh): scripts/ab_build.sh k<N> -DCPLXAMD_GEMM_DBG_BUILD=<N> -DCPLXAMD_GEMM_NO_PERSIST
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 for d in ${KSET:-2 130 258 770}; do

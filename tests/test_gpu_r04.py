@@ -174,3 +174,33 @@ def test_two_call_backward_with_fused_kl_under_dp_hook(kind, mode):
         p = dict(layer.named_parameters())[n]
         np.testing.assert_allclose(hook.store[id(p)].cpu().numpy(), r, rtol=2e-5, atol=2e-5 * np.abs(r).max(),
                                    err_msg=f"bucket of {n}")
+
+
+# ---- bench.py with two ranks AND a graph replay (gloo ranks sharing this GPU) ------------------------
+def test_bench_py_two_gloo_ranks_graph_replay():
+    """The N > 1 path of bench.py with the step's compute replayed from a hipGraph: gloo collectives synchronise on the
+    host and cannot be captured, so the exchange (bucket all-reduces in sync_gradients(), scalar KL all-reduce) runs
+    behind each replay; same KL as the eager two-rank run from the same seeds' first step is not expected (fresh noise
+    per step), finite and sane numbers are."""
+    import os
+    import subprocess
+    import sys
+    from test_gpu_r03 import _bench_line
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "3", "--warmup", "1", "--batch", "512", "--no-cpu-baseline"]
+    lines = {}
+    for graph, port in (("on", "29561"), ("off", "29563")):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--backend", "gloo", "--share-device", "--graph", graph] + common,
+                           env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        lines[graph] = _bench_line(r.stdout)
+    on, off = lines["on"], lines["off"]
+    assert "hipGraph replay of the compute" in on["config"]["launch"] and off["config"]["launch"] == "eager"
+    for line in (on, off):
+        assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024 and line["steps"] == 3
+        assert np.isfinite(line["value"]) and line["value"] > 0 and np.isfinite(line["kl"])
+    # the KL term is a function of the (identical, rank-0 broadcast) weights only: both runs report the same value
+    assert abs(on["kl"] - off["kl"]) <= 1e-4 * abs(off["kl"])
