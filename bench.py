@@ -120,9 +120,9 @@ def cpu_baseline(sample_rows, kl_rows=512):
 def gemm_traffic():
     """HBM bytes per launch of the complex GEMM from the tracked PMC summary (separate rocprofv3 --pmc passes of the
     bench's three launches at the bench shape, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE;
-    scripts/r03/profile_bench.sh): (mean over the three launches, {launch: bytes}).  PMC counters cannot be read from
+    scripts/r04/profile_bench.sh): (mean over the three launches, {launch: bytes}).  PMC counters cannot be read from
     inside this process, so this is the committed measurement of the same kernels and shapes, not of this run."""
-    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):
+    for name in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 d = json.load(fh)
@@ -566,7 +566,7 @@ def main():
                                    f"batch {B} per GPU, LRT fwd + KL + full bwd (BASELINE configs[1] + VD)",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "kl_weight": KLW, "noise": "in-kernel Philox4x32-7", "launch": mode},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<CPLX> (4M complex GEMM: fwd NN, dgrad NT, wgrad TT = 3 launches/step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_w4_kernel<CPLX> (4M complex GEMM, one wave per SIMD: fwd NN, dgrad NT + fused LRT term, wgrad TT + fused KL accumulate = 3 launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_PEAK_TFLOPS, 4) if achieved else None,
                          "traffic": traffic, "traffic_per_launch": traffic_per, "flop_per_launch": flops,
