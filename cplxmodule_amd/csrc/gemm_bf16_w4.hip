@@ -47,7 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W4_DBG
-#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores, 16 hot-source loads (always K tiles 0, 1)
+#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores, 16 hot-source loads (always K tiles 0, 1), 32 complex: only the MFMAs into the real-part accumulators (the instruction mix of pass 1 of a two-pass 3M loop: 32 MFMAs beside the full staging + fragment traffic of a K tile)
 #endif
 // where the two loads of a register pair go, in MFMA slots behind the pair's LDS write (experiments: scripts/r04/w4_build.sh)
 #ifndef W4_LDP
@@ -175,9 +175,11 @@ constexpr int slot_of_write(bool cplx, bool burst, int nw, int m, int off) {
 // LDS operations a sub-step issues behind its last fragment read (the counted wait in front of the barrier)
 constexpr int ops_after_last_read(bool cplx, bool burst, bool writes) { return !writes ? 0 : !burst ? 1 : cplx ? 0 : 2; }
 
+#ifndef W4_PGRID
+#define W4_PGRID 0   // experiment: > 0 = at most that many workgroups, each walking the tile list (lin, lin + grid, ...)
+#endif
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char* smem) {
   using C = Cfg<CPLX>;
   constexpr int NT = C::NT, BM = C::BM, BN = C::BN, IB = C::IB, JB = C::JB, NPL = C::NPL;
   constexpr int PA = C::PA, PB = C::PB, NL = C::NL, NFRAG = C::NFRAG, NM = C::NM, SLOT = C::SLOT;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   const int ntiles = tiles_m * tiles_n;
   int bm, bn, split = 0;
   {
-    int lin = blockIdx.x;
+    int lin = lin0;
     if (g.splits > 1) { split = lin / ntiles; lin -= split * ntiles; }     // split-K: block (split, tile), float32 slabs
     const int q = ntiles >> 3, r = ntiles & 7, xcd = lin & 7, idx = lin >> 3;
     lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     if constexpr (CPLX) {
       constexpr int i = m / 8, ph = (m % 8) / 4, j = (m % 4) / 2, c = m % 2;
       constexpr int d = i < IB - 1 ? i : IB - 1 + f;
+      if constexpr ((W4_DBG & 32) != 0 && c == 1) return;
       if constexpr (ph == 0) {
         if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ar[d], acc_r[i][j], 0, 0, 0);
         else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ai[d], acc_i[i][j], 0, 0, 0);
@@ -684,6 +687,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   }
 }
 
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#if W4_PGRID > 0
+  const int total = (g.M / Cfg<CPLX>::BM) * (g.N / Cfg<CPLX>::BN) * (g.splits > 1 ? g.splits : 1);
+  for (int lin = blockIdx.x; lin < total; lin += gridDim.x) {
+    w4_tile<TOUT, CPLX, CONJ, TA, TB>(g, lin, smem);
+    __syncthreads();
+  }
+#else
+  w4_tile<TOUT, CPLX, CONJ, TA, TB>(g, (int)blockIdx.x, smem);
+#endif
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -704,7 +721,9 @@ static int launch(const GemmArgs& g0, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
+  int64_t grid = tiles * g.splits;
+  if (W4_PGRID > 0 && grid > W4_PGRID) grid = W4_PGRID;
+  gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)grid), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }

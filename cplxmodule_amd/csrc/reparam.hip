@@ -59,7 +59,9 @@ __device__ __forceinline__ u32x4 philox4x32(uint64_t ctr_lo, uint64_t ctr_hi, ui
 }
 
 __device__ __forceinline__ float u01(uint32_t x) {
-  return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f;  // 2^-24
+  // ((x >> 8) + 0.5) * 2^-24 as ONE fused multiply-add: bit-identical to the add-then-multiply of the stream definition
+  // (below 2^23 both are exact; from 2^23 on the sum is a tie that either form rounds to the same even neighbour)
+  return fmaf((float)(x >> 8), 5.9604644775390625e-08f, 2.98023223876953125e-08f);
 }
 
 // scale = 1 for real noise, 1/sqrt(2) for complex
