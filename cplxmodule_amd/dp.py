@@ -19,10 +19,13 @@ A collective is launched ONLY from a parameter's post-accumulate-grad hook, i.e.
 every path into that leaf (an in-loss weight regulariser, the stand-alone KL node, a shared use): a
 gradient that is still being accumulated is never reduced.  The LRT linear layers additionally ANNOUNCE
 their parameter gradients before their own input-gradient GEMMs (`ops.dp_hook.early_ready`): the
-announcement records a HIP event behind the weight-gradient kernels, and a bucket whose gradients all
-arrived in place waits for that event only -- on a side stream -- so its all-reduce still overlaps the
-layer's own input-gradient GEMMs (the host runs ahead of the device), which gives the single-layer
-headline config its overlap.  Nothing waits inside backward: `sync_gradients()` waits for all buckets,
+announcement records a HIP event behind the weight-gradient kernels, and the bucket's all-reduce -- issued
+from a side stream -- waits for that event only, so it still overlaps the layer's own input-gradient GEMMs
+(the host runs ahead of the device), which gives the single-layer headline config its overlap.  A slice that
+was not announced (copied in, or accumulated into after the announcement) gets an event at the moment its
+hook runs; the collective waits for the slices' events, never for what the host queues afterwards, so a
+copied bias or BatchNorm parameter in the same bucket does not cost the in-place weights their early start.
+Nothing waits inside backward: `sync_gradients()` waits for all buckets,
 reduces what never completed (parameters without a gradient contribute zeros) and hands out the
 averaged views.
 
@@ -107,8 +110,9 @@ class _Bucket:
         self.launched = False
         self.events = []           # HIP events behind the kernels that wrote the slices in place
         self.dirty = False         # a gradient changed after the bucket's collective was launched
-        self.early = False         # launched on the side stream, behind the announced stream position only
-        self.in_order = False      # a gradient reached its slice by a copy on the current stream
+        self.early = False         # launched on the side stream, behind the recorded stream positions only
+        self.in_order = False      # no stream position could be recorded for a slice (host tensors): plain stream order
+        self.copy_bumps = 0        # version-counter increments of `flat` made by on_grad's own copies (see on_grad)
 
 
 class GradBuckets:
@@ -241,8 +245,11 @@ class BucketHook:
                 ev.record()
                 self._share_chip()       # the kernels queued from here on may run next to a collective
             # (the version counter is the bucket's: views share it.  Autograd summing another path INTO the announced
-            #  storage after this point bumps it, and the shortcut below is then not taken)
-            self._announced[id(p)] = (ev, self.buckets.where[id(p)][0].flat._version)
+            #  storage after this point bumps it, and the shortcut below is then not taken; the bumps of on_grad's own
+            #  copies of OTHER parameters into the same bucket are discounted -- ADVICE r3: a bias or BN parameter that
+            #  shares the bucket must not push the in-place weights off the early path)
+            b = self.buckets.where[id(p)][0]
+            self._announced[id(p)] = (ev, b.flat._version - b.copy_bumps)
 
     def on_grad(self, param):
         """post-accumulate-grad hook of every registered parameter: `param.grad` is final for this backward."""
@@ -267,12 +274,22 @@ class BucketHook:
         view = b.flat[off:off + numel].view(shape)
         ev, version = self._announced.pop(id(param), (None, None))
         if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
+            before = b.flat._version
             view.copy_(g)
+            b.copy_bumps += b.flat._version - before
             param.grad = view
-            b.in_order = True
-        elif ev is None or version != b.flat._version:
-            b.in_order = True      # in place, but not (only) by the kernels in front of a recorded stream position
-        else:
+            ev = None
+        elif ev is not None and version != b.flat._version - b.copy_bumps:
+            ev = None              # in place, but not (only) by the kernels in front of the announced stream position
+        if ev is None:
+            # the slice is final HERE: everything that wrote it is queued on this stream by now.  The bucket's collective
+            # waits for this position (and the other slices' positions), not for what the host queues afterwards
+            if b.flat.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            else:
+                b.in_order = True
+        if ev is not None:
             b.events.append(ev)
         self._ready(param, b)
 

@@ -14,6 +14,8 @@ What makes a step of this package capturable:
     runs with `.grad = None`, so every replay reproduces "zero_grad(set_to_none=True); backward()";
   * data parallel: the bucket all-reduces (RCCL kernels) are captured with the step -- the hook's side stream is
     joined back into the capturing stream (dp.BucketHook._launch), `sync_gradients()` must be called inside the step;
+    the capture waits for the process group's watchdog to retire the warm-up steps' collectives and runs in
+    thread-local capture mode (`_settle_collective_watchdog`);
   * no autograd graph of an EARLIER eager step may be alive when the capture starts: its AccumulateGrad nodes
     remember the stream they were created on (usually the default stream), autograd then runs them there, and work on a
     non-capturing stream in the middle of a capture makes hipStreamEndCapture crash.  `GraphedStep` therefore drops the
@@ -34,6 +36,20 @@ def drop_autograd_state(modules):
             if getattr(m, "_kl_cache", None) is not None:
                 m._kl_cache = None
     gc.collect()
+
+
+def _settle_collective_watchdog(seconds=0.3):
+    """The RCCL process group's watchdog thread polls the completion events of the collectives the eager warm-up steps
+    issued (every ~100 ms) until it has seen them complete; a `hipEventQuery` from that thread while THIS thread captures
+    in the default (global) capture mode fails with "operation not permitted when stream is capturing" and takes the
+    process down (seen once in ~10 runs of the data-parallel cfg5 capture).  The device is idle here, so every such
+    event is complete: give the watchdog a few polling periods to retire them.  (Collectives issued DURING a capture are
+    not handed to the watchdog.)"""
+    import time
+
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        time.sleep(seconds)
 
 
 class GraphedStep:
@@ -62,8 +78,10 @@ class GraphedStep:
             del out
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        _settle_collective_watchdog()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=pool, stream=side):
+        # thread_local: an event query from ANOTHER thread (the process group's watchdog) must not invalidate the capture
+        with torch.cuda.graph(self.graph, pool=pool, stream=side, capture_error_mode="thread_local"):
             self.outputs = fn(*self.static_inputs)
 
     def replay(self, *inputs):

@@ -204,3 +204,17 @@ def test_bench_py_two_gloo_ranks_graph_replay():
         assert np.isfinite(line["value"]) and line["value"] > 0 and np.isfinite(line["kl"])
     # the KL term is a function of the (identical, rank-0 broadcast) weights only: both runs report the same value
     assert abs(on["kl"] - off["kl"]) <= 1e-4 * abs(off["kl"])
+
+
+# ---- ADVICE r03 (dp.py, performance note): a copied neighbour must not push in-place slices off the early path ------------
+def test_mixed_bucket_is_exchanged_from_the_side_stream():
+    """tests/dp_mixed_bucket_check.py: dense layer + BatchNorm + LRT layer in ONE bucket under RCCL (world of one,
+    collectives forced): launched behind the per-slice stream positions, gradients equal to the run without the wrapper."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "dp_mixed_bucket_check.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "mixed bucket OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
