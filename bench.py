@@ -254,6 +254,9 @@ def conv_point(dev, batch=256):
             ms = timer.mean_ms(k)
             out[f"{k}_ms"] = round(ms, 4) if ms else None
             out[f"{k}_frac_of_mfma_peak"] = round(flop / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4) if ms else None
+        # the forward launch also forms the batch-norm layer's statistics in its epilogue (one pass over y less in the layer;
+        # its fraction is still the convolution's flop over the whole launch): CPLXAMD_CONV_BN_MOMENTS=0 for the A/B
+        out["bn_moments_in_conv_epilogue"] = bool(cv._MOMENTS and cv._MOMENTS_WANTED)
         return out
     except Exception as e:  # pragma: no cover
         return {"error": str(e)[:200]}

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -88,6 +88,8 @@ SIGNATURES = {
     "cplxamd_conv2d_cl2": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _P],
     "cplxamd_chansum2": [_P, _P, _P, _P, _L, _I, _L, _I, _P, _P],
     "cplxamd_conv2d_cl2_lrt_dx": [_P] * 8 + [_L] + [_I] * 6 + [_P, _L, _P],
+    "cplxamd_conv2d_cl2_mom_chunks": [_L] + [_I] * 10,
+    "cplxamd_conv2d_cl2_mom": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P, _L, _P],
     "cplxamd_conv2d_cl_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
     "cplxamd_conv2d_cl_wgrad": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
     "cplxamd_cgemm3m_ws_bytes": [_I, _I, _I],
@@ -124,9 +126,10 @@ SIGNATURES = {
     "cplxamd_gemm_set_family": [_I],
     "cplxamd_bn_moments": [_P, _P, _P, _P, _P, _L, _I, _L, _I, _P, _P, _L, _P],
     "cplxamd_bn_fwd_sync": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _L, _P],
+    "cplxamd_bn_fwd_partials": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _I, _P, _L, _P],
     "cplxamd_bn_bwd_sync": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P],
 }
-_RESTYPES = {"cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_lrt_reparam_bwd_cols_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
+_RESTYPES = {"cplxamd_conv2d_cl2_mom_chunks": c_int64, "cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_lrt_reparam_bwd_cols_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,
              "cplxamd_cgemm3m_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,

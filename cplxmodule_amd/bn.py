@@ -75,6 +75,10 @@ class CplxBatchNormFn(torch.autograd.Function):
         require_device(xr, xi, weight, bias, running_mean, running_var)
         if not training and running_mean is None:
             raise ValueError("evaluation mode requires running statistics")
+        # the convolution that produced x may have left this layer's moments on it (ops.attach_moments); if it could have
+        # but was not asked to, ask for the next step (conv.want_moments) -- in evaluation mode take the request back
+        hint = ops.moments_hint(xr, xi) if training else None
+        src = getattr(xr, "_cplxamd_conv_src", None)
         xr, xi, (B, F, S), ctx.cl = _prep(xr, xi)
         yr, yi = torch.empty_like(xr), torch.empty_like(xi)      # (preserve_format: channels-last stays channels-last)
         saved = torch.empty(8, F, dtype=torch.float32, device=xr.device)
@@ -82,7 +86,14 @@ class CplxBatchNormFn(torch.autograd.Function):
         w = None if weight is None else weight.detach().contiguous()
         b = None if bias is None else bias.detach().contiguous()
         ctx.group = _sync_group(process_group, training)
-        if ctx.group is not None:
+        if src is not None:
+            from . import conv
+            conv.want_moments(src(), on=bool(training and ctx.cl and ctx.group is None))
+        if hint is not None and ctx.cl and ctx.group is None and hint[0].numel() == hint[1] * F * 5:
+            call("cplxamd_bn_fwd_partials", ptr(xr), ptr(xi), ptr(yr), ptr(yi), B, F, S, ptr(w), ptr(b),
+                 ptr(running_mean), ptr(running_var), ptr(saved), dtype_code(xr), momentum, eps, ptr(tracked),
+                 ptr(hint[0]), hint[1], ptr(ws), ws.numel(), stream_ptr())
+        elif ctx.group is not None:
             m = torch.empty(F * 5 + 1, dtype=torch.float64, device=xr.device)
             m[-1] = float(B * S)
             call("cplxamd_bn_moments", ptr(xr), ptr(xi), None, None, None, B, F, S, dtype_code(xr), ptr(m), ptr(ws),

@@ -6,6 +6,7 @@ Reference: cplx.conv2d -> convnd (cplxmodule/cplx.py:770-838), CplxConvNdGaussia
 """
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -247,9 +248,35 @@ def _cl_pack(wr, wi, dgrad):
     return out
 
 
-def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False):
+# Convolutions whose output a training-mode batch-norm layer consumed last time (keyed by the weight parameter, weakly):
+# their next forward also forms that layer's statistics in its epilogue (cplxamd_conv2d_cl2_mom) -- armed by the
+# consumer, like the KL fusion of the relevance layers, so a convolution nothing normalises never pays for it.
+_MOMENTS_WANTED = {}          # id(weight plane) -> weak reference to it (tensors compare elementwise: no WeakSet)
+_MOMENTS = os.environ.get("CPLXAMD_CONV_BN_MOMENTS", "1") != "0"      # (A/B: 0 = the layer's own moment pass, always)
+
+
+def want_moments(weight_plane, on=True):
+    """Called by the batch-norm forward with the tag the convolution left on its output (`_cplxamd_conv_src`)."""
+    if weight_plane is None:
+        return
+    key = id(weight_plane)
+    if on:
+        if key not in _MOMENTS_WANTED:
+            _MOMENTS_WANTED[key] = weakref.ref(weight_plane, lambda _, k=key: _MOMENTS_WANTED.pop(k, None))
+    else:
+        _MOMENTS_WANTED.pop(key, None)
+
+
+def moments_wanted(weight_plane):
+    r = _MOMENTS_WANTED.get(id(weight_plane))
+    return r is not None and r() is weight_plane
+
+
+def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False, moments=False):
     """Forward (or, with dgrad, the data gradient read as a convolution of the output gradient with the flipped,
-    conjugated, channel-swapped kernel) on channels-last planes; returns channels-last [B, N, H, W] tensors."""
+    conjugated, channel-swapped kernel) on channels-last planes; returns channels-last [B, N, H, W] tensors.
+    moments (forward only): also leave the batch-norm moments of the output on it (ops.attach_moments) when the
+    kernel variant takes the shape."""
     B, Ci, Co, H, W, KH, KW = (geom[i] for i in range(7))
     C, N = (Co, Ci) if dgrad else (Ci, Co)
     xr, xi = to_channels_last(xr), to_channels_last(xi)
@@ -262,6 +289,14 @@ def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False):
     ws = _scratch(xr.device, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(N)))
     args = (ptr(xr), ptr(xi), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9],
             geom[10], int(dgrad), ptr(ws), ws.numel(), stream_ptr())
+    if moments and not dgrad and _CL_PATCH and _MOMENTS:
+        chunks = int(_lib.load().cplxamd_conv2d_cl2_mom_chunks(B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9], geom[10]))
+        if chunks > 0:
+            partials = torch.empty(chunks * N * 5, dtype=torch.float64, device=xr.device)
+            if try_call("cplxamd_conv2d_cl2_mom", *args[:18], ptr(partials), partials.numel() * 8, ptr(ws), ws.numel(),
+                        stream_ptr()):
+                ops.attach_moments(yr, yi, partials, chunks)
+                return yr, yi
     # dilation 1: the 2-d-patch kernel (activations staged once per channel slice for all nine taps); else the row kernel
     if not (_CL_PATCH and try_call("cplxamd_conv2d_cl2", *args)):
         call("cplxamd_conv2d_cl", *args)
@@ -536,14 +571,14 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
         B, Co, H, W = gr.shape
         dbr = hint_r if hint_r is not None else ops.colsum(gr.permute(0, 2, 3, 1).reshape(B * H * W, Co))
         dbi = hint_i if hint_i is not None else ops.colsum(gi.permute(0, 2, 3, 1).reshape(B * H * W, Co))
-    return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
+    return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None, None
 
 
 class CplxConv2dFn(torch.autograd.Function):
     """Zero-padded complex conv (A.1 algebra with cross-correlation)."""
 
     @staticmethod
-    def forward(ctx, xr, xi, wr, wi, br, bi, stride, padding, dilation, groups):
+    def forward(ctx, xr, xi, wr, wi, br, bi, stride, padding, dilation, groups, moments=False):
         require_device(xr, xi, wr, wi, br, bi)
         geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
@@ -555,7 +590,7 @@ class CplxConv2dFn(torch.autograd.Function):
             ctx.x_planar = xr.is_contiguous() and not xr.is_contiguous(memory_format=torch.channels_last)
             xr, xi = to_channels_last(xr), to_channels_last(xi)
             wcr, wci = ops.cast(wr.contiguous(), xr.dtype), ops.cast(wi.contiguous(), xr.dtype)
-            yr, yi = cl_conv(xr, xi, wcr, wci, b[0], b[1], geom)
+            yr, yi = cl_conv(xr, xi, wcr, wci, b[0], b[1], geom, moments=moments)
             ctx.save_for_backward(xr, xi, wcr, wci)
             ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, br is not None, wr.shape, xr.shape
             return yr, yi
@@ -588,7 +623,7 @@ class CplxConv2dFn(torch.autograd.Function):
                 dwr, dwi = conv_wgrad(gr, gi, xr, xi, ctx.geom, ctx.wshape, gp=gp, bias_out=bsum)
         if want_b:
             dbr, dbi = bsum if bsum else chansum2(gr, gi)
-        return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None
+        return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None, None
 
 
 class RealConv2dFn(torch.autograd.Function):
@@ -673,8 +708,11 @@ def cplx_conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, group
         rows = lambda t: ToChannelsLastFn.apply(t).permute(0, 2, 3, 1)  # noqa: E731  ([B, H, W, C] view of the storage)
         yr, yi = ops.CplxLinearFn.apply(rows(xr), rows(xi), weight.real.reshape(Co, C), weight.imag.reshape(Co, C), br, bi)
         return Cplx(yr.permute(0, 3, 1, 2), yi.permute(0, 3, 1, 2))
-    yr, yi = CplxConv2dFn.apply(xr, xi, weight.real, weight.imag, br, bi, stride, padding,
-                                dilation, groups)
+    wkey = weight.real
+    yr, yi = CplxConv2dFn.apply(xr, xi, wkey, weight.imag, br, bi, stride, padding,
+                                dilation, groups, _MOMENTS and moments_wanted(wkey))
+    if _MOMENTS and yr.dtype == torch.bfloat16:
+        yr._cplxamd_conv_src = weakref.ref(wkey)       # (a batch-norm layer that consumes yr arms the moments epilogue)
     return Cplx(yr, yi)
 
 

@@ -349,6 +349,7 @@ struct BnSync {
   long long* tracked_inc = nullptr;      // forward: *tracked_inc += 1 in the finalize launch (num_batches_tracked)
   double* moments_out = nullptr;
   const double* moments_in = nullptr;
+  int moments_chunks = 1;                // rows of moments_in ([row][F][NS]): 1 = totals
   const double* local_in = nullptr;
   const double* count_dev = nullptr;
 };
@@ -605,7 +606,7 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
   }
   const double count = (double)B * (double)S;
   const double* totals = sync.moments_in ? sync.moments_in : partial;
-  const int tchunks = sync.moments_in ? 1 : chunks;
+  const int tchunks = sync.moments_in ? sync.moments_chunks : chunks;
   if (!BWD)
     bn_fwd_finalize<<<F, 64, 0, st>>>(totals, tchunks, F, count, weight, bias, running_mean,
                                         running_var, training, momentum, eps, saved, coef, sync.count_dev, sync.tracked_inc);
@@ -765,6 +766,33 @@ int cplxamd_bn_fwd_sync(const void* xr, const void* xi, void* yr, void* yi, int6
   BnSync sync;
   sync.moments_in = moments;
   sync.count_dev = count;
+  if (dtype == CPLXAMD_F32)
+    return bn_run<float, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias, running_mean, running_var,
+                                saved, nullptr, nullptr, 1, momentum, eps, ws, st, nullptr, sync);
+  if (dtype == CPLXAMD_BF16)
+    return bn_run<bf16_t, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias, running_mean, running_var,
+                                 saved, nullptr, nullptr, 1, momentum, eps, ws, st, nullptr, sync);
+  return CPLXAMD_EINVAL;
+}
+
+// Training-mode forward whose statistics pass has been done by the PRODUCER of x: `partials` holds `chunks` rows
+// [row][F][5] float64 of (sum re, sum im, sum re^2, sum im^2, sum re im) over disjoint parts of the batch (the layout of
+// this file's own moment kernels; cplxamd_conv2d_cl2_mom writes one row per workgroup).  Finalize + apply only: x is read
+// once.  Arguments as cplxamd_bn_fwd_ex with training = 1.
+int cplxamd_bn_fwd_partials(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F, int64_t S,
+                            const float* weight, const float* bias, float* running_mean, float* running_var,
+                            float* saved, int dtype, float momentum, float eps, int64_t* tracked_inc,
+                            const double* partials, int chunks, void* ws, int64_t ws_bytes, void* stream) {
+  if (!xr || !xi || !yr || !yi || !saved || !ws || !partials || chunks <= 0 || B <= 0 || F <= 0 || S <= 0)
+    return CPLXAMD_EINVAL;
+  if ((weight == nullptr) != (bias == nullptr)) return CPLXAMD_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  BnSync sync;
+  sync.moments_in = partials;
+  sync.moments_chunks = chunks;
+  sync.tracked_inc = reinterpret_cast<long long*>(tracked_inc);
   if (dtype == CPLXAMD_F32)
     return bn_run<float, false>(xr, xi, nullptr, nullptr, yr, yi, B, F, S, weight, bias, running_mean, running_var,
                                 saved, nullptr, nullptr, 1, momentum, eps, ws, st, nullptr, sync);

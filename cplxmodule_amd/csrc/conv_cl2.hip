@@ -40,6 +40,10 @@ constexpr int W_PLANE = 3 * 64 * 32, W_BYTES = 2 * W_PLANE, PWN = 2;
 constexpr int A_RING = 2 * A_SLOT, W_RING = 3 * W_BYTES;
 constexpr int EPI = A_RING + W_RING, EPI_WAVE = 16 * 144 + 512;
 constexpr int DUMP = EPI + 8 * EPI_WAVE, SMEM = DUMP + 4096;
+// MOM (batch-norm moments of the output in the epilogue): both planes of a round staged at once -- the second plane's 16
+// rows per wave behind everything else
+constexpr int MOM_X = SMEM, SMEM_MOM = SMEM + 8 * 2048;
+static_assert(SMEM_MOM <= 160 * 1024, "LDS");
 constexpr int NST = 16;                                       // global stores per wave in the epilogue
 constexpr uint32_t OOB = 0xF8000000u;
 
@@ -50,6 +54,7 @@ struct Args {
   void* y_r; void* y_i;                      // [B][Ho][Wo][Cout] bf16
   void* dump;
   const void* fx_r; const void* fx_i; const void* fga;   // FUSE: y += 2 fx (*) fga, all laid out like y
+  double* mom;                                           // MOM: [workgroup][Cout][5] partial moments of y (bn.hip's layout)
   uint32_t x_bytes, w_bytes;
   int B, Hi, Wi, Ho, Wo, C, Cout, pad_h, pad_w;
   int C16, NS, tiles_x, tiles_y, tiles_n;
@@ -87,7 +92,11 @@ enum { FL_NORMAL = 0, FL_FIRST0 = 1, FL_LAST = 2, FL_FIRST1 = 3 };
 // FUSE: the input gradient of the local-reparameterization layers in one pass, y = conv(x; w) + 2 fx (*) fga per plane
 // (the mean-path data gradient plus the variance path's d|x|^2 term; util.hip dx_accum_kernel's arithmetic on the
 // bf16-rounded convolution result, so the fused and the two-launch forms agree to the last bit).
-template <bool FUSE>
+// MOM: the forward statistics of a batch-norm layer that consumes y (sum re, sum im, sum re^2, sum im^2, sum re im per
+// output channel over the pixels inside the image, of the bf16 values as stored) leave the kernel as per-workgroup
+// partials in the layout bn.hip's finalize sums (cplxamd_bn_fwd_partials): the moment pass over y -- one full read of both
+// planes -- is not launched.  Cout == 64 (one column tile), persistent launch.
+template <bool FUSE, bool MOM = false>
 __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntiles = g.B * g.tiles_y * g.tiles_x * g.tiles_n;
@@ -436,6 +445,80 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     }
   };
 
+  // ---- MOM epilogue: the same stores, both planes of a round staged at once (the second one in this wave's MOM_X rows),
+  // and a second, column-wise read of the staged bf16 rows: lane = (channel pair cp = lane & 31, row group rg = lane >> 5),
+  // 8 rows x 2 planes x 4 bytes -- the two row groups take rows of opposite parity in every read, i.e. opposite halves of
+  // the 64 banks (the row pitch is half of them; within a row the XOR swizzle keeps the 32 channel pairs on 32 banks).
+  // Ten per-lane sums live through the persistent loop; pixels outside the image contribute zeros.
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f2v m_r = {0.f, 0.f}, m_i = {0.f, 0.f}, m_rr = {0.f, 0.f}, m_ii = {0.f, 0.f}, m_ri = {0.f, 0.f};
+  auto epilogue_mom = [&]() __attribute__((always_inline)) {
+    const int t = opaque_tid();
+    const int ln = t & 63, w_ = t >> 6, q31 = ln & 31, qk = ln >> 5;
+    char* reg0 = smem + EPI + w_ * EPI_WAVE;
+    char* reg1 = smem + MOM_X + w_ * 2048;
+    constexpr int PITCH = 128;
+    const int r16 = q31 >> 4, rr = q31 & 15;
+    const int64_t ldc = g.Cout;
+    const int cp = ln & 31, rg = ln >> 5;
+    const bool interior = tc.x0 + TW <= g.Wo && tc.y0 + TH <= g.Ho;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (r16 == half) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                f4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x.v[e] = pl ? acc_i[i][j][4 * q + e] : acc_r[i][j][4 * q + e];
+                st4(reinterpret_cast<bf16_t*>((pl ? reg1 : reg0) + rr * PITCH + (((8 * j + 2 * q + qk) ^ rr) << 3)), x);
+              }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int y = tc.y0 + 2 * w_ + i;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          bf16_t* out = reinterpret_cast<bf16_t*>(pl ? g.y_i : g.y_r);
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const int sr = sub * 8 + (ln >> 3);
+            const uint4 raw = *reinterpret_cast<const uint4*>((pl ? reg1 : reg0) + sr * PITCH + (((ln & 7) ^ (sr >> 1)) << 4));
+            const bool odd = (ln >> 3) & 1;
+            const uint4 val = odd ? uint4{raw.z, raw.w, raw.x, raw.y} : raw;
+            const int x = tc.x0 + half * 16 + sub * 8 + (ln >> 3);
+            const int col = tc.nt * BN + (ln & 7) * 8;
+            const bool ok = y < g.Ho && x < g.Wo;
+            bf16_t* dst = ok ? out + (((int64_t)tc.b * g.Ho + y) * g.Wo + x) * ldc + col
+                             : reinterpret_cast<bf16_t*>(g.dump) + (int64_t)(w_ * 64 + i * 32 + half * 16 + sub * 8 + (ln >> 3)) * ldc + col;
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4_t{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4_t*>(dst));
+          }
+        }
+        if (interior || y < g.Ho) {                              // (wave-uniform)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = 8 * rg + (k ^ rg);
+            const int off = r * PITCH + ((((cp >> 1) ^ r) << 3) | ((cp & 1) << 2));
+            uint32_t dr = *reinterpret_cast<const uint32_t*>(reg0 + off), di = *reinterpret_cast<const uint32_t*>(reg1 + off);
+            if (!interior) {
+              const bool ok = tc.x0 + half * 16 + r < g.Wo;
+              dr = ok ? dr : 0u; di = ok ? di : 0u;
+            }
+            const f2v R = {__uint_as_float(dr << 16), __uint_as_float(dr & 0xffff0000u)};
+            const f2v I = {__uint_as_float(di << 16), __uint_as_float(di & 0xffff0000u)};
+            m_r += R; m_i += I;
+            m_rr += R * R; m_ii += I * I; m_ri += R * I;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+  };
+
   const uint32_t bias_lds = smem_off + (uint32_t)EPI + wid_u * (uint32_t)EPI_WAVE + 2304u;
   auto bias_dma = [&](int nt_) __attribute__((always_inline)) {
     const int t = opaque_tid();
@@ -502,7 +585,7 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     body(I1{}, I1{}, I0{}, I0{});
     body(I2{}, I1{}, I1{}, I2{});                          // LAST     (slice C / 16 - 1: patch slot 1)
     bias_dma(has_next ? tn.nt : tc.nt);                    // (older than the stores below)
-    epilogue();
+    if constexpr (MOM) epilogue_mom(); else epilogue();
     if (!has_next) break;
     wait_vmcnt<NST>();                                     // everything issued BEFORE the stores has landed
     v += nwg;
@@ -516,6 +599,28 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     first_frags();
   }
   wait_vmcnt<0>();
+  if constexpr (MOM) {
+    // per workgroup: row groups (lane ^ 32), then the eight waves through LDS (the rings are idle: nothing in flight)
+    const int t = opaque_tid();
+    const int ln = t & 63, w_ = t >> 6, cp = ln & 31;
+    float vals[10] = {m_r.x, m_r.y, m_i.x, m_i.y, m_rr.x, m_rr.y, m_ii.x, m_ii.y, m_ri.x, m_ri.y};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) vals[k] += __shfl_xor(vals[k], 32);
+    __builtin_amdgcn_s_barrier();
+    float* red = reinterpret_cast<float*>(smem);
+    if (ln < 32) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) red[(w_ * 32 + cp) * 10 + k] = vals[k];
+    }
+    __syncthreads();
+    if (t < 5 * BN) {
+      const int ch = t & (BN - 1), k = t / BN;
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) sum += (double)red[(w * 32 + (ch >> 1)) * 10 + 2 * k + (ch & 1)];
+      g.mom[((int64_t)blockIdx.x * g.Cout + ch) * 5 + k] = sum;
+    }
+  }
 }
 
 }  // namespace cl2
@@ -528,10 +633,21 @@ extern "C" {
 int64_t cplxamd_conv2d_cl_pack_bytes(int N, int C, int KH, int KW);
 int64_t cplxamd_conv2d_cl_ws_bytes(int Cout);
 
+static int cl2_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
+    ncu = n & ~7;
+  }
+  return ncu;
+}
+
 static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
                       const void* fx_r, const void* fx_i, const void* fga, void* y_r, void* y_i, int64_t B, int H, int W, int C,
                       int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes,
-                      void* stream) {
+                      void* stream, double* mom = nullptr, int64_t mom_bytes = 0) {
   if (!x_r || !x_i || !w_packed || !y_r || !y_i || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || pad_h < 0 || pad_w < 0 ||
       (bias_r == nullptr) != (bias_i == nullptr) || (mode != 0 && mode != 1))
     return CPLXAMD_EINVAL;
@@ -557,13 +673,7 @@ static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, co
   g.tiles_x = (g.Wo + cl2::TW - 1) / cl2::TW; g.tiles_y = (g.Ho + cl2::TH - 1) / cl2::TH; g.tiles_n = N / 64;
   const int64_t ntiles = B * g.tiles_x * g.tiles_y * g.tiles_n;
   if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
-    ncu = n & ~7;
-  }
+  const int ncu = cl2_cus();
   // chip shared with RCCL collectives (cplxamd_gemm_set_persistent(0), gemm.h): one workgroup per tile -- a launch that
   // expects every CU for its whole duration would wait for the held ones with its last workgroups
   const int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
@@ -575,10 +685,59 @@ static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, co
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  if (mom) {
+    // one partial row per workgroup: a persistent launch only (at most one workgroup per CU), one column tile
+    if (fga || mode != 0 || N != cl2::BN || grid > ncu) return CPLXAMD_ESHAPE;
+    if (mom_bytes < (int64_t)grid * N * 5 * (int64_t)sizeof(double)) return CPLXAMD_EWS;
+    static bool mom_attr = false;
+    if (!mom_attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         cl2::SMEM_MOM);
+      if (e != hipSuccess) return (int)e;
+      mom_attr = true;
+    }
+    g.mom = mom;
+    cl2::conv_cl2_kernel<false, true><<<dim3((unsigned)grid), cl2::NT, cl2::SMEM_MOM, (hipStream_t)stream>>>(g);
+    CPLXAMD_CHECK_LAUNCH();
+    return 0;
+  }
   if (fga) cl2::conv_cl2_kernel<true><<<dim3((unsigned)grid), cl2::NT, cl2::SMEM, (hipStream_t)stream>>>(g);
   else cl2::conv_cl2_kernel<false><<<dim3((unsigned)grid), cl2::NT, cl2::SMEM, (hipStream_t)stream>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
+}
+
+// Number of per-workgroup partial rows cplxamd_conv2d_cl2_mom writes for this problem ([rows][N][5] float64), or 0 when the
+// moments variant does not take it (N != 64, kernel / dilation / channel counts cplxamd_conv2d_cl2 declines, or the chip
+// is shared with collectives -- cplxamd_gemm_set_persistent(0) -- so that the launch is one workgroup per tile).
+int64_t cplxamd_conv2d_cl2_mom_chunks(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w, int pad_h,
+                                      int pad_w) {
+  const int Hs = H + 2 * pad_h - 2, Ws = W + 2 * pad_w - 2;
+  if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || KH != 3 || KW != 3 || dil_h != 1 || dil_w != 1 || C <= 0 ||
+      C % 32 || N != cl2::BN || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W)
+    return 0;
+  if (B * H * W * C * 2 >= (int64_t)0xF0000000 || B >= 65536) return 0;
+  const int64_t ntiles = B * ((Ws + cl2::TW - 1) / cl2::TW) * ((Hs + cl2::TH - 1) / cl2::TH);
+  if (ntiles > 0x7fffffff) return 0;
+  const int ncu = cl2_cus();
+  if (ntiles >= ncu && !g_gemm_persistent) return 0;
+  return ntiles < ncu ? ntiles : ncu;
+}
+
+// cplxamd_conv2d_cl2 (forward, mode 0) that ALSO leaves the batch-norm forward moments of its output -- per output
+// channel: sum re, sum im, sum re^2, sum im^2, sum re im over every pixel, of the bf16 values as stored -- as
+// cplxamd_conv2d_cl2_mom_chunks(...) partial rows [row][N][5] float64 in `partials`, the layout
+// cplxamd_bn_fwd_partials sums: the batch-norm layer behind this convolution then needs no pass over y for its
+// statistics (cplxmodule/nn/modules/batchnorm.py:62-123 after cplx.py:729-742).  CPLXAMD_ESHAPE when the variant does not
+// take the problem (see cplxamd_conv2d_cl2_mom_chunks).
+int cplxamd_conv2d_cl2_mom(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                           void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                           int pad_h, int pad_w, double* partials, int64_t partials_bytes, void* ws, int64_t ws_bytes,
+                           void* stream) {
+  if (!partials) return CPLXAMD_EINVAL;
+  if (cplxamd_conv2d_cl2_mom_chunks(B, H, W, C, N, KH, KW, dil_h, dil_w, pad_h, pad_w) <= 0) return CPLXAMD_ESHAPE;
+  return launch_cl2(x_r, x_i, w_packed, bias_r, bias_i, nullptr, nullptr, nullptr, y_r, y_i, B, H, W, C, N, KH, KW, dil_h,
+                    dil_w, pad_h, pad_w, 0, ws, ws_bytes, stream, partials, partials_bytes);
 }
 
 // Same arguments and semantics as cplxamd_conv2d_cl (weights packed by cplxamd_conv2d_cl_pack); built for KH = KW = 3,

@@ -100,6 +100,22 @@ def colsum_hint(t):
     return None
 
 
+def attach_moments(tr, ti, partials, chunks):
+    """Remember on the two planes of a convolution output that `partials` ([chunks][C][5] float64) holds the batch-norm
+    forward moments of exactly these tensors (conv.cl_conv, csrc/conv_cl2.hip MOM epilogue): the batch-norm layer that
+    consumes them skips its own moment pass.  Validated on use like attach_colsum."""
+    tr._cplxamd_moments = (partials, int(chunks), tr.data_ptr(), tr._version, ti.data_ptr(), ti._version, tuple(tr.shape))
+
+
+def moments_hint(tr, ti):
+    """(partials, chunks) attach_moments left for exactly this pair of planes (same storage, unmodified since), or None."""
+    h = getattr(tr, "_cplxamd_moments", None)
+    if (h is not None and h[2] == tr.data_ptr() and h[3] == tr._version and h[4] == ti.data_ptr() and h[5] == ti._version
+            and h[6] == tuple(tr.shape) == tuple(ti.shape)):
+        return h[0], h[1]
+    return None
+
+
 def colsum2(tr, ti, out=None):
     """Column sums of two planes (the complex bias gradient) -> float32 ([C], [C])."""
     if out is None and tr.dim() == 2 and tr.shape == ti.shape and tr.dtype == ti.dtype:

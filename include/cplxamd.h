@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 17
+#define CPLXAMD_ABI_VERSION 18
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -466,6 +466,20 @@ int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, c
 int cplxamd_conv2d_cl2_lrt_dx(const void* g_r, const void* g_i, const void* w_packed, const void* x_r, const void* x_i,
                               const void* ga, void* dx_r, void* dx_i, int64_t B, int H, int W, int C, int N, int pad_h,
                               int pad_w, void* ws, int64_t ws_bytes, void* stream);
+/* The convolution in front of a batch-norm layer (the conv -> BN pair of the reference's networks:
+ * cplxmodule/cplx.py:729-742 followed by nn/modules/batchnorm.py:62-123) with the layer's FORWARD STATISTICS formed in the
+ * convolution's epilogue: cplxamd_conv2d_cl2 (forward, mode 0, N == 64) that also writes, per workgroup, one row
+ * [N][5] float64 of (sum re, sum im, sum re^2, sum im^2, sum re im) over the output pixels it produced -- of the bf16
+ * values as stored -- into `partials`.  cplxamd_conv2d_cl2_mom_chunks: the number of rows (0: the variant does not take
+ * the problem -- N != 64, a shape cplxamd_conv2d_cl2 declines, or cplxamd_gemm_set_persistent(0) -- use
+ * cplxamd_conv2d_cl2 and the layer's own moment pass).  cplxamd_bn_fwd_partials then runs finalize + apply only: one
+ * read of y less (csrc/conv_cl2.hip: conv_cl2_kernel<false, true>). */
+int64_t cplxamd_conv2d_cl2_mom_chunks(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w, int pad_h,
+                                      int pad_w);
+int cplxamd_conv2d_cl2_mom(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                           void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                           int pad_h, int pad_w, double* partials, int64_t partials_bytes, void* ws, int64_t ws_bytes,
+                           void* stream);
 int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co);
 int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                             float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
@@ -547,6 +561,13 @@ int cplxamd_bn_fwd_sync(const void* xr, const void* xi, void* yr, void* yi, int6
                         const float* weight, const float* bias, float* running_mean, float* running_var,
                         float* saved, int dtype, float momentum, float eps, const double* moments,
                         const double* count, void* ws, int64_t ws_bytes, void* stream);
+/* Training-mode forward with the statistics pass done by the producer of x: `partials` = `chunks` rows [row][F][5]
+ * float64 of (sum re, sum im, sum re^2, sum im^2, sum re im) over disjoint parts of the batch (what
+ * cplxamd_conv2d_cl2_mom writes).  Finalize + apply; otherwise as cplxamd_bn_fwd_ex with training = 1. */
+int cplxamd_bn_fwd_partials(const void* xr, const void* xi, void* yr, void* yi, int64_t B, int F, int64_t S,
+                            const float* weight, const float* bias, float* running_mean, float* running_var,
+                            float* saved, int dtype, float momentum, float eps, int64_t* tracked_inc,
+                            const double* partials, int chunks, void* ws, int64_t ws_bytes, void* stream);
 int cplxamd_bn_bwd_sync(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr, void* dxi,
                         int64_t B, int F, int64_t S, const float* weight, const float* saved, float* dweight,
                         float* dbias, int dtype, float* dx_sums, const double* moments, const double* local_moments,

@@ -218,3 +218,93 @@ def test_mixed_bucket_is_exchanged_from_the_side_stream():
     r = subprocess.run([sys.executable, os.path.join(here, "dp_mixed_bucket_check.py")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "mixed bucket OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# ---- the batch-norm forward moments in the convolution epilogue ---------------------------------------
+@pytest.mark.parametrize("B,C,H,W,pad", [(3, 64, 50, 70, 0), (2, 64, 33, 37, 1), (2, 32, 16, 32, 1), (5, 64, 18, 34, 0),
+                                         (300, 64, 20, 40, 1)])
+def test_conv_epilogue_moments_match_a_pass_over_the_output(B, C, H, W, pad):
+    """cplxamd_conv2d_cl2_mom: same output bits as cplxamd_conv2d_cl2, and per-workgroup partial rows whose column sums are
+    the five batch-norm moments of the stored bf16 output (edge tiles, images smaller than a tile row, more tiles than
+    CUs: the persistent loop carries the sums through several tiles)."""
+    from cplxmodule_amd import conv, ops
+    bf = torch.bfloat16
+    cl = torch.channels_last
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + H)
+    mk = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    xr, xi = (mk(B, C, H, W).to(bf).contiguous(memory_format=cl) for _ in range(2))
+    xr, xi = xr + 0.5, xi - 0.25                                  # (non-zero means: the raw second moments carry them)
+    wr, wi = (mk(64, C, 3, 3).mul(0.05).to(bf) for _ in range(2))
+    br, bi = mk(64), mk(64)
+    geom, _ = conv._geom(xr.shape, wr.shape, (1, 1), (pad, pad), (1, 1), 1)
+    y0r, y0i = conv.cl_conv(xr, xi, wr, wi, br, bi, geom)
+    yr, yi = conv.cl_conv(xr, xi, wr, wi, br, bi, geom, moments=True)
+    hint = ops.moments_hint(yr, yi)
+    assert hint is not None and ops.moments_hint(y0r, y0i) is None
+    assert torch.equal(yr, y0r) and torch.equal(yi, y0i)
+    partials, chunks = hint
+    got = partials.view(chunks, 64, 5).sum(0).cpu().numpy()
+    r, i = yr.double().permute(1, 0, 2, 3).reshape(64, -1), yi.double().permute(1, 0, 2, 3).reshape(64, -1)
+    ref = torch.stack([r.sum(1), i.sum(1), (r * r).sum(1), (i * i).sum(1), (r * i).sum(1)], 1).cpu().numpy()
+    scale = np.abs(ref).max(0, keepdims=True)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * scale.max())
+    np.testing.assert_allclose(got / scale, ref / scale, rtol=0, atol=1e-5)
+    # a modified output no longer carries them
+    yr.add_(1)
+    assert ops.moments_hint(yr, yi) is None
+
+
+def test_conv_batchnorm_pair_uses_the_epilogue_moments():
+    """CplxConv2d -> CplxBatchNorm2d in training mode: the first step arms the convolution (the batch-norm layer finds the
+    producer's tag on its input), from the second step on the layer's statistics come out of the convolution's epilogue;
+    outputs, running statistics and gradients agree with the run in which the layer makes its own moment pass."""
+    from cplxmodule_amd import Cplx, conv, ops
+    from cplxmodule_amd.nn.modules.batchnorm import CplxBatchNorm2d
+    from cplxmodule_amd.nn.modules.conv import CplxConv2d
+    bf = torch.bfloat16
+    torch.manual_seed(4)
+    net = torch.nn.Sequential(CplxConv2d(64, 64, 3, padding=1), CplxBatchNorm2d(64)).to(DEV)
+    x = Cplx(torch.randn(6, 64, 40, 72, device=DEV).to(bf).contiguous(memory_format=torch.channels_last),
+             torch.randn(6, 64, 40, 72, device=DEV).to(bf).contiguous(memory_format=torch.channels_last))
+    gy = torch.randn(6, 64, 40, 72, device=DEV).to(bf).contiguous(memory_format=torch.channels_last)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    seen = []
+    handle = net[0].register_forward_hook(lambda m, a, out: seen.append(ops.moments_hint(out.real, out.imag) is not None))
+
+    def run(steps):
+        net.load_state_dict(state0)
+        net.train()
+        for _ in range(steps):
+            net.zero_grad(set_to_none=True)
+            y = net(x)
+            torch.autograd.backward((y.real, y.imag), (gy, gy))
+        return (y.real.detach().float(), y.imag.detach().float(), {k: v.clone() for k, v in net.state_dict().items()},
+                {n: p.grad.float().clone() for n, p in net.named_parameters()})
+
+    try:
+        conv._MOMENTS_WANTED.clear()
+        fused = run(3)
+        assert seen == [False, True, True], seen
+        seen.clear()
+        conv._MOMENTS = False
+        conv._MOMENTS_WANTED.clear()
+        plain = run(3)
+        assert seen == [False, False, False], seen
+    finally:
+        conv._MOMENTS = True
+        handle.remove()
+    for a, b in zip(fused[:2], plain[:2]):
+        assert float((a - b).abs().max()) <= 2 ** -6 * float(b.abs().max())          # a bf16 ulp of the largest entries
+        assert float((a != b).float().mean()) < 1e-3
+    for k in plain[2]:
+        np.testing.assert_allclose(N(fused[2][k].float()), N(plain[2][k].float()), rtol=2e-5, atol=2e-6, err_msg=k)
+    for k in plain[3]:
+        r = N(plain[3][k])
+        # (the bias of a convolution in front of a batch-norm layer has a zero gradient in exact arithmetic: what both runs
+        #  report is the sum of the bf16 rounding of dX over 17 280 pixels, which a handful of flipped last bits moves)
+        tol = 5e-2 if k.startswith("0.bias") else 2e-3
+        np.testing.assert_allclose(N(fused[3][k]), r, rtol=0, atol=tol * np.abs(r).max(), err_msg=k)
+    # evaluation mode takes the request back
+    net.eval()
+    net(x)
+    assert not conv._MOMENTS_WANTED
