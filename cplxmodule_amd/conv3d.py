@@ -69,7 +69,7 @@ def cplx_conv3d(input, weight, bias=None, stride=1, padding=0, dilation=1, group
                                     _tap(xi, a, dilation[0], stride[0], Dout),
                                     weight.real[:, :, a], weight.imag[:, :, a],
                                     br if a == 0 else None, bi if a == 0 else None,
-                                    stride[1:], pad2, dilation[1:], groups)
+                                    stride[1:], pad2, dilation[1:], groups, False)
         yr, yi = (tr, ti) if yr is None else (yr + tr, yi + ti)
     return Cplx(_fold(yr, B, Dout), _fold(yi, B, Dout))
 
