@@ -43,6 +43,9 @@ constexpr int DUMP = EPI + 8 * EPI_WAVE, SMEM = DUMP + 4096;
 // MOM (batch-norm moments of the output in the epilogue): both planes of a round staged at once -- the second plane's 16
 // rows per wave behind everything else
 constexpr int MOM_X = SMEM, SMEM_MOM = SMEM + 8 * 2048;
+#ifndef CL2_MOM_DBG
+#define CL2_MOM_DBG 0      // ablation (experiments only): 1 = no moment reads / sums, 2 = reads but no sums
+#endif
 static_assert(SMEM_MOM <= 160 * 1024, "LDS");
 constexpr int NST = 16;                                       // global stores per wave in the epilogue
 constexpr uint32_t OOB = 0xF8000000u;
@@ -461,7 +464,17 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     const int r16 = q31 >> 4, rr = q31 & 15;
     const int64_t ldc = g.Cout;
     const int cp = ln & 31, rg = ln >> 5;
-    const bool interior = tc.x0 + TW <= g.Wo && tc.y0 + TH <= g.Ho;
+    // row r = 8 rg + (k ^ rg) of read k: every field of its byte offset -- r << 7, ((cp >> 1) ^ r) << 3, (cp & 1) << 2 --
+    // is an XOR of a lane part and a k part, and the fields do not overlap: offset = lane part ^ (k << 7 | k << 3)
+    const uint32_t mbase = (uint32_t)((rg << 10) ^ (rg << 7) ^ ((((cp >> 1) ^ (rg << 3) ^ rg) & 15) << 3) ^ ((cp & 1) << 2));
+    const bool interior = __builtin_amdgcn_readfirstlane((int)(tc.x0 + TW <= g.Wo && tc.y0 + TH <= g.Ho)) != 0;
+    auto moments_of = [&](uint32_t dr, uint32_t di) __attribute__((always_inline)) {
+      if (CL2_MOM_DBG == 2) { asm volatile("" :: "v"(dr), "v"(di)); return; }
+      const f2v R = {__uint_as_float(dr << 16), __uint_as_float(dr & 0xffff0000u)};
+      const f2v I = {__uint_as_float(di << 16), __uint_as_float(di & 0xffff0000u)};
+      m_r += R; m_i += I;
+      m_rr += R * R; m_ii += I * I; m_ri += R * I;
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -481,15 +494,35 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int y = tc.y0 + 2 * w_ + i;
+        // every LDS read of the round first -- the four 16-byte rows of the stores, then the moment lanes' sixteen dwords --
+        // so that the moment reads land while the stores' addresses are formed and the stores issue
+        uint4 raw[2][2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const int sr = sub * 8 + (ln >> 3);
+            raw[pl][sub] = *reinterpret_cast<const uint4*>((pl ? reg1 : reg0) + sr * PITCH + (((ln & 7) ^ (sr >> 1)) << 4));
+          }
+        const bool rowin = interior || __builtin_amdgcn_readfirstlane((int)(y < g.Ho)) != 0;
+        uint32_t dr[8], di[8];
+        if (CL2_MOM_DBG != 1 && rowin) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t off = mbase ^ (uint32_t)((k << 7) | (k << 3));
+            dr[k] = *reinterpret_cast<const uint32_t*>(reg0 + off);
+            di[k] = *reinterpret_cast<const uint32_t*>(reg1 + off);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
           bf16_t* out = reinterpret_cast<bf16_t*>(pl ? g.y_i : g.y_r);
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub) {
-            const int sr = sub * 8 + (ln >> 3);
-            const uint4 raw = *reinterpret_cast<const uint4*>((pl ? reg1 : reg0) + sr * PITCH + (((ln & 7) ^ (sr >> 1)) << 4));
+            const uint4 rw = raw[pl][sub];
             const bool odd = (ln >> 3) & 1;
-            const uint4 val = odd ? uint4{raw.z, raw.w, raw.x, raw.y} : raw;
+            const uint4 val = odd ? uint4{rw.z, rw.w, rw.x, rw.y} : rw;
             const int x = tc.x0 + half * 16 + sub * 8 + (ln >> 3);
             const int col = tc.nt * BN + (ln & 7) * 8;
             const bool ok = y < g.Ho && x < g.Wo;
@@ -499,20 +532,17 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
             __builtin_nontemporal_store(u32x4_t{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4_t*>(dst));
           }
         }
-        if (interior || y < g.Ho) {                              // (wave-uniform)
+        __builtin_amdgcn_sched_barrier(0);
+        if (CL2_MOM_DBG != 1 && rowin) {
+          if (interior) {                                        // (scalar branch: most tiles)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int r = 8 * rg + (k ^ rg);
-            const int off = r * PITCH + ((((cp >> 1) ^ r) << 3) | ((cp & 1) << 2));
-            uint32_t dr = *reinterpret_cast<const uint32_t*>(reg0 + off), di = *reinterpret_cast<const uint32_t*>(reg1 + off);
-            if (!interior) {
-              const bool ok = tc.x0 + half * 16 + r < g.Wo;
-              dr = ok ? dr : 0u; di = ok ? di : 0u;
+            for (int k = 0; k < 8; ++k) moments_of(dr[k], di[k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const bool ok = tc.x0 + half * 16 + 8 * rg + (k ^ rg) < g.Wo;
+              moments_of(ok ? dr[k] : 0u, ok ? di[k] : 0u);
             }
-            const f2v R = {__uint_as_float(dr << 16), __uint_as_float(dr & 0xffff0000u)};
-            const f2v I = {__uint_as_float(di << 16), __uint_as_float(di & 0xffff0000u)};
-            m_r += R; m_i += I;
-            m_rr += R * R; m_ii += I * I; m_ri += R * I;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
