@@ -98,7 +98,8 @@ enum { FL_NORMAL = 0, FL_FIRST0 = 1, FL_LAST = 2, FL_FIRST1 = 3 };
 // MOM: the forward statistics of a batch-norm layer that consumes y (sum re, sum im, sum re^2, sum im^2, sum re im per
 // output channel over the pixels inside the image, of the bf16 values as stored) leave the kernel as per-workgroup
 // partials in the layout bn.hip's finalize sums (cplxamd_bn_fwd_partials): the moment pass over y -- one full read of both
-// planes -- is not launched.  Cout == 64 (one column tile), persistent launch.
+// planes -- is not launched.  Persistent launch whose workgroups each stay on ONE column tile (the per-lane sums belong to
+// one set of 64 channels): Cout == 64, or a grid whose per-XCD share is a multiple of the column-tile count.
 template <bool FUSE, bool MOM = false>
 __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -648,7 +649,8 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
       double sum = 0.0;
 #pragma unroll
       for (int w = 0; w < NT / 64; ++w) sum += (double)red[(w * 32 + (ch >> 1)) * 10 + 2 * k + (ch & 1)];
-      g.mom[((int64_t)blockIdx.x * g.Cout + ch) * 5 + k] = sum;
+      // (the row was zeroed by the launcher: the other column tiles' channels of this workgroup's row stay 0)
+      g.mom[((int64_t)blockIdx.x * g.Cout + tc.nt * BN + ch) * 5 + k] = sum;
     }
   }
 }
@@ -672,6 +674,14 @@ static int cl2_cus() {
     ncu = n & ~7;
   }
   return ncu;
+}
+
+// Does every workgroup of a `grid`-wide launch over `ntiles` tiles see ONE column tile?  Virtual tile v of workgroup w is
+// w, w + grid, ...; its linear index is base(v & 7) + (v >> 3) with the column tile fastest (conv_cl2_kernel: origin), so
+// a step of `grid` moves it by grid / 8: the column tile repeats when that is a multiple of the column-tile count.
+static bool cl2_mom_tiling_ok(int64_t ntiles, int grid, int tiles_n) {
+  if (tiles_n == 1 || ntiles <= grid) return true;
+  return (grid % 8) == 0 && ((grid / 8) % tiles_n) == 0;
 }
 
 static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
@@ -717,8 +727,11 @@ static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, co
   }
   if (mom) {
     // one partial row per workgroup: a persistent launch only (at most one workgroup per CU), one column tile
-    if (fga || mode != 0 || N != cl2::BN || grid > ncu) return CPLXAMD_ESHAPE;
+    if (fga || mode != 0 || grid > ncu || !cl2_mom_tiling_ok(ntiles, grid, g.tiles_n)) return CPLXAMD_ESHAPE;
     if (mom_bytes < (int64_t)grid * N * 5 * (int64_t)sizeof(double)) return CPLXAMD_EWS;
+    if (g.tiles_n > 1 &&
+        hipMemsetAsync(mom, 0, (size_t)grid * N * 5 * sizeof(double), (hipStream_t)stream) != hipSuccess)
+      return CPLXAMD_EINVAL;
     static bool mom_attr = false;
     if (!mom_attr) {
       hipError_t e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -738,20 +751,22 @@ static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, co
 }
 
 // Number of per-workgroup partial rows cplxamd_conv2d_cl2_mom writes for this problem ([rows][N][5] float64), or 0 when the
-// moments variant does not take it (N != 64, kernel / dilation / channel counts cplxamd_conv2d_cl2 declines, or the chip
+// moments variant does not take it (kernel / dilation / channel counts cplxamd_conv2d_cl2 declines, a grid whose workgroups
+// would change column tile, or the chip
 // is shared with collectives -- cplxamd_gemm_set_persistent(0) -- so that the launch is one workgroup per tile).
 int64_t cplxamd_conv2d_cl2_mom_chunks(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w, int pad_h,
                                       int pad_w) {
   const int Hs = H + 2 * pad_h - 2, Ws = W + 2 * pad_w - 2;
   if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || KH != 3 || KW != 3 || dil_h != 1 || dil_w != 1 || C <= 0 ||
-      C % 32 || N != cl2::BN || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W)
+      C % 32 || N % cl2::BN || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W)
     return 0;
   if (B * H * W * C * 2 >= (int64_t)0xF0000000 || B >= 65536) return 0;
-  const int64_t ntiles = B * ((Ws + cl2::TW - 1) / cl2::TW) * ((Hs + cl2::TH - 1) / cl2::TH);
+  const int64_t ntiles = B * ((Ws + cl2::TW - 1) / cl2::TW) * ((Hs + cl2::TH - 1) / cl2::TH) * (N / cl2::BN);
   if (ntiles > 0x7fffffff) return 0;
   const int ncu = cl2_cus();
   if (ntiles >= ncu && !g_gemm_persistent) return 0;
-  return ntiles < ncu ? ntiles : ncu;
+  const int grid = ntiles < ncu ? (int)ntiles : ncu;
+  return cl2_mom_tiling_ok(ntiles, grid, N / cl2::BN) ? grid : 0;
 }
 
 // cplxamd_conv2d_cl2 (forward, mode 0) that ALSO leaves the batch-norm forward moments of its output -- per output

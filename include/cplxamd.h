@@ -468,10 +468,11 @@ int cplxamd_conv2d_cl2_lrt_dx(const void* g_r, const void* g_i, const void* w_pa
                               int pad_w, void* ws, int64_t ws_bytes, void* stream);
 /* The convolution in front of a batch-norm layer (the conv -> BN pair of the reference's networks:
  * cplxmodule/cplx.py:729-742 followed by nn/modules/batchnorm.py:62-123) with the layer's FORWARD STATISTICS formed in the
- * convolution's epilogue: cplxamd_conv2d_cl2 (forward, mode 0, N == 64) that also writes, per workgroup, one row
+ * convolution's epilogue: cplxamd_conv2d_cl2 (forward, mode 0) that also writes, per workgroup, one row
  * [N][5] float64 of (sum re, sum im, sum re^2, sum im^2, sum re im) over the output pixels it produced -- of the bf16
  * values as stored -- into `partials`.  cplxamd_conv2d_cl2_mom_chunks: the number of rows (0: the variant does not take
- * the problem -- N != 64, a shape cplxamd_conv2d_cl2 declines, or cplxamd_gemm_set_persistent(0) -- use
+ * the problem -- a shape cplxamd_conv2d_cl2 declines, a grid whose workgroups would change column tile, or
+ * cplxamd_gemm_set_persistent(0) -- use
  * cplxamd_conv2d_cl2 and the layer's own moment pass).  cplxamd_bn_fwd_partials then runs finalize + apply only: one
  * read of y less (csrc/conv_cl2.hip: conv_cl2_kernel<false, true>). */
 int64_t cplxamd_conv2d_cl2_mom_chunks(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w, int pad_h,

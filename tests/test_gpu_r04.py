@@ -221,12 +221,14 @@ def test_mixed_bucket_is_exchanged_from_the_side_stream():
 
 
 # ---- the batch-norm forward moments in the convolution epilogue ---------------------------------------
-@pytest.mark.parametrize("B,C,H,W,pad", [(3, 64, 50, 70, 0), (2, 64, 33, 37, 1), (2, 32, 16, 32, 1), (5, 64, 18, 34, 0),
-                                         (300, 64, 20, 40, 1)])
-def test_conv_epilogue_moments_match_a_pass_over_the_output(B, C, H, W, pad):
+@pytest.mark.parametrize("B,C,H,W,pad,Nc", [(3, 64, 50, 70, 0, 64), (2, 64, 33, 37, 1, 64), (2, 32, 16, 32, 1, 64),
+                                            (5, 64, 18, 34, 0, 64), (300, 64, 20, 40, 1, 64), (70, 32, 30, 60, 1, 128),
+                                            (40, 64, 34, 66, 0, 256), (1, 32, 16, 32, 1, 128)])
+def test_conv_epilogue_moments_match_a_pass_over_the_output(B, C, H, W, pad, Nc):
     """cplxamd_conv2d_cl2_mom: same output bits as cplxamd_conv2d_cl2, and per-workgroup partial rows whose column sums are
     the five batch-norm moments of the stored bf16 output (edge tiles, images smaller than a tile row, more tiles than
-    CUs: the persistent loop carries the sums through several tiles)."""
+    CUs: the persistent loop carries the sums through several tiles; 128 / 256 output channels: every workgroup stays on
+    one column tile)."""
     from cplxmodule_amd import conv, ops
     bf = torch.bfloat16
     cl = torch.channels_last
@@ -234,8 +236,8 @@ def test_conv_epilogue_moments_match_a_pass_over_the_output(B, C, H, W, pad):
     mk = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
     xr, xi = (mk(B, C, H, W).to(bf).contiguous(memory_format=cl) for _ in range(2))
     xr, xi = xr + 0.5, xi - 0.25                                  # (non-zero means: the raw second moments carry them)
-    wr, wi = (mk(64, C, 3, 3).mul(0.05).to(bf) for _ in range(2))
-    br, bi = mk(64), mk(64)
+    wr, wi = (mk(Nc, C, 3, 3).mul(0.05).to(bf) for _ in range(2))
+    br, bi = mk(Nc), mk(Nc)
     geom, _ = conv._geom(xr.shape, wr.shape, (1, 1), (pad, pad), (1, 1), 1)
     y0r, y0i = conv.cl_conv(xr, xi, wr, wi, br, bi, geom)
     yr, yi = conv.cl_conv(xr, xi, wr, wi, br, bi, geom, moments=True)
@@ -243,8 +245,8 @@ def test_conv_epilogue_moments_match_a_pass_over_the_output(B, C, H, W, pad):
     assert hint is not None and ops.moments_hint(y0r, y0i) is None
     assert torch.equal(yr, y0r) and torch.equal(yi, y0i)
     partials, chunks = hint
-    got = partials.view(chunks, 64, 5).sum(0).cpu().numpy()
-    r, i = yr.double().permute(1, 0, 2, 3).reshape(64, -1), yi.double().permute(1, 0, 2, 3).reshape(64, -1)
+    got = partials.view(chunks, Nc, 5).sum(0).cpu().numpy()
+    r, i = yr.double().permute(1, 0, 2, 3).reshape(Nc, -1), yi.double().permute(1, 0, 2, 3).reshape(Nc, -1)
     ref = torch.stack([r.sum(1), i.sum(1), (r * r).sum(1), (i * i).sum(1), (r * i).sum(1)], 1).cpu().numpy()
     scale = np.abs(ref).max(0, keepdims=True)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * scale.max())
