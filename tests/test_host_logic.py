@@ -40,3 +40,37 @@ def test_complex_view_and_containers():
         cnn.CplxSequential(cnn.CplxIdentity(), torch.nn.ReLU())
     with pytest.raises(TypeError):
         cnn.CplxSequential(cnn.CplxReal())
+
+
+def test_moment_hints_and_arming_bookkeeping():
+    """The host side of the conv -> batch-norm moments path (no kernels): the hint on a pair of output planes is valid
+    only for exactly those tensors, unmodified; the request registry holds weight planes weakly and by identity (tensors
+    compare elementwise, so no set of tensors)."""
+    import gc
+    from cplxmodule_amd import conv, ops
+    yr, yi = torch.zeros(2, 4, 3, 3), torch.zeros(2, 4, 3, 3)
+    partials = torch.zeros(3 * 4 * 5, dtype=torch.float64)
+    assert ops.moments_hint(yr, yi) is None
+    ops.attach_moments(yr, yi, partials, 3)
+    got = ops.moments_hint(yr, yi)
+    assert got is not None and got[0] is partials and got[1] == 3
+    assert ops.moments_hint(yr, yi.clone()) is None                      # another imaginary plane
+    assert ops.moments_hint(yr.clone(), yi) is None                      # the attribute does not travel with a copy
+    yi.add_(1)                                                           # either plane modified in place: stale
+    assert ops.moments_hint(yr, yi) is None
+    ops.attach_moments(yr, yi, partials, 3)
+    yr.mul_(2)
+    assert ops.moments_hint(yr, yi) is None
+
+    conv._MOMENTS_WANTED.clear()
+    w1, w2 = torch.nn.Parameter(torch.ones(4, 4, 3, 3)), torch.nn.Parameter(torch.ones(4, 4, 3, 3))
+    conv.want_moments(w1)
+    conv.want_moments(w1)
+    assert conv.moments_wanted(w1) and not conv.moments_wanted(w2)       # equal values, different layer
+    conv.want_moments(w2)
+    conv.want_moments(w1, on=False)
+    assert not conv.moments_wanted(w1) and conv.moments_wanted(w2)
+    conv.want_moments(None)                                              # (the producer's weight is gone)
+    del w2
+    gc.collect()
+    assert not conv._MOMENTS_WANTED                                      # a dead layer leaves nothing behind
