@@ -687,10 +687,32 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
   }
 }
 
+#ifdef W4_PDYN
+__device__ unsigned w4_queue[8];
+#endif
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#if W4_PGRID > 0
+#if W4_PGRID > 0 && defined(W4_PDYN)
+  // experiment: the tile list as per-XCD ticket queues (a workgroup's first tile is static, the next ones are drawn;
+  // the drawer of an XCD's last ticket puts its counter back to 0 for the next launch)
+  const int total = (g.M / Cfg<CPLX>::BM) * (g.N / Cfg<CPLX>::BN) * (g.splits > 1 ? g.splits : 1);
+  const int xcd = blockIdx.x & 7;
+  const int tiles_x = (total - xcd + 7) >> 3, wgs_x = ((int)gridDim.x - xcd + 7) >> 3;
+  int slot = blockIdx.x >> 3;
+  for (;;) {
+    w4_tile<TOUT, CPLX, CONJ, TA, TB>(g, slot * 8 + xcd, smem);
+    if (threadIdx.x == 0) {
+      const unsigned t = atomicAdd(&w4_queue[xcd], 1u);
+      if ((int)t == tiles_x - 1) __hip_atomic_store(&w4_queue[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *reinterpret_cast<volatile unsigned*>(smem) = t;
+    }
+    __syncthreads();
+    slot = wgs_x + (int)*reinterpret_cast<volatile unsigned*>(smem);
+    __syncthreads();
+    if (slot >= tiles_x) break;
+  }
+#elif W4_PGRID > 0
   const int total = (g.M / Cfg<CPLX>::BM) * (g.N / Cfg<CPLX>::BN) * (g.splits > 1 ? g.splits : 1);
   for (int lin = blockIdx.x; lin < total; lin += gridDim.x) {
     w4_tile<TOUT, CPLX, CONJ, TA, TB>(g, lin, smem);
