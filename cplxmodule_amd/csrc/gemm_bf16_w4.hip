@@ -175,6 +175,9 @@ constexpr int slot_of_write(bool cplx, bool burst, int nw, int m, int off) {
 // LDS operations a sub-step issues behind its last fragment read (the counted wait in front of the barrier)
 constexpr int ops_after_last_read(bool cplx, bool burst, bool writes) { return !writes ? 0 : !burst ? 1 : cplx ? 0 : 2; }
 
+#ifndef W4_EPI_PIPE
+#define W4_EPI_PIPE 1   // epilogue operands of round r + 1 requested ahead of the stores of round r (0: behind them, A/B)
+#endif
 #ifndef W4_PGRID
 #define W4_PGRID 0   // experiment: > 0 = at most that many workgroups, each walking the tile list (lin, lin + grid, ...)
 #endif
@@ -560,62 +563,68 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
       const uint32_t p8c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(8 * g.ldc * 2));
       const uint32_t p8f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(8 * g.fld * 2));
       const __amdgpu_buffer_rsrc_t rga = tile_rsrc(fuse ? g.fga : g.c_r, fuse ? g.fld : g.ldc, 2);
+      const __amdgpu_buffer_rsrc_t rout0 = tile_rsrc(out_r, g.ldc, 2), rout1 = tile_rsrc(CPLX ? out_i : out_r, g.ldc, 2);
+      const __amdgpu_buffer_rsrc_t rx0 = tile_rsrc(fuse ? g.fx_r : g.c_r, fuse ? g.fld : g.ldc, 2);
+      const __amdgpu_buffer_rsrc_t rx1 = tile_rsrc(fuse ? (CPLX ? g.fx_i : g.fx_r) : g.c_r, fuse ? g.fld : g.ldc, 2);
+      // Rounds r = (plane, column half jh, row half ih).  The fused term's operands of round r + 1 (8 passes x (ga, x): 16
+      // loads per lane) are requested BEFORE the stores of round r -- vmcnt retires in issue order: requested behind
+      // them they could not be used until every one of those stores was acknowledged (see the float32 epilogue below).
+      constexpr int NR = NPL * (JB / 2) * (IB / 2);
+      u32x4 gv[2][fuse ? 8 : 1], xv[2][fuse ? 8 : 1];
+      auto load_ops = [&](int r) __attribute__((always_inline)) {
+        const int pl = r / ((JB / 2) * (IB / 2)), jh = (r / (IB / 2)) % (JB / 2), ih = r % (IB / 2);
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? out_i : out_r, g.ldc, 2);
-        const __amdgpu_buffer_rsrc_t rx = tile_rsrc(fuse ? (pl ? g.fx_i : g.fx_r) : g.c_r, fuse ? g.fld : g.ldc, 2);
+        for (int pass = 0; pass < 8; ++pass) {
+          const uint32_t so = (uint32_t)(ih * 8 + pass) * p8f + (uint32_t)(jh * 128);
+          gv[r & 1][pass] = ldb128(rga, vo_f, so);
+          xv[r & 1][pass] = ldb128(pl ? rx1 : rx0, vo_f, so);
+        }
+      };
+      if constexpr (fuse) load_ops(0);
 #pragma unroll
-        for (int jh = 0; jh < JB / 2; ++jh)
+      for (int r = 0; r < NR; ++r) {
+        const int pl = r / ((JB / 2) * (IB / 2)), jh = (r / (IB / 2)) % (JB / 2), ih = r % (IB / 2);
+        const __amdgpu_buffer_rsrc_t rout = pl ? rout1 : rout0;
+        if constexpr (fuse && !W4_EPI_PIPE) { if (r > 0) load_ops(r); }
 #pragma unroll
-          for (int ih = 0; ih < IB / 2; ++ih) {
-            // the fused term's operands of this round (8 passes x (ga, x): 16 loads per lane) are requested FIRST and fly
-            // while the accumulators are converted and staged
-            u32x4 gv[fuse ? 8 : 1], xv[fuse ? 8 : 1];
-            if constexpr (fuse) {
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-              for (int pass = 0; pass < 8; ++pass) {
-                const uint32_t so = (uint32_t)(ih * 8 + pass) * p8f + (uint32_t)(jh * 128);
-                gv[pass] = ldb128(rga, vo_f, so);
-                xv[pass] = ldb128(rx, vo_f, so);
-              }
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cl = jj * 32 + 8 * q + 4 * lk;
+              f4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v.v[e] = pl ? acc_i[CPLX ? ih * 2 + ii : 0][jh * 2 + jj][4 * q + e] : acc_r[ih * 2 + ii][jh * 2 + jj][4 * q + e];
+              st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is in LDS (in-order LDS, own region)
+        if constexpr (fuse && W4_EPI_PIPE) {
+          if (r + 1 < NR) { W4_SB(); load_ops(r + 1); W4_SB(); }
+        }
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+        for (int pass = 0; pass < 8; ++pass) {
+          const int rl = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(reg + rl * PITCH + c8 * 2);
+          const uint32_t so = (uint32_t)(ih * 8 + pass) * p8c + (uint32_t)(jh * 128);
+          if constexpr (fuse) {
+            // LRT input gradient's elementwise term (gemm.h: fga); arithmetic of util.hip dx_accum_kernel: bit-identical
+            u32x4 ow;
 #pragma unroll
-              for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const int cl = jj * 32 + 8 * q + 4 * lk;
-                  f4 v;
-#pragma unroll
-                  for (int e = 0; e < 4; ++e)
-                    v.v[e] = pl ? acc_i[CPLX ? ih * 2 + ii : 0][jh * 2 + jj][4 * q + e] : acc_r[ih * 2 + ii][jh * 2 + jj][4 * q + e];
-                  st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is in LDS (in-order LDS, own region)
-#pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-              const int rl = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-              const u32x4 v = *reinterpret_cast<const u32x4*>(reg + rl * PITCH + c8 * 2);
-              const uint32_t so = (uint32_t)(ih * 8 + pass) * p8c + (uint32_t)(jh * 128);
-              if constexpr (fuse) {
-                // LRT input gradient's elementwise term (gemm.h: fga); arithmetic of util.hip dx_accum_kernel: bit-identical
-                u32x4 ow;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float d0 = __uint_as_float(v[e] << 16), d1 = __uint_as_float(v[e] & 0xffff0000u);
-                  const float x0 = __uint_as_float(xv[pass][e] << 16), x1 = __uint_as_float(xv[pass][e] & 0xffff0000u);
-                  const float g0 = __uint_as_float(gv[pass][e] << 16), g1 = __uint_as_float(gv[pass][e] & 0xffff0000u);
-                  ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
-                }
-                stb128(ow, rout, vo_c, so);
-              } else {
-                stb128(v, rout, vo_c, so);
-              }
+            for (int e = 0; e < 4; ++e) {
+              const float d0 = __uint_as_float(v[e] << 16), d1 = __uint_as_float(v[e] & 0xffff0000u);
+              const float x0 = __uint_as_float(xv[r & 1][pass][e] << 16), x1 = __uint_as_float(xv[r & 1][pass][e] & 0xffff0000u);
+              const float g0 = __uint_as_float(gv[r & 1][pass][e] << 16), g1 = __uint_as_float(gv[r & 1][pass][e] & 0xffff0000u);
+              ow[e] = pack_bf16(fmaf(2.0f * x0, g0, d0), fmaf(2.0f * x1, g1, d1));
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
-            W4_SB();                                             // (keeps the next rounds' operand loads out of this round: registers)
+            stb128(ow, rout, vo_c, so);
+          } else {
+            stb128(v, rout, vo_c, so);
           }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
+        W4_SB();
       }
     };
     if (g.fga) epi16(std::true_type{}); else epi16(std::false_type{});
@@ -629,57 +638,66 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
       const uint32_t vo = (uint32_t)((((int64_t)(wm + (lane >> 4)) * g.ldc + wn + (lane & 15) * 4)) * 4);
       const uint32_t p4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(4 * g.ldc * 4));
       const __amdgpu_buffer_rsrc_t rm = tile_rsrc(hm ? (const void*)g.emul : g.c_r, g.ldc, 4);
+      const __amdgpu_buffer_rsrc_t rout0 = tile_rsrc(out_r, g.ldc, 4), rout1 = tile_rsrc(CPLX ? out_i : out_r, g.ldc, 4);
+      // Rounds r = (plane, column half jh, block row i).  The multiplier / accumulate operands of round r + 1 are
+      // requested BEFORE the stores of round r go out: vmcnt retires in issue order, so operands requested behind a
+      // round's stores could not be used before every one of those stores was acknowledged -- one store-acknowledgement
+      // latency per round, eight per tile, in an epilogue nothing overlaps (W4_EPI_PIPE 0: that order, for the A/B).
+      constexpr int NR = NPL * (JB / 2) * IB;
+      u32x4 mv[2][hm ? 8 : 1], pv[2][hacc ? 8 : 1];
+      auto load_ops = [&](int r) __attribute__((always_inline)) {
+        const int pl = r / ((JB / 2) * IB), jh = (r / IB) % (JB / 2), i = r % IB;
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(pl ? out_i : out_r, g.ldc, 4);
+        for (int pass = 0; pass < 8; ++pass) {
+          const uint32_t so = (uint32_t)(i * 8 + pass) * p4 + (uint32_t)(jh * 256);
+          if constexpr (hm) mv[r & 1][pass] = ldb128(rm, vo, so);
+          if constexpr (hacc) pv[r & 1][pass] = ldb128(pl ? rout1 : rout0, vo, so);
+        }
+      };
+      if constexpr (hm || hacc) load_ops(0);
 #pragma unroll
-        for (int jh = 0; jh < JB / 2; ++jh)
+      for (int r = 0; r < NR; ++r) {
+        const int pl = r / ((JB / 2) * IB), jh = (r / IB) % (JB / 2), i = r % IB;
+        const __amdgpu_buffer_rsrc_t rout = pl ? rout1 : rout0;
+        if constexpr ((hm || hacc) && !W4_EPI_PIPE) { if (r > 0) load_ops(r); }
 #pragma unroll
-          for (int i = 0; i < IB; ++i) {
-            // multiplier / accumulate operands of this round first (see the bf16 path)
-            u32x4 mv[hm ? 8 : 1], pv[hacc ? 8 : 1];
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-              const uint32_t so = (uint32_t)(i * 8 + pass) * p4 + (uint32_t)(jh * 256);
-              if constexpr (hm) mv[pass] = ldb128(rm, vo, so);
-              if constexpr (hacc) pv[pass] = ldb128(rout, vo, so);
-            }
+          for (int q = 0; q < 4; ++q) {
+            const int cl = jj * 32 + 8 * q + 4 * lk;
+            f4 v;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int cl = jj * 32 + 8 * q + 4 * lk;
-                f4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  v.v[e] = pl ? acc_i[CPLX ? i : 0][jh * 2 + jj][4 * q + e] : acc_r[i][jh * 2 + jj][4 * q + e];
-                st4(reinterpret_cast<float*>(reg + l31 * PITCH + cl * 4), v);
-              }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-              const int rl = pass * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-              f4 v = ld4(reinterpret_cast<const float*>(reg + rl * PITCH + c4 * 4));
-              const uint32_t so = (uint32_t)(i * 8 + pass) * p4 + (uint32_t)(jh * 256);
-              if constexpr (hm) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  v.v[e] *= gemm_emul(g, __uint_as_float(mv[pass][e]));
-                  // (rounded product: the 8-wave kernels apply the multiplier in a block of its own, so nothing there can
-                  //  contract it with the accumulate below; same bits here)
-                  asm volatile("" : "+v"(v.v[e]));
-                }
-              }
-              if constexpr (hacc) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v.v[e] += beta * __uint_as_float(pv[pass][e]);
-              }
-              const u32x4 w = {__float_as_uint(v.v[0]), __float_as_uint(v.v[1]), __float_as_uint(v.v[2]), __float_as_uint(v.v[3])};
-              stb128(w, rout, vo, so);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W4_SB();
+            for (int e = 0; e < 4; ++e)
+              v.v[e] = pl ? acc_i[CPLX ? i : 0][jh * 2 + jj][4 * q + e] : acc_r[i][jh * 2 + jj][4 * q + e];
+            st4(reinterpret_cast<float*>(reg + l31 * PITCH + cl * 4), v);
           }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr ((hm || hacc) && W4_EPI_PIPE) {
+          if (r + 1 < NR) { W4_SB(); load_ops(r + 1); W4_SB(); }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+          const int rl = pass * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+          f4 v = ld4(reinterpret_cast<const float*>(reg + rl * PITCH + c4 * 4));
+          const uint32_t so = (uint32_t)(i * 8 + pass) * p4 + (uint32_t)(jh * 256);
+          if constexpr (hm) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v.v[e] *= gemm_emul(g, __uint_as_float(mv[r & 1][pass][e]));
+              // (rounded product: the 8-wave kernels apply the multiplier in a block of its own, so nothing there can
+              //  contract it with the accumulate below; same bits here)
+              asm volatile("" : "+v"(v.v[e]));
+            }
+          }
+          if constexpr (hacc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] += beta * __uint_as_float(pv[r & 1][pass][e]);
+          }
+          const u32x4 w = {__float_as_uint(v.v[0]), __float_as_uint(v.v[1]), __float_as_uint(v.v[2]), __float_as_uint(v.v[3])};
+          stb128(w, rout, vo, so);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_SB();
       }
     };
     if (g.emul) { if (g.accumulate) epi32(std::true_type{}, std::true_type{}); else epi32(std::true_type{}, std::false_type{}); }
