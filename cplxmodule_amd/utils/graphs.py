@@ -48,7 +48,7 @@ def _settle_collective_watchdog(seconds=0.3):
     import time
 
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+    if dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()):
         time.sleep(seconds)
 
 
