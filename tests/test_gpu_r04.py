@@ -310,3 +310,24 @@ def test_conv_batchnorm_pair_uses_the_epilogue_moments():
     net.eval()
     net(x)
     assert not conv._MOMENTS_WANTED
+
+
+# ---- the boundary is a C ABI -- a C++ program with no Python / torch in it -----------------------------------
+def test_cabi_from_a_plain_cpp_program(tmp_path):
+    """examples/cabi_linear.cpp: includes include/cplxamd.h, links libcplxamd.so, allocates its own device buffers, runs the
+    complex linear map with float32 and with bf16 operands and checks both against host loops."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "cabi_linear")
+    lib = os.path.join(root, "cplxmodule_amd")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "examples", "cabi_linear.cpp"), "-L", lib, "-lcplxamd", f"-Wl,-rpath,{lib}", "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    deps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libcplxamd.so" in deps and "torch" not in deps and "python" not in deps, deps
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "cabi_linear OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
