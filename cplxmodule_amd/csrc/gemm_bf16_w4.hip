@@ -47,7 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W4_DBG
-#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores, 16 hot-source loads (always K tiles 0, 1), 32 complex: only the MFMAs into the real-part accumulators (the instruction mix of pass 1 of a two-pass 3M loop: 32 MFMAs beside the full staging + fragment traffic of a K tile)
+#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores, 16 hot-source loads (always K tiles 0, 1), 32 complex: only the MFMAs into the real-part accumulators (the instruction mix of pass 1 of a two-pass 3M loop: 32 MFMAs beside the full staging + fragment traffic of a K tile), 64 no barrier in the K loop (wrong results: what the per-K-tile barrier and the waves' skew cost)
 #endif
 // where the two loads of a register pair go, in MFMA slots behind the pair's LDS write (experiments: scripts/r04/w4_build.sh)
 #ifndef W4_LDP
@@ -496,7 +496,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     sub(I0{}, PP, I0{}, CUR{}, I1{}, WR{}, WSP{}, WSQ{}, ktn);
     // every wave: its F1 reads are complete (in-order LDS: all but the operations issued behind the last read)
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ops_after_last_read(CPLX, W4_BURST, !W4_BURST || par == 1)) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((W4_DBG & 64) == 0) __builtin_amdgcn_s_barrier();
     W4_SB();
     sub(I1{}, PP, I1{}, NXT{}, I0{}, WR{}, WSP{}, WSQ{}, ktn);
   };
