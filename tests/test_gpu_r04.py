@@ -331,3 +331,49 @@ def test_cabi_from_a_plain_cpp_program(tmp_path):
     assert "libcplxamd.so" in deps and "torch" not in deps and "python" not in deps, deps
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "cabi_linear OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_conv_batchnorm_moments_inside_a_graph_replay():
+    """The conv -> batch-norm moments path captured in a hipGraph (128 output channels: two column tiles, so the
+    launcher's memset of the partial rows is a graph node too): the warm-up steps arm the convolution, the capture records
+    the moments variant, and replays reproduce the eager step -- outputs, gradients, running statistics advancing."""
+    from cplxmodule_amd import Cplx, conv, ops
+    from cplxmodule_amd.nn.modules.batchnorm import CplxBatchNorm2d
+    from cplxmodule_amd.nn.modules.conv import CplxConv2d
+    from cplxmodule_amd.utils.graphs import GraphedStep
+    bf = torch.bfloat16
+    cl = torch.channels_last
+    torch.manual_seed(9)
+    net = torch.nn.Sequential(CplxConv2d(64, 128, 3, padding=1), CplxBatchNorm2d(128)).to(DEV)   # (5.7 GFLOP: channels-last path)
+    x = Cplx(torch.randn(8, 64, 48, 64, device=DEV).to(bf).contiguous(memory_format=cl),
+             torch.randn(8, 64, 48, 64, device=DEV).to(bf).contiguous(memory_format=cl))
+    gy = torch.randn(8, 128, 48, 64, device=DEV).to(bf).contiguous(memory_format=cl)
+    hinted = []
+    handle = net[0].register_forward_hook(lambda m, a, out: hinted.append(ops.moments_hint(out.real, out.imag) is not None))
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        y = net(x)
+        torch.autograd.backward((y.real, y.imag), (gy, gy))
+        return y.real, y.imag
+
+    try:
+        conv._MOMENTS_WANTED.clear()
+        net.train()
+        g = GraphedStep(step, modules=[net], warmup=2)
+        assert hinted == [False, True, True], hinted          # two warm-up steps, then the capture
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        yr, yi = g.replay()
+        torch.cuda.synchronize()
+        got = (yr.clone(), yi.clone(), {n: p.grad.clone() for n, p in net.named_parameters()},
+               {k: v.clone() for k, v in net.state_dict().items()})
+        net.load_state_dict(state)                             # the same step, eager, from the same running statistics
+        e_yr, e_yi = step()
+        assert torch.equal(e_yr, got[0]) and torch.equal(e_yi, got[1])
+        for n, p in net.named_parameters():
+            assert torch.equal(p.grad, got[2][n]), n
+        for k, v in net.state_dict().items():
+            assert torch.equal(v, got[3][k]), k
+        assert not torch.equal(state["1.running_mean"], got[3]["1.running_mean"])
+    finally:
+        handle.remove()
