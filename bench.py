@@ -453,7 +453,7 @@ def main():
         # share the compute stream's hardware queue and then runs in queue order (profiles/r03_dp_timeline.txt)
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if args.rccl_channels > 0:
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.rccl_channels))      # (dp.init_process_group: max_channels)
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)      # explicit flag wins (dp.init_process_group: max_channels)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

@@ -5,13 +5,14 @@ ABI version, or a kernel is asked to run on a non-HIP tensor, this module raises
 """
 import ctypes
 import os
+import threading
 from ctypes import c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -124,12 +125,27 @@ SIGNATURES = {
     "cplxamd_bn_rows_path": [_L, _I, _L],
     "cplxamd_gemm_set_persistent": [_I],
     "cplxamd_gemm_set_family": [_I],
+    # ABI 19: per-call launch policy (trailing `flags` in front of the stream) + the dispatch as a pure function
+    "cplxamd_cgemm_fl": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I,
+                         _I, _I, _P, _I, _P, _L, _I, _P],
+    "cplxamd_rgemm_fl": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _L, _I, _P],
+    "cplxamd_cgemm_lrt_dx_fl": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "cplxamd_rgemm_lrt_dx_fl": [_P, _L, _L, _P, _L, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    "cplxamd_gemm_plan": [_I] * 10,
+    "cplxamd_conv2d_cl_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_cl2_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_cl2_lrt_dx_fl": [_P] * 8 + [_L] + [_I] * 6 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_cl2_mom_chunks_fl": [_L] + [_I] * 11,
+    "cplxamd_conv2d_cl2_mom_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P, _L, _I, _P],
+    "cplxamd_conv2d_cl_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_clr_fl": [_P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_clr_wgrad_fl": [_P, _P, _P, _I, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
     "cplxamd_bn_moments": [_P, _P, _P, _P, _P, _L, _I, _L, _I, _P, _P, _L, _P],
     "cplxamd_bn_fwd_sync": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _L, _P],
     "cplxamd_bn_fwd_partials": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _I, _P, _L, _P],
     "cplxamd_bn_bwd_sync": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P],
 }
-_RESTYPES = {"cplxamd_conv2d_cl2_mom_chunks": c_int64, "cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_lrt_reparam_bwd_cols_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
+_RESTYPES = {"cplxamd_conv2d_cl2_mom_chunks": c_int64, "cplxamd_conv2d_cl2_mom_chunks_fl": c_int64, "cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_lrt_reparam_bwd_cols_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,
              "cplxamd_cgemm3m_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,
@@ -139,6 +155,58 @@ _RESTYPES = {"cplxamd_conv2d_cl2_mom_chunks": c_int64, "cplxamd_vd_kl_ws_bytes":
              "cplxamd_conv2d_clr_ws_bytes": c_int64, "cplxamd_conv2d_clr_wgrad_ws_bytes": c_int64}
 
 _lib = None
+
+# ---- per-call launch policy (include/cplxamd.h CPLXAMD_LAUNCH_*) ----------------------------------------------------
+# The C ABI keeps no mutable launch state: every GEMM / channels-last convolution call carries its flags.  WHO decides
+# lives here, on the host: (1) a per-thread override (`with launch_policy(flags):` -- tests, A/B runs, a serving thread
+# that knows it shares the chip), else (2) LAUNCH_SHARED while any data-parallel hook of this process has collectives in
+# flight (`shared_chip_enter` / `_leave`: cplxmodule_amd.dp.BucketHook; the window is a property of the CHIP, so every
+# model launching into it shares), else (3) 0 = the library's defaults.  A hipGraph capture bakes in the flags of its
+# capture pass, exactly as it bakes in every other launch argument.
+LAUNCH_DEFAULT, LAUNCH_SHARED, LAUNCH_EXCLUSIVE = 0, 1, 2
+
+
+def LAUNCH_FAMILY(mask):
+    return 0x100 | ((int(mask) & 0x7f) << 16)
+
+
+_policy = threading.local()
+_sharing = set()           # id() of the hooks whose collectives are in flight
+_sharing_lock = threading.Lock()
+
+
+def launch_flags():
+    """Flags of the next GEMM / convolution launch of the calling thread."""
+    f = getattr(_policy, "flags", None)
+    if f is not None:
+        return f
+    return LAUNCH_SHARED if _sharing else LAUNCH_DEFAULT
+
+
+class launch_policy:
+    """`with launch_policy(LAUNCH_SHARED):` -- the calling thread's launches carry these flags (None: back to automatic)."""
+
+    def __init__(self, flags):
+        self.flags = flags
+
+    def __enter__(self):
+        self.prev = getattr(_policy, "flags", None)
+        _policy.flags = self.flags
+        return self
+
+    def __exit__(self, *exc):
+        _policy.flags = self.prev
+        return False
+
+
+def shared_chip_enter(owner):
+    with _sharing_lock:
+        _sharing.add(id(owner))
+
+
+def shared_chip_leave(owner):
+    with _sharing_lock:
+        _sharing.discard(id(owner))
 
 
 class CplxAmdError(RuntimeError):

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, ops
-from ._lib import CplxAmdError, call, try_call, dtype_code, ptr, require_device, stream_ptr
+from ._lib import CplxAmdError, call, try_call, dtype_code, launch_flags, ptr, require_device, stream_ptr
 from .cplx import Cplx
 
 _ws_cache = {}
@@ -195,8 +195,8 @@ def cl_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
     ws = _scratch(gr.device, int(_lib.load().cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, Ci, Co)))
     dwr = torch.empty(w_shape, dtype=torch.float32, device=gr.device)
     dwi = torch.empty_like(dwr)
-    call("cplxamd_conv2d_cl_wgrad", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul), ptr(dwr), ptr(dwi), B, H, W, Ci, Co,
-         geom[5], geom[6], geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr())
+    call("cplxamd_conv2d_cl_wgrad_fl", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(emul), ptr(dwr), ptr(dwi), B, H, W, Ci, Co,
+         geom[5], geom[6], geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), launch_flags(), stream_ptr())
     return dwr, dwi
 
 
@@ -287,19 +287,21 @@ def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False, moments=False):
     yr = torch.empty(oshape, dtype=xr.dtype, device=xr.device, memory_format=torch.channels_last)
     yi = torch.empty_like(yr)
     ws = _scratch(xr.device, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(N)))
+    flags = launch_flags()          # one policy for the whole call (the moments variant and its chunk count must agree)
     args = (ptr(xr), ptr(xi), ptr(wp), ptr(br), ptr(bi), ptr(yr), ptr(yi), B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9],
-            geom[10], int(dgrad), ptr(ws), ws.numel(), stream_ptr())
+            geom[10], int(dgrad), ptr(ws), ws.numel(), flags, stream_ptr())
     if moments and not dgrad and _CL_PATCH and _MOMENTS:
-        chunks = int(_lib.load().cplxamd_conv2d_cl2_mom_chunks(B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9], geom[10]))
+        chunks = int(_lib.load().cplxamd_conv2d_cl2_mom_chunks_fl(B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9], geom[10],
+                                                                  flags))
         if chunks > 0:
             partials = torch.empty(chunks * N * 5, dtype=torch.float64, device=xr.device)
-            if try_call("cplxamd_conv2d_cl2_mom", *args[:18], ptr(partials), partials.numel() * 8, ptr(ws), ws.numel(),
-                        stream_ptr()):
+            if try_call("cplxamd_conv2d_cl2_mom_fl", *args[:18], ptr(partials), partials.numel() * 8, ptr(ws), ws.numel(),
+                        flags, stream_ptr()):
                 ops.attach_moments(yr, yi, partials, chunks)
                 return yr, yi
     # dilation 1: the 2-d-patch kernel (activations staged once per channel slice for all nine taps); else the row kernel
-    if not (_CL_PATCH and try_call("cplxamd_conv2d_cl2", *args)):
-        call("cplxamd_conv2d_cl", *args)
+    if not (_CL_PATCH and try_call("cplxamd_conv2d_cl2_fl", *args)):
+        call("cplxamd_conv2d_cl_fl", *args)
     return yr, yi
 
 
@@ -318,8 +320,8 @@ def cl_conv_lrt_dx(gr, gi, wr, wi, geom, xr, xi, ga):
         dxr = torch.empty((B, Ci, H, W), dtype=xr.dtype, device=xr.device, memory_format=torch.channels_last)
         dxi = torch.empty_like(dxr)
         ws = _scratch(xr.device, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(Ci)))
-        if try_call("cplxamd_conv2d_cl2_lrt_dx", ptr(gr), ptr(gi), ptr(wp), ptr(xr), ptr(xi), ptr(ga), ptr(dxr), ptr(dxi),
-                    B, H, W, Co, Ci, geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr()):
+        if try_call("cplxamd_conv2d_cl2_lrt_dx_fl", ptr(gr), ptr(gi), ptr(wp), ptr(xr), ptr(xi), ptr(ga), ptr(dxr), ptr(dxi),
+                    B, H, W, Co, Ci, geom[9], geom[10], ptr(ws), ws.numel(), launch_flags(), stream_ptr()):
             return dxr, dxi
     dxr, dxi = cl_conv(gr, gi, wr, wi, None, None, geom, dgrad=True)
     ops.lrt_dx_accum(dxr, dxi, xr, xi, ga)
@@ -339,8 +341,8 @@ def cl_conv_real(x, w, b, geom, dgrad=False):
     oshape = (B, N, H, W) if dgrad else (B, N, Ho, Wo)
     y = torch.empty(oshape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ws = _scratch(x.device, int(lib.cplxamd_conv2d_clr_ws_bytes(N)))
-    call("cplxamd_conv2d_clr", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9],
-         geom[10], int(dgrad), ptr(ws), ws.numel(), stream_ptr())
+    call("cplxamd_conv2d_clr_fl", ptr(x), ptr(wp), ptr(b), ptr(y), B, H, W, C, N, KH, KW, geom[11], geom[12], geom[9],
+         geom[10], int(dgrad), ptr(ws), ws.numel(), launch_flags(), stream_ptr())
     return y
 
 
@@ -350,8 +352,8 @@ def cl_wgrad_real(g, x, geom, w_shape, emul=None, emul_exp=False):
     g, x = to_channels_last(g), to_channels_last(x)
     ws = _scratch(g.device, int(_lib.load().cplxamd_conv2d_clr_wgrad_ws_bytes(B, H, W, Ci, Co)))
     dw = torch.empty(w_shape, dtype=torch.float32, device=g.device)
-    call("cplxamd_conv2d_clr_wgrad", ptr(g), ptr(x), ptr(emul), int(emul_exp), ptr(dw), B, H, W, Ci, Co, geom[5], geom[6],
-         geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), stream_ptr())
+    call("cplxamd_conv2d_clr_wgrad_fl", ptr(g), ptr(x), ptr(emul), int(emul_exp), ptr(dw), B, H, W, Ci, Co, geom[5], geom[6],
+         geom[11], geom[12], geom[9], geom[10], ptr(ws), ws.numel(), launch_flags(), stream_ptr())
     return dw
 
 

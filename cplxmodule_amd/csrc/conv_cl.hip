@@ -28,7 +28,7 @@
 #include <type_traits>
 
 #include "common.h"
-#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
+#include "launch.h"   // per-call launch policy (CPLXAMD_LAUNCH_SHARED: the chip is shared with collectives)
 
 namespace cplxamd {
 namespace cl {
@@ -658,6 +658,14 @@ int cplxamd_conv2d_cl_pack(const void* w_r, const void* w_i, void* out, int Co, 
 int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
                       void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
                       int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream) {
+  return cplxamd_conv2d_cl_fl(x_r, x_i, w_packed, bias_r, bias_i, y_r, y_i, B, H, W, C, N, KH, KW, dil_h, dil_w, pad_h, pad_w,
+                              mode, ws, ws_bytes, CPLXAMD_LAUNCH_DEFAULT, stream);
+}
+
+int cplxamd_conv2d_cl_fl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                         void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                         int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, int flags, void* stream) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
   if (!x_r || !x_i || !w_packed || !y_r || !y_i || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || KH <= 0 ||
       KW <= 0 || dil_h <= 0 || dil_w <= 0 || pad_h < 0 || pad_w < 0 || (bias_r == nullptr) != (bias_i == nullptr) ||
       (mode != 0 && mode != 1))
@@ -688,17 +696,11 @@ int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, co
   g.tiles_n = N / 64;
   g.div_w = cl::make_div((uint32_t)W); g.div_h = cl::make_div((uint32_t)H);
   static const int stagger_pct = [] { const char* e = getenv("CPLXAMD_CL_STAGGER"); return e ? atoi(e) : 100; }();
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
-    ncu = n & ~7;
-  }
+  const int ncu = device_cus() & ~7;
   const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n;
   if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
-  // chip shared with RCCL collectives (cplxamd_gemm_set_persistent(0), gemm.h): one workgroup per tile
-  int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
+  // chip shared with RCCL collectives (CPLXAMD_LAUNCH_SHARED, launch.h): one workgroup per tile
+  int grid = (ntiles < ncu || !launch_owns_chip(flags)) ? (int)ntiles : ncu;
   // Start stagger.  A tile takes ~ NS stages x 2 waves per SIMD x 48 MFMAs x 32 clocks / 0.5; the workgroups that get
   // one tile less than the longest ones (ntiles % grid != 0) have that much slack: their starts are spread over it.
   g.stagger = 0; g.stagger_from = 0;
@@ -708,12 +710,8 @@ int cplxamd_conv2d_cl(const void* x_r, const void* x_i, const void* w_packed, co
     g.stagger = (int)(tile_clk * stagger_pct / 100 / (grid - g.stagger_from));
   }
   using G3 = cl::Geo<3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)cl::conv_cl_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G3::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static PerDeviceOnce attr_set;
+  if (const int e = set_max_dyn_lds(attr_set, cl::conv_cl_kernel<3>, G3::SMEM)) return e;
   cl::conv_cl_kernel<3><<<dim3((unsigned)grid), cl::NT, G3::SMEM, (hipStream_t)stream>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;

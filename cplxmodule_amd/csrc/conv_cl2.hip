@@ -22,7 +22,7 @@
 #include <type_traits>
 
 #include "common.h"
-#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
+#include "launch.h"   // per-call launch policy (CPLXAMD_LAUNCH_SHARED: the chip is shared with collectives)
 
 namespace cplxamd {
 namespace cl2 {
@@ -665,16 +665,7 @@ extern "C" {
 int64_t cplxamd_conv2d_cl_pack_bytes(int N, int C, int KH, int KW);
 int64_t cplxamd_conv2d_cl_ws_bytes(int Cout);
 
-static int cl2_cus() {
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
-    ncu = n & ~7;
-  }
-  return ncu;
-}
+static int cl2_cus() { return device_cus() & ~7; }
 
 // Does every workgroup of a `grid`-wide launch over `ntiles` tiles see ONE column tile?  Virtual tile v of workgroup w is
 // w, w + grid, ...; its linear index is base(v & 7) + (v >> 3) with the column tile fastest (conv_cl2_kernel: origin), so
@@ -687,7 +678,8 @@ static bool cl2_mom_tiling_ok(int64_t ntiles, int grid, int tiles_n) {
 static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
                       const void* fx_r, const void* fx_i, const void* fga, void* y_r, void* y_i, int64_t B, int H, int W, int C,
                       int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes,
-                      void* stream, double* mom = nullptr, int64_t mom_bytes = 0) {
+                      int flags, void* stream, double* mom = nullptr, int64_t mom_bytes = 0) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
   if (!x_r || !x_i || !w_packed || !y_r || !y_i || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || pad_h < 0 || pad_w < 0 ||
       (bias_r == nullptr) != (bias_i == nullptr) || (mode != 0 && mode != 1))
     return CPLXAMD_EINVAL;
@@ -714,17 +706,12 @@ static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, co
   const int64_t ntiles = B * g.tiles_x * g.tiles_y * g.tiles_n;
   if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
   const int ncu = cl2_cus();
-  // chip shared with RCCL collectives (cplxamd_gemm_set_persistent(0), gemm.h): one workgroup per tile -- a launch that
+  // chip shared with RCCL collectives (CPLXAMD_LAUNCH_SHARED, launch.h): one workgroup per tile -- a launch that
   // expects every CU for its whole duration would wait for the held ones with its last workgroups
-  const int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cl2::SMEM);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cl2::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  const int grid = (ntiles < ncu || !launch_owns_chip(flags)) ? (int)ntiles : ncu;
+  static PerDeviceOnce attr_set, attr_set_f;
+  if (const int e = set_max_dyn_lds(attr_set, cl2::conv_cl2_kernel<false>, cl2::SMEM)) return e;
+  if (const int e = set_max_dyn_lds(attr_set_f, cl2::conv_cl2_kernel<true>, cl2::SMEM)) return e;
   if (mom) {
     // one partial row per workgroup: a persistent launch only (at most one workgroup per CU), one column tile
     if (fga || mode != 0 || grid > ncu || !cl2_mom_tiling_ok(ntiles, grid, g.tiles_n)) return CPLXAMD_ESHAPE;
@@ -732,13 +719,8 @@ static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, co
     if (g.tiles_n > 1 &&
         hipMemsetAsync(mom, 0, (size_t)grid * N * 5 * sizeof(double), (hipStream_t)stream) != hipSuccess)
       return CPLXAMD_EINVAL;
-    static bool mom_attr = false;
-    if (!mom_attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)cl2::conv_cl2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         cl2::SMEM_MOM);
-      if (e != hipSuccess) return (int)e;
-      mom_attr = true;
-    }
+    static PerDeviceOnce mom_attr;
+    if (const int e = set_max_dyn_lds(mom_attr, cl2::conv_cl2_kernel<false, true>, cl2::SMEM_MOM)) return e;
     g.mom = mom;
     cl2::conv_cl2_kernel<false, true><<<dim3((unsigned)grid), cl2::NT, cl2::SMEM_MOM, (hipStream_t)stream>>>(g);
     CPLXAMD_CHECK_LAUNCH();
@@ -753,9 +735,15 @@ static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, co
 // Number of per-workgroup partial rows cplxamd_conv2d_cl2_mom writes for this problem ([rows][N][5] float64), or 0 when the
 // moments variant does not take it (kernel / dilation / channel counts cplxamd_conv2d_cl2 declines, a grid whose workgroups
 // would change column tile, or the chip
-// is shared with collectives -- cplxamd_gemm_set_persistent(0) -- so that the launch is one workgroup per tile).
+// is shared with collectives -- CPLXAMD_LAUNCH_SHARED -- so that the launch is one workgroup per tile).
 int64_t cplxamd_conv2d_cl2_mom_chunks(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w, int pad_h,
                                       int pad_w) {
+  return cplxamd_conv2d_cl2_mom_chunks_fl(B, H, W, C, N, KH, KW, dil_h, dil_w, pad_h, pad_w, CPLXAMD_LAUNCH_DEFAULT);
+}
+
+int64_t cplxamd_conv2d_cl2_mom_chunks_fl(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                                         int pad_h, int pad_w, int flags) {
+  if (!launch_flags_ok(flags)) return 0;
   const int Hs = H + 2 * pad_h - 2, Ws = W + 2 * pad_w - 2;
   if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || KH != 3 || KW != 3 || dil_h != 1 || dil_w != 1 || C <= 0 ||
       C % 32 || N % cl2::BN || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W)
@@ -764,7 +752,7 @@ int64_t cplxamd_conv2d_cl2_mom_chunks(int64_t B, int H, int W, int C, int N, int
   const int64_t ntiles = B * ((Ws + cl2::TW - 1) / cl2::TW) * ((Hs + cl2::TH - 1) / cl2::TH) * (N / cl2::BN);
   if (ntiles > 0x7fffffff) return 0;
   const int ncu = cl2_cus();
-  if (ntiles >= ncu && !g_gemm_persistent) return 0;
+  if (ntiles >= ncu && !launch_owns_chip(flags)) return 0;
   const int grid = ntiles < ncu ? (int)ntiles : ncu;
   return cl2_mom_tiling_ok(ntiles, grid, N / cl2::BN) ? grid : 0;
 }
@@ -779,10 +767,18 @@ int cplxamd_conv2d_cl2_mom(const void* x_r, const void* x_i, const void* w_packe
                            void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
                            int pad_h, int pad_w, double* partials, int64_t partials_bytes, void* ws, int64_t ws_bytes,
                            void* stream) {
-  if (!partials) return CPLXAMD_EINVAL;
-  if (cplxamd_conv2d_cl2_mom_chunks(B, H, W, C, N, KH, KW, dil_h, dil_w, pad_h, pad_w) <= 0) return CPLXAMD_ESHAPE;
+  return cplxamd_conv2d_cl2_mom_fl(x_r, x_i, w_packed, bias_r, bias_i, y_r, y_i, B, H, W, C, N, KH, KW, dil_h, dil_w, pad_h, pad_w,
+                                   partials, partials_bytes, ws, ws_bytes, CPLXAMD_LAUNCH_DEFAULT, stream);
+}
+
+int cplxamd_conv2d_cl2_mom_fl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r,
+                              const float* bias_i, void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW,
+                              int dil_h, int dil_w, int pad_h, int pad_w, double* partials, int64_t partials_bytes, void* ws,
+                              int64_t ws_bytes, int flags, void* stream) {
+  if (!partials || !launch_flags_ok(flags)) return CPLXAMD_EINVAL;
+  if (cplxamd_conv2d_cl2_mom_chunks_fl(B, H, W, C, N, KH, KW, dil_h, dil_w, pad_h, pad_w, flags) <= 0) return CPLXAMD_ESHAPE;
   return launch_cl2(x_r, x_i, w_packed, bias_r, bias_i, nullptr, nullptr, nullptr, y_r, y_i, B, H, W, C, N, KH, KW, dil_h,
-                    dil_w, pad_h, pad_w, 0, ws, ws_bytes, stream, partials, partials_bytes);
+                    dil_w, pad_h, pad_w, 0, ws, ws_bytes, flags, stream, partials, partials_bytes);
 }
 
 // Same arguments and semantics as cplxamd_conv2d_cl (weights packed by cplxamd_conv2d_cl_pack); built for KH = KW = 3,
@@ -791,7 +787,14 @@ int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, c
                        void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
                        int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, void* stream) {
   return launch_cl2(x_r, x_i, w_packed, bias_r, bias_i, nullptr, nullptr, nullptr, y_r, y_i, B, H, W, C, N, KH, KW, dil_h,
-                    dil_w, pad_h, pad_w, mode, ws, ws_bytes, stream);
+                    dil_w, pad_h, pad_w, mode, ws, ws_bytes, CPLXAMD_LAUNCH_DEFAULT, stream);
+}
+
+int cplxamd_conv2d_cl2_fl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                          void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                          int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, int flags, void* stream) {
+  return launch_cl2(x_r, x_i, w_packed, bias_r, bias_i, nullptr, nullptr, nullptr, y_r, y_i, B, H, W, C, N, KH, KW, dil_h,
+                    dil_w, pad_h, pad_w, mode, ws, ws_bytes, flags, stream);
 }
 
 // Input gradient of the local-reparameterization convolutions (CplxConv2dVD / ARD, cplxmodule/nn/relevance/complex.py
@@ -803,9 +806,16 @@ int cplxamd_conv2d_cl2(const void* x_r, const void* x_i, const void* w_packed, c
 int cplxamd_conv2d_cl2_lrt_dx(const void* g_r, const void* g_i, const void* w_packed, const void* x_r, const void* x_i,
                               const void* ga, void* dx_r, void* dx_i, int64_t B, int H, int W, int C, int N, int pad_h,
                               int pad_w, void* ws, int64_t ws_bytes, void* stream) {
+  return cplxamd_conv2d_cl2_lrt_dx_fl(g_r, g_i, w_packed, x_r, x_i, ga, dx_r, dx_i, B, H, W, C, N, pad_h, pad_w, ws, ws_bytes,
+                                      CPLXAMD_LAUNCH_DEFAULT, stream);
+}
+
+int cplxamd_conv2d_cl2_lrt_dx_fl(const void* g_r, const void* g_i, const void* w_packed, const void* x_r, const void* x_i,
+                                 const void* ga, void* dx_r, void* dx_i, int64_t B, int H, int W, int C, int N, int pad_h,
+                                 int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream) {
   if (!x_r || !x_i || !ga) return CPLXAMD_EINVAL;
   return launch_cl2(g_r, g_i, w_packed, nullptr, nullptr, x_r, x_i, ga, dx_r, dx_i, B, H, W, C, N, 3, 3, 1, 1, pad_h, pad_w, 1,
-                    ws, ws_bytes, stream);
+                    ws, ws_bytes, flags, stream);
 }
 
 }  // extern "C"

@@ -11,7 +11,7 @@
 #include <type_traits>
 
 #include "common.h"
-#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
+#include "launch.h"   // per-call launch policy (CPLXAMD_LAUNCH_SHARED: the chip is shared with collectives)
 
 namespace cplxamd {
 namespace clr {
@@ -569,6 +569,14 @@ int cplxamd_conv2d_clr_pack(const void* w, void* out, int Co, int Ci, int KH, in
 int cplxamd_conv2d_clr(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int H, int W, int C,
                        int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws,
                        int64_t ws_bytes, void* stream) {
+  return cplxamd_conv2d_clr_fl(x, w_packed, bias, y, B, H, W, C, N, KH, KW, dil_h, dil_w, pad_h, pad_w, mode, ws, ws_bytes,
+                               CPLXAMD_LAUNCH_DEFAULT, stream);
+}
+
+int cplxamd_conv2d_clr_fl(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int H, int W, int C,
+                          int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws,
+                          int64_t ws_bytes, int flags, void* stream) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
   if (!x || !w_packed || !y || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || KH <= 0 || KW <= 0 || dil_h <= 0 ||
       dil_w <= 0 || pad_h < 0 || pad_w < 0 || (mode != 0 && mode != 1))
     return CPLXAMD_EINVAL;
@@ -597,17 +605,11 @@ int cplxamd_conv2d_clr(const void* x, const void* w_packed, const float* bias, v
   g.tiles_n = N / 64;
   g.div_w = clr::make_div((uint32_t)W); g.div_h = clr::make_div((uint32_t)H);
   static const int stagger_pct = [] { const char* e = getenv("CPLXAMD_CL_STAGGER"); return e ? atoi(e) : 100; }();
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
-    ncu = n & ~7;
-  }
+  const int ncu = device_cus() & ~7;
   const int64_t ntiles = (int64_t)g.tiles_m * g.tiles_n;
   if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
-  // chip shared with RCCL collectives (cplxamd_gemm_set_persistent(0), gemm.h): one workgroup per tile
-  int grid = (ntiles < ncu || !g_gemm_persistent) ? (int)ntiles : ncu;
+  // chip shared with RCCL collectives (CPLXAMD_LAUNCH_SHARED, launch.h): one workgroup per tile
+  int grid = (ntiles < ncu || !launch_owns_chip(flags)) ? (int)ntiles : ncu;
   g.stagger = 0; g.stagger_from = 0;
   if (ntiles > 2 * grid && ntiles % grid) {
     const int64_t tile_clk = (int64_t)g.NS * 2 * 24 * 32 * 2;
@@ -615,12 +617,8 @@ int cplxamd_conv2d_clr(const void* x, const void* w_packed, const float* bias, v
     g.stagger = (int)(tile_clk * stagger_pct / 100 / (grid - g.stagger_from));
   }
   using G3 = clr::Geo<3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)clr::conv_clr_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G3::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static PerDeviceOnce attr_set;
+  if (const int e = set_max_dyn_lds(attr_set, clr::conv_clr_kernel<3>, G3::SMEM)) return e;
   clr::conv_clr_kernel<3><<<dim3((unsigned)grid), clr::NT, G3::SMEM, (hipStream_t)stream>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;

@@ -5,7 +5,7 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "gemm.h"   // g_gemm_persistent: the process-wide chip-sharing switch (cplxamd_gemm_set_persistent)
+#include "launch.h"   // per-call launch policy (CPLXAMD_LAUNCH_SHARED: the chip is shared with collectives)
 
 namespace cplxamd {
 namespace clwr {
@@ -319,17 +319,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
   dw[i] = emul ? acc * (emul_exp ? __expf(emul[i]) : emul[i]) : acc;
 }
 
-// shared: the chip is shared with RCCL collectives (cplxamd_gemm_set_persistent(0)): twice as many, half as long splits,
+// shared: the chip is shared with RCCL collectives (CPLXAMD_LAUNCH_SHARED): twice as many, half as long splits,
 // so that the workgroups that find their CU taken do not make the launch take two rounds (the workspace is always sized
 // for this plan)
 static int plan(int64_t nstages, int tiles, int& per_split, bool shared) {
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
-    ncu = n;
-  }
+  const int ncu = device_cus();
   int64_t s = ncu / tiles;                            // one workgroup per CU (120 KiB of LDS each), one round
   if (s < 1) s = 1;
   if (shared) s *= 2;
@@ -369,6 +363,14 @@ int64_t cplxamd_conv2d_clr_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int C
 int cplxamd_conv2d_clr_wgrad(const void* g_, const void* x, const float* emul, int emul_exp, float* dw, int64_t B, int H,
                              int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, void* ws,
                              int64_t ws_bytes, void* stream) {
+  return cplxamd_conv2d_clr_wgrad_fl(g_, x, emul, emul_exp, dw, B, H, W, Ci, Co, KH, KW, dil_h, dil_w, pad_h, pad_w, ws, ws_bytes,
+                                     CPLXAMD_LAUNCH_DEFAULT, stream);
+}
+
+int cplxamd_conv2d_clr_wgrad_fl(const void* g_, const void* x, const float* emul, int emul_exp, float* dw, int64_t B, int H,
+                                int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, void* ws,
+                                int64_t ws_bytes, int flags, void* stream) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
   if (!g_ || !x || !dw || B < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return CPLXAMD_EINVAL;
   if (!clwr_shape_ok(B, H, W, Ci, Co, KH, KW, dil_h, dil_w, pad_h, pad_w)) return CPLXAMD_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
@@ -389,14 +391,10 @@ int cplxamd_conv2d_clr_wgrad(const void* g_, const void* x, const float* emul, i
   g.nstages = (int)(B * H * g.strips);
   g.tiles_ci = Ci / 64;
   const int tiles = (Co / 64) * g.tiles_ci;
-  g.splits = clwr::plan(g.nstages, tiles, g.per_split, !g_gemm_persistent);
+  g.splits = clwr::plan(g.nstages, tiles, g.per_split, !launch_owns_chip(flags));
   constexpr int smem = 3 * clwr::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)clwr::conv_clr_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static PerDeviceOnce attr_set;
+  if (const int e = set_max_dyn_lds(attr_set, clwr::conv_clr_wgrad_kernel, smem)) return e;
   clwr::conv_clr_wgrad_kernel<<<dim3((unsigned)g.splits, (unsigned)tiles), clwr::NT, smem, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   clwr::wgrad_reduce_kernel<<<dim3(36 * 1024 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, Co, Ci,

@@ -1,6 +1,7 @@
 // Internal interface between the GEMM translation units.
 #pragma once
 #include "common.h"
+#include "launch.h"
 
 namespace cplxamd {
 
@@ -30,6 +31,11 @@ struct GemmArgs {
   // cplxamd_lrt_dx_accum pass (7 plane passes over [B, I]) disappears.  Same arithmetic as the two-kernel path:
   // round(acc) to bf16 first, then fmaf(2 x, ga, that) rounded to bf16.
   const void* fx_r = nullptr; const void* fx_i = nullptr; const void* fga = nullptr; int64_t fld = 0;
+  // per-call launch policy (host side only; include/cplxamd.h CPLXAMD_LAUNCH_*, launch.h)
+  int flags = 0;
+  // dry run (cplxamd_gemm_plan): the launchers write the code of the kernel they WOULD launch here and return; ncu > 0
+  // replaces the device's CU count (so that the dispatch can be read without a device)
+  int* plan = nullptr; int ncu = 0;
 };
 
 __device__ __forceinline__ float gemm_beta(const GemmArgs& g) { return (g.accumulate && g.beta) ? *g.beta : 1.0f; }
@@ -54,14 +60,11 @@ int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bo
 int launch_gemm_bf16_gauss(const GemmArgs& g, int out_dtype, hipStream_t st);
 int64_t gemm_bf16_gauss_ws_bytes(int M, int N, int K);
 
-// Run-time switch of the persistent form (cplxamd_gemm_set_persistent; 1 at start).  A persistent launch owns every CU for
-// its whole duration and gives workgroup j the tiles j, j + #CU, ...: if other kernels hold some CUs (an RCCL all-reduce
-// overlapping the backward pass), the workgroups that find no CU start only when the first ones END, and the launch
-// takes twice as long.  One workgroup per tile degrades by the share of CUs taken instead: the data-parallel hook turns
-// the persistent form off while its collectives are in flight.
-extern int g_gemm_persistent;
-// kernel family switch (cplxamd_gemm_set_family): 1 = the one-wave-per-SIMD kernels where they apply
-extern int g_gemm_w4;
+// Launch form, per call (g.flags; launch.h).  A persistent launch owns every CU for its whole duration and gives workgroup
+// j the tiles j, j + #CU, ...: if other kernels hold some CUs (an RCCL all-reduce overlapping the backward pass), the
+// workgroups that find no CU start only when the first ones END, and the launch takes twice as long.  One workgroup per
+// tile degrades by the share of CUs taken instead: the data-parallel hook passes CPLXAMD_LAUNCH_SHARED while its
+// collectives are in flight.  The kernel family (one-wave-per-SIMD where it applies) is launch_family(g.flags).
 
 // workspace the bf16 path wants for split-K at this shape (0: no split-K)
 int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx);

@@ -713,13 +713,9 @@ static int launch_kernel_r(const GemmArgs& g0, hipStream_t st) {
   g.order = order; g.group_m = gm > 0 ? gm : 1;
   const int64_t tiles = (int64_t)((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   if (tiles * g.splits > 0x7fffffff) return CPLXAMD_ESHAPE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (g.plan) { *g.plan = 1; return 0; }
+  static PerDeviceOnce attr_set;
+  if (const int e = set_max_dyn_lds(attr_set, gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB>, C::SMEM)) return e;
   gemm_bf16_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)(tiles * g.splits)), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
@@ -735,15 +731,9 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   using C = Cfg<CPLX>;
   taken = false;
   static const int enabled = env_int("CPLXAMD_GEMM_PERSIST", 1);     // (A/B at run time)
-  static int ncu = 0;
-  if (!enabled || !g_gemm_persistent) return 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
-    ncu = n & ~7;
-  }
   const GemmArgs& g = g0;
+  if (!enabled || !launch_owns_chip(g.flags)) return 0;
+  const int ncu = (g.ncu > 0 ? g.ncu : device_cus()) & ~7;
   if (g.splits > 1 || g.g1 || g.emul || g.accumulate || (g.M % C::BM) || (g.N % C::BN) || g.K / BK < 12) return 0;
   if (g.fga && (!((CPLX ? CONJ : true) && TB && !TA && sizeof(TOUT) == 2) || (g.fld & 7) || !aligned16(g.fga) ||
                 !aligned16(g.fx_r) || (CPLX && !aligned16(g.fx_i)) || g.bias_r)) return 0;   // (the caller runs the two-kernel path)
@@ -767,27 +757,18 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
     constexpr bool kFusable = (CPLX ? CONJ : true) && TB && kBf16Out;   // the LRT input gradient, complex and real (gemm.h: fga)
     auto go = [&](auto RR) -> int {
       constexpr int R = decltype(RR)::value;
+      if (g.plan) { *g.plan = 2; return 0; }
       if constexpr (kFusable) {
         if (g.fga) {
-          static bool attr_set_f = false;
-          if (!attr_set_f) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            if (e != hipSuccess) return (int)e;
-            attr_set_f = true;
-          }
+          static PerDeviceOnce attr_set_f;
+          if (const int e = set_max_dyn_lds(attr_set_f, gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R, true>, smem)) return e;
           gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R, true><<<dim3((unsigned)ncu), C::NT, smem, st>>>(a);
           CPLXAMD_CHECK_LAUNCH();
           return 0;
         }
       }
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-      }
+      static PerDeviceOnce attr_set;
+      if (const int e = set_max_dyn_lds(attr_set, gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R>, smem)) return e;
       gemm_bf16_persist_kernel<TOUT, CPLX, CONJ, TA, TB, R><<<dim3((unsigned)ncu), C::NT, smem, st>>>(a);
       CPLXAMD_CHECK_LAUNCH();
       return 0;
@@ -911,6 +892,7 @@ static int launch_splitk(const GemmArgs& g0, int splits, bool ta, bool tb, hipSt
   k.ldc = g.N; k.bias_r = k.bias_i = nullptr; k.emul = nullptr; k.accumulate = 0;
   const int rc = launch_dtype<CPLX>(k, CPLXAMD_F32, ta, tb, st);
   if (rc) return rc;
+  if (g.plan) { *g.plan = *g.plan == 3 ? 5 : 4; return 0; }
   const int64_t slab = (int64_t)g.M * g.N, stride = (CPLX ? 2 : 1) * slab;
   const int grid = stream_grid(slab >> 2, 256);
   gemm_slab_reduce_kernel<<<grid, 256, 0, st>>>((const float*)g.ws, splits, stride, g.M, g.N, g.ldc,

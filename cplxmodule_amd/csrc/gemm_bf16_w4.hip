@@ -754,13 +754,9 @@ static int launch(const GemmArgs& g0, hipStream_t st) {
   static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
   g.group_m = gm > 0 ? gm : 1;
   const int64_t tiles = (int64_t)(g.M / C::BM) * (g.N / C::BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (g.plan) { *g.plan = 3; return 0; }
+  static PerDeviceOnce attr_set;
+  if (const int e = set_max_dyn_lds(attr_set, gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB>, C::SMEM)) return e;
   int64_t grid = tiles * g.splits;
   if (W4_PGRID > 0 && grid > W4_PGRID) grid = W4_PGRID;
   gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)grid), C::NT, C::SMEM, st>>>(g);
@@ -779,7 +775,7 @@ static int launch_layout(const GemmArgs& g, bool ta, bool tb, hipStream_t st) {
 // 0 and taken = true: launched.  taken = false: the shape / epilogue is not one this kernel takes.
 int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bool tb, hipStream_t st, bool& taken) {
   taken = false;
-  // which launches the family takes (cplxamd_gemm_set_family): bit 0 complex bf16-out, 1 complex bf16-out with the fused LRT
+  // which launches the family takes (launch_family(g.flags): CPLXAMD_LAUNCH_FAMILY per call, else the process default): bit 0 complex bf16-out, 1 complex bf16-out with the fused LRT
   // term, 2 complex float32-out, 3 real bf16-out (4: with the fused term), 5 real float32-out; bit 6: regardless of K.
   // Without bit 6 the K depth decides too (profiles/r04_gemm_w4_ab.txt): this family pays a full prologue / epilogue per
   // output tile where the 8-wave (N,N) / (N,T) kernels run persistent, so it wins from K = 4096 on, at 1024 <= K < 4096 only
@@ -787,8 +783,9 @@ int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bo
   {
     const bool f32o = out_dtype == CPLXAMD_F32;
     const int bit = cplx ? (f32o ? 2 : g.fga ? 1 : 0) : (f32o ? 5 : g.fga ? 4 : 3);
-    if (!((g_gemm_w4 >> bit) & 1)) return 0;
-    if (!((g_gemm_w4 >> 6) & 1)) {
+    const int family = launch_family(g.flags);
+    if (!((family >> bit) & 1)) return 0;
+    if (!((family >> 6) & 1)) {
       const int keff = g.splits > 1 ? g.kchunk : g.K;      // K loop per output tile
       if (keff < 1024) return 0;
       if (keff < 4096 && (ta || tb || g.fga)) return 0;

@@ -31,15 +31,24 @@ averaged views.
 
 Sharing the chip.  While a bucket's all-reduce is in flight its RCCL kernels hold CUs next to the rest of the backward
 pass.  The persistent GEMM launches (one workgroup per CU, tiles dealt out statically) would wait for those CUs with
-their last workgroups -- until the first ones END -- so the hook switches the GEMMs and the channels-last convolution
-kernels to one workgroup per tile (`cplxamd_gemm_set_persistent(0)`, bit-identical results, 1-2 % slower alone) from the
-first announcement / asynchronous launch until `sync_gradients()` has waited for all of them.
+their last workgroups -- until the first ones END -- so from the first announcement / asynchronous launch until
+`sync_gradients()` has waited for all of them every GEMM and channels-last convolution launch carries
+`CPLXAMD_LAUNCH_SHARED` (one workgroup per tile; bit-identical results, 1-2 % slower alone).  The flag is an ARGUMENT of
+each call (`_lib.launch_flags()`, ABI 19): the library holds no launch state, so other threads / streams of the process
+are affected only through this host-side window, which they can override (`_lib.launch_policy`).
 
 The collective is the only cross-rank traffic: forward / backward kernels never communicate.  The KL
 penalty is a function of the replicated weights only, so its gradient is identical on every rank and the
 mean leaves it unchanged; `all_reduce_scalar_mean` is the north star's "scalar KL term".
-Gradient accumulation over several backward passes per exchange and parameters shared between layers
-are not supported (call `zero_grad()` -- which sets every `.grad` to None -- before each step).
+Several backward passes per exchange (gradient accumulation over micro-batches, or the reference's two-call pattern
+`nll.backward(); (c * kl).backward()`): wrap every pass but the LAST in `DataParallel.no_sync()` -- no collective is
+launched inside it, gradients accumulate in `.grad` as autograd would without the wrapper, and the last pass exchanges
+the totals.  A backward pass that reaches a parameter whose bucket's all-reduce is already in flight (i.e. a second
+pass WITHOUT no_sync) raises: the collective may be reading the storage autograd has just accumulated into, and no
+ordering applied afterwards can undo that.  A parameter used by several layers is fine: bucket storage is
+handed to at most one producer per pass (the others get private tensors and autograd sums), and the exchange starts only
+from the post-accumulate hook, i.e. after every use has been summed.  Call `zero_grad()` -- which sets every `.grad` to
+None -- before each step.
 """
 import torch
 import torch.distributed as dist
@@ -62,7 +71,7 @@ def init_process_group(backend="nccl", device=None, max_channels=None, **kwargs)
 
     max_channels (or env CPLXAMD_RCCL_MAX_CHANNELS): the CU split between the collectives and the GEMMs they overlap.
     An RCCL ring / tree kernel holds one CU per channel for as long as it runs; while a bucket is in flight the GEMM
-    kernels launch one workgroup per tile (`cplxamd_gemm_set_persistent(0)`) and simply get the remaining CUs, so the
+    kernels launch one workgroup per tile (`CPLXAMD_LAUNCH_SHARED`) and simply get the remaining CUs, so the
     price of C channels is C / 256 of the matrix throughput for the duration of the exchange.  Eight ranks on xGMI are
     link-bound long before they need 32+ CUs (7 links x ~153 GB/s per GPU against ~25 GB/s a CU can copy), so a cap of
     8-16 is the value to try first when an 8-GPU run shows the input-gradient GEMMs starving; None (default) leaves
@@ -72,7 +81,11 @@ def init_process_group(backend="nccl", device=None, max_channels=None, **kwargs)
     if max_channels is None and os.environ.get("CPLXAMD_RCCL_MAX_CHANNELS"):
         max_channels = int(os.environ["CPLXAMD_RCCL_MAX_CHANNELS"])
     if max_channels:
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(max_channels)))
+        prev = os.environ.get("NCCL_MAX_NCHANNELS")
+        if prev is not None and prev != str(int(max_channels)):
+            import warnings
+            warnings.warn(f"NCCL_MAX_NCHANNELS={prev} in the environment is replaced by max_channels={int(max_channels)}")
+        os.environ["NCCL_MAX_NCHANNELS"] = str(int(max_channels))      # an explicit argument wins
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend == "nccl" and device is not None:
         kwargs.setdefault("device_id", torch.device(device))
@@ -109,7 +122,6 @@ class _Bucket:
         self.work = None           # async handle once launched
         self.launched = False
         self.events = []           # HIP events behind the kernels that wrote the slices in place
-        self.dirty = False         # a gradient changed after the bucket's collective was launched
         self.early = False         # launched on the side stream, behind the recorded stream positions only
         self.in_order = False      # no stream position could be recorded for a slice (host tensors): plain stream order
         self.copy_bumps = 0        # version-counter increments of `flat` made by on_grad's own copies (see on_grad)
@@ -173,10 +185,21 @@ class BucketHook:
         self._shared_chip = False  # collectives in flight next to compute kernels (see _share_chip)
         self._announced = {}       # id(param) -> HIP event recorded behind the kernels that wrote its slice
         self._side = None          # stream the early collectives are issued from
+        self.accumulate = False    # inside DataParallel.no_sync(): no exchange, gradients pile up in .grad
+        self._handed = set()       # id(param) whose bucket slice a producer holds in this pass (view_for)
 
     # -- storage for gradients (zero-copy path of the linear layers) ---------------------------
     def view_for(self, param):
-        return self.buckets.view(param)
+        """Bucket storage for the gradient `param` is about to receive, or None = use a private tensor: when a gradient
+        has been accumulated already (an earlier pass under no_sync: writing the slice would destroy it -- autograd adds
+        the private tensor instead) and when another producer holds the slice in this pass (a parameter shared by two
+        layers: both writing the same storage would make autograd sum one of them twice)."""
+        if param.grad is not None or id(param) in self._handed:
+            return None
+        v = self.buckets.view(param)
+        if v is not None:
+            self._handed.add(id(param))
+        return v
 
     # -- sharing the chip with RCCL -----------------------------------------------------------------
     def _share_chip(self):
@@ -185,13 +208,13 @@ class BucketHook:
             # (one workgroup per CU for its whole duration) would wait for them with its last workgroups and take
             # twice as long, one workgroup per tile just runs on the CUs that are left (csrc/gemm.h)
             from . import _lib
-            _lib.load().cplxamd_gemm_set_persistent(0)
+            _lib.shared_chip_enter(self)       # every launch from here on carries CPLXAMD_LAUNCH_SHARED (per call: _lib)
             self._shared_chip = True
 
     def _chip_is_ours(self):
         if self._shared_chip:
             from . import _lib
-            _lib.load().cplxamd_gemm_set_persistent(1)
+            _lib.shared_chip_leave(self)
             self._shared_chip = False
 
     # -- readiness ------------------------------------------------------------------------------
@@ -234,7 +257,7 @@ class BucketHook:
         `view_for` storage by kernels already queued.  Nothing is launched here -- other autograd paths may still add
         to these leaves -- but the stream position is remembered: if the gradient autograd finally delivers IS that
         storage, its bucket's all-reduce waits for this point only."""
-        if not self.overlap:
+        if not self.overlap or self.accumulate:
             return
         ev = None
         for p in params:
@@ -260,17 +283,19 @@ class BucketHook:
         if e is None:
             return
         b, off, numel, shape = e
+        self._handed.discard(id(param))
+        if self.accumulate:
+            return                 # no_sync(): .grad keeps accumulating (in the bucket slice or in a private tensor)
         if b.launched:
-            # a second backward pass into an exchanged bucket (see the module docstring): autograd has just accumulated into
-            # the bucket view on the compute stream while the asynchronous all-reduce may still be reading / writing
-            # b.flat.  Order the two: wait for the collective NOW (the accumulate is already queued behind nothing, so this
-            # only bounds the damage window to "before this hook"); sync() re-reduces the bucket.  Training loops that need
-            # several backward passes per exchange call zero_grad() / sync_gradients() between them.
-            for pb, work, _ in self.pending:
-                if pb is b and work is not None:
-                    work.wait()
-            b.dirty = True
-            return
+            # a second backward pass into an exchanged bucket: autograd has ALREADY accumulated into storage the in-flight
+            # all-reduce may be reading or writing -- nothing done here can order the two any more.  Fail loudly instead of
+            # exchanging a gradient that may be torn; the pattern has a supported spelling.
+            name = next((n for n, p, _, _ in b.entries if p is param), "?")
+            raise RuntimeError(
+                f"cplxmodule_amd.dp: a backward pass reached parameter '{name}' after the all-reduce of its bucket was "
+                "launched in this step.  Wrap every backward pass of a step except the last one in "
+                "`DataParallel.no_sync()` (gradient accumulation; `nll.backward(); (c * kl).backward()`), and call "
+                "`zero_grad()` + `sync_gradients()` once per step.")
         view = b.flat[off:off + numel].view(shape)
         ev, version = self._announced.pop(id(param), (None, None))
         if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
@@ -295,9 +320,13 @@ class BucketHook:
 
     # -- step boundary --------------------------------------------------------------------------
     def reset(self):
+        for _, work, _ in self.pending:      # (a step abandoned mid-exchange: never drop a collective that is in flight)
+            if work is not None:
+                work.wait()
         self._chip_is_ours()
         self.pending = []
         self._announced = {}
+        self._handed = set()
         for b in self.buckets.buckets:
             b.reset()
 
@@ -310,8 +339,7 @@ class BucketHook:
                 b.flat.div_(dist.get_world_size())
         self.pending = []
         for b in bk.buckets:
-            redo = b.launched and b.dirty
-            if not b.launched or redo:
+            if not b.launched:
                 # parameters that received no gradient contribute zeros; a gradient that was produced but never
                 # delivered through the hook (hooks bypassed, or accumulated after the exchange) is taken from .grad
                 for n, p, off, numel in b.entries:
@@ -321,7 +349,6 @@ class BucketHook:
                             sl.zero_()
                     elif p.grad.data_ptr() != sl.data_ptr():
                         sl.view_as(p).copy_(p.grad)
-                b.dirty = False
                 self._launch(b, async_op=False)
         for b, work, div in self.pending:
             if div:
@@ -356,6 +383,22 @@ def convert_sync_batchnorm(module, process_group=True):
         if isinstance(m, _CplxBatchNorm):
             m.process_group = process_group
     return module
+
+
+class _NoSync:
+    def __init__(self, hook):
+        self.hook = hook
+
+    def __enter__(self):
+        if self.hook is not None:
+            self.prev = self.hook.accumulate
+            self.hook.accumulate = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.hook is not None:
+            self.hook.accumulate = self.prev
+        return False
 
 
 class DataParallel(torch.nn.Module):
@@ -398,6 +441,20 @@ class DataParallel(torch.nn.Module):
         """Wait for / finish the gradient exchange; afterwards every `.grad` is the mean over ranks."""
         if self.hook is not None:
             self.hook.sync()
+
+    def no_sync(self):
+        """Context manager for every backward pass of a step EXCEPT the last (torch DDP's name and meaning): gradients
+        accumulate in `.grad`, nothing is exchanged; the first backward pass outside it exchanges the totals.
+
+            dpm.zero_grad()
+            with dpm.no_sync():
+                for xb in micro_batches[:-1]:
+                    loss(dpm(xb)).backward()
+            loss(dpm(micro_batches[-1])).backward()
+            dpm.sync_gradients()
+
+        In a world of one (no hook) it does nothing."""
+        return _NoSync(self.hook)
 
     def remove(self):
         """Detach the hooks (tests that wrap the same module more than once)."""

@@ -10,7 +10,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import call, dtype_code, ptr, require_device, scratch_key, stream_ptr, try_call
+from ._lib import call, dtype_code, launch_flags, ptr, require_device, scratch_key, stream_ptr, try_call
 
 _ws_cache = {}
 
@@ -227,10 +227,10 @@ def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False
     b_r, b_i = (None, None) if bias is None else bias
     ws = _gauss_ws(M, N, K, ar.device) if algo == 1 else _gemm_ws(M, N, K, True, ar, cr)
     beta = _beta(beta) if accumulate else None
-    call("cplxamd_cgemm_ex", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
+    call("cplxamd_cgemm_fl", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
          b_strides[0], b_strides[1], ptr(b_r), ptr(b_i), ptr(emul), ptr(cr), ptr(ci), N, M, N, K,
          int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), ptr(beta), int(algo), ptr(ws),
-         0 if ws is None else ws.numel(), stream_ptr())
+         0 if ws is None else ws.numel(), launch_flags(), stream_ptr())
     return cr, ci
 
 
@@ -252,9 +252,9 @@ def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=t
     c = torch.empty(M, N, dtype=out_dtype, device=a.device) if out is None else out
     ws = _gemm_ws(M, N, K, False, a, c)
     beta = _beta(beta) if accumulate else None
-    call("cplxamd_rgemm_ex", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
+    call("cplxamd_rgemm_fl", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
          ptr(bias), ptr(emul), int(emul_exp), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c),
-         int(accumulate), ptr(beta), ptr(ws), 0 if ws is None else ws.numel(), stream_ptr())
+         int(accumulate), ptr(beta), ptr(ws), 0 if ws is None else ws.numel(), launch_flags(), stream_ptr())
     return c
 
 
@@ -522,8 +522,8 @@ def _cplx_lrt_dx(g2r, g2i, wr, wi, x2r, x2i, ga):
             and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (g2r, g2i, wr, wi, x2r, x2i, ga))):
         dxr = torch.empty(B, I, dtype=torch.bfloat16, device=g2r.device)
         dxi = torch.empty_like(dxr)
-        if try_call("cplxamd_cgemm_lrt_dx", ptr(g2r), ptr(g2i), O, 1, ptr(wr), ptr(wi), 1, I, ptr(x2r), ptr(x2i), ptr(ga), I,
-                    ptr(dxr), ptr(dxi), I, B, I, O, dtype_code(g2r), stream_ptr()):
+        if try_call("cplxamd_cgemm_lrt_dx_fl", ptr(g2r), ptr(g2i), O, 1, ptr(wr), ptr(wi), 1, I, ptr(x2r), ptr(x2i), ptr(ga), I,
+                    ptr(dxr), ptr(dxi), I, B, I, O, dtype_code(g2r), launch_flags(), stream_ptr()):
             return dxr, dxi
     dxr, dxi = _cplx_linear_dx(g2r, g2i, wr, wi, x2r.dtype)
     lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
@@ -538,8 +538,8 @@ def _real_lrt_dx(g2, w, x2, ga):
     if (_LRT_DX_FUSE and _is_bf16(g2) and _is_bf16(x2) and _is_bf16(ga) and _is_bf16(w) and I % 8 == 0 and O % 8 == 0
             and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (g2, w, x2, ga))):
         dx = torch.empty(B, I, dtype=torch.bfloat16, device=g2.device)
-        if try_call("cplxamd_rgemm_lrt_dx", ptr(g2), O, 1, ptr(w), 1, I, ptr(x2), ptr(ga), I, ptr(dx), I, B, I, O,
-                    dtype_code(g2), stream_ptr()):
+        if try_call("cplxamd_rgemm_lrt_dx_fl", ptr(g2), O, 1, ptr(w), 1, I, ptr(x2), ptr(ga), I, ptr(dx), I, B, I, O,
+                    dtype_code(g2), launch_flags(), stream_ptr()):
             return dx
     dx = _real_linear_dx(g2, w, x2.dtype)
     lrt_dx_accum(dx, None, x2, None, ga)
@@ -661,6 +661,23 @@ class CplxLinearFn(torch.autograd.Function):
         return dxr, dxi, dwr, dwi, dbr, dbi, None, None
 
 
+def _kl_recompute(ctx):
+    """The (unscaled) KL gradients of a layer once more, for a backward pass that finds its forward-pass buffers consumed
+    (they hold totals by then: a second pass through a retained graph, or the KL-only pass after the data pass under a
+    data-parallel hook).  The recomputation reads the CURRENT parameters: refuse when they changed since the forward pass
+    (optimizer.step() with a retained graph would otherwise give silently wrong numbers -- ADVICE r4)."""
+    if tuple(t._version for t in ctx.kl_params) != ctx.kl_versions:
+        raise RuntimeError("a parameter of this layer was modified in place between its forward pass and a "
+                           "backward pass that has to recompute the KL gradients (e.g. optimizer.step() "
+                           "with a retained graph): the recomputation would use the NEW values")
+    if len(ctx.kl_params) == 3:
+        wr, wi, ls2 = ctx.kl_params
+        return kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:]
+    w, ls2 = ctx.kl_params
+    r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
+    return (r[1], r[2])
+
+
 class CplxLinearLRTFn(torch.autograd.Function):
     """CplxLinearGaussian.forward in training mode (nn/relevance/complex/base.py:43-56):
     mu GEMM + variance GEMM + noise injection, backward per SURVEY A.2.
@@ -726,12 +743,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
             # reference's two-call pattern): needs no saved tensor, so it also works after the data backward freed them
             if gkl is not None and ctx.kl_kind is not None:
                 if ctx.klg is None:          # the buffers hold totals by now: redo the KL part
-                    wr, wi, ls2 = ctx.kl_params
-                    if tuple(t._version for t in ctx.kl_params) != ctx.kl_versions:
-                        raise RuntimeError("a parameter of this layer was modified in place between its forward pass and a "
-                                           "backward pass that has to recompute the KL gradients (e.g. optimizer.step() "
-                                           "with a retained graph): the recomputation would use the NEW values")
-                    ctx.klg, ctx.klg_shared = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:], False
+                    ctx.klg, ctx.klg_shared = _kl_recompute(ctx), False
                 dls2, dwr, dwi = (_scaled(gkl, t) for t in ctx.klg)
                 if ctx.klg_shared:
                     ctx.klg = None           # the hook overwrites the bucket slices with what this pass returns
@@ -743,7 +755,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
         klg = None
         if gkl is not None and ctx.kl_kind is not None:
             # (a second backward through a retained graph: the buffers hold totals by then, redo the KL part)
-            klg = kl_fwd_bwd(ctx.kl_kind, wr, wi, ls2)[1:] if ctx.klg is None else ctx.klg
+            klg = _kl_recompute(ctx) if ctx.klg is None else ctx.klg
         g2r = torch.zeros(B, O, dtype=x2r.dtype, device=x2r.device) if gr is None else gr.reshape(B, O).contiguous()
         g2i = torch.zeros(B, O, dtype=x2r.dtype, device=x2r.device) if gi is None else gi.reshape(B, O).contiguous()
         eps = None if eps_r is None else (eps_r.reshape(B, O), eps_i.reshape(B, O))
@@ -891,6 +903,7 @@ class RealLinearLRTFn(torch.autograd.Function):
         ctx.has_bias, ctx.lead, ctx.seed, ctx.offset = b is not None, x.shape[:-1], seed, offset
         ctx.kl_kind = kl_kind
         ctx.kl_params = (w, ls2) if kl_kind is not None else None
+        ctx.kl_versions = tuple(t._version for t in ctx.kl_params) if kl_kind is not None else None
         return y.view(*ctx.lead, O), kl
 
     @staticmethod
@@ -900,9 +913,7 @@ class RealLinearLRTFn(torch.autograd.Function):
         if g is None:                                        # only the KL term reached the loss (see CplxLinearLRTFn)
             if gkl is not None and ctx.kl_kind is not None:
                 if ctx.klg is None:
-                    w, ls2 = ctx.kl_params
-                    r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
-                    ctx.klg, ctx.klg_shared = (r[1], r[2]), False
+                    ctx.klg, ctx.klg_shared = _kl_recompute(ctx), False
                 dls2, dw = _scaled(gkl, ctx.klg[0]), _scaled(gkl, ctx.klg[1])
                 if ctx.klg_shared:
                     ctx.klg = None
@@ -913,11 +924,7 @@ class RealLinearLRTFn(torch.autograd.Function):
         B = x2.shape[0]
         klg = None
         if gkl is not None and ctx.kl_kind is not None:
-            if ctx.klg is None:                              # second backward through a retained graph
-                r = kl_fwd_bwd(ctx.kl_kind, w, None, ls2)
-                klg = (r[1], r[2])
-            else:
-                klg = ctx.klg
+            klg = _kl_recompute(ctx) if ctx.klg is None else ctx.klg   # (second backward through a retained graph)
         g2 = g.reshape(B, O).contiguous()
         dt = x2.dtype
         e = None if eps is None else eps.reshape(B, O)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 18
+#define CPLXAMD_ABI_VERSION 19
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -54,6 +54,29 @@ enum {
   CPLXAMD_ESHAPE = -3,   /* shape not supported by this entry point */
   CPLXAMD_EWS = -4       /* workspace too small */
 };
+
+/* Per-call launch policy (ABI 19): the `flags` argument of the `*_fl` entry points.  The library keeps NO mutable state
+ * that a launch depends on (SURVEY 8(b) "Threading": re-entrant, no globals except read-only tuning tables): two threads /
+ * streams / models in one process choose their launch forms independently, call by call.  Results do not depend on the
+ * flags (every form of a launch produces the same bits; tests/test_gpu_r04.py, test_gpu_gemm_persist.py, test_gpu_r05.py).
+ *   CPLXAMD_LAUNCH_SHARED     other kernels hold compute units while this launch runs (an RCCL all-reduce overlapping the
+ *                             backward pass): one workgroup per tile instead of the persistent forms, twice as many weight-
+ *                             gradient splits -- a launch that expects every CU would wait for the held ones with its last
+ *                             workgroups.
+ *   CPLXAMD_LAUNCH_EXCLUSIVE  the chip is this launch's: persistent forms wherever they exist.
+ *   neither                   the process default (cplxamd_gemm_set_persistent, deprecated; 1 = exclusive at start).
+ *   CPLXAMD_LAUNCH_FAMILY(m)  bf16 GEMM kernel family mask of THIS launch (bit layout of cplxamd_gemm_set_family);
+ *                             without it the process default applies (0x3f, env CPLXAMD_GEMM_W4).
+ * Both SHARED and EXCLUSIVE, or unknown bits: CPLXAMD_EINVAL.  The flag-less entry points are the `*_fl` ones with
+ * flags = 0. */
+enum {
+  CPLXAMD_LAUNCH_DEFAULT = 0,
+  CPLXAMD_LAUNCH_SHARED = 1,
+  CPLXAMD_LAUNCH_EXCLUSIVE = 2,
+  CPLXAMD_LAUNCH_FAMILY_SET = 0x100,
+  CPLXAMD_LAUNCH_FAMILY_SHIFT = 16
+};
+#define CPLXAMD_LAUNCH_FAMILY(mask) (CPLXAMD_LAUNCH_FAMILY_SET | (((mask) & 0x7f) << CPLXAMD_LAUNCH_FAMILY_SHIFT))
 
 int cplxamd_abi_version(void);
 
@@ -210,9 +233,17 @@ int cplxamd_cgemm_ex(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_c
                      int64_t ldc, int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
                      const float* beta, int algo, void* ws, int64_t ws_bytes, void* stream);
 
+/* cplxamd_cgemm_ex with a per-call launch policy (CPLXAMD_LAUNCH_*, top of this file). */
+int cplxamd_cgemm_fl(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
+                     const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
+                     const float* bias_r, const float* bias_i, const float* emul, void* c_r, void* c_i,
+                     int64_t ldc, int M, int N, int K, int conj_b, int in_dtype, int out_dtype, int accumulate,
+                     const float* beta, int algo, void* ws, int64_t ws_bytes, int flags, void* stream);
+
 int64_t cplxamd_cgemm3m_ws_bytes(int M, int N, int K);
 
-/* Process-wide switch of the persistent form of the bf16 GEMM kernels (returns the previous setting; 1 at start).
+/* DEPRECATED (ABI 19: pass CPLXAMD_LAUNCH_SHARED / _EXCLUSIVE to the `*_fl` entry points instead; this setter only moves
+ * the default that calls with neither flag read).  Process-wide switch of the persistent form of the bf16 GEMM kernels (returns the previous setting; 1 at start).
  * Persistent launches assume the whole chip: turn them off (0) while other kernels are expected to hold CUs -- e.g. an
  * RCCL all-reduce overlapping the backward pass -- and the GEMMs run one workgroup per tile, which shares CUs gracefully.
  * Results are bit-identical either way (tests/test_gpu_gemm_persist.py). */
@@ -229,7 +260,7 @@ int cplxamd_gemm_set_persistent(int on);
  * 0 = the 8-wave LDS-DMA kernels of rounds 1-3 everywhere, -1 = every bit.  Start value 0x3f (env CPLXAMD_GEMM_W4=<mask>
  * overrides).  Both families produce the same bits (same
  * MFMA sequence per accumulator; tests/test_gpu_r04.py). */
-int cplxamd_gemm_set_family(int mask);
+int cplxamd_gemm_set_family(int mask);   /* DEPRECATED as a run-time switch: CPLXAMD_LAUNCH_FAMILY(mask) per call */
 
 /* Optional scratch for split-K (few output tiles, long K -- e.g. the weight gradient at batch
  * 2^20, or a 10-output head): pass >= this many bytes as `ws` to cgemm / rgemm; ws may be NULL
@@ -242,7 +273,7 @@ int64_t cplxamd_gemm_ws_bytes(int M, int N, int K, int cplx, int in_dtype, int o
  * input and ga = d s2 . exp(log_sigma2) [M, N] (cplxamd_rgemm), all bf16, X / ga with row pitch ldx.  The elementwise
  * term rides in the epilogue of the persistent complex kernel (same arithmetic as cplxamd_cgemm followed by
  * cplxamd_lrt_dx_accum: bit-identical results), which saves the 7 plane passes of that second kernel.
- * Launches the persistent kernel does not take (partial tiles, fewer tiles than CUs, cplxamd_gemm_set_persistent(0) = the
+ * Launches the persistent kernel does not take (partial tiles, fewer tiles than CUs, CPLXAMD_LAUNCH_SHARED = the
  * data-parallel form) carry the term in the one-tile kernel's staged epilogue, same bits.  CPLXAMD_ESHAPE when neither
  * epilogue applies (row pitches / N not multiples of 8 elements, unaligned operands): run the two calls instead --
  * nothing is dropped silently. */
@@ -256,6 +287,26 @@ int cplxamd_cgemm_lrt_dx(const void* g_r, const void* g_i, int64_t g_rs, int64_t
 int cplxamd_rgemm_lrt_dx(const void* g, int64_t g_rs, int64_t g_cs, const void* w, int64_t w_rs, int64_t w_cs,
                          const void* x, const void* ga, int64_t ldx, void* dx, int64_t ldc, int M, int N, int K, int dtype,
                          void* stream);
+
+/* The two fused input gradients and cplxamd_rgemm_ex with a per-call launch policy (CPLXAMD_LAUNCH_*). */
+int cplxamd_cgemm_lrt_dx_fl(const void* g_r, const void* g_i, int64_t g_rs, int64_t g_cs,
+                            const void* w_r, const void* w_i, int64_t w_rs, int64_t w_cs,
+                            const void* x_r, const void* x_i, const void* ga, int64_t ldx,
+                            void* dx_r, void* dx_i, int64_t ldc, int M, int N, int K, int dtype, int flags, void* stream);
+int cplxamd_rgemm_lrt_dx_fl(const void* g, int64_t g_rs, int64_t g_cs, const void* w, int64_t w_rs, int64_t w_cs,
+                            const void* x, const void* ga, int64_t ldx, void* dx, int64_t ldc, int M, int N, int K,
+                            int dtype, int flags, void* stream);
+int cplxamd_rgemm_fl(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs,
+                     int64_t b_cs, const float* bias, const float* emul, int emul_exp, void* c, int64_t ldc,
+                     int M, int N, int K, int in_dtype, int out_dtype, int accumulate, const float* beta,
+                     void* ws, int64_t ws_bytes, int flags, void* stream);
+/* Which kernel a bf16 cplxamd_cgemm_fl / cplxamd_rgemm_fl call with these shapes, layouts ("N" = K-contiguous rows: ta /
+ * tb = 0) and flags launches -- a pure function of its arguments and of `ncu`, the device's CU count (0: ask the current
+ * device): 0 generic float32-exact kernel (the bf16 path declines), 1 8-wave one-tile, 2 8-wave persistent, 3
+ * one-wave-per-SIMD (w4), 4 split-K slabs on the 8-wave kernels, 5 split-K slabs on w4.  `epi`: 0 plain / bias, 1 fused
+ * LRT input-gradient term, 2 float32 accumulate / multiplier epilogue.  Dense operands, aligned pointers and a
+ * workspace of cplxamd_gemm_ws_bytes are assumed.  (Dispatch made inspectable: the test of the per-call flags reads it.) */
+int cplxamd_gemm_plan(int cplx, int M, int N, int K, int ta, int tb, int out_dtype, int epi, int flags, int ncu);
 
 /* Batched complex GEMM (Cplx.__matmul__ on [..., M, K] @ [..., K, N], cplx.py:167-181): `batch`
  * independent products in ONE launch of the exact-f32 MFMA kernel (any strides, any dtype pair);
@@ -472,7 +523,7 @@ int cplxamd_conv2d_cl2_lrt_dx(const void* g_r, const void* g_i, const void* w_pa
  * [N][5] float64 of (sum re, sum im, sum re^2, sum im^2, sum re im) over the output pixels it produced -- of the bf16
  * values as stored -- into `partials`.  cplxamd_conv2d_cl2_mom_chunks: the number of rows (0: the variant does not take
  * the problem -- a shape cplxamd_conv2d_cl2 declines, a grid whose workgroups would change column tile, or
- * cplxamd_gemm_set_persistent(0) -- use
+ * CPLXAMD_LAUNCH_SHARED -- use
  * cplxamd_conv2d_cl2 and the layer's own moment pass).  cplxamd_bn_fwd_partials then runs finalize + apply only: one
  * read of y less (csrc/conv_cl2.hip: conv_cl2_kernel<false, true>). */
 int64_t cplxamd_conv2d_cl2_mom_chunks(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w, int pad_h,
@@ -485,6 +536,26 @@ int64_t cplxamd_conv2d_cl_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co
 int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                             float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
                             int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, void* stream);
+/* The six launches above with a per-call launch policy (CPLXAMD_LAUNCH_SHARED: one workgroup per tile / twice the
+ * weight-gradient splits; cplxamd_conv2d_cl2_mom declines under it -- CPLXAMD_ESHAPE, cplxamd_conv2d_cl2_mom_chunks_fl 0). */
+int cplxamd_conv2d_cl_fl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                         void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                         int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, int flags, void* stream);
+int cplxamd_conv2d_cl2_fl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
+                          void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                          int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes, int flags, void* stream);
+int cplxamd_conv2d_cl2_lrt_dx_fl(const void* g_r, const void* g_i, const void* w_packed, const void* x_r, const void* x_i,
+                                 const void* ga, void* dx_r, void* dx_i, int64_t B, int H, int W, int C, int N, int pad_h,
+                                 int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream);
+int64_t cplxamd_conv2d_cl2_mom_chunks_fl(int64_t B, int H, int W, int C, int N, int KH, int KW, int dil_h, int dil_w,
+                                         int pad_h, int pad_w, int flags);
+int cplxamd_conv2d_cl2_mom_fl(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r,
+                              const float* bias_i, void* y_r, void* y_i, int64_t B, int H, int W, int C, int N, int KH, int KW,
+                              int dil_h, int dil_w, int pad_h, int pad_w, double* partials, int64_t partials_bytes, void* ws,
+                              int64_t ws_bytes, int flags, void* stream);
+int cplxamd_conv2d_cl_wgrad_fl(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
+                               float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
+                               int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream);
 /* REAL-valued twins of the three entry points above (csrc/conv_cl_real.hip, conv_cl_wgrad_real.hip): one plane each,
  * same shapes and conditions.  They carry the variance path of the local-reparameterization convolution layers
  * (conv of |x|^2 with exp(log_sigma2): nn/relevance/complex/base.py:120-135, real/base.py:116-163) and the real
@@ -500,6 +571,12 @@ int64_t cplxamd_conv2d_clr_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int C
 int cplxamd_conv2d_clr_wgrad(const void* g, const void* x, const float* emul, int emul_exp, float* dw, int64_t B, int H,
                              int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, void* ws,
                              int64_t ws_bytes, void* stream);
+int cplxamd_conv2d_clr_fl(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int H, int W, int C,
+                          int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws,
+                          int64_t ws_bytes, int flags, void* stream);
+int cplxamd_conv2d_clr_wgrad_fl(const void* g, const void* x, const float* emul, int emul_exp, float* dw, int64_t B, int H,
+                                int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, void* ws,
+                                int64_t ws_bytes, int flags, void* stream);
 /* out[c] = sum over (batch, spatial) of an NCHW tensor (conv bias gradient); ws >= 64*C*8 bytes */
 int cplxamd_chansum(const void* x, float* out, int64_t B, int C, int64_t S, int dtype, void* ws,
                     void* stream);

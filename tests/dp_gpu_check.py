@@ -125,9 +125,11 @@ def main():
             run_fn()
             # persistent GEMM launches are off exactly while RCCL collectives are in flight (dp.BucketHook._launch)
             in_flight = dist.get_backend() == "nccl" and kw.get("overlap", True) and any(b.launched for b in model.buckets.buckets)
-            assert lib.cplxamd_gemm_set_persistent(0 if in_flight else 1) == (0 if in_flight else 1)
-            model.sync_gradients()
+            # ... as a per-call flag (ABI 19): the hook moves no process state of the library
+            assert _lib.launch_flags() == (_lib.LAUNCH_SHARED if in_flight else _lib.LAUNCH_DEFAULT)
             assert lib.cplxamd_gemm_set_persistent(1) == 1
+            model.sync_gradients()
+            assert _lib.launch_flags() == _lib.LAUNCH_DEFAULT
             for n, p in module.named_parameters():
                 if n not in ref:
                     assert p.grad is None, n

@@ -54,3 +54,83 @@ def test_no_gpu_arguments_are_rejected_not_crashed(lib):
     assert rc == -1
     lib.cplxamd_vd_kl_ws_bytes.restype = ctypes.c_int64
     assert lib.cplxamd_vd_kl_ws_bytes() > 0
+
+
+# ---- ABI 19: per-call launch policy; the dispatch as a pure function (no GPU needed) ---------------------------------
+def test_launch_flags_validation_needs_no_gpu(lib):
+    from cplxmodule_amd import _lib
+    L = _lib.load()
+    both = _lib.LAUNCH_SHARED | _lib.LAUNCH_EXCLUSIVE
+    # rejected before any pointer is looked at
+    assert L.cplxamd_cgemm_fl(*([None] * 2), 0, 0, *([None] * 2), 0, 0, *([None] * 5), 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None,
+                              0, both, None) == -1
+    assert L.cplxamd_gemm_plan(1, 256, 128, 128, 0, 0, _lib.BF16, 0, both, 256) == -1
+    assert L.cplxamd_gemm_plan(1, 256, 128, 128, 0, 0, _lib.BF16, 0, 0x8, 256) == -1          # unknown bit
+    assert L.cplxamd_conv2d_cl2_mom_chunks_fl(8, 64, 64, 64, 64, 3, 3, 1, 1, 1, 1, both) == 0
+
+
+def test_gemm_dispatch_follows_the_per_call_flags(lib):
+    """cplxamd_gemm_plan runs the launchers dry: 0 generic, 1 8-wave one-tile, 2 8-wave persistent, 3 one-wave-per-SIMD,
+    4 / 5 split-K slabs (8-wave / w4).  The flags of ONE call decide; the deprecated process defaults only fill in what
+    the flags leave open."""
+    from cplxmodule_amd import _lib
+    L = _lib.load()
+    S, E, F, BF, F32 = _lib.LAUNCH_SHARED, _lib.LAUNCH_EXCLUSIVE, _lib.LAUNCH_FAMILY, _lib.BF16, _lib.F32
+    plan = lambda *a: L.cplxamd_gemm_plan(*a, 256)  # noqa: E731       (ncu = 256: no device is asked)
+    c_fwd = (1, 8192, 4096, 4096, 0, 0, BF, 0)                # the six launches of the bench step
+    c_dx = (1, 8192, 4096, 4096, 0, 1, BF, 1)
+    c_dw = (1, 4096, 4096, 8192, 1, 1, F32, 2)
+    r_fwd = (0, 8192, 4096, 4096, 0, 0, BF, 0)
+    r_dw = (0, 4096, 4096, 8192, 1, 1, F32, 2)
+    for shape in (c_fwd, c_dx, c_dw, r_fwd, r_dw):
+        assert plan(*shape, 0) == plan(*shape, S) == plan(*shape, E) == 3           # w4 is one workgroup per tile anyway
+        assert plan(*shape, F(0x7f)) == 3
+    # without the w4 family: persistent where it exists, and only if the chip is this launch's
+    assert [plan(*c_fwd, F(0) | f) for f in (E, S)] == [2, 1]
+    assert [plan(*c_dx, F(0) | f) for f in (E, S)] == [2, 1]
+    assert [plan(*r_fwd, F(0) | f) for f in (E, S)] == [2, 1]
+    assert plan(*c_dw, F(0) | E) == 1                                               # (accumulate epilogue: one-tile kernel)
+    # configs[3] (K = 2048): the K-depth rule of the w4 family, and its override bit 6
+    cfg4_dx = (1, 65536, 2048, 2048, 0, 1, BF, 1)
+    assert [plan(*cfg4_dx, f) for f in (E, S, F(0x7f) | S)] == [2, 1, 3]
+    assert plan(1, 2048, 2048, 1 << 20, 1, 1, F32, 2, 0) == 5                       # split-K slabs on w4 (complex)
+    assert plan(0, 2048, 2048, 1 << 20, 1, 1, F32, 2, 0) == 4                       # real slabs stay on the 8-wave kernel
+    assert plan(1, 64, 128, 128, 0, 0, BF, 0, 0) == 1 and plan(1, 100, 50, 40, 0, 0, BF, 0, 0) == 0
+    # the deprecated setter moves the DEFAULT only: explicit flags are unaffected
+    prev = L.cplxamd_gemm_set_persistent(0)
+    fam = L.cplxamd_gemm_set_family(0)
+    try:
+        assert plan(*c_fwd, 0) == 1 and plan(*c_fwd, E) == 2 and plan(*c_fwd, F(0x7f)) == 3
+    finally:
+        L.cplxamd_gemm_set_persistent(prev)
+        L.cplxamd_gemm_set_family(fam)
+    assert plan(*c_fwd, 0) == 3
+
+
+def test_host_launch_policy_is_per_thread_and_windowed():
+    """_lib.launch_flags(): thread-local override, else SHARED while any hook's collectives are in flight, else 0."""
+    import threading
+    from cplxmodule_amd import _lib
+    assert _lib.launch_flags() == 0
+    seen = {}
+
+    def other():
+        seen["before"] = _lib.launch_flags()
+        with _lib.launch_policy(_lib.LAUNCH_EXCLUSIVE):
+            seen["inside"] = _lib.launch_flags()
+        seen["after"] = _lib.launch_flags()
+
+    owner = object()
+    with _lib.launch_policy(_lib.LAUNCH_SHARED | _lib.LAUNCH_FAMILY(0)):
+        assert _lib.launch_flags() == 1 | 0x100
+        t = threading.Thread(target=other)
+        t.start(); t.join()
+    assert seen == {"before": 0, "inside": 2, "after": 0}, "one thread's policy is invisible to another"
+    _lib.shared_chip_enter(owner)
+    try:
+        assert _lib.launch_flags() == _lib.LAUNCH_SHARED
+        with _lib.launch_policy(_lib.LAUNCH_EXCLUSIVE):
+            assert _lib.launch_flags() == _lib.LAUNCH_EXCLUSIVE
+    finally:
+        _lib.shared_chip_leave(owner)
+    assert _lib.launch_flags() == 0

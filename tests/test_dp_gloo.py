@@ -171,3 +171,127 @@ def test_shard_rows_cover_everything():
             spans = [dp.shard_rows(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+# ---- the same logic at the world size the driver will launch (8 ranks, CPU, gloo) ---------------
+def _worker8(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from cplxmodule_amd import dp, ops
+    from cplxmodule_amd.nn import relevance as rel
+    from cplxmodule_amd.nn.relevance.noise import noise
+    torch.manual_seed(1000 + rank)
+    model = torch.nn.Sequential()
+    model.add_module("vd", rel.CplxLinearVD(6, 5))             # parameters only (bucket layout); its kernels need the GPU
+    model.add_module("fc1", torch.nn.Linear(7, 16))
+    model.add_module("fc2", torch.nn.Linear(16, 16))
+    model.add_module("fc3", torch.nn.Linear(16, 3))
+    wrapped = dp.DataParallel(model, overlap=True, bucket_mb=150 * 4 / (1 << 20))     # ~150 floats per bucket
+    nb = len(wrapped.buckets.buckets)
+    key = noise.seed
+    net = lambda x: model.fc3(torch.tanh(model.fc2(torch.tanh(model.fc1(x)))))  # noqa: E731
+
+    # one global data set, rows sharded unevenly (1003 = 8 * 125 + 3); per-row losses weighted so that the MEAN over
+    # ranks of the local gradients is the gradient of the global mean loss
+    N = 1003
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(N, 7, generator=g), torch.randn(N, 3, generator=g)
+    lo, hi = dp.shard_rows(N)
+
+    def local_loss(x, y):
+        return ((net(x) - y) ** 2).sum() * (world / N)
+
+    wrapped.zero_grad()
+    local_loss(X[lo:hi], Y[lo:hi]).backward()
+    async_launched = sum(1 for b in wrapped.buckets.buckets if b.launched)
+    wrapped.sync_gradients()
+    got = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    wrapped.zero_grad()
+    model.zero_grad(set_to_none=True)
+    full = torch.autograd.grad(((net(X) - Y) ** 2).sum() / N, [p for n, p in model.named_parameters() if n.startswith("fc")])
+    names = [n for n, _ in model.named_parameters() if n.startswith("fc")]
+    err = max(float((got[n] - f).abs().max() / (f.abs().max() + 1e-12)) for n, f in zip(names, full))
+    vd_none = all(p.grad is None for n, p in model.named_parameters() if n.startswith("vd"))
+
+    # gradient accumulation: two micro-batches under no_sync + a third outside == one pass over the three
+    mid1, mid2 = lo + (hi - lo) // 3, lo + 2 * (hi - lo) // 3
+    wrapped.zero_grad()
+    with wrapped.no_sync():
+        local_loss(X[lo:mid1], Y[lo:mid1]).backward()
+        none_in_flight = not any(b.launched for b in wrapped.buckets.buckets)
+        local_loss(X[mid1:mid2], Y[mid1:mid2]).backward()
+        none_in_flight &= not any(b.launched for b in wrapped.buckets.buckets)
+    local_loss(X[mid2:hi], Y[mid2:hi]).backward()
+    wrapped.sync_gradients()
+    acc_err = max(float((model.get_parameter(n).grad - got[n]).abs().max() / (got[n].abs().max() + 1e-12)) for n in names)
+    in_bucket = all(model.get_parameter(n).grad.data_ptr() == wrapped.buckets.view(model.get_parameter(n)).data_ptr()
+                    for n in names)
+
+    # a second backward pass WITHOUT no_sync reaches an exchanged bucket: loud error, not a torn gradient
+    wrapped.zero_grad()
+    local_loss(X[lo:mid1], Y[lo:mid1]).backward()
+    raised = False
+    try:
+        local_loss(X[mid1:hi], Y[mid1:hi]).backward()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    wrapped.zero_grad()                 # (waits for what is in flight)
+
+    # a parameter used by two zero-copy producers in one pass (tied weights): the second one must not get the same
+    # bucket storage -- autograd would add one of the two gradients twice
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, gy):
+            x, w = ctx.saved_tensors
+            dw = ops.grad_buffer(w)
+            torch.mm(gy.t(), x, out=dw)
+            ops._announce(w)
+            return gy @ w, dw
+
+    w2 = model.fc2.weight
+    h = torch.randn(9, 16, generator=torch.Generator().manual_seed(11 + rank))
+    tied = lambda f: (f(torch.tanh(f(h, w2)), w2) ** 2).sum()  # noqa: E731
+    expect = torch.autograd.grad(tied(lambda a, w: a @ w.t()), w2)[0]
+    dist.all_reduce(expect)
+    wrapped.zero_grad()
+    tied(Producer.apply).backward()
+    wrapped.sync_gradients()
+    tied_err = float((w2.grad - expect / world).abs().max() / expect.abs().max())
+
+    kl = float(dp.all_reduce_scalar_mean(torch.tensor(float(rank))))
+    wrapped.remove()
+    out.put((rank, nb, key, (lo, hi), err, vd_none, async_launched, acc_err, none_in_flight, in_bucket, raised, tied_err, kl))
+    dist.destroy_process_group()
+
+
+def test_dp_world8_gloo():
+    world = 8
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[1] >= 3 for r in res), "at least three buckets per rank"
+    assert len({r[2] for r in res}) == world, "eight distinct rank-folded Philox keys"
+    spans = [r[3] for r in res]
+    assert spans[0][0] == 0 and spans[-1][1] == 1003 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert sorted(b - a for a, b in spans) == [125] * 5 + [126] * 3, "uneven shards differ by one row"
+    for r in res:
+        assert r[4] < 2e-5, ("mean over ranks of the weighted local gradients == gradient of the global mean loss", r[4])
+        assert r[5] and r[6] >= 1
+        assert r[7] < 2e-5 and r[8] and r[9], "no_sync: accumulated micro-batches == one pass; nothing launched inside"
+        assert r[10], "second backward without no_sync raises"
+        assert r[11] < 2e-5, "tied weights with two zero-copy producers"
+        assert r[12] == 3.5
