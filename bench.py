@@ -28,7 +28,9 @@ IN_F = OUT_F = 4096
 BATCH = 8192
 KLW = 1e-3
 BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak, MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3      # ... float32 MFMA (the 1e-5 parity mode's kernels)
 HBM_PEAK_GBS = 8000.0
+HBM_COPY_GBS = 6300.0         # what a plain copy reaches (same guide): anything above was not served by HBM alone
 
 
 def parse():
@@ -217,7 +219,7 @@ def hbm_points(dev):
     return out
 
 
-def conv_point(dev, batch=256):
+def conv_point(dev, batch=256, dtype=torch.bfloat16):
     """BASELINE configs[2] beside the headline (rank 0, N = 1, outside the timed region): CplxConv2d(64, 64, 3) on
     256 x 256 bf16 images + CplxBatchNorm2d, forward + backward, channels-last input, `batch` images per step;
     images/s over 10 steps and the three convolution kernels' share of the dense bf16 MFMA peak (HIP events around
@@ -229,7 +231,7 @@ def conv_point(dev, batch=256):
         timer.wrap(cv, "cl_wgrad", lambda *a, **k: "wgrad")
         torch.manual_seed(0)
         layer, bn = nn.CplxConv2d(64, 64, 3).to(dev), nn.CplxBatchNorm2d(64).to(dev)
-        mk = lambda: (torch.randn(batch, 64, 256, 256, device=dev).bfloat16()  # noqa: E731
+        mk = lambda: (torch.randn(batch, 64, 256, 256, device=dev).to(dtype)  # noqa: E731
                       .contiguous(memory_format=torch.channels_last).requires_grad_(True))
         x = Cplx(mk(), mk())
 
@@ -248,8 +250,13 @@ def conv_point(dev, batch=256):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
         flop = 8.0 * batch * 64 * 254 * 254 * 64 * 9
-        out = {"workload": f"CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, bf16, batch {batch}, fwd+bwd, channels-last",
+        name = "bf16" if dtype == torch.bfloat16 else "fp32"
+        out = {"workload": f"CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, {name}, batch {batch}, fwd+bwd, channels-last",
                "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flop_per_launch": flop}
+        if dtype != torch.bfloat16:
+            # the 1e-5 mode (exact-float32 MFMA kernels): three convolution launches' flop over the whole step
+            out["frac_of_fp32_mfma_peak_whole_step"] = round(3 * flop / dt / 1e12 / FP32_PEAK_TFLOPS, 4)
+            return out
         for k in ("fwd", "dgrad", "wgrad"):
             ms = timer.mean_ms(k)
             out[f"{k}_ms"] = round(ms, 4) if ms else None
@@ -260,6 +267,108 @@ def conv_point(dev, batch=256):
         return out
     except Exception as e:  # pragma: no cover
         return {"error": str(e)[:200]}
+
+
+def fp32_points(dev):
+    """The float32 mode -- the one the 1e-5 parity bar is stated in -- at BASELINE's FULL sizes, so that it has a throughput
+    on record: configs[3] at batch 2^20 (about 150 GB of float32 planes: only on a GPU with that much
+    free) and configs[2] at batch 256 channels-last.  Exact-float32 MFMA kernels (157.3 TF/s peak); rank 0, N = 1,
+    outside the timed region."""
+    out = {}
+    try:
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info(dev)
+        if free >= 200 << 30:
+            out["cfg4_lrt_fp32"] = cfg4_point(dev, dtype=torch.float32, steps=2)
+        else:
+            out["cfg4_lrt_fp32"] = {"skipped": f"{free >> 30} GiB free, the float32 step at batch 2^20 wants ~150"}
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info(dev)
+        if free >= 120 << 30:
+            out["conv_cfg3_fp32"] = conv_point(dev, dtype=torch.float32)
+        else:
+            out["conv_cfg3_fp32"] = {"skipped": f"{free >> 30} GiB free"}
+        torch.cuda.empty_cache()
+    except Exception as e:  # pragma: no cover
+        out["error"] = str(e)[:200]
+    return out
+
+
+def dp_projection(dev):
+    """COMPUTE SIDE ONLY -- NOT A SCALING MEASUREMENT.  What one GPU needs for the per-rank share
+    of a STRONG-scaling run: the step of configs[1] (+VD) and configs[3] at per-rank batch B / N, N in {1, 2, 4, 8}, on this
+    one GPU, eager, with the gradient exchange's host path switched on where a process group exists (world-of-one RCCL
+    collectives, bench.py --force-collectives) -- otherwise plain.  The weight-side work (KL, operand preparation, weight
+    gradient epilogues, the bucket exchange) does not shrink with N; `ideal_over_this` = (time at N = 1) / (N x time at
+    N): the ceiling the compute side puts on strong-scaling efficiency before any link is involved."""
+    out = {"note": "compute side only, one GPU, per-rank batch B/N -- not a scaling measurement"}
+    try:
+        from cplxmodule_amd import Cplx, dp
+        from cplxmodule_amd.nn import relevance as rel
+        klw = torch.tensor(KLW, device=dev)
+        own_group = False
+        if not dp.is_initialized():
+            # a world-of-one RCCL group for the duration of the sweep, so that the bucket all-reduces are really issued
+            # (RCCL prints a banner to stdout when the communicator is created: keep this process's one JSON line clean)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29591")
+                dp.init_process_group("nccl", device=dev, rank=0, world_size=1)
+                own_group = True
+                warm = torch.zeros(8, device=dev)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            except Exception as e:  # pragma: no cover
+                out["process_group_error"] = str(e)[:120]
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
+        forced, dp.FORCE_COLLECTIVES = dp.FORCE_COLLECTIVES, dp.is_initialized()
+        exchanging = dp._exchanging()
+        out["gradient_exchange"] = "RCCL world of one, forced collectives" if exchanging else "none (no process group)"
+        for name, feat, full in (("cfg2_vd(4096->4096, global batch 8192)", 4096, 8192),
+                                 ("cfg4(2048->2048, global batch 2^20)", 2048, 1 << 20)):
+            torch.manual_seed(0)
+            layer = rel.CplxLinearVD(feat, feat).to(dev)
+            model = dp.DataParallel(layer)
+            rows = {}
+            for n in (1, 2, 4, 8):
+                B = full // n
+                x = Cplx(torch.randn(B, feat, device=dev, dtype=torch.bfloat16).requires_grad_(True),
+                         torch.randn(B, feat, device=dev, dtype=torch.bfloat16).requires_grad_(True))
+
+                def step():
+                    model.zero_grad()
+                    x.real.grad = x.imag.grad = None
+                    y = model(x)
+                    kl = sum(rel.penalties(layer))
+                    torch.autograd.backward((y.real, y.imag, kl), (y.real.detach() * 2, y.imag.detach() * 2, klw))
+                    model.sync_gradients()
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                k = 3 if full > 8192 else 20
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    step()
+                torch.cuda.synchronize()
+                rows[n] = (time.perf_counter() - t0) / k * 1e3
+                del x
+            model.remove()
+            out[name] = {f"N={n}": {"per_rank_batch": full // n, "ms_per_step": round(t, 4),
+                                     "ideal_over_this": round(rows[1] / (n * t), 4)} for n, t in rows.items()}
+            del layer, model
+            torch.cuda.empty_cache()
+        dp.FORCE_COLLECTIVES = forced
+        if own_group:
+            dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        out["error"] = str(e)[:200]
+    return out
 
 
 # The reference itself (PyTorch CPU path of ivannz/cplxmodule) cannot travel to the GPU box; its numbers are the ones taken
@@ -285,7 +394,7 @@ def gemm_launch_table(spans_mean, B, I, O):
     return launches, frac
 
 
-def cfg4_point(dev, log2_batch=20, timer=None):
+def cfg4_point(dev, log2_batch=20, timer=None, dtype=torch.bfloat16, batch=None, steps=3):
     """BASELINE configs[3] (rank 0, N = 1, outside the timed region): CplxLinearVD(2048, 2048), bf16 activations, batch
     2^20, LRT forward + fused KL + full backward, loss = sum |y|^2 + 1e-3 KL; ms per step over 3 steps; then one more
     step with HIP events around every GEMM launch (K = 2048: half the K depth of the headline layer)."""
@@ -293,12 +402,12 @@ def cfg4_point(dev, log2_batch=20, timer=None):
         from cplxmodule_amd import Cplx
         from cplxmodule_amd.nn import relevance as rel
         torch.manual_seed(0)
-        B, F = 1 << log2_batch, 2048
+        B, F = (1 << log2_batch) if batch is None else batch, 2048
         layer = rel.CplxLinearVD(F, F).to(dev)
         with torch.no_grad():
             layer.log_sigma2.uniform_(-12, 4)
-        x = Cplx(torch.randn(B, F, device=dev, dtype=torch.bfloat16).requires_grad_(True),
-                 torch.randn(B, F, device=dev, dtype=torch.bfloat16).requires_grad_(True))
+        x = Cplx(torch.randn(B, F, device=dev, dtype=dtype).requires_grad_(True),
+                 torch.randn(B, F, device=dev, dtype=dtype).requires_grad_(True))
         klw = torch.tensor(KLW, device=dev)
 
         def step():
@@ -308,19 +417,22 @@ def cfg4_point(dev, log2_batch=20, timer=None):
             kl = sum(rel.penalties(layer))
             gr, gi = y.real.detach() * 2, y.imag.detach() * 2
             torch.autograd.backward((y.real, y.imag, kl), (gr, gi, klw))
-        for _ in range(2):
+        for _ in range(2 if dtype == torch.bfloat16 else 1):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
+        dt = (time.perf_counter() - t0) / steps
         flop = 3 * (8 + 2) * float(B) * F * F
-        out = {"workload": f"CplxLinearVD(2048,2048), bf16, batch 2^{log2_batch}, LRT fwd + KL + full bwd",
+        bf = dtype == torch.bfloat16
+        out = {"workload": f"CplxLinearVD(2048,2048), {'bf16' if bf else 'fp32'}, batch "
+                           f"{('2^%d' % log2_batch) if batch is None else batch}, LRT fwd + KL + full bwd",
                "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1),
                "tflops_whole_step": round(flop / dt / 1e12, 1),
-               "frac_of_mfma_peak_whole_step": round(flop / dt / 1e12 / BF16_PEAK_TFLOPS, 4)}
+               ("frac_of_mfma_peak_whole_step" if bf else "frac_of_fp32_mfma_peak_whole_step"):
+                   round(flop / dt / 1e12 / (BF16_PEAK_TFLOPS if bf else FP32_PEAK_TFLOPS), 4)}
         if timer is not None:
             keep, timer.spans, timer.enabled = timer.spans, {}, True
             step()
@@ -386,8 +498,9 @@ def cfg5_point(dev, batch=256, width=8, steps=100):
 def cfg2_point(dev):
     """BASELINE configs[1] as written (rank 0, N = 1, outside the timed region): plain CplxLinear(4096, 4096), bf16,
     batch 8192, forward + backward with the 4-GEMM kernel (`cplx.linear`, one fused 4M launch per pass) and with
-    Gauss's 3-GEMM form (`cplx.linear_3m`): ms per step and samples/s of each, fraction of the MFMA peak on the
-    flop each algorithm must execute (8 / 6 B I O per pass, 3 passes)."""
+    Gauss's 3-GEMM form (`cplx.linear_3m(..., true_3m=True)`; the plain `cplx.linear_3m` call is routed to the 4M kernel
+    for bf16 and is timed as "3m"): ms per step and samples/s of each, fraction of the MFMA peak on the flop each
+    algorithm must execute (8 / 6 B I O per pass, 3 passes)."""
     try:
         from cplxmodule_amd import Cplx, cplx, nn
         torch.manual_seed(0)
@@ -395,7 +508,10 @@ def cfg2_point(dev):
         x = Cplx(torch.randn(BATCH, IN_F, device=dev, dtype=torch.bfloat16).requires_grad_(True),
                  torch.randn(BATCH, IN_F, device=dev, dtype=torch.bfloat16).requires_grad_(True))
         out = {"workload": "CplxLinear(4096,4096), bf16, batch 8192, fwd+bwd (dX, dW, db)"}
-        for name, fn, mul in (("4m", cplx.linear, 8.0), ("3m", cplx.linear_3m, 6.0)):
+        true_3m = lambda x_, w_, b_: cplx.linear_3m(x_, w_, b_, true_3m=True)  # noqa: E731
+        # "3m" = cplx.linear_3m as a user gets it (bf16: routed to the 4M kernel, priced on ITS 8 B I O flop);
+        # "3m_true" = the three real MFMA GEMMs + combine (CPLXAMD_TRUE_3M=1), priced on 6 B I O
+        for name, fn, mul in (("4m", cplx.linear, 8.0), ("3m", cplx.linear_3m, 8.0), ("3m_true", true_3m, 6.0)):
             def step():
                 layer.zero_grad(set_to_none=True)
                 x.real.grad = x.imag.grad = None
@@ -635,6 +751,14 @@ def main():
             line["conv_cfg3"] = conv_point(dev)
             line["cfg4_lrt"] = cfg4_point(dev, timer=timer)
             line["cfg5_train_step"] = cfg5_point(dev)
+            line["fp32_full_size"] = fp32_points(dev)
+            line["dp_projection"] = dp_projection(dev)
+            # a figure above what a copy reaches on this chip (6.3 TB/s, MI355X_MICROARCH.md) was not served by HBM: an
+            # in-step kernel whose operands the preceding GEMM left in the 256-MiB Infinity Cache.  Mark, do not boast.
+            hk = line["hbm_kernels_GBps"]
+            hk["cache_assisted"] = {k: True for k, v in list(hk.items())
+                                    if isinstance(v, (int, float)) and k != "peak" and v > HBM_COPY_GBS}
+            hk["cache_assisted_rule"] = f"> {HBM_COPY_GBS:.0f} GB/s = above the achievable HBM copy rate: fed from the Infinity Cache"
             line["cpu_baseline"] = cpu_baseline(512)
             line["reference_cpu"] = REFERENCE_CPU
         print(json.dumps(line), flush=True)

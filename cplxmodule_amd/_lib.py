@@ -158,11 +158,13 @@ _lib = None
 
 # ---- per-call launch policy (include/cplxamd.h CPLXAMD_LAUNCH_*) ----------------------------------------------------
 # The C ABI keeps no mutable launch state: every GEMM / channels-last convolution call carries its flags.  WHO decides
-# lives here, on the host: (1) a per-thread override (`with launch_policy(flags):` -- tests, A/B runs, a serving thread
-# that knows it shares the chip), else (2) LAUNCH_SHARED while any data-parallel hook of this process has collectives in
-# flight (`shared_chip_enter` / `_leave`: cplxmodule_amd.dp.BucketHook; the window is a property of the CHIP, so every
-# model launching into it shares), else (3) 0 = the library's defaults.  A hipGraph capture bakes in the flags of its
-# capture pass, exactly as it bakes in every other launch argument.
+# lives here, on the host: (1) an override registered for the STREAM the call is launched on (`with launch_policy(flags):`
+# -- tests, A/B runs, a serving stream that knows it shares the chip; keyed by stream, not by thread, because autograd
+# runs a layer's backward on an engine thread but on the forward's stream), else (2) LAUNCH_SHARED while any
+# data-parallel hook of this process has collectives in flight (`shared_chip_enter` / `_leave`:
+# cplxmodule_amd.dp.BucketHook; the window is a property of the CHIP, so every model launching into it shares), else
+# (3) 0 = the library's defaults.  A hipGraph capture bakes in the flags of its capture pass, exactly as it bakes in every
+# other launch argument.
 LAUNCH_DEFAULT, LAUNCH_SHARED, LAUNCH_EXCLUSIVE = 0, 1, 2
 
 
@@ -170,42 +172,57 @@ def LAUNCH_FAMILY(mask):
     return 0x100 | ((int(mask) & 0x7f) << 16)
 
 
-_policy = threading.local()
+_policy = {}               # (device index, raw stream handle) -> flags
 _sharing = set()           # id() of the hooks whose collectives are in flight
-_sharing_lock = threading.Lock()
+_policy_lock = threading.Lock()
+
+
+def _stream_key():
+    if not torch.cuda.is_available():
+        return (-1, 0)
+    idx = torch.cuda.current_device()
+    return (idx, _current_stream_handle(idx))
 
 
 def launch_flags():
-    """Flags of the next GEMM / convolution launch of the calling thread."""
-    f = getattr(_policy, "flags", None)
-    if f is not None:
-        return f
+    """Flags of the next GEMM / convolution launch on the current stream."""
+    if _policy:
+        f = _policy.get(_stream_key())
+        if f is not None:
+            return f
     return LAUNCH_SHARED if _sharing else LAUNCH_DEFAULT
 
 
 class launch_policy:
-    """`with launch_policy(LAUNCH_SHARED):` -- the calling thread's launches carry these flags (None: back to automatic)."""
+    """`with launch_policy(LAUNCH_SHARED):` -- launches on the stream that is current at entry carry these flags until
+    exit (forward AND backward: autograd replays a node's backward on its forward's stream)."""
 
     def __init__(self, flags):
-        self.flags = flags
+        self.flags = int(flags)
 
     def __enter__(self):
-        self.prev = getattr(_policy, "flags", None)
-        _policy.flags = self.flags
+        self.key = _stream_key()
+        with _policy_lock:
+            self.prev = _policy.get(self.key)
+            _policy[self.key] = self.flags
         return self
 
     def __exit__(self, *exc):
-        _policy.flags = self.prev
+        with _policy_lock:
+            if self.prev is None:
+                _policy.pop(self.key, None)
+            else:
+                _policy[self.key] = self.prev
         return False
 
 
 def shared_chip_enter(owner):
-    with _sharing_lock:
+    with _policy_lock:
         _sharing.add(id(owner))
 
 
 def shared_chip_leave(owner):
-    with _sharing_lock:
+    with _policy_lock:
         _sharing.discard(id(owner))
 
 

@@ -248,28 +248,72 @@ def _cl_pack(wr, wi, dgrad):
     return out
 
 
-# Convolutions whose output a training-mode batch-norm layer consumed last time (keyed by the weight parameter, weakly):
+# Convolutions whose output a training-mode batch-norm layer consumed recently (keyed by the weight parameter, weakly):
 # their next forward also forms that layer's statistics in its epilogue (cplxamd_conv2d_cl2_mom) -- armed by the
 # consumer, like the KL fusion of the relevance layers, so a convolution nothing normalises never pays for it.
-_MOMENTS_WANTED = {}          # id(weight plane) -> weak reference to it (tensors compare elementwise: no WeakSet)
+#  * A request is a CREDIT, not a switch: every armed forward spends one, every consuming batch-norm forward refills it to
+#    _MOMENTS_CREDIT.  A convolution whose output stops feeding a batch-norm layer (the model was edited, the layer went to
+#    evaluation mode, another consumer took over) therefore pays the +10 % epilogue for at most that many more steps.
+#  * Implicit arming means step 1 (the layer's own moment pass: float64 sums over the stored output) and steps >= 2 (the
+#    epilogue's per-workgroup float32 partial sums, summed in float64) take different kernels; both are within 1e-6 of the
+#    exact moments but not bit-equal to each other, and the epilogue's summation order follows the launch grid (i.e. the
+#    per-call launch flags).  For bit-reproducible statistics from the first step on, arm at model-build time with
+#    `arm_conv_bn(model)` (permanent requests), or switch the path off (CPLXAMD_CONV_BN_MOMENTS=0).
+_MOMENTS_WANTED = {}          # id(weight plane) -> [weak reference to it, credit]   (tensors compare elementwise: no WeakSet)
 _MOMENTS = os.environ.get("CPLXAMD_CONV_BN_MOMENTS", "1") != "0"      # (A/B: 0 = the layer's own moment pass, always)
+_MOMENTS_CREDIT = 2
+_PERMANENT = 1 << 60
 
 
-def want_moments(weight_plane, on=True):
-    """Called by the batch-norm forward with the tag the convolution left on its output (`_cplxamd_conv_src`)."""
+def want_moments(weight_plane, on=True, permanent=False):
+    """Called by the batch-norm forward with the tag the convolution left on its output (`_cplxamd_conv_src`);
+    on=False withdraws the request (evaluation mode, synchronised statistics) unless it is a permanent one."""
     if weight_plane is None:
         return
     key = id(weight_plane)
+    cur = _MOMENTS_WANTED.get(key)
+    if cur is not None and cur[0]() is not weight_plane:
+        cur = None                                     # (an id re-used by another tensor)
     if on:
-        if key not in _MOMENTS_WANTED:
-            _MOMENTS_WANTED[key] = weakref.ref(weight_plane, lambda _, k=key: _MOMENTS_WANTED.pop(k, None))
-    else:
+        credit = _PERMANENT if permanent or (cur is not None and cur[1] >= _PERMANENT) else _MOMENTS_CREDIT
+        if cur is None:
+            _MOMENTS_WANTED[key] = [weakref.ref(weight_plane, lambda _, k=key: _MOMENTS_WANTED.pop(k, None)), credit]
+        else:
+            cur[1] = credit
+    elif cur is None or cur[1] < _PERMANENT or permanent:
         _MOMENTS_WANTED.pop(key, None)
 
 
-def moments_wanted(weight_plane):
+def moments_wanted(weight_plane, spend=False):
+    """Is the moments epilogue requested for this convolution?  spend=True (the convolution's forward): uses up one
+    credit of the request."""
     r = _MOMENTS_WANTED.get(id(weight_plane))
-    return r is not None and r() is weight_plane
+    if r is None or r[0]() is not weight_plane:
+        return False
+    if spend and r[1] < _PERMANENT:
+        r[1] -= 1
+        if r[1] <= 0:
+            _MOMENTS_WANTED.pop(id(weight_plane), None)
+    return True
+
+
+def arm_conv_bn(module, on=True):
+    """Arm (permanently, at model-build time) the moments epilogue of every CplxConv2d that is DIRECTLY followed by a
+    CplxBatchNorm2d inside a torch.nn.Sequential of `module`: the first training step then runs the same kernels as every
+    later one (bit-reproducible batch statistics from step 1, a hipGraph captured without warm-up steps captures the armed
+    variant).  The pair still falls back to the layer's own moment pass whenever the kernel variant does not take the
+    shape or the launch flags (float32, dilation, CPLXAMD_LAUNCH_SHARED).  Returns the number of pairs (un)armed."""
+    from .nn.modules.batchnorm import CplxBatchNorm2d
+    from .nn.modules.conv import CplxConv2d
+    n = 0
+    for m in module.modules():
+        if isinstance(m, torch.nn.Sequential):
+            kids = list(m.children())
+            for a, b in zip(kids, kids[1:]):
+                if type(a) is CplxConv2d and isinstance(b, CplxBatchNorm2d):
+                    want_moments(a.weight.real, on=on, permanent=True)
+                    n += 1
+    return n
 
 
 def cl_conv(xr, xi, wr, wi, br, bi, geom, dgrad=False, moments=False):
@@ -712,7 +756,7 @@ def cplx_conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, group
         return Cplx(yr.permute(0, 3, 1, 2), yi.permute(0, 3, 1, 2))
     wkey = weight.real
     yr, yi = CplxConv2dFn.apply(xr, xi, wkey, weight.imag, br, bi, stride, padding,
-                                dilation, groups, _MOMENTS and moments_wanted(wkey))
+                                dilation, groups, _MOMENTS and moments_wanted(wkey, spend=True))
     if _MOMENTS and yr.dtype == torch.bfloat16:
         yr._cplxamd_conv_src = weakref.ref(wkey)       # (a batch-norm layer that consumes yr arms the moments epilogue)
     return Cplx(yr, yi)

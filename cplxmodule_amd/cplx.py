@@ -6,6 +6,7 @@ functions (`linear`, `conv2d`, `@`) and `abs` run on the HIP kernels of libcplxa
 pointwise arithmetic and views stay as torch plumbing on the two planes.
 """
 import math
+import os
 from copy import deepcopy
 
 import torch
@@ -289,10 +290,19 @@ def linear(input, weight, bias=None):
     return Cplx(yr, yi)
 
 
-def linear_3m(input, weight, bias=None):
-    """Gauss's three-product form (cplxmodule/cplx.py:651-672): three real MFMA GEMMs + a fused
-    combine for bf16 activations (operand sums rounded to bf16); float32 runs the exact 4M kernel.
-    Slower than `linear` on MI355X (DESIGN.md "3M vs 4M"), kept for the reference's API."""
+# CPLXAMD_TRUE_3M=1: `linear_3m` really runs Gauss's three products (A/B, accuracy studies); default 0 -- see linear_3m
+_TRUE_3M = os.environ.get("CPLXAMD_TRUE_3M", "0") == "1"
+
+
+def linear_3m(input, weight, bias=None, true_3m=None):
+    """Gauss's three-product form (cplxmodule/cplx.py:669-694).  On the reference's CPU path it is the FAST spelling of
+    `linear` (0.64x the time); here it must not be a pessimisation: for bf16 activations the one-loop 4M MFMA kernel is
+    both faster (2.32 vs 2.60 ms fwd+bwd at configs[1]: the K loop is issue / LDS bound, not MFMA bound, so dropping a
+    quarter of the MFMAs buys nothing -- profiles/r04_gemm_w4_ab.txt section 8) and more accurate (no bf16-rounded operand
+    sums), so by default `linear_3m` IS `linear`.  `true_3m=True` (or env CPLXAMD_TRUE_3M=1) runs the three real MFMA
+    GEMMs + fused combine (operand sums rounded to bf16; float32 activations always take the exact 4M kernel)."""
+    if not (_TRUE_3M if true_3m is None else true_3m):
+        return linear(input, weight, bias)
     br, bi = (None, None) if bias is None else (bias.real, bias.imag)
     yr, yi = ops.CplxLinearFn.apply(input.real, input.imag, weight.real, weight.imag, br, bi, 1)
     return Cplx(yr, yi)

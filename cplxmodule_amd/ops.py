@@ -1384,11 +1384,31 @@ class CplxMulFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
-    @once_differentiable      # raw kernels: a double backward (gradient penalties) raises instead of returning zeros
     def backward(ctx, gr, gi):
-        gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
         need_a, need_b = ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         da = db = (None, None)
+        if torch.is_grad_enabled():
+            # create_graph=True (gradient penalties, Hessian-vector products): the reference's product is a composition of
+            # differentiable torch ops (cplx.py:135-146), so its backward is differentiable too -- the raw kernels below are
+            # not.  Same formulas, spelled with torch ops on the saved (graph-connected) tensors.
+            gr = torch.zeros_like(ctx.saved_tensors[0]) if gr is None else gr
+            gi = torch.zeros_like(ctx.saved_tensors[0]) if gi is None else gi
+            if ctx.div:
+                br, bi, yr, yi = ctx.saved_tensors
+                n2 = br * br + bi * bi
+                if need_a:            # g / conj(b) = g b / |b|^2
+                    da = ((gr * br - gi * bi) / n2, (gr * bi + gi * br) / n2)
+                if need_b:            # -g conj(y) / conj(b)
+                    tr, ti = gr * yr + gi * yi, gi * yr - gr * yi
+                    db = (-(tr * br - ti * bi) / n2, -(tr * bi + ti * br) / n2)
+            else:
+                ar, ai, br, bi = ctx.saved_tensors
+                if need_a:            # g conj(b)
+                    da = (gr * br + gi * bi, gi * br - gr * bi)
+                if need_b:            # g conj(a)
+                    db = (gr * ar + gi * ai, gi * ar - gr * ai)
+            return da[0], da[1], db[0], db[1], None
+        gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
         if ctx.div:
             br, bi, yr, yi = ctx.saved_tensors
             if need_a:
@@ -1424,9 +1444,11 @@ class SplitReluFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gr, gi):
         yr, yi = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True: differentiable spelling (d/dg of g * [y > 0]; see CplxMulFn.backward)
+            return (None if gr is None else gr * (yr > 0).to(gr.dtype)), (None if gi is None else gi * (yi > 0).to(gi.dtype))
         gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
         dxr, dxi = torch.empty_like(yr), torch.empty_like(yi)
         call("cplxamd_split_relu", ptr(yr), ptr(yi), ptr(gr), ptr(gi), ptr(dxr), ptr(dxi), yr.numel(), 1, dtype_code(yr),

@@ -148,6 +148,63 @@ def main():
     check(layer, run, ref, 2e-3, overlap=False)
     check(layer, run, ref, 2e-3, overlap=True, bucket_mb=0.01)
 
+    # ---- several backward passes per exchange (round 5: DataParallel.no_sync) on the real kernels ----------------------
+    # (a) the reference's two-call pattern nll.backward(); (c * kl).backward(): the first pass under no_sync, the exchange
+    #     happens once, with the totals == the single combined backward (fused KL epilogues, bucket storage and all)
+    def run_two_calls(model):
+        noise.manual_seed(77 + rank)
+        y = layer(x)
+        kl = sum(rel.penalties(layer))
+        with model.no_sync():
+            (y.real.float().square().sum() + y.imag.float().square().sum()).backward()
+            assert not any(b.launched for b in model.buckets.buckets), "nothing is exchanged inside no_sync"
+        (klw * kl).backward()
+
+    # (b) gradient accumulation over two micro-batches (rows 0:64 under no_sync, rows 64:128 outside) == one pass over
+    #     both with the same noise per row is not expressible (the noise stream is per launch), so compare with the
+    #     hand-made sum of the two micro-batch gradients instead
+    halves = [Cplx(x.real[i:i + 64].contiguous(), x.imag[i:i + 64].contiguous()) for i in (0, 64)]
+
+    def micro(i):
+        noise.manual_seed(500 + 10 * rank + i)
+        y = layer(halves[i])
+        kl = sum(rel.penalties(layer))
+        (y.real.float().square().sum() + y.imag.float().square().sum() + 0.5 * klw * kl).backward()
+
+    def run_micro_plain():
+        micro(0)
+        micro(1)                          # plain autograd accumulation into .grad
+
+    ref_micro = hand_average(layer, run_micro_plain)
+    model = dp.DataParallel(layer)
+    for _ in range(2):
+        model.zero_grad()
+        run_two_calls(model)
+        model.sync_gradients()
+        for n, p in layer.named_parameters():
+            err = float((p.grad - ref[n]).abs().max() / (ref[n].abs().max() + 1e-12))
+            assert err < 2e-3, ("two-call pattern under no_sync", n, err)
+            assert p.grad.data_ptr() == model.buckets.view(p).data_ptr(), n
+        model.zero_grad()
+        with model.no_sync():
+            micro(0)
+        micro(1)
+        model.sync_gradients()
+        for n, p in layer.named_parameters():
+            err = float((p.grad - ref_micro[n]).abs().max() / (ref_micro[n].abs().max() + 1e-12))
+            assert err < 2e-3, ("micro-batches under no_sync", n, err)
+    # (c) WITHOUT no_sync a second pass into exchanged buckets is an error, not a torn gradient
+    model.zero_grad()
+    micro(0)
+    if any(b.launched for b in model.buckets.buckets):
+        try:
+            micro(1)
+            raise AssertionError("a second backward pass into an exchanged bucket must raise")
+        except RuntimeError as e:
+            assert "no_sync" in str(e), e
+    model.zero_grad()
+    model.remove()
+
     # cfg5-shaped model: 6 x (CplxConv2d + CplxBatchNorm2d + split-ReLU) + CplxLinearARD head, several
     # buckets; every parameter's averaged gradient == the hand-averaged one
     import importlib.util

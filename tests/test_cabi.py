@@ -107,25 +107,18 @@ def test_gemm_dispatch_follows_the_per_call_flags(lib):
     assert plan(*c_fwd, 0) == 3
 
 
-def test_host_launch_policy_is_per_thread_and_windowed():
-    """_lib.launch_flags(): thread-local override, else SHARED while any hook's collectives are in flight, else 0."""
-    import threading
+def test_host_launch_policy_is_per_stream_and_windowed():
+    """_lib.launch_flags(): the override registered for the current stream, else SHARED while any hook's collectives are
+    in flight, else 0.  (No GPU here: one pseudo-stream; the two-stream case is tests/test_gpu_r05.py.)"""
     from cplxmodule_amd import _lib
     assert _lib.launch_flags() == 0
-    seen = {}
-
-    def other():
-        seen["before"] = _lib.launch_flags()
-        with _lib.launch_policy(_lib.LAUNCH_EXCLUSIVE):
-            seen["inside"] = _lib.launch_flags()
-        seen["after"] = _lib.launch_flags()
-
-    owner = object()
     with _lib.launch_policy(_lib.LAUNCH_SHARED | _lib.LAUNCH_FAMILY(0)):
         assert _lib.launch_flags() == 1 | 0x100
-        t = threading.Thread(target=other)
-        t.start(); t.join()
-    assert seen == {"before": 0, "inside": 2, "after": 0}, "one thread's policy is invisible to another"
+        with _lib.launch_policy(_lib.LAUNCH_EXCLUSIVE):
+            assert _lib.launch_flags() == 2
+        assert _lib.launch_flags() == 1 | 0x100
+    assert _lib.launch_flags() == 0 and not _lib._policy
+    owner = object()
     _lib.shared_chip_enter(owner)
     try:
         assert _lib.launch_flags() == _lib.LAUNCH_SHARED

@@ -152,7 +152,7 @@ def test_batchnorm_channels_last_rows_kernels(shape, dtype):
     torch.autograd.backward((y.real, y.imag), (cl(gr), cl(gi)))
     bw = orc.cplx_batch_norm_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), None, None, W.astype(f), True, 1e-5)
     for n, t in dict(dxr=txr.grad, dxi=txi.grad, dweight=bn.weight.grad, dbias=bn.bias.grad).items():
-        r = 2e-5 if dtype == "f32" else (2e-2 if n[1] == "x" else 1e-3)
+        r = 1e-5 if dtype == "f32" else (2e-2 if n[1] == "x" else 1e-3)      # (achieved 1.9e-7: profiles/r04_parity_report.txt)
         np.testing.assert_allclose(N(t), bw[n], **_tol(bw[n], r), err_msg=n)
     bn.eval()
     z = bn(Cplx(cl(xr), cl(xi)))

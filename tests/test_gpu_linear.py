@@ -197,7 +197,11 @@ def test_linear_3m_layer_fwd_bwd(pkg, B, I, O):
     x = Cplx(torch.randn(B, I, device=DEV).bfloat16().requires_grad_(True),
              torch.randn(B, I, device=DEV).bfloat16().requires_grad_(True))
     outs = []
-    for fn in (cplx.linear, cplx.linear_3m):
+    true_3m = lambda x_, w_, b_: cplx.linear_3m(x_, w_, b_, true_3m=True)  # noqa: E731
+    # (the plain cplx.linear_3m call is routed to the 4M kernel for bf16: bit-identical to cplx.linear)
+    y4, y3 = cplx.linear(x, w, b), cplx.linear_3m(x, w, b)
+    assert torch.equal(y4.real, y3.real) and torch.equal(y4.imag, y3.imag)
+    for fn in (cplx.linear, true_3m):
         for t in (w.real, w.imag, b.real, b.imag, x.real, x.imag):
             t.grad = None
         y = fn(x, w, b)

@@ -74,3 +74,49 @@ def test_moment_hints_and_arming_bookkeeping():
     del w2
     gc.collect()
     assert not conv._MOMENTS_WANTED                                      # a dead layer leaves nothing behind
+
+
+def test_moment_requests_are_credits_that_expire():
+    """a convolution whose output stops feeding a batch-norm layer must stop paying for the moments
+    epilogue by itself (not only on eval()): every armed forward spends a credit, every consuming BN forward refills."""
+    from cplxmodule_amd import conv
+    conv._MOMENTS_WANTED.clear()
+    w = torch.nn.Parameter(torch.ones(4, 4, 3, 3))
+    conv.want_moments(w)                                   # a batch-norm layer consumed the output once
+    spent = 0
+    while conv.moments_wanted(w, spend=True):              # ... and never again: the convolution's next forwards
+        spent += 1
+        assert spent <= 8
+    assert spent == conv._MOMENTS_CREDIT and not conv._MOMENTS_WANTED
+    for _ in range(5):                                     # consumed every step: stays armed
+        conv.want_moments(w)
+        assert conv.moments_wanted(w, spend=True)
+    assert conv.moments_wanted(w)
+    # a permanent request (arm_conv_bn) is neither spent nor withdrawn by a consumer in evaluation mode
+    conv.want_moments(w, permanent=True)
+    for _ in range(10):
+        assert conv.moments_wanted(w, spend=True)
+    conv.want_moments(w, on=False)
+    assert conv.moments_wanted(w)
+    conv.want_moments(w)                                   # a consuming layer must not downgrade it to a credit either
+    for _ in range(10):
+        assert conv.moments_wanted(w, spend=True)
+    conv.want_moments(w, on=False, permanent=True)
+    assert not conv._MOMENTS_WANTED
+
+
+def test_arm_conv_bn_finds_the_direct_pairs_only():
+    from cplxmodule_amd import conv, nn
+    conv._MOMENTS_WANTED.clear()
+    c1, c2, c3 = nn.CplxConv2d(4, 4, 3), nn.CplxConv2d(4, 4, 3), nn.CplxConv2d(4, 4, 3)
+    net = torch.nn.Sequential(c1, nn.CplxBatchNorm2d(4),
+                              torch.nn.Sequential(c2, nn.CplxBatchNorm2d(4)),
+                              c3, nn.CplxIdentity() if hasattr(nn, "CplxIdentity") else torch.nn.Identity(),
+                              nn.CplxBatchNorm2d(4))
+    assert conv.arm_conv_bn(net) == 2
+    assert conv.moments_wanted(c1.weight.real) and conv.moments_wanted(c2.weight.real)
+    assert not conv.moments_wanted(c3.weight.real)         # something sits between the pair
+    import copy
+    twin = copy.deepcopy(net)                              # requests are keyed by the parameter OBJECT: a copy starts unarmed
+    assert not conv.moments_wanted(twin[0].weight.real)
+    assert conv.arm_conv_bn(net, on=False) == 2 and not conv._MOMENTS_WANTED
