@@ -325,6 +325,8 @@ def dp_projection(dev):
                 out["process_group_error"] = str(e)[:120]
             finally:
                 sys.stdout.flush()
+                import ctypes
+                ctypes.CDLL(None).fflush(None)         # (the banner sits in the C library's stdout buffer)
                 os.dup2(saved, 1)
                 os.close(saved)
         forced, dp.FORCE_COLLECTIVES = dp.FORCE_COLLECTIVES, dp.is_initialized()

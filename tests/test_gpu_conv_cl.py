@@ -440,7 +440,7 @@ def test_patch_kernel_matches_row_kernel(B, Ci, Co, H, W, pad):
                 got = conv.cl_conv(*a, **k)
             finally:
                 conv.try_call = real_try
-            assert seen == [("cplxamd_conv2d_cl2", True)], name          # the patch kernel took it
+            assert seen == [("cplxamd_conv2d_cl2_fl", True)], name          # the patch kernel took it
             conv._CL_PATCH = False
             want = conv.cl_conv(*a, **k)
             for p, q in zip(got, want):
