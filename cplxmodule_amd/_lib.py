@@ -169,7 +169,7 @@ LAUNCH_DEFAULT, LAUNCH_SHARED, LAUNCH_EXCLUSIVE = 0, 1, 2
 
 
 def LAUNCH_FAMILY(mask):
-    return 0x100 | ((int(mask) & 0x7f) << 16)
+    return 0x100 | ((int(mask) & 0xff) << 16)
 
 
 _policy = {}               # (device index, raw stream handle) -> flags

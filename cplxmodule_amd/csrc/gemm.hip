@@ -7,7 +7,7 @@ namespace cplxamd {
 // DEPRECATED process-wide defaults (launch.h): read only by launches whose flags leave the choice open
 std::atomic<int> g_default_persistent{1};
 // default: every launch kind, subject to the K-depth rule of gemm_bf16_w4.hip (profiles/r04_gemm_w4_ab.txt)
-static int env_w4() { const char* e = getenv("CPLXAMD_GEMM_W4"); return e ? (int)strtol(e, nullptr, 0) & 0x7f : 0x3f; }
+static int env_w4() { const char* e = getenv("CPLXAMD_GEMM_W4"); return e ? (int)strtol(e, nullptr, 0) & 0xff : 0xbf; }
 std::atomic<int> g_default_family{env_w4()};
 }
 using namespace cplxamd;
@@ -19,7 +19,7 @@ int cplxamd_gemm_set_persistent(int on) {
 }
 
 int cplxamd_gemm_set_family(int w4) {
-  return g_default_family.exchange(w4 < 0 ? 0x7f : (w4 & 0x7f));
+  return g_default_family.exchange(w4 < 0 ? 0xff : (w4 & 0xff));
 }
 
 /* scratch the bf16 path wants for split-K at this shape (0 = none) */
@@ -177,7 +177,7 @@ int cplxamd_gemm_plan(int cplx, int M, int N, int K, int ta, int tb, int out_dty
   void* const p = reinterpret_cast<void*>(uintptr_t{1} << 20);
   const float* const pf = reinterpret_cast<const float*>(p);
   GemmArgs g{p, cplx ? p : nullptr, ta ? 1 : K, ta ? M : 1, p, cplx ? p : nullptr, tb ? 1 : K, tb ? N : 1,
-             nullptr, nullptr, (epi == 2 && !cplx) ? pf : nullptr, p, cplx ? p : nullptr, N, M, N, K, (cplx && epi != 0) ? 1 : 0, epi == 2};
+             nullptr, nullptr, (epi == 2 && !cplx) ? pf : nullptr, p, cplx ? p : nullptr, N, M, N, K, (cplx && (epi != 0 || tb)) ? 1 : 0, epi == 2};   // (the layers' transposed-weight launches are the conjugated ones)
   if (epi == 1) { g.fx_r = p; g.fx_i = cplx ? p : nullptr; g.fga = p; g.fld = N; }
   if (epi == 2) { g.beta = pf; g.emul_exp = cplx ? 0 : 1; }   // the layers' weight gradients: + beta * dKL (real: times exp(log_sigma2))
   g.ws = p; g.ws_bytes = INT64_MAX; g.flags = flags;

@@ -150,6 +150,8 @@ __device__ __forceinline__ void store16(float* p, const f4& a) {
 }
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+#define W4_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 0xF) | ((((N) >> 4) & 3) << 14))
 
 // ---- where the LDS writes sit among the MFMA slots of a K sub-step ---------------------------------------------------
 // spread (W4_BURST 0): every sub-step writes half of ITS tile parity's registers (NL / 2 writes): tile u+2 is written over
@@ -178,10 +180,21 @@ constexpr int ops_after_last_read(bool cplx, bool burst, bool writes) { return !
 #ifndef W4_EPI_PIPE
 #define W4_EPI_PIPE 1   // epilogue operands of round r + 1 requested ahead of the stores of round r (0: behind them, A/B)
 #endif
+#ifndef W4P_SPLIT
+#define W4P_SPLIT 0   // PERSIST: 1 = a select-free copy of the six-tile body for the steady part of the K range (see the K loop)
+#endif
 #ifndef W4_PGRID
 #define W4_PGRID 0   // experiment: > 0 = at most that many workgroups, each walking the tile list (lin, lin + grid, ...)
 #endif
-template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
+// PERSIST (round 5 experiment, family bit 7; bf16 output, plain epilogue, no bias, (N,N) / (N,T)): ONE workgroup per CU walks
+// the tiles lin0, lin0 + grid, ... and the K-tile ring runs THROUGH the output-tile boundaries -- the loads the one-tile
+// form issues past the end of its K range (surplus, unused) fetch the NEXT tile's K tiles 0 .. 3 instead, so that tile's K
+// tiles 0, 1 are in the ring and 2, 3 in the registers when the current tile's last MFMA retires; nothing of a prologue is
+// left but the accumulator reset.  The ring position advances by nt % 3 per output tile: instead of rotating slot offsets
+// in scalar registers (round 4's attempt: adds in the K loop, or spilled staging registers) the per-slot LDS BASE
+// REGISTERS swap roles at the boundary (18 v_mov per output tile, none in the K loop), so the K loop is the one-tile
+// kernel's instruction for instruction.  The epilogue stages through the ring slot that died with the last K tile.
+template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB, bool PERSIST = false>
 __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char* smem) {
   using C = Cfg<CPLX>;
   constexpr int NT = C::NT, BM = C::BM, BN = C::BN, IB = C::IB, JB = C::JB, NPL = C::NPL;
@@ -190,9 +203,8 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
   // ---- tile coordinates: XCD-contiguous grouped order (as gemm_bf16_kernel) ---------------------------------
   const int tiles_m = g.M / BM, tiles_n = g.N / BN;
   const int ntiles = tiles_m * tiles_n;
-  int bm, bn, split = 0;
-  {
-    int lin = lin0;
+  int split = 0;
+  auto origin = [&](int lin, int& om, int& on) __attribute__((always_inline)) {
     if (g.splits > 1) { split = lin / ntiles; lin -= split * ntiles; }     // split-K: block (split, tile), float32 slabs
     const int q = ntiles >> 3, r = ntiles & 7, xcd = lin & 7, idx = lin >> 3;
     lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective
@@ -201,9 +213,11 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     const int grp = lin / per_group, in_grp = lin - grp * per_group;
     const int first_m = grp * GM;
     const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    bm = first_m + in_grp % gm; bn = in_grp / gm;
-  }
-  const int m0 = __builtin_amdgcn_readfirstlane(bm * BM), n0 = __builtin_amdgcn_readfirstlane(bn * BN);
+    om = __builtin_amdgcn_readfirstlane((first_m + in_grp % gm) * BM);
+    on = __builtin_amdgcn_readfirstlane((in_grp / gm) * BN);
+  };
+  int m0, n0;
+  origin(lin0, m0, n0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -213,14 +227,31 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
 
   const int64_t lda = TA ? g.a_cs : g.a_rs, ldb = TB ? g.b_cs : g.b_rs;
   // plane base pointers of this tile (wave-uniform); a K tile pair advances them by `kstep` bytes
-  const char* pa[NPL]; const char* pb[NPL];
-  pa[0] = (const char*)g.a_r + (TA ? (int64_t)m0 : (int64_t)m0 * lda) * 2;
-  pb[0] = (const char*)g.b_r + (TB ? (int64_t)n0 : (int64_t)n0 * ldb) * 2;
-  if (CPLX) {
-    pa[NPL - 1] = (const char*)g.a_i + (TA ? (int64_t)m0 : (int64_t)m0 * lda) * 2;
-    pb[NPL - 1] = (const char*)g.b_i + (TB ? (int64_t)n0 : (int64_t)n0 * ldb) * 2;
-  }
   const int64_t ka = TA ? lda * 2 : 2, kb = TB ? ldb * 2 : 2;       // bytes per k step
+  const char* pa[NPL]; const char* pb[NPL];
+  auto plane_bases = [&](int tm, int tn, const char* (&qa)[NPL], const char* (&qb)[NPL]) __attribute__((always_inline)) {
+    qa[0] = (const char*)g.a_r + (TA ? (int64_t)tm : (int64_t)tm * lda) * 2;
+    qb[0] = (const char*)g.b_r + (TB ? (int64_t)tn : (int64_t)tn * ldb) * 2;
+    if (CPLX) {
+      qa[NPL - 1] = (const char*)g.a_i + (TA ? (int64_t)tm : (int64_t)tm * lda) * 2;
+      qb[NPL - 1] = (const char*)g.b_i + (TB ? (int64_t)tn : (int64_t)tn * ldb) * 2;
+    }
+  };
+  plane_bases(m0, n0, pa, pb);
+  // PERSIST: the tile after this one (its K tiles 0 .. 3 are requested during this tile's last K tiles), and the source
+  // of the register pairs being requested right now (set once per request group: set_request)
+  const char* pan[NPL]; const char* pbn[NPL]; const char* rqa[NPL]; const char* rqb[NPL];
+  const int ntp = __builtin_amdgcn_readfirstlane(g.K / BK);
+  auto set_request = [&](int kt, auto REDIR) __attribute__((always_inline)) {
+    // REDIR false: kt is inside this tile's K range (the steady part of the K loop: no select in it)
+    const bool nx = decltype(REDIR)::value && kt >= ntp;
+    const int kk = (nx ? kt - ntp : kt) & ~1;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      rqa[pl] = (nx ? pan[pl] : pa[pl]) + (int64_t)kk * BK * ka;
+      rqb[pl] = (nx ? pbn[pl] : pb[pl]) + (int64_t)kk * BK * kb;
+    }
+  };
   const int kbase = __builtin_amdgcn_readfirstlane(split * g.kchunk);
   if (g.splits > 1) {
 #pragma unroll
@@ -259,8 +290,13 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     constexpr bool isa = r < PA;
     constexpr int j = isa ? r : r - PA;
     // pair base = K tile (kt & ~1); the odd tile of the pair is +32 k
-    const int64_t kby = (W4_DBG & 16) ? 0 : (int64_t)(kt & ~1) * BK * (isa ? ka : kb);
-    const char* base = (isa ? pa[pl] : pb[pl]) + kby;
+    const char* base;
+    if constexpr (PERSIST) {
+      base = isa ? rqa[pl] : rqb[pl];          // (set_request(kt) ran for this request group)
+    } else {
+      const int64_t kby = (W4_DBG & 16) ? 0 : (int64_t)(kt & ~1) * BK * (isa ? ka : kb);
+      base = (isa ? pa[pl] : pb[pl]) + kby;
+    }
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffe, 0x00020000);
     const uint32_t so = (uint32_t)j * (isa ? psa : psb) + (par ? (isa ? qa : qb) : 0u);
     const uint32_t vo = (isa ? voa : vob) + ((par && !(isa ? TA : TB)) ? 64u : 0u);
@@ -269,10 +305,12 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
   // LDS addresses: per ring slot one register per operand for the writes ...
   const uint32_t smem_off = (uint32_t)(uintptr_t)smem;
   uint32_t wa[3], wb[3];
+  uint32_t sl[3];                            // PERSIST: byte offset of the ring slot in each ROLE (scalar)
 #pragma unroll
   for (int s3 = 0; s3 < 3; ++s3) {
     wa[s3] = opaque(smem_off + s3 * SLOT + wra);
     wb[s3] = opaque(smem_off + s3 * SLOT + C::A_BYTES + wrb);
+    sl[s3] = (uint32_t)(s3 * SLOT);
   }
   auto write_piece = [&](auto PAR, auto Q, auto WS) __attribute__((always_inline)) {
     constexpr int par = decltype(PAR)::value, q = decltype(Q)::value, ws = decltype(WS)::value;
@@ -444,6 +482,16 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     };
     go(go, I0{});
   };
+  // PERSIST: the tile walk of this workgroup (lin0, lin0 + grid, ...) and the tile behind the first one
+  int lin = lin0, mn = m0, nn = n0;
+  bool has_next = false;
+  auto look_ahead = [&]() __attribute__((always_inline)) {
+    has_next = lin + (int)gridDim.x < ntiles;
+    mn = m0; nn = n0;
+    if (has_next) origin(lin + (int)gridDim.x, mn, nn);
+    plane_bases(mn, nn, pan, pbn);          // (no next tile: this one again -- the look-ahead loads land nowhere that is read)
+  };
+  if constexpr (PERSIST) { look_ahead(); set_request(0, std::false_type{}); }
   for_pieces([&](auto Q) __attribute__((always_inline)) { load_piece(I0{}, Q, 0); load_piece(I1{}, Q, 0); });
   // acc = bias[n] (or 0)
 #pragma unroll
@@ -463,11 +511,12 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
   });
   {
     const int kt = nt > 2 ? 2 : nt - 2;
+    if constexpr (PERSIST) set_request(kt, std::true_type{});
     for_pieces([&](auto Q) __attribute__((always_inline)) { load_piece(I0{}, Q, kt); load_piece(I1{}, Q, kt); });
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  {
+  auto first_frags = [&]() __attribute__((always_inline)) {
     // fragments of (tile 0, sub 0) -> set 0
     auto goa = [&](auto self, auto I) __attribute__((always_inline)) {
       constexpr int i = decltype(I)::value;
@@ -479,17 +528,22 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     };
     gob(gob, I0{});
     goa(goa, I0{});
-  }
+  };
+  first_frags();
 
   // ---- K loop ---------------------------------------------------------------------------------------------------
   // K tile t in ring slot S (compile time), parity P (compile time)
-  auto tile = [&](auto SS, auto PP, int t) __attribute__((always_inline)) {
+  auto tile = [&](auto SS, auto PP, int t, auto REDIR) __attribute__((always_inline)) {
     constexpr int s = decltype(SS)::value, par = decltype(PP)::value;
     using CUR = std::integral_constant<int, s>; using NXT = std::integral_constant<int, (s + 1) % 3>;
     using WR = std::integral_constant<int, (s + 2) % 3>;
     // the register pairs are re-requested with the K tiles two pairs ahead; past the end: the last pair again (unused)
     constexpr int ahead = (W4_BURST && par == 0) ? 4 : 3;
-    const int ktn = (t + ahead < nt) ? t + ahead : nt - 2;
+    int ktn = (t + ahead < nt) ? t + ahead : nt - 2;
+    if constexpr (PERSIST) {
+      ktn = t + ahead;                       // past the end of this tile's K range: the next tile's K tiles 0 .. 3
+      if constexpr (par == 1) set_request(ktn, REDIR);
+    }
     // burst: P (tile u+2) -> even tile's WR slot = odd tile's NXT slot; Q (tile u+3) -> even tile's CUR = odd tile's WR
     using WSP = std::conditional_t<par == 0, WR, NXT>;
     using WSQ = std::conditional_t<par == 0, CUR, WR>;
@@ -500,23 +554,55 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     W4_SB();
     sub(I1{}, PP, I1{}, NXT{}, I0{}, WR{}, WSP{}, WSQ{}, ktn);
   };
+  // role swap of the per-slot LDS base registers: new[S] = old[(S + R) % 3]
+  auto rotate = [&](auto R) __attribute__((always_inline)) {
+    constexpr int r = decltype(R)::value;
+    auto rot3 = [&](uint32_t& x0, uint32_t& x1, uint32_t& x2) __attribute__((always_inline)) {
+      const uint32_t a = x0, b = x1, c = x2;
+      if constexpr (r == 1) { x0 = b; x1 = c; x2 = a; } else { x0 = c; x1 = a; x2 = b; }
+    };
+    rot3(wa[0], wa[1], wa[2]); rot3(wb[0], wb[1], wb[2]); rot3(sl[0], sl[1], sl[2]);
+#pragma unroll
+    for (int x = 0; x < NFA; ++x) rot3(fa[0][x], fa[1][x], fa[2][x]);
+#pragma unroll
+    for (int x = 0; x < NFB; ++x) rot3(fb[0][x], fb[1][x], fb[2][x]);
+  };
+  do {       // (one pass unless PERSIST)
   {
     int t = 0;
+    using RD = std::true_type;            // (only PERSIST looks at it)
+    if constexpr (PERSIST && W4P_SPLIT) {
+      // steady part: every request of the six tiles (K tiles t + 3 .. t + 8) lies inside this tile's K range.  (Measured
+      // as a compile: with two copies of the six-tile body the register allocator reconciles their accumulator
+      // assignments with 192 v_accvgpr moves INSIDE the first one -- off by default.)
+      for (; t + 9 <= nt; t += 6) {
+        using NR = std::false_type;
+        tile(I0{}, I0{}, t, NR{});
+        tile(I1{}, I1{}, t + 1, NR{});
+        tile(I2{}, I0{}, t + 2, NR{});
+        tile(I0{}, I1{}, t + 3, NR{});
+        tile(I1{}, I0{}, t + 4, NR{});
+        tile(I2{}, I1{}, t + 5, NR{});
+      }
+    }
     for (; t + 6 <= nt; t += 6) {
-      tile(I0{}, I0{}, t);
-      tile(I1{}, I1{}, t + 1);
-      tile(I2{}, I0{}, t + 2);
-      tile(I0{}, I1{}, t + 3);
-      tile(I1{}, I0{}, t + 4);
-      tile(I2{}, I1{}, t + 5);
+      tile(I0{}, I0{}, t, RD{});
+      tile(I1{}, I1{}, t + 1, RD{});
+      tile(I2{}, I0{}, t + 2, RD{});
+      tile(I0{}, I1{}, t + 3, RD{});
+      tile(I1{}, I0{}, t + 4, RD{});
+      tile(I2{}, I1{}, t + 5, RD{});
     }
     if (t < nt) {
-      tile(I0{}, I0{}, t);
-      tile(I1{}, I1{}, t + 1);
+      tile(I0{}, I0{}, t, RD{});
+      tile(I1{}, I1{}, t + 1, RD{});
       t += 2;
       if (t < nt) {
-        tile(I2{}, I0{}, t);
-        tile(I0{}, I1{}, t + 1);
+        tile(I2{}, I0{}, t, RD{});
+        tile(I0{}, I1{}, t + 1, RD{});
+        if constexpr (PERSIST) rotate(I1{});     // last K tile in slot 0: the next tile's K tile 0 sits in slot 1
+      } else {
+        if constexpr (PERSIST) rotate(I2{});     // last K tile in slot 1: ... in slot 2
       }
     }
   }
@@ -533,7 +619,9 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
   }
   const float beta = gemm_beta(g);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the surplus loads of the loop's tail target registers nothing reads: the compiler waits for them only where it reuses one)
-  __builtin_amdgcn_s_barrier();                       // every wave is done with the ring
+  // every wave is done with the ring.  PERSIST: the staging slot below is the one whose K tile every wave finished reading
+  // before the last mid-tile barrier (role 2 after the swap); the waves still in the last K sub-step touch the other two
+  if constexpr (!PERSIST) __builtin_amdgcn_s_barrier();
   // The epilogue's optional operands (fused LRT term; multiplier / accumulate operand) are tested ONCE, outside: a per-load
   // "if (g.fga)" inside the unrolled passes makes the compiler branch around every load and wait for each one separately
   // (cdna_hip_programming.md, "three .s-level traps" (c)) -- and at one wave per SIMD nothing else hides that latency.
@@ -556,9 +644,18 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     auto epi16 = [&](auto FUSE) __attribute__((always_inline)) {
       constexpr bool fuse = decltype(FUSE)::value;
       constexpr int PITCH = 144;                        // bytes per staged row (64 bf16 + 16 B pad)
-      char* reg = smem + wid * (64 * PITCH);
+      // PERSIST: the dead ring slot (complex: 48 KiB >= 4 x 9 KiB); the real kernel's slots are 32 KiB -- its staging rows
+      // live behind the ring (96 + 36 KiB of LDS: launch_w4p)
       // lane part: row (lane >> 3) of an 8-row pass, 16-byte column group (lane & 7); wave origin (wm, wn)
+      // PERSIST: everything per-lane below is derived from an OPAQUE copy of the thread index, made here: otherwise the
+      // loop-invariant epilogue addresses are hoisted out of the tile loop, live across the K loop -- which has not one
+      // register to spare -- and a staging register is spilled (with a vmcnt(0)) inside it
+      const int tid_e = PERSIST ? (int)opaque((uint32_t)tid) : tid;
+      const int lane = tid_e & 63, wid = tid_e >> 6;
+      const int wm = (wid / C::WN) * (32 * IB), wn = (wid % C::WN) * (32 * JB);
+      const int l31 = lane & 31, lk = lane >> 5;
       const uint32_t vo_c = (uint32_t)((((int64_t)(wm + (lane >> 3)) * g.ldc + wn + (lane & 7) * 8)) * 2);
+      char* reg = smem + (PERSIST ? (CPLX ? sl[2] : (uint32_t)C::SMEM) : 0u) + wid * (64 * PITCH);
       const uint32_t vo_f = fuse ? (uint32_t)((((int64_t)(wm + (lane >> 3)) * g.fld + wn + (lane & 7) * 8)) * 2) : 0u;
       const uint32_t p8c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(8 * g.ldc * 2));
       const uint32_t p8f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(8 * g.fld * 2));
@@ -581,11 +678,22 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
         }
       };
       if constexpr (fuse) load_ops(0);
+      // PERSIST: stores count in vmcnt on this target, and the K loop's counted waits are ONE static instruction each for
+      // the first trip after a tile boundary and for every steady trip.  With this epilogue's 64 stores on top of the 24
+      // look-ahead loads the compiler's bookkeeping overflows the 6-bit counter and it settles on vmcnt(0) INSIDE the K loop
+      // (a full drain of the staging stream every six K tiles: measured +2.5 %).  So: the look-ahead loads are waited for
+      // here, once (they were requested one to two K tiles ago), and the stores in flight are kept below 32
+      if constexpr (PERSIST) W4_VMCNT(0);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int pl = r / ((JB / 2) * (IB / 2)), jh = (r / (IB / 2)) % (JB / 2), ih = r % (IB / 2);
         const __amdgpu_buffer_rsrc_t rout = pl ? rout1 : rout0;
         if constexpr (fuse && !W4_EPI_PIPE) { if (r > 0) load_ops(r); }
+        // (PERSIST, complex: the compiler copies all 256 accumulators out of the AGPRs at the K loop's exit and spills ~56
+        //  registers of the next tile's ring state around this epilogue.  Pinning the tuples in the AGPRs per round with an
+        //  empty asm ("+a" on the 16-register tuple, or an asm v_accvgpr_read per element) makes the allocator shuffle
+        //  accumulator tuples INSIDE the K loop instead -- 144 to 192 v_accvgpr moves per six K tiles; both tried, both
+        //  worse: profiles/r05_gemm_w4_persistent.txt.  The real kernel has the registers to spare and spills nothing.)
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -595,9 +703,16 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
               const int cl = jj * 32 + 8 * q + 4 * lk;
               f4 v;
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                v.v[e] = pl ? acc_i[CPLX ? ih * 2 + ii : 0][jh * 2 + jj][4 * q + e] : acc_r[ih * 2 + ii][jh * 2 + jj][4 * q + e];
+              for (int e = 0; e < 4; ++e) {
+                const float a = pl ? acc_i[CPLX ? ih * 2 + ii : 0][jh * 2 + jj][4 * q + e] : acc_r[ih * 2 + ii][jh * 2 + jj][4 * q + e];
+                // PERSIST: the staging and fragment registers of the NEXT tile are live across this epilogue -- the scheduling
+                // barrier behind every staged group keeps the accumulator reads where they are used (otherwise all 256 are
+                // copied out of the AGPRs up front and ~100 registers of the ring state are spilled around every tile
+                // boundary; an asm read with an "a" operand instead splits the accumulator tuples: moves in the K loop)
+                v.v[e] = a;
+              }
               st4(reinterpret_cast<bf16_t*>(reg + (ii * 32 + l31) * PITCH + cl * 2), v);
+              if constexpr (PERSIST) W4_SB();
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is in LDS (in-order LDS, own region)
         if constexpr (fuse && W4_EPI_PIPE) {
@@ -624,10 +739,12 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
+        if constexpr (PERSIST) W4_VMCNT(16);                 // (at most two rounds of stores in flight: see above)
         W4_SB();
       }
     };
-    if (g.fga) epi16(std::true_type{}); else epi16(std::false_type{});
+    if constexpr (PERSIST) epi16(std::false_type{});
+    else { if (g.fga) epi16(std::true_type{}); else epi16(std::false_type{}); }
   } else {
     // float32: 32 rows x 64 columns per round; the elementwise multiplier (LRT log_sigma2 gradient, mask: both planes of a
     // complex result -- the launcher declines a real-plane-only multiplier) and the accumulate operand are read row-major
@@ -703,6 +820,34 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     if (g.emul) { if (g.accumulate) epi32(std::true_type{}, std::true_type{}); else epi32(std::true_type{}, std::false_type{}); }
     else { if (g.accumulate) epi32(std::false_type{}, std::true_type{}); else epi32(std::false_type{}, std::false_type{}); }
   }
+  if constexpr (!PERSIST) {
+    break;
+  } else {
+    if (!has_next) break;
+    // the next tile: its K tiles 0, 1 are in the ring (roles 0, 1), 2, 3 in the staging registers, the fragments of its
+    // first K sub-step in set 0.  Its first LDS writes go to role 2 -- the slot every wave has just staged its rows in
+    __builtin_amdgcn_s_barrier();
+    lin += (int)gridDim.x; m0 = mn; n0 = nn;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) { pa[pl] = pan[pl]; pb[pl] = pbn[pl]; }
+    look_ahead();
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          acc_r[i][j][e] = 0.f;
+          if (CPLX) acc_i[i][j][e] = 0.f;
+        }
+    // the fragments of the new tile's first K sub-step once more (the last K sub-step read them already: re-reading
+    // here makes those 48 registers free during the epilogue -- an LDS round trip per tile against spilled ring state)
+    first_frags();
+    // nothing of the boundary (the stores, reloads of whatever the allocator spilled around the epilogue) may be in flight
+    // when the K loop's counted waits start counting: they are the same static instructions in every trip
+    W4_VMCNT(0);
+  }
+  } while (true);
 }
 
 #ifdef W4_PDYN
@@ -741,6 +886,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
 #endif
 }
 
+// PERSIST form (w4_tile<..., true>): one workgroup per CU, bf16 output, plain epilogue
+template <bool CPLX, bool CONJ, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_w4p_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  w4_tile<bf16_t, CPLX, CONJ, false, TB, true>(g, (int)blockIdx.x, smem);
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -754,6 +906,27 @@ static int launch(const GemmArgs& g0, hipStream_t st) {
   static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
   g.group_m = gm > 0 ? gm : 1;
   const int64_t tiles = (int64_t)(g.M / C::BM) * (g.N / C::BN);
+  if constexpr (sizeof(TOUT) == 2 && !TA) {
+    // round 5 (family bit 7): the ring through the tile boundaries; needs the chip (one workgroup per CU), more than one
+    // round of tiles, the plain epilogue and no bias, K tile count even (K % 64 == 0 holds).  Taken where measured faster
+    // (profiles/r05_gemm_w4_persistent.txt): the REAL launches -- (N,N) at every K depth this family runs at, (N,T) from
+    // K = 4096 -- whose boundary code compiles without a spill.  The complex form is bit-identical too but 1.6-2.9 %
+    // SLOWER than one tile per workgroup (the allocator spills ring state around its epilogue): env CPLXAMD_W4P_CPLX=1
+    // selects it for the A/B only.
+    static const int cplx_too = env_int("CPLXAMD_W4P_CPLX", 0);
+    const int ncu = (g.ncu > 0 ? g.ncu : device_cus()) & ~7;
+    const bool measured_faster = CPLX ? cplx_too != 0 : (!TB || g.K >= 4096);
+    if (((launch_family(g.flags) >> 7) & 1) && measured_faster && launch_owns_chip(g.flags) && tiles > ncu && !g.fga &&
+        !g.bias_r && g.splits <= 1) {
+      if (g.plan) { *g.plan = 6; return 0; }
+      static PerDeviceOnce attr_p;
+      constexpr int smem_p = C::SMEM + (CPLX ? 0 : 4 * 64 * 144);      // (real: epilogue staging behind the ring)
+      if (const int e = set_max_dyn_lds(attr_p, gemm_bf16_w4p_kernel<CPLX, CONJ, TB>, smem_p)) return e;
+      gemm_bf16_w4p_kernel<CPLX, CONJ, TB><<<dim3((unsigned)ncu), C::NT, smem_p, st>>>(g);
+      CPLXAMD_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (g.plan) { *g.plan = 3; return 0; }
   static PerDeviceOnce attr_set;
   if (const int e = set_max_dyn_lds(attr_set, gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB>, C::SMEM)) return e;

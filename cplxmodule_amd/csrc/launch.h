@@ -26,12 +26,12 @@ inline bool launch_owns_chip(int flags) {
 }
 // bf16 GEMM kernel family mask of this launch (cplxamd_gemm_set_family's bit layout)
 inline int launch_family(int flags) {
-  if (flags & CPLXAMD_LAUNCH_FAMILY_SET) return (flags >> CPLXAMD_LAUNCH_FAMILY_SHIFT) & 0x7f;
+  if (flags & CPLXAMD_LAUNCH_FAMILY_SET) return (flags >> CPLXAMD_LAUNCH_FAMILY_SHIFT) & 0xff;
   return g_default_family.load(std::memory_order_relaxed);
 }
 inline bool launch_flags_ok(int flags) {
   const int known = CPLXAMD_LAUNCH_SHARED | CPLXAMD_LAUNCH_EXCLUSIVE | CPLXAMD_LAUNCH_FAMILY_SET |
-                    (0x7f << CPLXAMD_LAUNCH_FAMILY_SHIFT);
+                    (0xff << CPLXAMD_LAUNCH_FAMILY_SHIFT);
   return (flags & ~known) == 0 && (flags & (CPLXAMD_LAUNCH_SHARED | CPLXAMD_LAUNCH_EXCLUSIVE)) !=
                                       (CPLXAMD_LAUNCH_SHARED | CPLXAMD_LAUNCH_EXCLUSIVE);
 }

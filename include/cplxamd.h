@@ -76,7 +76,7 @@ enum {
   CPLXAMD_LAUNCH_FAMILY_SET = 0x100,
   CPLXAMD_LAUNCH_FAMILY_SHIFT = 16
 };
-#define CPLXAMD_LAUNCH_FAMILY(mask) (CPLXAMD_LAUNCH_FAMILY_SET | (((mask) & 0x7f) << CPLXAMD_LAUNCH_FAMILY_SHIFT))
+#define CPLXAMD_LAUNCH_FAMILY(mask) (CPLXAMD_LAUNCH_FAMILY_SET | (((mask) & 0xff) << CPLXAMD_LAUNCH_FAMILY_SHIFT))
 
 int cplxamd_abi_version(void);
 
@@ -257,7 +257,11 @@ int cplxamd_gemm_set_persistent(int on);
  *   bit 3 real, bf16 out             bit 4 real, bf16 out with the fused term                           bit 5 real, float32 out
  *   bit 6 regardless of the K depth (without it: K >= 4096, or 1024 <= K < 4096 on (N,N) launches -- the family pays a
  *         prologue and an epilogue per output tile where the 8-wave kernels run persistent; profiles/r04_gemm_w4_ab.txt)
- * 0 = the 8-wave LDS-DMA kernels of rounds 1-3 everywhere, -1 = every bit.  Start value 0x3f (env CPLXAMD_GEMM_W4=<mask>
+ *   bit 7 (round 5) the PERSISTENT form of the family -- one workgroup per CU, the K-tile ring running through the output-
+ *         tile boundaries -- where it is built and measured faster: real bf16-out launches with the plain epilogue and no
+ *         bias ((N,N); (N,T) from K = 4096), more tiles than CUs, and only for a launch that owns the chip
+ *         (not CPLXAMD_LAUNCH_SHARED).  profiles/r05_gemm_w4_persistent.txt
+ * 0 = the 8-wave LDS-DMA kernels of rounds 1-3 everywhere, -1 = every bit.  Start value 0xbf (env CPLXAMD_GEMM_W4=<mask>
  * overrides).  Both families produce the same bits (same
  * MFMA sequence per accumulator; tests/test_gpu_r04.py). */
 int cplxamd_gemm_set_family(int mask);   /* DEPRECATED as a run-time switch: CPLXAMD_LAUNCH_FAMILY(mask) per call */
@@ -303,7 +307,7 @@ int cplxamd_rgemm_fl(const void* a, int64_t a_rs, int64_t a_cs, const void* b, i
 /* Which kernel a bf16 cplxamd_cgemm_fl / cplxamd_rgemm_fl call with these shapes, layouts ("N" = K-contiguous rows: ta /
  * tb = 0) and flags launches -- a pure function of its arguments and of `ncu`, the device's CU count (0: ask the current
  * device): 0 generic float32-exact kernel (the bf16 path declines), 1 8-wave one-tile, 2 8-wave persistent, 3
- * one-wave-per-SIMD (w4), 4 split-K slabs on the 8-wave kernels, 5 split-K slabs on w4.  `epi`: 0 plain / bias, 1 fused
+ * one-wave-per-SIMD (w4), 4 split-K slabs on the 8-wave kernels, 5 split-K slabs on w4, 6 w4 persistent.  `epi`: 0 plain / bias, 1 fused
  * LRT input-gradient term, 2 float32 accumulate / multiplier epilogue.  Dense operands, aligned pointers and a
  * workspace of cplxamd_gemm_ws_bytes are assumed.  (Dispatch made inspectable: the test of the per-call flags reads it.) */
 int cplxamd_gemm_plan(int cplx, int M, int N, int K, int ta, int tb, int out_dtype, int epi, int flags, int ncu);

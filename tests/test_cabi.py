@@ -82,9 +82,15 @@ def test_gemm_dispatch_follows_the_per_call_flags(lib):
     c_dw = (1, 4096, 4096, 8192, 1, 1, F32, 2)
     r_fwd = (0, 8192, 4096, 4096, 0, 0, BF, 0)
     r_dw = (0, 4096, 4096, 8192, 1, 1, F32, 2)
-    for shape in (c_fwd, c_dx, c_dw, r_fwd, r_dw):
-        assert plan(*shape, 0) == plan(*shape, S) == plan(*shape, E) == 3           # w4 is one workgroup per tile anyway
+    for shape in (c_fwd, c_dx, c_dw, r_dw):
+        assert plan(*shape, 0) == plan(*shape, S) == plan(*shape, E) == 3           # w4, one workgroup per tile
         assert plan(*shape, F(0x7f)) == 3
+    # round 5: the real plain bf16 launches run the persistent form of that family when the chip is theirs
+    assert [plan(*r_fwd, f) for f in (0, E, S, F(0x7f) | E)] == [6, 6, 3, 3]
+    assert [plan(0, 8192, 4096, 4096, 0, 1, BF, 0, f) for f in (E, S)] == [6, 3]    # real (N,T), K = 4096
+    assert plan(0, 65536, 2048, 2048, 0, 1, BF, 0, E) == 2                          # ... K = 2048: 8-wave persistent
+    assert plan(0, 65536, 2048, 2048, 0, 0, BF, 0, E) == 6
+    assert plan(*c_fwd, F(0xff) | E) == 3                                           # complex: not by default (slower)
     # without the w4 family: persistent where it exists, and only if the chip is this launch's
     assert [plan(*c_fwd, F(0) | f) for f in (E, S)] == [2, 1]
     assert [plan(*c_dx, F(0) | f) for f in (E, S)] == [2, 1]
@@ -104,7 +110,7 @@ def test_gemm_dispatch_follows_the_per_call_flags(lib):
     finally:
         L.cplxamd_gemm_set_persistent(prev)
         L.cplxamd_gemm_set_family(fam)
-    assert plan(*c_fwd, 0) == 3
+    assert plan(*c_fwd, 0) == 3 and plan(*r_fwd, 0) == 6
 
 
 def test_host_launch_policy_is_per_stream_and_windowed():
