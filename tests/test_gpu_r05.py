@@ -48,7 +48,8 @@ def test_two_models_two_streams_two_threads_choose_their_launch_forms_independen
     B, F = 8192, 2048                                   # K = 2048: the input gradients run on the 8-wave family
     assert L.cplxamd_gemm_plan(1, B, F, F, 0, 1, _lib.BF16, 1, S, 0) == 1      # fused input gradient: one-tile kernel ...
     assert L.cplxamd_gemm_plan(1, B, F, F, 0, 1, _lib.BF16, 1, E, 0) == 2      # ... or the persistent one
-    assert L.cplxamd_gemm_plan(0, B, F, F, 0, 1, _lib.BF16, 1, S, 0) != L.cplxamd_gemm_plan(0, B, F, F, 0, 1, _lib.BF16, 1, E, 0)
+    # (the real launches of this layer are 256 tiles = one per CU: one form only; the channels-last convolutions and the
+    #  real GEMMs of larger layers switch like the complex one above)
     torch.manual_seed(0)
     models = [rel.CplxLinearVD(F, F).to(DEV) for _ in range(2)]
     for m in models:
