@@ -411,3 +411,64 @@ def test_w4_persistent_complex_form_in_its_own_process():
                         os.path.join(here, "test_gpu_r05.py") + "::test_w4_persistent_form_is_bit_identical"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
     assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cfg3_float32_conv_at_full_batch_matches_float64():
+    """CplxConv2d(64, 64, 3) on 256 float32 256 x 256 images, channels-last -- the 1e-5 mode at BASELINE configs[2]'s size:
+    forward pixels of the last images, the data gradient of the last image and sampled weight-gradient entries against
+    float64 (reference: cplx.py:717-742 and its autograd).  ~25 GB of planes."""
+    import oracle.cplx_oracle as orc
+    from cplxmodule_amd import Cplx, nn
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip(f"{free >> 30} GiB free")
+    B, C, H = 256, 64, 256
+    cl = torch.channels_last
+    g = torch.Generator(device=DEV).manual_seed(31)
+    mk = lambda *s: torch.randn(*s, device=DEV, generator=g).contiguous(memory_format=cl)  # noqa: E731
+    xr, xi = mk(B, C, H, H).requires_grad_(True), mk(B, C, H, H).requires_grad_(True)
+    torch.manual_seed(2)
+    conv = nn.CplxConv2d(C, C, 3).to(DEV)
+    y = conv(Cplx(xr, xi))
+    assert y.real.shape == (B, C, H - 2, H - 2) and y.real.dtype == torch.float32
+    f = np.float64
+    w, b = conv.weight, conv.bias
+    Wr, Wi = N(w.real).astype(f), N(w.imag).astype(f)
+    sub = (slice(254, 256), slice(None), slice(100, 110), slice(200, 212))
+    rr, ri = orc.cplx_conv2d(xr[sub].detach().double().cpu().numpy(), xi[sub].detach().double().cpu().numpy(), Wr, Wi,
+                             N(b.real).astype(f), N(b.imag).astype(f))
+    np.testing.assert_allclose(N(y.real[254:256, :, 100:108, 200:210]), rr, rtol=1e-5, atol=1e-5 * np.abs(rr).max())
+    np.testing.assert_allclose(N(y.imag[254:256, :, 100:108, 200:210]), ri, rtol=1e-5, atol=1e-5 * np.abs(ri).max())
+    # backward: upstream gradient = a fixed random field (kept: the references below need it)
+    gr, gi = mk(B, C, H - 2, H - 2) * 0.1, mk(B, C, H - 2, H - 2) * 0.1
+    torch.autograd.backward((y.real, y.imag), (gr, gi))
+    del y
+    # data gradient of the LAST image on a window: dX = full correlation of G with conj(W) flipped; float64 by torch on the host
+    n0 = B - 1
+    G = torch.complex(gr[n0:n0 + 1, :, 40:60, 50:70].double(), gi[n0:n0 + 1, :, 40:60, 50:70].double()).cpu()
+    Wc = torch.complex(w.real.detach().double(), w.imag.detach().double()).cpu()
+    # dx[c, p] = sum_{o, t} G[o, p - t] conj(W[o, c, t])  -> conv_transpose2d of G with conj(W)
+    dx_r = torch.nn.functional.conv_transpose2d(G.real, Wc.real) + torch.nn.functional.conv_transpose2d(G.imag, Wc.imag)
+    dx_i = torch.nn.functional.conv_transpose2d(G.imag, Wc.real) - torch.nn.functional.conv_transpose2d(G.real, Wc.imag)
+    # interior of the window only (its border lacks the contributions of output pixels outside the window)
+    got_r = xr.grad[n0, :, 42:60, 52:70].double().cpu().numpy()
+    got_i = xi.grad[n0, :, 42:60, 52:70].double().cpu().numpy()
+    ref_r, ref_i = dx_r[0, :, 2:20, 2:20].numpy(), dx_i[0, :, 2:20, 2:20].numpy()
+    np.testing.assert_allclose(got_r, ref_r, rtol=1e-5, atol=1e-5 * np.abs(ref_r).max())
+    np.testing.assert_allclose(got_i, ref_i, rtol=1e-5, atol=1e-5 * np.abs(ref_i).max())
+    # weight gradient entries: dW[o, c, kh, kw] = sum_{b, p} G[b, o, p] conj(X[b, c, p + k]) over the WHOLE batch
+    for (o, c, kh, kw) in ((0, 0, 0, 0), (63, 17, 2, 1), (31, 63, 1, 2)):
+        Xr = xr.detach()[:, c, kh:kh + H - 2, kw:kw + H - 2].double()
+        Xi = xi.detach()[:, c, kh:kh + H - 2, kw:kw + H - 2].double()
+        Gr, Gi = gr[:, o].double(), gi[:, o].double()
+        ref_wr = float((Gr * Xr + Gi * Xi).sum())
+        ref_wi = float((Gi * Xr - Gr * Xi).sum())
+        scale = float(w.real.grad.abs().max())
+        # (each entry is a float32 sum of 16.5 M products in split-K slabs: 3e-5 of the largest entry, norm-wise)
+        assert abs(float(w.real.grad[o, c, kh, kw]) - ref_wr) <= 3e-5 * scale, (o, c, kh, kw, float(w.real.grad[o, c, kh, kw]), ref_wr)
+        assert abs(float(w.imag.grad[o, c, kh, kw]) - ref_wi) <= 3e-5 * scale, (o, c, kh, kw, float(w.imag.grad[o, c, kh, kw]), ref_wi)
+    ref_b = float(gr[:, 5].double().sum())
+    assert abs(float(b.real.grad[5]) - ref_b) <= 3e-5 * float(b.real.grad.abs().max())
+    del xr, xi, gr, gi
+    torch.cuda.empty_cache()
