@@ -183,6 +183,9 @@ constexpr int ops_after_last_read(bool cplx, bool burst, bool writes) { return !
 #ifndef W4P_SPLIT
 #define W4P_SPLIT 0   // PERSIST: 1 = a select-free copy of the six-tile body for the steady part of the K range (see the K loop)
 #endif
+#ifndef W4P_RELOAD
+#define W4P_RELOAD 1   // PERSIST: re-request the next tile's K tiles 2, 3 behind the epilogue (see the tile loop)
+#endif
 #ifndef W4_PGRID
 #define W4_PGRID 0   // experiment: > 0 = at most that many workgroups, each walking the tile list (lin, lin + grid, ...)
 #endif
@@ -843,9 +846,16 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     // the fragments of the new tile's first K sub-step once more (the last K sub-step read them already: re-reading
     // here makes those 48 registers free during the epilogue -- an LDS round trip per tile against spilled ring state)
     first_frags();
+    if constexpr (W4P_RELOAD && CPLX) {      // (the real kernel has the registers: nothing is spilled there)
+      // the new tile's K tiles 2, 3 ONCE MORE: the look-ahead requested them before the epilogue, but registers that stay
+      // live across it are what the allocator spills around it (complex: 96 staging registers beside 256 accumulators on
+      // their way out).  Re-requested here, the earlier request is a prefetch into the L2 and the registers are free.
+      set_request(2, std::false_type{});
+      for_pieces([&](auto Q) __attribute__((always_inline)) { load_piece(I0{}, Q, 2); load_piece(I1{}, Q, 2); });
+    }
     // nothing of the boundary (the stores, reloads of whatever the allocator spilled around the epilogue) may be in flight
     // when the K loop's counted waits start counting: they are the same static instructions in every trip
-    W4_VMCNT(0);
+    if constexpr (!(W4P_RELOAD && CPLX)) W4_VMCNT(0);
   }
   } while (true);
 }
