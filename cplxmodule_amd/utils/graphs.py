@@ -61,7 +61,10 @@ class GraphedStep:
     inputs   : example tensors; their storage becomes the static input buffers.
     modules  : the modules `fn` runs (their cached autograd state is dropped before the warm-up, see above).
     warmup   : eager invocations on the capture stream before the capture (allocator warm-up, lazy initialisation,
-               KL-fusion arming).
+               KL-fusion arming).  The capture records the kernels of the step as it is AT THAT MOMENT: paths that arm
+               themselves on first use (the fused KL of the VD / ARD layers; the conv -> batch-norm moments epilogue,
+               which a batch-norm layer requests for the NEXT step) need at least one warm-up step -- or explicit arming
+               at build time (`conv.arm_conv_bn(model)`) -- to be part of a capture made with warmup=0.
     """
 
     def __init__(self, fn, inputs=(), modules=(), warmup=3, pool=None):
