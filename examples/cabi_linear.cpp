@@ -1,7 +1,8 @@
 // The drop-in boundary without Python or torch: a C++ program that links libcplxamd.so through include/cplxamd.h only,
 // runs the complex linear map of cplxmodule/cplx.py:634-648 (y = x W^T + b, W [out, in]) on device buffers it allocated
 // itself -- float32 operands (the generic kernel) and bf16 operands (the MFMA kernels) -- and checks both against plain
-// loops on the host.  Build + run (tests/test_gpu_r04.py does exactly this on the GPU box):
+// loops on the host; then (ABI 19) the same entry point with per-call launch flags from two threads on two streams.
+// Build + run (tests/test_gpu_r04.py does exactly this on the GPU box):
 //   hipcc --offload-arch=gfx950 -O2 -I include examples/cabi_linear.cpp -L cplxmodule_amd -lcplxamd \
 //         -Wl,-rpath,$PWD/cplxmodule_amd -o /tmp/cabi_linear && /tmp/cabi_linear
 #include <hip/hip_runtime.h>
@@ -11,6 +12,7 @@
 #include <string.h>
 
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "cplxamd.h"
@@ -81,7 +83,47 @@ int main() {
   double e16 = 0;
   for (int j = 0; j < B * O; ++j) e16 = std::fmax(e16, std::fmax(std::fabs(yr[j] - ref_r[j]), std::fabs(yi[j] - ref_i[j])));
   printf("bf16 operands   : max |err| / max |ref| = %.3g\n", e16 / scale);
-  const bool ok = e32 <= 1e-5 * scale && e16 <= 1e-5 * scale;       // exact products of bf16 values, float32 accumulation
+  bool ok = e32 <= 1e-5 * scale && e16 <= 1e-5 * scale;       // exact products of bf16 values, float32 accumulation
+
+  // ABI 19: the launch form is an ARGUMENT.  Two host threads, two HIP streams, opposite policies (one launching as if a
+  // collective held compute units, one as the owner of the chip), at the same time, on one larger problem -- the library
+  // keeps no launch state, so neither sees the other's choice, and the results are the same bits.
+  {
+    const int Bb = 4096, Kb = 512, Nb = 4096;       // 16 x 32 complex tiles: more than one per CU
+    std::vector<uint16_t> ha((size_t)Bb * Kb), hb((size_t)Nb * Kb);
+    for (auto& e : ha) e = to_bf16(rnd());
+    for (auto& e : hb) e = to_bf16(0.1f * rnd());
+    void *a_r, *a_i, *b_r, *b_i;
+    if (upload(&a_r, ha) || upload(&a_i, ha) || upload(&b_r, hb) || upload(&b_i, hb)) return 2;
+    void* out[3][2];
+    for (auto& o : out) for (auto& pl : o) HIP_OK(hipMalloc(&pl, (size_t)Bb * Nb * 2));
+    const int fam0 = CPLXAMD_LAUNCH_FAMILY(0);      // the 8-wave family: it has both forms for this launch
+    const int kinds[2] = {cplxamd_gemm_plan(1, Bb, Nb, Kb, 0, 0, CPLXAMD_BF16, 0, fam0 | CPLXAMD_LAUNCH_SHARED, 0),
+                          cplxamd_gemm_plan(1, Bb, Nb, Kb, 0, 0, CPLXAMD_BF16, 0, fam0 | CPLXAMD_LAUNCH_EXCLUSIVE, 0)};
+    printf("cplxamd_gemm_plan: SHARED -> kernel %d, EXCLUSIVE -> kernel %d (1 one tile per workgroup, 2 persistent)\n", kinds[0], kinds[1]);
+    auto launch = [&](int flags, void** o, hipStream_t st) {
+      return cplxamd_cgemm_fl(a_r, a_i, Kb, 1, b_r, b_i, Kb, 1, nullptr, nullptr, nullptr, o[0], o[1], Nb, Bb, Nb, Kb, 0,
+                              CPLXAMD_BF16, CPLXAMD_BF16, 0, nullptr, CPLXAMD_ALGO_4M, nullptr, 0, flags, st);
+    };
+    if (launch(CPLXAMD_LAUNCH_DEFAULT, out[2], nullptr)) return 1;                  // serial reference, library defaults
+    HIP_OK(hipDeviceSynchronize());
+    hipStream_t st[2];
+    HIP_OK(hipStreamCreate(&st[0])); HIP_OK(hipStreamCreate(&st[1]));
+    int rcs[2] = {0, 0};
+    std::thread t0([&] { for (int r = 0; r < 8 && !rcs[0]; ++r) rcs[0] = launch(fam0 | CPLXAMD_LAUNCH_SHARED, out[0], st[0]); });
+    std::thread t1([&] { for (int r = 0; r < 8 && !rcs[1]; ++r) rcs[1] = launch(fam0 | CPLXAMD_LAUNCH_EXCLUSIVE, out[1], st[1]); });
+    t0.join(); t1.join();
+    HIP_OK(hipDeviceSynchronize());
+    if (rcs[0] || rcs[1]) { fprintf(stderr, "cplxamd_cgemm_fl: error %d / %d\n", rcs[0], rcs[1]); return 1; }
+    std::vector<uint16_t> h[3];
+    for (int v = 0; v < 3; ++v) { h[v].resize((size_t)Bb * Nb); HIP_OK(hipMemcpy(h[v].data(), out[v][0], h[v].size() * 2, hipMemcpyDeviceToHost)); }
+    const bool same = h[0] == h[2] && h[1] == h[2] && kinds[0] == 1 && kinds[1] == 2;
+    printf("two threads / two streams, SHARED and EXCLUSIVE concurrently: %s\n", same ? "identical bits, different kernels" : "MISMATCH");
+    if (cplxamd_cgemm_fl(a_r, a_i, Kb, 1, b_r, b_i, Kb, 1, nullptr, nullptr, nullptr, out[0][0], out[0][1], Nb, Bb, Nb, Kb, 0,
+                         CPLXAMD_BF16, CPLXAMD_BF16, 0, nullptr, CPLXAMD_ALGO_4M, nullptr, 0,
+                         CPLXAMD_LAUNCH_SHARED | CPLXAMD_LAUNCH_EXCLUSIVE, nullptr) != CPLXAMD_EINVAL) ok = false;   // contradictory flags
+    ok = ok && same;
+  }
   printf(ok ? "cabi_linear OK\n" : "cabi_linear FAILED\n");
   return ok ? 0 : 1;
 }
