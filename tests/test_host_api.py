@@ -2,6 +2,7 @@
 walker names, error behaviour, complex-parameter promotion, the Cplx container -- compared with
 what the reference itself reports (tests/golden/api.npz)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -185,3 +186,53 @@ def test_convert_sync_batchnorm_is_a_flag_outside_the_state_dict():
     assert bn._sync_group(True, True) is None and bn._sync_group(True, False) is None     # no process group here
     dp.convert_sync_batchnorm(net, None)
     assert net[1].process_group is None
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cplxmodule"), reason="the reference tree exists in the build container only")
+def test_state_dicts_travel_between_this_package_and_the_reference():
+    """No CPU execution path here -- but a model built by this package loads into the REFERENCE package
+    for CPU evaluation and back: same keys, shapes and dtypes, strict=True both ways.  (Runs only where /root/reference
+    exists; never on the GPU box.)"""
+    import subprocess
+    import sys
+    import tempfile
+    import torch
+    from cplxmodule_amd import nn
+    from cplxmodule_amd.nn import relevance as rel
+    torch.manual_seed(0)
+    ours = torch.nn.Sequential()
+    ours.add_module("lin", nn.CplxLinear(6, 5))
+    ours.add_module("vd", rel.CplxLinearVD(5, 4))
+    ours.add_module("conv", nn.CplxConv2d(3, 2, 3))
+    ours.add_module("bn", nn.CplxBatchNorm2d(2))
+    ours.add_module("ard", rel.LinearARD(4, 3))
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, "ours.pt"), os.path.join(d, "ref.pt")
+        torch.save(ours.state_dict(), src)
+        # the reference in its own interpreter (its package name must not meet ours in one sys.modules)
+        code = f'''
+import sys, types, torch
+sys.path.insert(0, "/root/reference")
+m = types.ModuleType("cplxmodule.__version__"); m.__version__ = open("/root/reference/VERSION").read().strip()
+sys.modules["cplxmodule.__version__"] = m
+from cplxmodule import nn, cplx
+from cplxmodule.nn import relevance as rel
+net = torch.nn.Sequential()
+net.add_module("lin", nn.CplxLinear(6, 5)); net.add_module("vd", rel.CplxLinearVD(5, 4))
+net.add_module("conv", nn.CplxConv2d(3, 2, 3)); net.add_module("bn", nn.CplxBatchNorm2d(2)); net.add_module("ard", rel.LinearARD(4, 3))
+missing = net.load_state_dict(torch.load("{src}"), strict=True)
+net.eval()
+x = cplx.Cplx(torch.ones(2, 6), torch.zeros(2, 6))
+y = net.vd(net.lin(x))                       # the reference evaluates OUR parameters on the CPU
+assert y.real.shape == (2, 4) and torch.isfinite(y.real).all()
+torch.save(net.state_dict(), "{dst}")
+print("REF_OK", float(y.real.sum()))
+'''
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "REF_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        back = torch.load(dst)
+        mine = ours.state_dict()
+        assert list(back.keys()) == list(mine.keys())
+        for k in mine:
+            assert back[k].shape == mine[k].shape and back[k].dtype == mine[k].dtype and torch.equal(back[k], mine[k]), k
+        ours.load_state_dict(back, strict=True)
