@@ -27,5 +27,7 @@ for tag in sys.argv[1:]:
         print(name[-48:]); print("label n mfma sld sst accv bst")
         for c in stats:
             if c[1]>20: print(c)
+        if not stats:
+            continue
         best=max(stats,key=lambda c:c[2])
         print(best[0], dict(collections.Counter(ops[best[0]]).most_common(16)))
