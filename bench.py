@@ -519,7 +519,7 @@ def cfg2_point(dev):
                 x.real.grad = x.imag.grad = None
                 y = fn(x, layer.weight, layer.bias)
                 torch.autograd.backward((y.real, y.imag), (y.real.detach(), y.imag.detach()))
-            for _ in range(3):
+            for _ in range(8):                     # (the first steps after an idle moment run a few per cent slow)
                 step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
