@@ -295,3 +295,28 @@ def test_dp_world8_gloo():
         assert r[10], "second backward without no_sync raises"
         assert r[11] < 2e-5, "tied weights with two zero-copy producers"
         assert r[12] == 3.5
+
+
+def test_init_process_group_channel_cap_wins_over_the_environment(monkeypatch):
+    """ADVICE r04: an explicit max_channels must not be ignored because NCCL_MAX_NCHANNELS is already set (setdefault did);
+    the env form CPLXAMD_RCCL_MAX_CHANNELS feeds the same argument; no process group is created here."""
+    import warnings
+    from cplxmodule_amd import dp
+    seen = {}
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: seen.update(backend=backend, **kw))
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "32")
+    monkeypatch.delenv("CPLXAMD_RCCL_MAX_CHANNELS", raising=False)
+    monkeypatch.delenv("TORCH_NCCL_HIGH_PRIORITY", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        dp.init_process_group("gloo", max_channels=8, rank=0, world_size=1)
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and any("NCCL_MAX_NCHANNELS" in str(x.message) for x in w)
+    assert os.environ["TORCH_NCCL_HIGH_PRIORITY"] == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    assert seen["backend"] == "gloo" and seen["rank"] == 0
+    monkeypatch.setenv("CPLXAMD_RCCL_MAX_CHANNELS", "12")
+    dp.init_process_group("gloo", rank=0, world_size=1)
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "12"
+    monkeypatch.delenv("CPLXAMD_RCCL_MAX_CHANNELS")
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "20")
+    dp.init_process_group("gloo", rank=0, world_size=1)              # no cap asked for: the environment stands
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "20"
