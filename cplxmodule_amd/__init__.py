@@ -9,3 +9,4 @@ __version__ = "0.1.0"
 
 from .cplx import Cplx, from_real, to_real  # noqa: F401
 from . import nn  # noqa: F401
+from .x3 import fp32_mode, get_fp32_mode, set_fp32_mode  # noqa: F401  (float32 products: 'auto' | 'x3' | 'exact')

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 F32, BF16 = 0, 1
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -98,6 +98,7 @@ SIGNATURES = {
     "cplxamd_modulus": [_P, _P, _P, _L, _P],
     "cplxamd_exp": [_P, _P, _L, _I, _P],
     "cplxamd_cast": [_P, _P, _L, _I, _I, _P],
+    "cplxamd_split3": [_P, _P, _L, _P, _L, _L, _L, _I, _I, _I, _P],
     "cplxamd_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "cplxamd_colsum_ws_bytes": [_I],
     "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P, _P],

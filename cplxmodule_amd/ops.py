@@ -9,7 +9,7 @@ import os
 import torch
 from torch.autograd.function import once_differentiable
 
-from . import _lib
+from . import _lib, x3
 from ._lib import call, dtype_code, launch_flags, ptr, require_device, scratch_key, stream_ptr, try_call
 
 _ws_cache = {}
@@ -487,23 +487,55 @@ def _is_bf16(t):
     return t.dtype == torch.bfloat16
 
 
-def _cplx_linear_fwd(x2r, x2i, wr, wi, bias, algo=0):
-    """[B,I] x [O,I]^T -> [B,O]; weights are cast to the activation dtype (bf16 MFMA path)."""
+class _Pieces:
+    """bf16 pieces (x3.split, A side) of float32 planes, made on first use and shared by the products of one pass that
+    read them (the output gradient feeds the weight gradient AND the input gradient).  `abs2`: ONE plane of pieces of
+    xr^2 + xi^2 (xi None: xr^2) -- the |x|^2 operand of the variance products, never materialised in float32."""
+
+    def __init__(self, *planes, abs2=False, made=None):
+        self.planes, self.abs2, self.v = planes, abs2, made
+
+    def get(self):
+        if self.v is None:
+            if self.abs2:
+                self.v = (x3.split(self.planes[0], op=x3.OP_ABS2, t2=self.planes[1] if len(self.planes) > 1 else None),)
+            else:
+                self.v = tuple(x3.split(t) for t in self.planes)
+        return self.v
+
+
+# float32 split products: keep the input's bf16 pieces (6 bytes per element and plane, + 6 for |x|^2) from the forward for
+# the backward's weight gradients instead of splitting again (one HBM pass per plane less; CPLXAMD_X3_SAVE=0: remake them)
+_X3_SAVE = os.environ.get("CPLXAMD_X3_SAVE", "1") != "0"
+
+
+def _cplx_linear_fwd(x2r, x2i, wr, wi, bias, algo=0, mode=None, xs=None):
+    """[B,I] x [O,I]^T -> [B,O]; weights are cast to the activation dtype (bf16 MFMA path).  float32 activations: split
+    operands on the bf16 pipe where x3.take says so (float32-level results), else the exact float32-MFMA kernel."""
     B, I = x2r.shape
     O = wr.shape[0]
+    if x2r.dtype == torch.float32 and x3.take(B, O, I, x2r, x2i, wr, wi, mode=mode):
+        Xs = (xs or _Pieces(x2r, x2i)).get()
+        Ws = (x3.split(wr, x3.SPLIT_B), x3.split(wi, x3.SPLIT_B))
+        yr, yi = x3.gemm_nn(Xs, Ws, B, O, I, bias=bias)
+        return yr, yi, (wr, wi)
     wcr, wci = cast(wr, x2r.dtype), cast(wi, x2r.dtype)
     yr, yi = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype,
                    algo=algo if gauss_ok(B, O, I) else 0)
     return yr, yi, (wcr, wci)
 
 
-def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype, algo=0):
+def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype, algo=0, mode=None, gs=None):
     """dX = G conj(W):  dX[b,i] = sum_o G[b,o] conj(W[o,i]).  The weight is read as stored
     ([O, I] = K-major for this product): no transposed copy."""
     B, O = g2r.shape
     I = wr.shape[1]
     if _is_bf16(g2r):
         wr, wi = cast(wr, torch.bfloat16), cast(wi, torch.bfloat16)
+    elif out_dtype == torch.float32 and x3.take(B, I, O, g2r, g2i, wr, wi, mode=mode):
+        Gs = (gs or _Pieces(g2r, g2i)).get()
+        Wst = (x3.split(wr, x3.SPLIT_B, stacked=True), x3.split(wi, x3.SPLIT_B, stacked=True))
+        return x3.gemm_nt(Gs, Wst, B, I, O, conj_b=True)
     return cgemm(g2r, g2i, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=out_dtype,
                  algo=algo if gauss_ok(B, I, O) and I % 8 == 0 else 0)
 
@@ -512,7 +544,7 @@ _LRT_DX_FUSE = os.environ.get("CPLXAMD_LRT_DX_FUSE", "1") != "0"     # (A/B swit
 _EARLY_W = os.environ.get("CPLXAMD_DP_EARLY_W", "1") != "0"           # (A/B switch: announce dW before the variance dW)
 
 
-def _cplx_lrt_dx(g2r, g2i, wr, wi, x2r, x2i, ga):
+def _cplx_lrt_dx(g2r, g2i, wr, wi, x2r, x2i, ga, mode=None, gs=None):
     """Input gradient of the complex LRT layer: dX = G conj(W) + 2 X (*) ga in ONE launch when the persistent bf16
     kernel takes the shape (cplxamd_cgemm_lrt_dx: the elementwise term rides in its epilogue), otherwise the GEMM and
     the accumulate pass -- bit-identical results either way (tests/test_gpu_r03.py)."""
@@ -525,12 +557,12 @@ def _cplx_lrt_dx(g2r, g2i, wr, wi, x2r, x2i, ga):
         if try_call("cplxamd_cgemm_lrt_dx_fl", ptr(g2r), ptr(g2i), O, 1, ptr(wr), ptr(wi), 1, I, ptr(x2r), ptr(x2i), ptr(ga), I,
                     ptr(dxr), ptr(dxi), I, B, I, O, dtype_code(g2r), launch_flags(), stream_ptr()):
             return dxr, dxi
-    dxr, dxi = _cplx_linear_dx(g2r, g2i, wr, wi, x2r.dtype)
+    dxr, dxi = _cplx_linear_dx(g2r, g2i, wr, wi, x2r.dtype, mode=mode, gs=gs)
     lrt_dx_accum(dxr, dxi, x2r, x2i, ga)
     return dxr, dxi
 
 
-def _real_lrt_dx(g2, w, x2, ga):
+def _real_lrt_dx(g2, w, x2, ga, mode=None, gs=None):
     """Input gradient of the real LRT layer, dX = G W + 2 X (*) ga: one launch (cplxamd_rgemm_lrt_dx) when the persistent
     bf16 kernel takes the shape, else the GEMM and the accumulate pass (bit-identical)."""
     B, O = g2.shape
@@ -541,34 +573,60 @@ def _real_lrt_dx(g2, w, x2, ga):
         if try_call("cplxamd_rgemm_lrt_dx_fl", ptr(g2), O, 1, ptr(w), 1, I, ptr(x2), ptr(ga), I, ptr(dx), I, B, I, O,
                     dtype_code(g2), launch_flags(), stream_ptr()):
             return dx
-    dx = _real_linear_dx(g2, w, x2.dtype)
+    dx = _real_linear_dx(g2, w, x2.dtype, mode=mode, gs=gs)
     lrt_dx_accum(dx, None, x2, None, ga)
     return dx
 
 
-def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0, accumulate=False, beta=None, emul=None):
+def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0, accumulate=False, beta=None, emul=None, mode=None, gs=None,
+                    xs=None):
     """dW = G^T conj(X):  dW[o,i] = sum_b G[b,o] conj(X[b,i]) -> float32 [O,I]; both operands
     are K-major as stored (the bf16 kernel reads them through ds_read_b64_tr_b16).
     accumulate: out = dW + beta * out (beta a device scalar, None = 1)."""
     B, O = g2r.shape
     I = x2r.shape[1]
+    if g2r.dtype == torch.float32 and x3.take(O, I, B, g2r, g2i, x2r, x2i, mode=mode):
+        return x3.gemm_tt((gs or _Pieces(g2r, g2i)).get(), (xs or _Pieces(x2r, x2i)).get(), O, I, B, conj_b=True, out=out,
+                          accumulate=accumulate, beta=beta, emul=emul)
     plain = not accumulate and emul is None
     return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True, out=out,
                  accumulate=accumulate, beta=beta, emul=emul,
                  algo=algo if plain and gauss_ok(O, I, B) and O % 8 == 0 and I % 8 == 0 else 0)
 
 
-def _real_linear_dx(g2, w, out_dtype):
+def _real_linear_fwd(x2, w, bias, out_dtype=None, mode=None, xs=None):
+    """x W^T (+ bias) for float32 or bf16 activations -> (y, the weight as the input gradient wants it)."""
+    B, I = x2.shape
+    O = w.shape[0]
+    if x2.dtype == torch.float32 and x3.take(B, O, I, x2, w, mode=mode):
+        return x3.gemm_nn((xs or _Pieces(x2)).get(), (x3.split(w, x3.SPLIT_B),), B, O, I, bias=bias), w
+    wm = cast(w, x2.dtype)
+    return rgemm(x2, (I, 1), wm, (I, 1), B, O, I, bias=bias, out_dtype=out_dtype or x2.dtype), wm
+
+
+def _real_linear_dx(g2, w, out_dtype, mode=None, gs=None, w_exp=False):
+    """G W -> [B, I].  `w_exp` (float32 split products only): the weight operand is exp(w) -- the variance path's
+    sigma^2 = exp(log_sigma2), formed inside the split pass."""
     B, O = g2.shape
     I = w.shape[1]
     if _is_bf16(g2):
         w = cast(w, torch.bfloat16)
+    elif out_dtype == torch.float32 and x3.take(B, I, O, g2, w, mode=mode):
+        Wst = x3.split(w, x3.SPLIT_B, op=x3.OP_EXP if w_exp else x3.OP_ID, stacked=True)
+        return x3.gemm_nt((gs or _Pieces(g2)).get(), (Wst,), B, I, O)
+    if w_exp:
+        w = exp(w)
     return rgemm(g2, (O, 1), w, (1, I), B, I, O, out_dtype=out_dtype)
 
 
-def _real_linear_dw(g2, x2, emul=None, out=None, emul_exp=False, accumulate=False, beta=None):
+def _real_linear_dw(g2, x2, emul=None, out=None, emul_exp=False, accumulate=False, beta=None, mode=None, gs=None, xs=None):
+    """G^T X (* emul) -> float32 [O, I].  x2 may be None when `xs` (pieces of it, e.g. of |x|^2) is given and the
+    split products take the shape (the caller checked with x3.take)."""
     B, O = g2.shape
-    I = x2.shape[1]
+    I = x2.shape[1] if x2 is not None else xs.get()[0].shape[1] // 3
+    if g2.dtype == torch.float32 and (x2 is None or x3.take(O, I, B, g2, x2, mode=mode)):
+        return x3.gemm_tt((gs or _Pieces(g2)).get(), (xs or _Pieces(x2)).get(), O, I, B, out=out, accumulate=accumulate,
+                          beta=beta, emul=emul, emul_exp=emul_exp)
     if g2.dtype != x2.dtype:
         g2, x2 = cast(g2, torch.float32), cast(x2, torch.float32)
     return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul, out=out, emul_exp=emul_exp,
@@ -635,28 +693,33 @@ class CplxLinearFn(torch.autograd.Function):
             wmr, wmi = mask_mul(wr, wi, mask, out_dtype=x2r.dtype)
         else:
             wmr, wmi = _c(wr), _c(wi)
-        yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, wmr, wmi, bias, algo)
-        ctx.save_for_backward(x2r, x2i, wr, wi, mask)
+        ctx.mode = x3.get_fp32_mode()        # (the backward runs on an autograd thread: it follows this pass's choice)
+        xs = _Pieces(x2r, x2i)
+        yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, wmr, wmi, bias, algo, mode=ctx.mode, xs=xs)
+        keep = xs.v if (_X3_SAVE and xs.v is not None and x3.take(O, I, x2r.shape[0], mode=ctx.mode)) else (None, None)
+        ctx.save_for_backward(x2r, x2i, wr, wi, mask, *keep)
         ctx.has_bias = br is not None
         ctx.lead = xr.shape[:-1]
         return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O)
 
     @staticmethod
     def backward(ctx, gr, gi):
-        x2r, x2i, wr, wi, mask = ctx.saved_tensors
+        x2r, x2i, wr, wi, mask, xsr, xsi = ctx.saved_tensors
         O, I = wr.shape
         g2r, g2i = gr.reshape(-1, O).contiguous(), gi.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
+        gs = _Pieces(g2r, g2i)               # (float32 split products: the pieces of G serve dW and dX)
+        xs = _Pieces(x2r, x2i, made=None if xsr is None else (xsr, xsi))
         # parameter gradients first (into their data-parallel bucket, announced before the dX GEMM)
         if need[2] or need[3]:
             dwr, dwi = grad_buffer(wr), grad_buffer(wi)
-            _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), algo=ctx.algo, emul=mask)
+            _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), algo=ctx.algo, emul=mask, mode=ctx.mode, gs=gs, xs=xs)
             _announce(wr, wi)
         if ctx.has_bias and (need[4] or need[5]):
             dbr, dbi = colsum2(g2r, g2i)
         if need[0] or need[1]:
-            dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r.dtype, ctx.algo)
+            dxr, dxi = _cplx_linear_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r.dtype, ctx.algo, mode=ctx.mode, gs=gs)
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         return dxr, dxi, dwr, dwi, dbr, dbi, None, None
 
@@ -706,27 +769,40 @@ class CplxLinearLRTFn(torch.autograd.Function):
             # returns is copied into (or IS) that storage, so the pending KL gradients survive only the pass that
             # consumes them (nll.backward(); (c * kl).backward() returned the data gradient as the KL one)
             ctx.klg_shared = dp_hook is not None
+        # float32 layers: the three products of the forward (and the five of the backward) on split bf16 operands where
+        # x3.take says so -- float32-level results at the bf16 pipe's rate / 6 instead of the float32 MFMA's
+        ctx.mode = mode = x3.get_fp32_mode()
+        use3 = x2r.dtype == torch.float32 and x3.take(B, O, I, x2r, x2i, wrc, wic, ls2c, mode=mode)
         if _prep_ok(x2r, wrc, wic, ls2c):
             wcr, wci, S, kl, _ = prep_kl(kl_kind, wrc, wic, ls2c, kl_kind is not None, ctx.klg)
         else:
             wcr, wci = cast(wrc, x2r.dtype), cast(wic, x2r.dtype)
-            S = exp(ls2c, out_dtype=x2r.dtype)                # [O,I]
+            S = None if use3 else exp(ls2c, out_dtype=x2r.dtype)                # [O,I]
             if kl_kind is not None:
                 kl = torch.empty((), dtype=torch.float32, device=x2r.device)
                 g = ctx.klg
                 call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wrc)), ptr(_f32(wic)), ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind],
                      1.0, ptr(kl), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(_ws(x2r.device)), O * I, stream_ptr())
         ctx.wc, ctx.S = (wcr, wci), S
-        mur, mui = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
-        a = abs2(x2r, x2i)                                   # [B,I], activation dtype
-        # [B,O]; bf16 layers keep the variance in bf16 (2 bytes per output less in the GEMM epilogue and in both noise
-        # passes; sigma enters y = mu + eps sigma, itself rounded to bf16, with a relative error of 2^-10)
-        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I, out_dtype=_s2_dtype(x2r))
+        keep = (None, None, None)
+        if use3:
+            xs, xa = _Pieces(x2r, x2i), _Pieces(x2r, x2i, abs2=True)
+            mur, mui, _ = _cplx_linear_fwd(x2r, x2i, wcr, wci, bias, mode=mode, xs=xs)
+            a = None                                         # |x|^2 exists as bf16 pieces only
+            s2 = x3.gemm_nn(xa.get(), (x3.split(ls2c, x3.SPLIT_B, op=x3.OP_EXP),), B, O, I)
+            if _X3_SAVE and x3.take(O, I, B, mode=mode):     # the weight gradients will read them
+                keep = (*xs.get(), *xa.get())
+        else:
+            mur, mui = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
+            a = abs2(x2r, x2i)                                   # [B,I], activation dtype
+            # [B,O]; bf16 layers keep the variance in bf16 (2 bytes per output less in the GEMM epilogue and in both noise
+            # passes; sigma enters y = mu + eps sigma, itself rounded to bf16, with a relative error of 2^-10)
+            s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I, out_dtype=_s2_dtype(x2r))
         eps = None
         if eps_r is not None:
             eps = (eps_r.reshape(B, O), eps_i.reshape(B, O))
         yr, yi = reparam_fwd(mur, mui, s2, eps, seed, offset, inplace=True)
-        ctx.save_for_backward(x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi)
+        ctx.save_for_backward(x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi, *keep)
         ctx.has_bias = br is not None
         ctx.lead, ctx.seed, ctx.offset = xr.shape[:-1], seed, offset
         ctx.kl_kind = kl_kind
@@ -749,7 +825,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
                     ctx.klg = None           # the hook overwrites the bucket slices with what this pass returns
             ctx.kl_only_ran = True
             return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
-        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi = _saved(ctx)
+        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi, xsr, xsi, xsa = _saved(ctx)
         O, I = wr.shape
         B = x2r.shape[0]
         klg = None
@@ -777,13 +853,22 @@ class CplxLinearLRTFn(torch.autograd.Function):
         # a data-only backward with the KL buffers still pending (the two-call pattern) must not write into them
         own = (lambda p: torch.empty(p.shape, dtype=torch.float32, device=p.device)) if (ctx.klg is not None and not fused) \
             else grad_buffer
+        # float32 split products: pieces made once per pass, shared by the products that read them
+        m3 = ctx.mode
+        gs, g2s, xa = _Pieces(g2r, g2i), _Pieces(gs2), None
+        xs = _Pieces(x2r, x2i, made=None if xsr is None else (xsr, xsi))
+        if a is None:                                        # the forward ran on pieces of |x|^2
+            if x3.take(O, I, B, gs2, mode=m3):
+                xa = _Pieces(x2r, x2i, abs2=True, made=None if xsa is None else (xsa,))
+            else:
+                a = abs2(x2r, x2i)
         if want_w:
             if fused:
                 dwr, dwi = klg[1], klg[2]
-                _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), accumulate=True, beta=gkl)
+                _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), accumulate=True, beta=gkl, mode=m3, gs=gs, xs=xs)
             else:
                 dwr, dwi = own(wr), own(wi)
-                _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi))
+                _cplx_linear_dw(g2r, g2i, x2r, x2i, out=(dwr, dwi), mode=m3, gs=gs, xs=xs)
                 if klg is not None:
                     dwr.add_(klg[1] * gkl)
                     dwi.add_(klg[2] * gkl)
@@ -794,10 +879,10 @@ class CplxLinearLRTFn(torch.autograd.Function):
         if need[6]:
             if fused:
                 dls2 = klg[0]
-                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl, mode=m3, gs=g2s, xs=xa)
             else:
                 dls2 = own(ls2)
-                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)  # (gs2^T a) * exp(ls2)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, mode=m3, gs=g2s, xs=xa)  # (gs2^T a) * exp(ls2)
                 if klg is not None:
                     dls2.add_(klg[0] * gkl)
         if fused or getattr(ctx, "klg_shared", False):
@@ -806,8 +891,11 @@ class CplxLinearLRTFn(torch.autograd.Function):
             _announce(wr if dwr is not None else None, wi if dwi is not None else None)
         _announce(ls2 if dls2 is not None else None, br if dbr is not None else None, bi if dbi is not None else None)
         if need[0] or need[1]:
-            ga = _real_linear_dx(gs2, ctx.S, dt)             # gs2 . S -> [B,I]
-            dxr, dxi = _cplx_lrt_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r, x2i, ga)   # G conj(W) + 2 x ga
+            if ctx.S is None:                                # gs2 . exp(ls2) -> [B,I], sigma^2 formed in the split pass
+                ga = _real_linear_dx(gs2, ls2c, dt, mode=m3, gs=g2s, w_exp=True)
+            else:
+                ga = _real_linear_dx(gs2, ctx.S, dt)
+            dxr, dxi = _cplx_lrt_dx(g2r, g2i, ctx.wc[0], ctx.wc[1], x2r, x2i, ga, mode=m3, gs=gs)   # G conj(W) + 2 x ga
             dxr, dxi = dxr.view(*ctx.lead, I), dxi.view(*ctx.lead, I)
         return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
 
@@ -825,28 +913,32 @@ class RealLinearFn(torch.autograd.Function):
             mask = _f32(_c(mask.expand_as(w)))
             wm, _ = mask_mul(w, None, mask, out_dtype=x2.dtype)
         else:
-            wm = cast(_c(w), x2.dtype)
-        y = rgemm(x2, (I, 1), wm, (I, 1), x2.shape[0], O, I, bias=_c(b), out_dtype=x2.dtype)
+            wm = _c(w)
+        ctx.mode = x3.get_fp32_mode()
+        xs = _Pieces(x2)
+        y, wm = _real_linear_fwd(x2, wm, _c(b), mode=ctx.mode, xs=xs)
         ctx.wm = wm
-        ctx.save_for_backward(x2, w, mask)
+        keep = xs.v[0] if (_X3_SAVE and xs.v is not None and x3.take(O, I, x2.shape[0], mode=ctx.mode)) else None
+        ctx.save_for_backward(x2, w, mask, keep)
         ctx.has_bias, ctx.lead = b is not None, x.shape[:-1]
         return y.view(*ctx.lead, O)
 
     @staticmethod
     def backward(ctx, g):
-        x2, w, mask = ctx.saved_tensors
+        x2, w, mask, xsv = ctx.saved_tensors
         O, I = w.shape
         g2 = g.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
         dx = dw = db = None
+        gs = _Pieces(g2)
         if need[1]:
             dw = grad_buffer(w)
-            _real_linear_dw(g2, x2, emul=mask, out=dw)
+            _real_linear_dw(g2, x2, emul=mask, out=dw, mode=ctx.mode, gs=gs, xs=None if xsv is None else _Pieces(x2, made=(xsv,)))
             _announce(w)
         if ctx.has_bias and need[2]:
             db = colsum(g2)
         if need[0]:
-            dx = _real_linear_dx(g2, ctx.wm, x2.dtype).view(*ctx.lead, I)
+            dx = _real_linear_dx(g2, ctx.wm, x2.dtype, mode=ctx.mode, gs=gs).view(*ctx.lead, I)
         return dx, dw, db, None
 
 
@@ -884,22 +976,33 @@ class RealLinearLRTFn(torch.autograd.Function):
         if kl_kind is not None:
             ctx.klg = (grad_buffer(ls2), grad_buffer(w))
             ctx.klg_shared = dp_hook is not None             # (see CplxLinearLRTFn.forward)
+        ctx.mode = mode = x3.get_fp32_mode()                 # (see CplxLinearLRTFn.forward)
+        use3 = x2.dtype == torch.float32 and x3.take(B, O, I, x2, wc_, ls2c, mode=mode)
         if _prep_ok(x2, wc_, ls2c):
             wb, _, S, kl, _ = prep_kl(kl_kind, wc_, None, ls2c, kl_kind is not None,
                                       None if ctx.klg is None else (*ctx.klg, None))
         else:
-            wb, S = cast(wc_, x2.dtype), exp(ls2c, out_dtype=x2.dtype)
+            wb, S = cast(wc_, x2.dtype), (None if use3 else exp(ls2c, out_dtype=x2.dtype))
             if kl_kind is not None:
                 kl = torch.empty((), dtype=torch.float32, device=x2.device)
                 call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wc_)), None, ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind], 1.0,
                      ptr(kl), ptr(ctx.klg[0]), ptr(ctx.klg[1]), None, ptr(_ws(x2.device)), O * I, stream_ptr())
         ctx.wb, ctx.S = wb, S
-        mu = rgemm(x2, (I, 1), wb, (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
-        a = abs2(x2)
-        s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I, out_dtype=_s2_dtype(x2))
+        keep = (None, None)
+        if use3:
+            xs, xa = _Pieces(x2), _Pieces(x2, abs2=True)
+            mu, _ = _real_linear_fwd(x2, wb, _c(b), mode=mode, xs=xs)
+            a = None
+            s2 = x3.gemm_nn(xa.get(), (x3.split(ls2c, x3.SPLIT_B, op=x3.OP_EXP),), B, O, I)
+            if _X3_SAVE and x3.take(O, I, B, mode=mode):
+                keep = (*xs.get(), *xa.get())
+        else:
+            mu = rgemm(x2, (I, 1), wb, (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
+            a = abs2(x2)
+            s2 = rgemm(a, (I, 1), S, (I, 1), B, O, I, out_dtype=_s2_dtype(x2))
         e = None if eps is None else eps.reshape(B, O)
         y, _ = reparam_fwd(mu, None, s2, e, seed, offset, inplace=True)
-        ctx.save_for_backward(x2, w, ls2, s2, a, eps, b)
+        ctx.save_for_backward(x2, w, ls2, s2, a, eps, b, *keep)
         ctx.has_bias, ctx.lead, ctx.seed, ctx.offset = b is not None, x.shape[:-1], seed, offset
         ctx.kl_kind = kl_kind
         ctx.kl_params = (w, ls2) if kl_kind is not None else None
@@ -919,7 +1022,7 @@ class RealLinearLRTFn(torch.autograd.Function):
                     ctx.klg = None
             ctx.kl_only_ran = True
             return dx, dw, db, dls2, None, None, None, None
-        x2, w, ls2, s2, a, eps, b = _saved(ctx)
+        x2, w, ls2, s2, a, eps, b, xsv, xsa = _saved(ctx)
         O, I = w.shape
         B = x2.shape[0]
         klg = None
@@ -937,30 +1040,41 @@ class RealLinearLRTFn(torch.autograd.Function):
         fused = klg is not None and klg is ctx.klg           # per tensor, in place (see CplxLinearLRTFn.backward)
         own = (lambda p: torch.empty(p.shape, dtype=torch.float32, device=p.device)) if (ctx.klg is not None and not fused) \
             else grad_buffer
+        m3 = ctx.mode
+        gs, g2s, xa = _Pieces(g2), _Pieces(gs2), None        # (see CplxLinearLRTFn.backward)
+        xs = None if xsv is None else _Pieces(x2, made=(xsv,))
+        if a is None:
+            if x3.take(O, I, B, gs2, mode=m3):
+                xa = _Pieces(x2, abs2=True, made=None if xsa is None else (xsa,))
+            else:
+                a = abs2(x2)
         if need[1]:
             if fused:
                 dw = klg[1]
-                _real_linear_dw(g2, x2, out=dw, accumulate=True, beta=gkl)
+                _real_linear_dw(g2, x2, out=dw, accumulate=True, beta=gkl, mode=m3, gs=gs, xs=xs)
             else:
                 dw = own(w)
-                _real_linear_dw(g2, x2, out=dw)
+                _real_linear_dw(g2, x2, out=dw, mode=m3, gs=gs, xs=xs)
                 if klg is not None:
                     dw.add_(klg[1] * gkl)
         if need[3]:
             if fused:
                 dls2 = klg[0]
-                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, accumulate=True, beta=gkl, mode=m3, gs=g2s, xs=xa)
             else:
                 dls2 = own(ls2)
-                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2)
+                _real_linear_dw(gs2, a, emul=ls2c, emul_exp=True, out=dls2, mode=m3, gs=g2s, xs=xa)
                 if klg is not None:
                     dls2.add_(klg[0] * gkl)
         if fused or getattr(ctx, "klg_shared", False):
             ctx.klg = None
         _announce(ls2 if dls2 is not None else None, w if dw is not None else None, b if db is not None else None)
         if need[0]:
-            ga = _real_linear_dx(gs2, ctx.S, dt)
-            dx = _real_lrt_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), x2, ga)
+            if ctx.S is None:
+                ga = _real_linear_dx(gs2, ls2c, dt, mode=m3, gs=g2s, w_exp=True)
+            else:
+                ga = _real_linear_dx(gs2, ctx.S, dt)
+            dx = _real_lrt_dx(g2, ctx.wb if _is_bf16(g2) else _c(w), x2, ga, mode=m3, gs=gs)
             dx = dx.view(*ctx.lead, I)
         return dx, dw, db, dls2, None, None, None, None
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 19
+#define CPLXAMD_ABI_VERSION 20
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
@@ -357,6 +357,30 @@ int cplxamd_mask_mul(const void* in_r, const void* in_i, const float* mask, void
 int cplxamd_exp(const float* x, void* out, int64_t n, int out_dtype, void* stream);
 /* dtype conversion */
 int cplxamd_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
+
+/* ---- float32-accurate products on the bf16 matrix pipe ("x3" operands; csrc/split.hip) -------------------------------
+ * Replaces the float32 arithmetic of cplx.linear (cplxmodule/cplx.py:641-646) and of the local-reparameterization
+ * variance products (nn/relevance/complex/base.py:43-56, real/base.py:43-49) at 2^-24-level accuracy without the 157-TFLOP/s
+ * float32 MFMA: a float32 value is the exact sum of three bf16 values x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1),
+ * and a product needs the six terms x0 w0, x0 w1, x1 w0, x0 w2, x2 w0, x1 w1 (the other three are below 2^-24 |x w|), each
+ * exact in the bf16 MFMA with float32 accumulation.
+ * cplxamd_split3 writes the pieces of  op(src)  [rows][cols] (row pitch ld_src; float32) as bf16 matrices
+ *     dst + p * piece_stride + r * ld_dst + c,   p = 0 .. 2 (pattern A) or 0 .. 5 (pattern B)
+ *   CPLXAMD_SPLIT_A   (x2, x1, x0)               -- the activation side; SUFFIXES of it are GEMM operands
+ *   CPLXAMD_SPLIT_B   (w2, w1, w1, w0, w0, w0)   -- the weight side, replicated so that the six terms are three launches of
+ *                     cplxamd_cgemm_fl / cplxamd_rgemm_fl (bf16 in, float32 out, accumulate from the second on) with
+ *                     the pieces concatenated along K:   x0 . w2,   [x1|x0] . [w1|w1],   [x2|x1|x0] . [w0|w0|w0]
+ *   (piece_stride = cols, ld_dst = 3 cols / 6 cols: pieces side by side in a row = K-concatenation of K-contiguous operands;
+ *    piece_stride = rows * ld_dst: pieces stacked = K-concatenation of a K-major operand.)
+ * op: CPLXAMD_SPLIT_ID  src;  CPLXAMD_SPLIT_ABS2  src^2 + src2^2 (src2 NULL: src^2; complex/base.py:51);
+ *     CPLXAMD_SPLIT_EXP  exp(src) (log_sigma2 -> sigma^2, complex/base.py:52).  src2 only with ABS2.
+ * A non-finite value is carried by the leading piece alone (the others 0).
+ * cols % 8 == 0, ld_src % 4 == 0, ld_dst % 8 == 0, piece_stride % 8 == 0 (CPLXAMD_ESHAPE), 16-byte aligned pointers (CPLXAMD_EALIGN).
+ * HBM: 4 (8 with src2) bytes read, 6 (pattern A) / 12 (pattern B) bytes written per element. */
+enum { CPLXAMD_SPLIT_A = 0, CPLXAMD_SPLIT_B = 1 };
+enum { CPLXAMD_SPLIT_ID = 0, CPLXAMD_SPLIT_ABS2 = 1, CPLXAMD_SPLIT_EXP = 2 };
+int cplxamd_split3(const float* src, const float* src2, int64_t ld_src, void* dst, int64_t ld_dst, int64_t piece_stride,
+                   int64_t rows, int cols, int op, int pattern, void* stream);
 /* out[c, r] = in[r, c]  (rows x cols row-major in, ld = leading dims) */
 int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
                       int cols, int dtype, void* stream);

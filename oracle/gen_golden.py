@@ -1053,10 +1053,75 @@ def gen_trajectory_conv():
     save("trajectory_conv", d)
 
 
+def gen_x3():
+    """Shapes the float32 split-operand products take (every dimension a multiple of 32, ragged against the kernels'
+    256 / 128 tiles): CplxLinear, CplxLinearVD and LinearVD forward + autograd gradients in float32 (the reference's own
+    numbers) and float64 (the same seeds: what the float32 numbers approximate)."""
+    d = {}
+    B, I, O = 32, 64, 96
+    for tag, dt in DT.items():
+        torch.set_default_dtype(dt)
+        torch.manual_seed(111)
+        xr, xi = leaf(B, I, dtype=dt), leaf(B, I, dtype=dt)
+        wr, wi = leaf(O, I, dtype=dt, scale=0.1), leaf(O, I, dtype=dt, scale=0.1)
+        br, bi = leaf(O, dtype=dt), leaf(O, dtype=dt)
+        gr, gi = torch.randn(B, O, dtype=dt), torch.randn(B, O, dtype=dt)
+        k = f"{tag}_lin_"
+        for nm, t in dict(xr=xr, xi=xi, wr=wr, wi=wi, br=br, bi=bi, gr=gr, gi=gi).items():
+            d[k + nm] = npy(t)
+        y = cplx.linear(C(xr, xi), C(wr, wi), C(br, bi))
+        d[k + "yr"], d[k + "yi"] = npy(y.real), npy(y.imag)
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), [xr, xi, wr, wi, br, bi])
+        for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi"], grads):
+            d[k + nm] = npy(g)
+        # complex VD layer, training mode, noise tape recorded
+        torch.manual_seed(121)
+        layer = rel.CplxLinearVD(I, O, bias=True)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-8, 1)
+        x = cplx.randn(B, I)
+        xr, xi = x.real.clone().requires_grad_(True), x.imag.clone().requires_grad_(True)
+        gr, gi = torch.randn(B, O), torch.randn(B, O)
+        layer.train()
+        torch.manual_seed(177)
+        y = layer(C(xr, xi))
+        torch.manual_seed(177)
+        tape = torch.randn(2, B, O)
+        kl = sum(rel.penalties(layer))
+        ps = [xr, xi, layer.weight.real, layer.weight.imag, layer.bias.real, layer.bias.imag, layer.log_sigma2]
+        grads = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum() + 1e-2 * kl, ps)
+        k = f"{tag}_cvd_"
+        for nm, t in dict(xr=xr, xi=xi, wr=ps[2], wi=ps[3], br=ps[4], bi=ps[5], ls2=ps[6], gr=gr, gi=gi, tape=tape,
+                          yr=y.real, yi=y.imag, kl=kl).items():
+            d[k + nm] = npy(t)
+        for nm, g in zip(["dxr", "dxi", "dwr", "dwi", "dbr", "dbi", "dls2"], grads):
+            d[k + nm] = npy(g)
+        # real VD layer
+        torch.manual_seed(122)
+        layer = rel.LinearVD(I, O, bias=True)
+        with torch.no_grad():
+            layer.log_sigma2.uniform_(-8, 1)
+        x = torch.randn(B, I).requires_grad_(True)
+        g = torch.randn(B, O)
+        layer.train()
+        torch.manual_seed(179)
+        y = layer(x)
+        torch.manual_seed(179)
+        eps = torch.randn(B, O)
+        kl = sum(rel.penalties(layer))
+        grads = torch.autograd.grad((y * g).sum() + 1e-2 * kl, [x, layer.weight, layer.bias, layer.log_sigma2])
+        k = f"{tag}_rvd_"
+        for nm, t in dict(x=x, w=layer.weight, b=layer.bias, ls2=layer.log_sigma2, g=g, eps=eps, y=y, kl=kl,
+                          dx=grads[0], dw=grads[1], db=grads[2], dls2=grads[3]).items():
+            d[k + nm] = npy(t)
+    torch.set_default_dtype(torch.float32)
+    save("x3", d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reproducible summation order
     gens = dict(linear=gen_linear, lrt_linear=gen_lrt_linear, penalty=gen_penalty, conv=gen_conv,
                 batchnorm=gen_batchnorm, api=gen_api, extras=gen_extras, bilinear=gen_bilinear, conv3d=gen_conv3d, conv_transpose=gen_conv_transpose,
-                r02=gen_r02, trajectory=gen_trajectory, trajectory_conv=gen_trajectory_conv)
+                r02=gen_r02, trajectory=gen_trajectory, trajectory_conv=gen_trajectory_conv, x3=gen_x3)
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()
