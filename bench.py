@@ -5,7 +5,8 @@ One step = zero_grad + LRT forward (complex GEMM + variance GEMM + Philox noise 
 + fused KL + loss (sum |y|^2 + 1e-3 KL, upstream gradient 2y) + full backward (dX, dW, db,
 dlog_sigma2, dKL) [+ flat-bucket gradient all-reduce and scalar KL all-reduce for N > 1].
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                            torch.distributed.run, one rank per GPU, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
@@ -52,7 +53,25 @@ def parse():
                     "passed to dp.init_process_group(max_channels=...)")
     ap.add_argument("--force-collectives", action="store_true", help="world of one: initialise the process group and "
                     "issue every collective of the N > 1 path anyway (tests: RCCL calls on a single-GPU box)")
+    ap.add_argument("--check", action="store_true", help="after the timed region (untimed, rank 0, N = 1): value-check one "
+                    "more step of exactly this workload -- as a hipGraph replay -- against float64 numpy with the numpy "
+                    "Philox statement (tests/headline_check.py); the result is the line's `check` object")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
+    <same arguments>` -- one rank per GPU; rank 0 still prints the one JSON line on this process's stdout."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 class KernelTimer:
@@ -254,8 +273,14 @@ def conv_point(dev, batch=256, dtype=torch.bfloat16):
         out = {"workload": f"CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, {name}, batch {batch}, fwd+bwd, channels-last",
                "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flop_per_launch": flop}
         if dtype != torch.bfloat16:
-            # the 1e-5 mode (exact-float32 MFMA kernels): three convolution launches' flop over the whole step
+            # the 1e-5 mode: three convolution launches' flop over the whole step, against the float32-MFMA peak and, when
+            # the split-operand products ran, against their bound (bf16 peak / 6)
+            from cplxmodule_amd import get_fp32_mode
+            out["fp32_mode"] = get_fp32_mode()
+            out["tflops_whole_step"] = round(3 * flop / dt / 1e12, 1)
             out["frac_of_fp32_mfma_peak_whole_step"] = round(3 * flop / dt / 1e12 / FP32_PEAK_TFLOPS, 4)
+            if out["fp32_mode"] != "exact":
+                out["frac_of_x3_bound_whole_step"] = round(3 * flop / dt / 1e12 / X3_BOUND_TFLOPS, 4)
             return out
         for k in ("fwd", "dgrad", "wgrad"):
             ms = timer.mean_ms(k)
@@ -269,26 +294,39 @@ def conv_point(dev, batch=256, dtype=torch.bfloat16):
         return {"error": str(e)[:200]}
 
 
+X3_BOUND_TFLOPS = BF16_PEAK_TFLOPS / 6.0   # float32 products as six bf16 piece products: what the bf16 pipe allows
+
+
 def fp32_points(dev):
-    """The float32 mode -- the one the 1e-5 parity bar is stated in -- at BASELINE's FULL sizes, so that it has a throughput
-    on record: configs[3] at batch 2^20 (about 150 GB of float32 planes: only on a GPU with that much
-    free) and configs[2] at batch 256 channels-last.  Exact-float32 MFMA kernels (157.3 TF/s peak); rank 0, N = 1,
-    outside the timed region."""
-    out = {}
+    """The float32 mode -- the one the 1e-5 parity bar is stated in -- at BASELINE's FULL sizes: configs[3] at batch 2^20
+    (about 180 GB of float32 planes and bf16 pieces: only on a GPU with that much free) and configs[2] at batch 256
+    channels-last.  Default arithmetic since round 6: split operands on the bf16 matrix pipe (cplxmodule_amd/x3.py: six
+    bf16 piece products per float32 product, bound 2500 / 6 = 417 TFLOP/s); `*_exact` = the float32-MFMA kernels (157.3
+    TFLOP/s peak) the mode replaced, same process, for the ratio.  Rank 0, N = 1, outside the timed region."""
+    out = {"x3_bound_tflops": round(X3_BOUND_TFLOPS, 1), "fp32_mfma_peak_tflops": FP32_PEAK_TFLOPS}
     try:
+        from cplxmodule_amd import fp32_mode
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info(dev)
-        if free >= 200 << 30:
-            out["cfg4_lrt_fp32"] = cfg4_point(dev, dtype=torch.float32, steps=2)
-        else:
-            out["cfg4_lrt_fp32"] = {"skipped": f"{free >> 30} GiB free, the float32 step at batch 2^20 wants ~150"}
-        torch.cuda.empty_cache()
-        free, _ = torch.cuda.mem_get_info(dev)
-        if free >= 120 << 30:
-            out["conv_cfg3_fp32"] = conv_point(dev, dtype=torch.float32)
-        else:
-            out["conv_cfg3_fp32"] = {"skipped": f"{free >> 30} GiB free"}
-        torch.cuda.empty_cache()
+        for tag, mode in (("cfg4_lrt_fp32", "auto"), ("cfg4_lrt_fp32_exact", "exact")):
+            if free >= 220 << 30:
+                with fp32_mode(mode):
+                    out[tag] = cfg4_point(dev, dtype=torch.float32, steps=2)
+            else:
+                out[tag] = {"skipped": f"{free >> 30} GiB free, the float32 step at batch 2^20 wants ~180"}
+            torch.cuda.empty_cache()
+        for tag, mode in (("conv_cfg3_fp32", "auto"), ("conv_cfg3_fp32_exact", "exact")):
+            free, _ = torch.cuda.mem_get_info(dev)
+            if free >= 140 << 30:
+                with fp32_mode(mode):
+                    out[tag] = conv_point(dev, dtype=torch.float32)
+            else:
+                out[tag] = {"skipped": f"{free >> 30} GiB free"}
+            torch.cuda.empty_cache()
+        for a in ("cfg4_lrt_fp32", "conv_cfg3_fp32"):
+            p, e = out.get(a, {}), out.get(a + "_exact", {})
+            if "ms_per_step" in p and "ms_per_step" in e:
+                p["speedup_over_fp32_mfma_kernels"] = round(e["ms_per_step"] / p["ms_per_step"], 3)
     except Exception as e:  # pragma: no cover
         out["error"] = str(e)[:200]
     return out
@@ -373,6 +411,43 @@ def dp_projection(dev):
     return out
 
 
+def expected_weak_8(ms_n1, B):
+    """What the WEAK-scaling run at N = 8 (8192 rows per GPU, this step on every rank) should print, from this run's
+    N = 1 step time and the exchange at link rate -- a projection to hold the driver's SCALE record against, not a
+    measurement.  Exchange: one flat float32 bucket set of 3 x 4096^2 + 2 x 4096 gradients = 201 MB per rank
+    (log_sigma2, weight.imag, weight.real, biases), mean all-reduce over xGMI (7 links x ~153 GB/s per GPU):
+    ring = 2 (7/8) S over ONE link, direct reduce-scatter + all-gather = 2 S / 8 per link over all seven.  The
+    weight-gradient buckets are announced before the input-gradient GEMMs (~1.0 ms of launches: dX complex + its
+    variance part), which is the window the collective can hide in."""
+    S = (3 * IN_F * OUT_F + 2 * OUT_F) * 4.0
+    link = 153e9
+    ring_ms, direct_ms = 2 * (7 / 8) * S / link * 1e3, 2 * S / 8 / link * 1e3
+    window_ms = 1.0
+    out = {"per_gpu_batch": B, "bucket_bytes": int(S), "ring_allreduce_ms": round(ring_ms, 3),
+           "direct_rs_ag_ms": round(direct_ms, 3), "overlap_window_ms": window_ms, "n1_ms_per_step": round(ms_n1, 4)}
+    for name, ex in (("ring", ring_ms), ("direct", direct_ms)):
+        for ov, hidden in (("overlapped", min(ex, window_ms)), ("unoverlapped", 0.0)):
+            t = ms_n1 + ex - hidden
+            out[f"{name}_{ov}"] = {"ms_per_step": round(t, 4), "samples_per_s": round(8 * B / (t * 1e-3), 1),
+                                   "efficiency_vs_8x_n1": round(ms_n1 / t, 4)}
+    return out
+
+
+def headline_check(B, dev):
+    """bench.py --check: tests/headline_check.py on this workload (graph replay), untimed; errors are reported, not raised."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from headline_check import check_headline_step
+        res = check_headline_step(B=B, F=IN_F, graph=True, dev=str(dev))
+        return {"passed": True, "against": "float64 numpy + numpy Philox statement (tests/headline_check.py)",
+                "max_err_over_max_ref": {k: float(f"{v[0]:.3e}") for k, v in res.items()},
+                "asserted": {k: v[1] for k, v in res.items()}}
+    except AssertionError as e:
+        return {"passed": False, "error": str(e)[:300]}
+    except Exception as e:  # pragma: no cover
+        return {"passed": None, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+
+
 # The reference itself (PyTorch CPU path of ivannz/cplxmodule) cannot travel to the GPU box; its numbers are the ones taken
 # in the build container (BASELINE.md section 2, rows 2 / 2' / 2'' / 4): context beside `cpu_baseline`, never a target.
 REFERENCE_CPU = {
@@ -435,6 +510,11 @@ def cfg4_point(dev, log2_batch=20, timer=None, dtype=torch.bfloat16, batch=None,
                "tflops_whole_step": round(flop / dt / 1e12, 1),
                ("frac_of_mfma_peak_whole_step" if bf else "frac_of_fp32_mfma_peak_whole_step"):
                    round(flop / dt / 1e12 / (BF16_PEAK_TFLOPS if bf else FP32_PEAK_TFLOPS), 4)}
+        if not bf:
+            from cplxmodule_amd import get_fp32_mode
+            out["fp32_mode"] = get_fp32_mode()
+            if out["fp32_mode"] != "exact":      # (a fraction of the float32-MFMA peak above 1 is possible and means nothing)
+                out["frac_of_x3_bound_whole_step"] = round(flop / dt / 1e12 / X3_BOUND_TFLOPS, 4)
         if timer is not None:
             keep, timer.spans, timer.enabled = timer.spans, {}, True
             step()
@@ -549,9 +629,10 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                      # does not return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.share_device:
         local = 0
     torch.cuda.set_device(local)
@@ -763,6 +844,7 @@ def main():
             line["cfg5_train_step"] = cfg5_point(dev)
             line["fp32_full_size"] = fp32_points(dev)
             line["dp_projection"] = dp_projection(dev)
+            line["dp_projection"]["expected_weak_8"] = expected_weak_8(ms, B)
             # a figure above what a copy reaches on this chip (6.3 TB/s, MI355X_MICROARCH.md) was not served by HBM: an
             # in-step kernel whose operands the preceding GEMM left in the 256-MiB Infinity Cache.  Mark, do not boast.
             hk = line["hbm_kernels_GBps"]
@@ -771,6 +853,8 @@ def main():
             hk["cache_assisted_rule"] = f"> {HBM_COPY_GBS:.0f} GB/s = above the achievable HBM copy rate: fed from the Infinity Cache"
             line["cpu_baseline"] = cpu_baseline(512)
             line["reference_cpu"] = REFERENCE_CPU
+        if world == 1 and args.check:
+            line["check"] = headline_check(B, dev)
         print(json.dumps(line), flush=True)
     if grouped:
         dist.destroy_process_group()

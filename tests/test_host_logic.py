@@ -120,3 +120,59 @@ def test_arm_conv_bn_finds_the_direct_pairs_only():
     twin = copy.deepcopy(net)                              # requests are keyed by the parameter OBJECT: a copy starts unarmed
     assert not conv.moments_wanted(twin[0].weight.real)
     assert conv.arm_conv_bn(net, on=False) == 2 and not conv._MOMENTS_WANTED
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N (N > 1) without a launcher: the command it becomes (no GPU needed: os.execv is intercepted)."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_execv(path, argv):
+        seen["path"], seen["argv"] = path, list(argv)
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    import pytest
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert seen["path"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in a and "--nproc-per-node=4" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    i = a.index(os.path.join(root, "bench.py"))
+    assert a[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # under a launcher (WORLD_SIZE set) with a mismatching world it refuses instead of re-launching
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "argv" not in seen and "WORLD_SIZE=2" in str(e.value)
+    w = bench.expected_weak_8(3.2, 8192)
+    assert w["bucket_bytes"] == (3 * 4096 * 4096 + 2 * 4096) * 4
+    assert w["ring_unoverlapped"]["samples_per_s"] < w["direct_overlapped"]["samples_per_s"] <= 8 * 8192 / 3.2e-3 + 1
+
+
+def test_x3_take_rules_host():
+    from cplxmodule_amd import x3
+    assert not x3.take(64, 64, 32, mode="exact") and x3.take(64, 64, 32, mode="x3") and not x3.take(64, 64, 32, mode="auto")
+    assert x3.take(1024, 1024, 1024, mode="auto") and not x3.take(1024, 1020, 1024, mode="x3")
+    assert not x3.take(1024, 1024, 1000, mode="x3") and not x3.take(1 << 21, 64, 64, mode="x3")
+    import torch
+    assert not x3.take(64, 64, 32, torch.zeros(1), mode="x3")            # CPU tensor: never
+    prev = x3.set_fp32_mode("exact")
+    try:
+        assert x3.get_fp32_mode() == "exact"
+        with x3.fp32_mode("x3"):
+            assert x3.get_fp32_mode() == "x3"
+        assert x3.get_fp32_mode() == "exact"
+    finally:
+        x3.set_fp32_mode(prev)
