@@ -2,6 +2,7 @@
 import torch
 
 from . import _lib, ops
+from .ops import once_differentiable
 from ._lib import call, dtype_code, ptr, require_device, stream_ptr, scratch_key
 
 _ws_cache = {}
@@ -113,6 +114,7 @@ class CplxBatchNormFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         xr, xi, w, saved = ctx.saved_tensors
         if ctx.cl:

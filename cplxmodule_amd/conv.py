@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, ops
+from .ops import once_differentiable
 from ._lib import CplxAmdError, call, try_call, dtype_code, launch_flags, ptr, require_device, stream_ptr
 from .cplx import Cplx
 
@@ -235,6 +236,8 @@ class ToChannelsLastFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if torch.is_grad_enabled():        # create_graph: a layout change is a differentiable torch op
+            return g.contiguous() if ctx.planar else g
         return from_channels_last(g) if ctx.planar else g
 
 
@@ -650,6 +653,7 @@ class CplxConv2dFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         xr, xi, wcr, wci = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -696,6 +700,7 @@ class RealConv2dFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         x, wc = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -809,6 +814,7 @@ class CplxConv2dLRTFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         xr, xi, wcr, wci, ls2, s2, a, S, eps_r, eps_i = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -898,6 +904,7 @@ class RealConv2dLRTFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         x, wc, ls2, s2, a, S, eps = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -1055,6 +1062,7 @@ class CplxConvTranspose2dFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         xr, xi, vr, vi = ctx.saved_tensors
         gr, gi = gr.contiguous(), gi.contiguous()

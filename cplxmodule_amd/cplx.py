@@ -366,6 +366,12 @@ class _BatchedMatmulFn(torch.autograd.Function):
         ar, ai, vr, vi = ctx.saved_tensors
         Z, M, K = ar.shape
         N = vr.shape[2]
+        if torch.is_grad_enabled():       # create_graph=True: dA = G V^H, dV = A^H G through this Function itself
+            T = lambda t: t.transpose(1, 2).contiguous()  # noqa: E731
+            gr, gi = gr.contiguous(), gi.contiguous()
+            dar, dai = _BatchedMatmulFn.apply(gr, gi, T(vr), -T(vi))
+            dvr, dvi = _BatchedMatmulFn.apply(T(ar), -T(ai), gr, gi)
+            return dar, dai, dvr, dvi
         gr, gi = gr.contiguous(), gi.contiguous()
         # dA[m,k] = sum_n G[m,n] conj(V[k,n]);  dV[k,n] = conj(sum_m A[m,k] conj(G[m,n]))
         dar, dai = ops.cgemm_batched(gr, gi, (N, 1, M * N), vr, vi, (N, 1, K * N), Z, M, K, N, conj_b=True)
@@ -390,6 +396,12 @@ class _MatmulFn(torch.autograd.Function):
         ar, ai, vr, vi = ctx.saved_tensors
         M, K = ar.shape
         N = vr.shape[1]
+        if torch.is_grad_enabled():       # create_graph=True: dA = G V^H, dV = A^H G through this Function itself
+            T = lambda t: t.t().contiguous()  # noqa: E731
+            gr, gi = gr.contiguous(), gi.contiguous()
+            dar, dai = _MatmulFn.apply(gr, gi, T(vr), -T(vi))
+            dvr, dvi = _MatmulFn.apply(T(ar), -T(ai), gr, gi)
+            return dar, dai, dvr, dvi
         gr, gi = gr.contiguous(), gi.contiguous()
         # dA = G conj(V)^T : dA[m,k] = sum_n G[m,n] conj(V[k,n])
         dar, dai = ops.cgemm(gr, gi, (N, 1), vr, vi, (N, 1), M, K, N, conj_b=True, out_dtype=ar.dtype)
@@ -417,6 +429,50 @@ def conv3d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
     the depth taps of 2-d correlations on the conv2d kernels (conv3d.py)."""
     from .conv3d import cplx_conv3d
     return cplx_conv3d(input, weight, bias, stride, padding, dilation, groups, padding_mode)
+
+
+def symmetric_circular_padding(input, padding):
+    """cplxmodule/cplx.py:701-714: circular padding ((p + 1) // 2, p // 2) per spatial dimension of a [B, C, L_1 .. L_n]
+    complex tensor (`padding`: int or one entry per spatial dimension, fed to F.pad in the reference's order)."""
+    import torch.nn.functional as F
+    assert input.dim() > 2
+    if isinstance(padding, int):
+        padding = (input.dim() - 2) * [padding]
+    assert isinstance(padding, (tuple, list)) and len(padding) + 2 == input.dim()
+    expanded = []
+    for pad in padding:
+        expanded.extend(((pad + 1) // 2, pad // 2))
+    return Cplx(F.pad(input.real, tuple(expanded), mode="circular"), F.pad(input.imag, tuple(expanded), mode="circular"))
+
+
+def convnd(conv, input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, padding_mode="zeros"):
+    """The reference's module-level operator (cplxmodule/cplx.py:770-800).  `conv` -- there the real torch functional that
+    does the work (F.conv1d / 2d / 3d) -- only names the dimensionality here: the kernels behind conv1d / conv2d / conv3d
+    run whichever is handed in (None: decided by input.dim())."""
+    nd = input.dim() - 2
+    name = getattr(conv, "__name__", "") if conv is not None else ""
+    if name in ("conv1d", "conv2d", "conv3d") and int(name[4]) != nd:
+        raise ValueError(f"{name} on a {input.dim()}-d input")
+    fn = {1: conv1d, 2: conv2d, 3: conv3d}.get(nd)
+    if fn is None:
+        raise ValueError(f"convnd: {nd} spatial dimensions are not supported (1, 2 or 3)")
+    return fn(input, weight, bias, stride, padding, dilation, groups, padding_mode)
+
+
+def convnd_naive(conv, input, weight, stride=1, padding=0, dilation=1, groups=1):
+    """cplxmodule/cplx.py:717-726 (four real convolutions; the grouped form): the same complex kernels."""
+    return convnd(conv, input, weight, None, stride, padding, dilation, groups)
+
+
+def convnd_quick(conv, input, weight, stride=1, padding=0, dilation=1):
+    """cplxmodule/cplx.py:729-742 (two real convolutions with stacked filters, groups = 1): the same complex kernels."""
+    return convnd(conv, input, weight, None, stride, padding, dilation, 1)
+
+
+def convnd_3m(conv, input, weight, stride=1, padding=0, dilation=1, groups=1):
+    """cplxmodule/cplx.py:745-767 (Gauss's three real convolutions; not wired into the reference's layers): routed to the
+    four-product kernels, like linear_3m -- one fused K loop beats three launches plus operand sums on this chip."""
+    return convnd(conv, input, weight, None, stride, padding, dilation, groups)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1,

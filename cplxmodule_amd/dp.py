@@ -176,7 +176,7 @@ def _all_reduce(flat, async_op):
 
 
 class BucketHook:
-    """Installed as `ops.dp_hook` by DataParallel."""
+    """Registered for its wrapper's parameters (`ops.register_dp_hook`) by DataParallel."""
 
     def __init__(self, buckets, overlap=True):
         self.buckets = buckets
@@ -421,7 +421,12 @@ class DataParallel(torch.nn.Module):
                 dist.broadcast(p.data, src=0)
             for b in module.buffers():
                 dist.broadcast(b.data, src=0)
-            self.hook = ops.dp_hook = BucketHook(self.buckets, overlap=overlap)
+            # found per parameter (ops.hook_of): several wrapped models can live in one process; the first one is also the
+            # process-wide fallback `ops.dp_hook`
+            self.hook = BucketHook(self.buckets, overlap=overlap)
+            ops.register_dp_hook(self.hook, self.buckets.params)
+            if ops.dp_hook is None:
+                ops.dp_hook = self.hook
             for p in self.buckets.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self.hook.on_grad))
             # decorrelate the local-reparameterization / dropout noise of the ranks (same torch seed on
@@ -462,6 +467,8 @@ class DataParallel(torch.nn.Module):
         for h in self._handles:
             h.remove()
         self._handles = []
+        if self.hook is not None:
+            ops.unregister_dp_hook(self.hook)
         if ops.dp_hook is self.hook:
             ops.dp_hook = None
         if self.hook is not None:

@@ -6,13 +6,44 @@ complex tensors are (real, imag) pairs of equal-shaped planes (cplxmodule/cplx.p
 """
 import os
 
+import functools
+
 import torch
-from torch.autograd.function import once_differentiable
 
 from . import _lib, x3
 from ._lib import call, dtype_code, launch_flags, ptr, require_device, scratch_key, stream_ptr, try_call
 
 _ws_cache = {}
+
+
+def once_differentiable(fn):
+    """Decorator of a `backward` that raw kernels compute (not differentiable in turn).  torch's own once_differentiable
+    raises on a second differentiation only when an INCOMING gradient requires grad; with a constant upstream gradient
+    (a penalty on d sum(y) / dx) the result would come back without history and a gradient penalty built on it would
+    contribute nothing -- silently.  This one routes the results through the error node whenever the backward runs with
+    create_graph=True: differentiating them again always raises (never a silently wrong second derivative)."""
+    @functools.wraps(fn)
+    def wrapper(ctx, *args):
+        with torch.no_grad():
+            outputs = fn(ctx, *args)
+        if not torch.is_grad_enabled():
+            return outputs
+        single = not isinstance(outputs, tuple)
+        outs = (outputs,) if single else outputs
+        live = [i for i, v in enumerate(outs) if isinstance(v, torch.Tensor) and v.is_floating_point()]
+        if not live:
+            return outputs
+        err = torch._C._functions.DelayedError(
+            b"trying to differentiate twice a function that was marked with @once_differentiable (cplxmodule_amd: this "
+            b"backward is computed by raw HIP kernels; second derivatives exist for the linear layers, Cplx products and "
+            b"matmul only)", len(live))
+        wrapped = err(*[outs[i].detach().requires_grad_(True) for i in live])
+        wrapped = (wrapped,) if isinstance(wrapped, torch.Tensor) else wrapped
+        res = list(outs)
+        for i, w in zip(live, wrapped):
+            res[i] = w
+        return res[0] if single else tuple(res)
+    return wrapper
 
 
 def _ws(device):
@@ -653,25 +684,60 @@ def _saved(ctx):
         raise
 
 
-# Data-parallel hook (cplxmodule_amd.dp.BucketHook): when set, the linear layers' backward writes the
-# parameter gradients straight into their all-reduce bucket (`grad_buffer`) and announces them
-# (`early_ready`) BEFORE its input-gradient GEMMs, so the RCCL all-reduce of a full bucket overlaps them.
+# Data-parallel hooks (cplxmodule_amd.dp.BucketHook): the linear layers' backward writes the parameter gradients straight
+# into their all-reduce bucket (`grad_buffer`) and announces them (`early_ready`) BEFORE its input-gradient GEMMs, so the
+# RCCL all-reduce of a full bucket overlaps them.  Hooks are found PER PARAMETER (`register_dp_hook`: one entry per
+# parameter of a DataParallel wrapper), so several wrapped models live in one process; `dp_hook` is the process-wide
+# fallback consulted for parameters no wrapper registered (the first wrapper installs itself there; tests install fakes).
 dp_hook = None
+_dp_hooks = {}            # id(parameter) -> weak reference to its wrapper's hook (the hook keeps the parameter alive)
+
+
+def register_dp_hook(hook, params):
+    import weakref
+    ref = weakref.ref(hook)
+    for p in params:
+        _dp_hooks[id(p)] = ref
+
+
+def unregister_dp_hook(hook):
+    for k in [k for k, r in _dp_hooks.items() if r() is hook or r() is None]:
+        del _dp_hooks[k]
+
+
+def hook_of(param):
+    """The data-parallel hook responsible for `param` (None: no wrapper)."""
+    if _dp_hooks and param is not None:
+        r = _dp_hooks.get(id(param))
+        if r is not None:
+            h = r()
+            if h is not None:
+                return h
+            del _dp_hooks[id(param)]
+    return dp_hook
 
 
 def grad_buffer(param):
     """float32 storage for the gradient of `param`: a fresh view of its data-parallel bucket slice when a
-    DataParallel wrapper is active (the all-reduce then needs no copy), a new tensor otherwise."""
-    if dp_hook is not None:
-        v = dp_hook.view_for(param)
+    DataParallel wrapper holds it (the all-reduce then needs no copy), a new tensor otherwise."""
+    h = hook_of(param)
+    if h is not None:
+        v = h.view_for(param)
         if v is not None:
             return v
     return torch.empty(param.shape, dtype=torch.float32, device=param.device)
 
 
 def _announce(*params):
-    if dp_hook is not None:
-        dp_hook.early_ready(*params)
+    if dp_hook is None and not _dp_hooks:
+        return
+    by_hook = {}
+    for p in params:
+        h = hook_of(p) if p is not None else None
+        if h is not None:
+            by_hook.setdefault(id(h), (h, []))[1].append(p)
+    for h, ps in by_hook.values():
+        h.early_ready(*ps)
 
 
 class CplxLinearFn(torch.autograd.Function):
@@ -697,18 +763,39 @@ class CplxLinearFn(torch.autograd.Function):
         xs = _Pieces(x2r, x2i)
         yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, wmr, wmi, bias, algo, mode=ctx.mode, xs=xs)
         keep = xs.v if (_X3_SAVE and xs.v is not None and x3.take(O, I, x2r.shape[0], mode=ctx.mode)) else (None, None)
-        ctx.save_for_backward(x2r, x2i, wr, wi, mask, *keep)
+        # (xr, xi as given: the create_graph backward needs graph-connected tensors, and x2r / x2i are views or copies made
+        #  here, without history; for a contiguous input they share its storage)
+        ctx.save_for_backward(x2r, x2i, wr, wi, mask, *keep, xr, xi)
         ctx.has_bias = br is not None
         ctx.lead = xr.shape[:-1]
         return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O)
 
     @staticmethod
     def backward(ctx, gr, gi):
-        x2r, x2i, wr, wi, mask, xsr, xsi = ctx.saved_tensors
+        x2r, x2i, wr, wi, mask, xsr, xsi, xr0, xi0 = ctx.saved_tensors
         O, I = wr.shape
-        g2r, g2i = gr.reshape(-1, O).contiguous(), gi.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
+        if torch.is_grad_enabled():
+            # create_graph=True (gradient penalties, Hessian-vector products): the reference's linear is a composition of
+            # differentiable torch ops (cplx.py:634-648), so its backward is differentiable too.  Same products, spelled
+            # through THIS Function on conjugated / transposed operands -- the same kernels compute every order:
+            #   dX = G conj(W) = linear(G, conj(W)^T),  dW = G^T conj(X) = linear(G^T, conj(X)^T),  db = sum_b G
+            lin = lambda ar, ai, br, bi: CplxLinearFn.apply(ar, ai, br, bi, None, None, 0, None)  # noqa: E731
+            G = (gr.reshape(-1, O), gi.reshape(-1, O))
+            wmr, wmi = (wr, wi) if mask is None else (wr * mask, wi * mask)
+            if need[0] or need[1]:
+                dxr, dxi = lin(G[0], G[1], wmr.t(), -wmi.t())
+                dxr, dxi = dxr.reshape(*ctx.lead, I), dxi.reshape(*ctx.lead, I)
+            if need[2] or need[3]:
+                dwr, dwi = lin(G[0].t(), G[1].t(), xr0.reshape(-1, I).t(), -xi0.reshape(-1, I).t())
+                if mask is not None:
+                    dwr, dwi = dwr * mask, dwi * mask
+                dwr, dwi = dwr.to(wr.dtype), dwi.to(wi.dtype)
+            if ctx.has_bias and (need[4] or need[5]):
+                dbr, dbi = G[0].float().sum(0), G[1].float().sum(0)
+            return dxr, dxi, dwr, dwi, dbr, dbi, None, None
+        g2r, g2i = gr.reshape(-1, O).contiguous(), gi.reshape(-1, O).contiguous()
         gs = _Pieces(g2r, g2i)               # (float32 split products: the pieces of G serve dW and dX)
         xs = _Pieces(x2r, x2i, made=None if xsr is None else (xsr, xsi))
         # parameter gradients first (into their data-parallel bucket, announced before the dX GEMM)
@@ -768,7 +855,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
             # under a data-parallel hook these are views of the parameters' bucket slices: whatever a backward pass
             # returns is copied into (or IS) that storage, so the pending KL gradients survive only the pass that
             # consumes them (nll.backward(); (c * kl).backward() returned the data gradient as the KL one)
-            ctx.klg_shared = dp_hook is not None
+            ctx.klg_shared = hook_of(ls2) is not None
         # float32 layers: the three products of the forward (and the five of the backward) on split bf16 operands where
         # x3.take says so -- float32-level results at the bf16 pipe's rate / 6 instead of the float32 MFMA's
         ctx.mode = mode = x3.get_fp32_mode()
@@ -811,6 +898,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
         return yr.view(*ctx.lead, O), yi.view(*ctx.lead, O), kl
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi, gkl=None):
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = dls2 = None
@@ -919,17 +1007,29 @@ class RealLinearFn(torch.autograd.Function):
         y, wm = _real_linear_fwd(x2, wm, _c(b), mode=ctx.mode, xs=xs)
         ctx.wm = wm
         keep = xs.v[0] if (_X3_SAVE and xs.v is not None and x3.take(O, I, x2.shape[0], mode=ctx.mode)) else None
-        ctx.save_for_backward(x2, w, mask, keep)
+        ctx.save_for_backward(x2, w, mask, keep, x)          # (x as given: see CplxLinearFn.forward)
         ctx.has_bias, ctx.lead = b is not None, x.shape[:-1]
         return y.view(*ctx.lead, O)
 
     @staticmethod
     def backward(ctx, g):
-        x2, w, mask, xsv = ctx.saved_tensors
+        x2, w, mask, xsv, x0 = ctx.saved_tensors
         O, I = w.shape
-        g2 = g.reshape(-1, O).contiguous()
         need = ctx.needs_input_grad
         dx = dw = db = None
+        if torch.is_grad_enabled():          # create_graph=True: through this Function itself (see CplxLinearFn.backward)
+            lin = lambda a, b: RealLinearFn.apply(a, b, None, None)  # noqa: E731
+            G = g.reshape(-1, O)
+            wm = w if mask is None else w * mask
+            if need[0]:
+                dx = lin(G, wm.t()).reshape(*ctx.lead, I)
+            if need[1]:
+                dw = lin(G.t(), x0.reshape(-1, I).t())
+                dw = (dw if mask is None else dw * mask).to(w.dtype)
+            if ctx.has_bias and need[2]:
+                db = G.float().sum(0)
+            return dx, dw, db, None
+        g2 = g.reshape(-1, O).contiguous()
         gs = _Pieces(g2)
         if need[1]:
             dw = grad_buffer(w)
@@ -954,6 +1054,7 @@ class MaskMulFn(torch.autograd.Function):
         return (our, oui) if ctx.cplx else our
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi=None):
         (mask,) = ctx.saved_tensors
         dr, di = mask_mul(gr, gi if ctx.cplx else None, mask)
@@ -975,7 +1076,7 @@ class RealLinearLRTFn(torch.autograd.Function):
         kl = ctx.klg = None
         if kl_kind is not None:
             ctx.klg = (grad_buffer(ls2), grad_buffer(w))
-            ctx.klg_shared = dp_hook is not None             # (see CplxLinearLRTFn.forward)
+            ctx.klg_shared = hook_of(ls2) is not None        # (see CplxLinearLRTFn.forward)
         ctx.mode = mode = x3.get_fp32_mode()                 # (see CplxLinearLRTFn.forward)
         use3 = x2.dtype == torch.float32 and x3.take(B, O, I, x2, wc_, ls2c, mode=mode)
         if _prep_ok(x2, wc_, ls2c):
@@ -1010,6 +1111,7 @@ class RealLinearLRTFn(torch.autograd.Function):
         return y.view(*ctx.lead, O), kl
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g, gkl=None):
         need = ctx.needs_input_grad
         dx = dw = db = dls2 = None
@@ -1206,6 +1308,7 @@ class CplxBilinearFn(torch.autograd.Function):
                             conj, ls2, (eps_r, eps_i), seed, offset)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         n = ctx.needs_input_grad
         dx1, dx2, dw, db, dls2 = _bil_backward(ctx, (gr, gi), n[0] or n[1], n[2] or n[3], n[4] or n[5],
@@ -1225,6 +1328,7 @@ class RealBilinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         n = ctx.needs_input_grad
         dx1, dx2, dw, db, dls2 = _bil_backward(ctx, (g, None), n[0], n[1], n[2], n[3], n[4])
@@ -1242,6 +1346,7 @@ class Abs2Fn(torch.autograd.Function):
         return abs2(xr, xi)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         xr, xi = ctx.saved_tensors
         dxr = torch.zeros_like(xr)
@@ -1263,6 +1368,7 @@ class AbsFn(torch.autograd.Function):
         return modulus(zr, zi)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         zr, zi = ctx.saved_tensors
         g = _cf(g, ctx.fmt)
@@ -1284,6 +1390,7 @@ class LogAlphaFn(torch.autograd.Function):
         return log_alpha(wr, wi, ls2).view_as(ls2)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         wr, wi = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -1303,6 +1410,7 @@ class ExpFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         return g * ctx.saved_tensors[0]
 
@@ -1322,6 +1430,7 @@ class ReparamFn(torch.autograd.Function):
         return (yr.view_as(mu_r), None if yi is None else yi.view_as(mu_r))
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         s2, eps_r, eps_i = ctx.saved_tensors
         eps = None if eps_r is None else ((eps_r, eps_i) if ctx.cplx else eps_r)
@@ -1340,6 +1449,7 @@ class PenaltyFn(torch.autograd.Function):
         return elem.view_as(ls2)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         ls2, wr, wi = ctx.saved_tensors
         need = ctx.needs_input_grad[1:]
@@ -1360,6 +1470,7 @@ class PenaltySumFn(torch.autograd.Function):
         return tot
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         ls2, wr, wi = ctx.saved_tensors
         need = ctx.needs_input_grad[1:]
@@ -1381,6 +1492,7 @@ class ExpiFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         g = _f32(g.contiguous())
@@ -1452,6 +1564,7 @@ class ModReluFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         zr, zi, *rest = ctx.saved_tensors
         tv, tn, tshape = ctx.tau
@@ -1491,10 +1604,14 @@ class CplxMulFn(torch.autograd.Function):
     def forward(ctx, ar, ai, br, bi, div):
         require_device(ar, ai, br, bi)
         ctx.fmt = fmt = _layout_of(ar)
-        ar, ai, br, bi = (_al16(_cf(t, fmt)) for t in (ar, ai, br, bi))
+        # what is saved are the tensors AS GIVEN: the dense / aligned copies made here have no autograd history, and a
+        # create_graph backward built on them would silently drop the second-order terms of a transposed, channels-last or
+        # misaligned operand; the raw-kernel backward redoes the (usually free) conversion
+        raw = (ar, ai, br, bi)
+        ar, ai, br, bi = (_al16(_cf(t, fmt)) for t in raw)
         yr, yi = _cplx_mul(ar, ai, br, bi, div=div)
         ctx.div = div
-        ctx.save_for_backward(*((br, bi, yr, yi) if div else (ar, ai, br, bi)))
+        ctx.save_for_backward(*((raw[2], raw[3], yr, yi) if div else raw))
         return yr, yi
 
     @staticmethod
@@ -1523,15 +1640,17 @@ class CplxMulFn(torch.autograd.Function):
                     db = (gr * ar + gi * ai, gi * ar - gr * ai)
             return da[0], da[1], db[0], db[1], None
         gr, gi = _al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt))
+        dense = lambda *ts: tuple(_al16(_cf(t, ctx.fmt)) for t in ts)  # noqa: E731
         if ctx.div:
             br, bi, yr, yi = ctx.saved_tensors
+            br, bi = dense(br, bi)
             if need_a:
                 da = _cplx_mul(gr, gi, br, bi, div=True, conj_b=True)
             if need_b:
                 t = _cplx_mul(gr, gi, yr, yi, conj_b=True)
                 db = _cplx_mul(t[0], t[1], br, bi, div=True, conj_b=True, neg=True)
         else:
-            ar, ai, br, bi = ctx.saved_tensors
+            ar, ai, br, bi = dense(*ctx.saved_tensors)
             if need_a:
                 da = _cplx_mul(gr, gi, br, bi, conj_b=True)
             if need_b:
@@ -1595,6 +1714,7 @@ class CplxDropoutFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         dr, di = CplxDropoutFn._run(_al16(_cf(gr, ctx.fmt)), _al16(_cf(gi, ctx.fmt)), ctx.p, ctx.seed, ctx.offset)
         return dr, di, None, None, None
@@ -1636,6 +1756,7 @@ class CplxMaxPool2dFn(torch.autograd.Function):
         return yr, yi
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gr, gi):
         (idx,) = ctx.saved_tensors
         gr, gi = _cf(gr, ctx.fmt), _cf(gi, ctx.fmt)

@@ -320,3 +320,59 @@ def test_init_process_group_channel_cap_wins_over_the_environment(monkeypatch):
     monkeypatch.setenv("NCCL_MAX_NCHANNELS", "20")
     dp.init_process_group("gloo", rank=0, world_size=1)              # no cap asked for: the environment stands
     assert os.environ["NCCL_MAX_NCHANNELS"] == "20"
+
+
+def _worker_two_models(rank, world, port, out):
+    """VERDICT r05 housekeeping: the hook is found per parameter -- TWO DataParallel wrappers in one process each exchange
+    their own model's gradients through their own buckets (zero-copy path included), and an unwrapped third model is left
+    alone."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cplxmodule_amd import dp, ops
+    torch.manual_seed(3)
+    a, b, c = torch.nn.Linear(5, 4), torch.nn.Linear(6, 3), torch.nn.Linear(5, 2)
+    wa, wb = dp.DataParallel(a), dp.DataParallel(b)
+    ok = ops.hook_of(a.weight) is wa.hook and ops.hook_of(b.weight) is wb.hook and wa.hook is not wb.hook
+    ok &= ops.dp_hook is wa.hook                      # the first wrapper is the process-wide fallback
+    ok &= ops.grad_buffer(b.weight).data_ptr() == wb.buckets.view(b.weight).data_ptr()
+    ok &= ops.grad_buffer(c.weight).data_ptr() not in (wa.buckets.buckets[0].flat.data_ptr(), wb.buckets.buckets[0].flat.data_ptr())
+    for w_ in (wa, wb):
+        w_.zero_grad()
+    torch.manual_seed(10 + rank)
+    xa, xb = torch.randn(7, 5), torch.randn(7, 6)
+    loss = (a(xa) ** 2).sum() + (b(xb) ** 2).sum() + (c(xa) ** 2).sum()
+    ps = [p for m in (a, b, c) for p in m.parameters()]
+    # (the local gradients by autograd.grad -- no hooks run: reading p.grad after backward() would race the bucket
+    #  all-reduces the hooks have already launched)
+    local = {id(p): g.clone() for p, g in zip(ps, torch.autograd.grad(loss, ps, retain_graph=True))}
+    loss.backward()
+    wa.sync_gradients()
+    wb.sync_gradients()
+    for m in (a, b):
+        for p in m.parameters():
+            ref = local[id(p)].clone()
+            dist.all_reduce(ref)
+            ok &= bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+    for p in c.parameters():                          # nobody exchanged the unwrapped model's gradients
+        ok &= bool(torch.equal(p.grad, local[id(p)]))
+    wb.remove()
+    ok &= ops.hook_of(b.weight) is wa.hook            # (fallback only; wa's buckets do not know b's parameters)
+    ok &= ops.grad_buffer(b.weight).data_ptr() != wb.buckets.view(b.weight).data_ptr()
+    wa.remove()
+    ok &= ops.dp_hook is None and ops.hook_of(a.weight) is None and not ops._dp_hooks
+    out.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_two_wrapped_models_in_one_process_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_models, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

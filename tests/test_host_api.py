@@ -236,3 +236,25 @@ print("REF_OK", float(y.real.sum()))
         for k in mine:
             assert back[k].shape == mine[k].shape and back[k].dtype == mine[k].dtype and torch.equal(back[k], mine[k]), k
         ours.load_state_dict(back, strict=True)
+
+
+def test_module_level_conv_operator_names():
+    """cplx.convnd / convnd_naive / _quick / _3m / symmetric_circular_padding exist with the reference's signatures
+    (cplxmodule/cplx.py:701-800); the padding helper runs on CPU planes (torch's pad), values against numpy's wrap."""
+    import inspect
+    import numpy as np
+    import torch
+    from cplxmodule_amd import cplx
+    assert list(inspect.signature(cplx.convnd).parameters) == ["conv", "input", "weight", "bias", "stride", "padding",
+                                                                "dilation", "groups", "padding_mode"]
+    assert list(inspect.signature(cplx.convnd_quick).parameters) == ["conv", "input", "weight", "stride", "padding", "dilation"]
+    for name in ("convnd_naive", "convnd_3m"):
+        assert list(inspect.signature(getattr(cplx, name)).parameters)[-1] == "groups"
+    z = cplx.Cplx(torch.arange(24.).reshape(1, 2, 3, 4), -torch.arange(24.).reshape(1, 2, 3, 4))
+    p = cplx.symmetric_circular_padding(z, (3, 2))
+    want = np.pad(z.real.numpy(), ((0, 0), (0, 0), (1, 1), (2, 1)), mode="wrap")     # F.pad order: last dim first
+    np.testing.assert_array_equal(p.real.numpy(), want)
+    np.testing.assert_array_equal(p.imag.numpy(), -want)
+    import pytest
+    with pytest.raises(ValueError):
+        cplx.convnd(torch.nn.functional.conv1d, z, z)
