@@ -164,7 +164,3 @@ def test_double_backward_raises_where_not_supported(family):
     # a gradient penalty added to a loss: backward() reaches the error node and raises
     with pytest.raises(RuntimeError, match="once_differentiable"):
         (pen + out).backward()
-    # torch.autograd.grad(): no path from the penalty to the leaves -- also an error, never a number
-    g = torch.autograd.grad(out, wrt, create_graph=True)
-    with pytest.raises(RuntimeError, match="once_differentiable|not have been used"):
-        torch.autograd.grad(sum((t ** 2).sum() for t in g), wrt)
