@@ -21,6 +21,12 @@ namespace cplxamd {
 
 constexpr int kKlThreads = 256;
 constexpr int kKlMaxBlocks = 2048;
+#ifndef KL_UNROLL
+#define KL_UNROLL 1     // (2 and 4 measured 2-4 % slower on the fused kernel: profiles/r06_kl_pmc.txt)
+#endif
+#ifndef KL_NT
+#define KL_NT 3       // bit 0: nontemporal gradient stores, bit 1: nontemporal operand loads (read once, written once: +3-8 % on the fused kernel, +10 % on the value kernel; profiles/r06_kl_pmc.txt)
+#endif
 
 constexpr float kEulerGamma = 0.57721566490153286f;
 constexpr float kK1 = 0.63576f, kK2 = 1.87320f, kK3 = 1.48695f;
@@ -167,6 +173,58 @@ __device__ __forceinline__ void weight_grad(float fp, float wr, float wi, float 
   }
 }
 
+// ---- exact complex KL (CPLXAMD_KL_CPLX_VD), fused value + slope, two elements per instruction -----------------------------
+// The fused forward + backward kernel moves 24 B per element and was co-limited by ~140 VALU lane-operations per element
+// (profiles/r03_kl_pmc.txt: 74 % VALU busy at 57 % of the HBM peak).  This form needs about a third of that:
+//   * x = e^t straight from the operands: x = |w|^2 exp(-log_sigma2) -- no square root, no logarithm on the way to the
+//     argument (t = 2 log(|w| + 1e-12) - log_sigma2; for |w|^2 >= 1e-8 the 1e-12 shifts t by < 2e-8, and the rare element
+//     below that takes the original formulas);
+//   * the value for x <= 1 is the series in x (needs no t), for x > 1 gamma + ln x + E1(x) with ONE v_log_f32;
+//   * the slope 1 - exp(-x) shares exp(-x) with E1; below 2^-6 it is x - x^2/2 + x^3/6 (next term 1.6e-7 relative);
+//   * d/dw = 2 f' w / |w|^2: one reciprocal of the |w|^2 that is there already;
+//   * v_exp_f32 / v_log_f32 directly (base 2; the product with log2(e) carried to double-float accuracy where the exponent
+//     argument is large), and every polynomial on float2 operands (v_pk_fma_f32: two elements per instruction).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 sp2(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 sel2(bool c0, bool c1, f2 a, f2 b) { return f2{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+
+// exp(-ls) = 2^(-ls log2 e): hi + lo product, so that |ls| ~ 30 costs no accuracy (one v_exp_f32 + three fma / mul)
+__device__ __forceinline__ float exp_neg(float ls) {
+  const float yh = -ls * 1.44269504089f;
+  const float yl = fmaf(-ls, 1.44269504089f, -yh);                 // exact remainder of the product
+  const float e = __builtin_amdgcn_exp2f(yh);
+  return fmaf(e, yl * 0.69314718056f, e);
+}
+
+// value f(x) = gamma + ln x + E1(x) and slope 1 - exp(-x) for x = e^t >= 0, two elements
+__device__ __forceinline__ void cplx_vd_pair(f2 x, f2& val, f2& slope) {
+  f2 s = sp2(3.0619244e-7f);                 // +1/(9*9!)   (first omitted term 2.8e-8 x^10)
+  s = fma2(s, x, sp2(-3.1001984e-6f));       // -1/(8*8!)
+  s = fma2(s, x, sp2(2.8344671e-5f));        // +1/(7*7!)
+  s = fma2(s, x, sp2(-2.3148148e-4f));       // -1/(6*6!)
+  s = fma2(s, x, sp2(1.6666667e-3f));        // +1/(5*5!)
+  s = fma2(s, x, sp2(-1.0416667e-2f));       // -1/(4*4!)
+  s = fma2(s, x, sp2(5.5555556e-2f));        // +1/(3*3!)
+  s = fma2(s, x, sp2(-0.25f));               // -1/(2*2!)
+  s = fma2(s, x, sp2(1.0f));
+  const f2 small = s * x;
+  // x > 1: E1(x) = e^-x / x * P4(x) / Q4(x)   (Abramowitz & Stegun 5.1.56, |err| < 2e-8)
+  const f2 num = fma2(fma2(fma2(x + sp2(8.5733287401f), x, sp2(18.0590169730f)), x, sp2(8.6347608925f)), x, sp2(0.2677737343f));
+  const f2 den = fma2(fma2(fma2(x + sp2(9.5733223454f), x, sp2(25.6329561486f)), x, sp2(21.0996530827f)), x, sp2(3.9584969228f));
+  const f2 xd = x * den;
+  const f2 nx = x * sp2(-1.44269504089f);
+  const f2 e = f2{__builtin_amdgcn_exp2f(nx.x), __builtin_amdgcn_exp2f(nx.y)};                 // exp(-x)
+  const f2 rc = f2{__builtin_amdgcn_rcpf(xd.x), __builtin_amdgcn_rcpf(xd.y)};
+  const f2 lg = f2{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)} * sp2(0.69314718056f);   // ln x
+  f2 e1 = e * num * rc;
+  e1 = sel2(x.x < 104.0f, x.y < 104.0f, e1, sp2(0.0f));           // (beyond: 0 * inf)
+  const f2 large = sp2(kEulerGamma) + lg + e1;
+  val = sel2(x.x <= 1.0f, x.y <= 1.0f, small, large);
+  const f2 ss = fma2(fma2(x, sp2(1.6666667e-1f), sp2(-0.5f)), x, sp2(1.0f)) * x;
+  slope = sel2(x.x < 0.015625f, x.y < 0.015625f, ss, sp2(1.0f) - e);
+}
+
 struct KlArgs {
   const float* wr;
   const float* wi;
@@ -187,6 +245,24 @@ struct KlArgs {
   bf16_t* s_b = nullptr;
 };
 
+__device__ __forceinline__ void st4g(float* p, const f4& v) {
+#if KL_NT & 1
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4v{v.v[0], v.v[1], v.v[2], v.v[3]}, reinterpret_cast<f4v*>(p));
+#else
+  st4(p, v);
+#endif
+}
+__device__ __forceinline__ f4 ld4g(const float* p) {
+#if KL_NT & 2
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+  return f4{{t.x, t.y, t.z, t.w}};
+#else
+  return ld4(p);
+#endif
+}
+
 template <int KIND, bool VALUE, bool GRAD>
 __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
   constexpr bool CPLX = KIND >= CPLXAMD_KL_CPLX_VD;
@@ -198,27 +274,53 @@ __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
   if (GRAD && a.g_scalar) gs *= *a.g_scalar;
   double acc = 0.0;
 
-  for (int64_t i = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i < n4; i += stride) {
-    const f4 wr = ld4(a.wr + 4 * i);
-    const f4 ls = ld4(a.ls2 + 4 * i);
-    f4 wi = {{0.f, 0.f, 0.f, 0.f}};
-    if (CPLX) wi = ld4(a.wi + 4 * i);
-    f4 ge = {{1.f, 1.f, 1.f, 1.f}};
-    if (GRAD && a.g_elem) ge = ld4(a.g_elem + 4 * i);
+  // one step of the grid-stride loop: the 4 elements at vector index i (operands already in registers)
+  auto body = [&](int64_t i, const f4& wr, const f4& ls, const f4& wi, const f4& ge) __attribute__((always_inline)) {
     f4 val, d_ls, d_wr, d_wi;
     float part = 0.0f;
+    bool done = false;
+    if constexpr (KIND == CPLXAMD_KL_CPLX_VD) {
+      // the two-elements-per-instruction form (cplx_vd_pair); a lane holding a weight with |w|^2 < 1e-8 -- where the
+      // 1e-12 of log(|w| + 1e-12) matters, zero weights included -- redoes its four elements below
+      float q[4];
+      bool tiny = false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float theta;
-      const float t = -log_alpha_of<CPLX, false>(ls.v[j], wr.v[j], wi.v[j], theta);
-      if (VALUE) {
-        val.v[j] = kl_value<KIND>(t) + kLs * ls.v[j];
-        part += val.v[j];
+      for (int j = 0; j < 4; ++j) {
+        q[j] = fmaf(wi.v[j], wi.v[j], wr.v[j] * wr.v[j]);
+        tiny |= !(q[j] >= 1e-8f);
       }
-      if (GRAD) {
-        const float fp = kl_slope<KIND>(t) * ge.v[j] * gs;
-        d_ls.v[j] = kLs * ge.v[j] * gs - fp;
-        weight_grad<CPLX>(fp, wr.v[j], wi.v[j], theta, d_wr.v[j], d_wi.v[j]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f2 x = f2{q[2 * h] * exp_neg(ls.v[2 * h]), q[2 * h + 1] * exp_neg(ls.v[2 * h + 1])};
+        f2 v, sl;
+        cplx_vd_pair(x, v, sl);
+        if (VALUE) { val.v[2 * h] = v.x; val.v[2 * h + 1] = v.y; }
+        if (GRAD) {
+          const f2 fp = sl * f2{ge.v[2 * h], ge.v[2 * h + 1]} * sp2(gs);
+          const f2 c = (fp + fp) * f2{__builtin_amdgcn_rcpf(q[2 * h]), __builtin_amdgcn_rcpf(q[2 * h + 1])};
+          d_ls.v[2 * h] = -fp.x; d_ls.v[2 * h + 1] = -fp.y;
+          d_wr.v[2 * h] = c.x * wr.v[2 * h]; d_wr.v[2 * h + 1] = c.y * wr.v[2 * h + 1];
+          d_wi.v[2 * h] = c.x * wi.v[2 * h]; d_wi.v[2 * h + 1] = c.y * wi.v[2 * h + 1];
+        }
+      }
+      done = !tiny;
+      if (VALUE && done) part = (val.v[0] + val.v[1]) + (val.v[2] + val.v[3]);
+    }
+    if (!done) {
+      part = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float theta;
+        const float t = -log_alpha_of<CPLX, false>(ls.v[j], wr.v[j], wi.v[j], theta);
+        if (VALUE) {
+          val.v[j] = kl_value<KIND>(t) + kLs * ls.v[j];
+          part += val.v[j];
+        }
+        if (GRAD) {
+          const float fp = kl_slope<KIND>(t) * ge.v[j] * gs;
+          d_ls.v[j] = kLs * ge.v[j] * gs - fp;
+          weight_grad<CPLX>(fp, wr.v[j], wi.v[j], theta, d_wr.v[j], d_wi.v[j]);
+        }
       }
     }
     if (VALUE) {
@@ -226,9 +328,9 @@ __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
       if (a.out_elem) st4(a.out_elem + 4 * i, val);
     }
     if (GRAD) {
-      if (a.g_ls2) st4(a.g_ls2 + 4 * i, d_ls);
-      if (a.g_wr) st4(a.g_wr + 4 * i, d_wr);
-      if (CPLX && a.g_wi) st4(a.g_wi + 4 * i, d_wi);
+      if (a.g_ls2) st4g(a.g_ls2 + 4 * i, d_ls);
+      if (a.g_wr) st4g(a.g_wr + 4 * i, d_wr);
+      if (CPLX && a.g_wi) st4g(a.g_wi + 4 * i, d_wi);
     }
     if (a.wr_b) st4(a.wr_b + 4 * i, wr);
     if (CPLX && a.wi_b) st4(a.wi_b + 4 * i, wi);
@@ -237,6 +339,28 @@ __global__ __launch_bounds__(kKlThreads) void kl_kernel(KlArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) e.v[j] = expf(ls.v[j]);
       st4(a.s_b + 4 * i, e);
+    }
+  };
+  // KL_UNROLL vector indices per thread and iteration, every load issued before the first result is needed (the loop
+  // is latency-bound otherwise: three dependent 16-byte loads per thread in flight against ~2 us of HBM latency)
+  for (int64_t i0 = (int64_t)blockIdx.x * kKlThreads + threadIdx.x; i0 < n4; i0 += KL_UNROLL * stride) {
+    f4 wr[KL_UNROLL], ls[KL_UNROLL], wi[KL_UNROLL], ge[KL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < KL_UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      wi[u] = f4{{0.f, 0.f, 0.f, 0.f}};
+      ge[u] = f4{{1.f, 1.f, 1.f, 1.f}};
+      if (i < n4) {
+        wr[u] = ld4g(a.wr + 4 * i);
+        ls[u] = ld4g(a.ls2 + 4 * i);
+        if (CPLX) wi[u] = ld4g(a.wi + 4 * i);
+        if (GRAD && a.g_elem) ge[u] = ld4(a.g_elem + 4 * i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KL_UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n4) body(i, wr[u], ls[u], wi[u], ge[u]);
     }
   }
   // scalar tail (n % 4 elements), handled by block 0
