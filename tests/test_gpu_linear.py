@@ -35,6 +35,12 @@ def test_cplx_linear_fp32_golden(golden, pkg, case):
         np.testing.assert_allclose(N(leaves[n].grad), g[k + m], **_scale_tol(g[k + m], 1e-5))
     y = cplx.linear(cplx.Cplx(leaves["xr"], leaves["xi"]), cplx.Cplx(leaves["wr"], leaves["wi"]), None)
     np.testing.assert_allclose(N(y.real), g[k + "y_nobias_r"], **_scale_tol(g[k + "y_nobias_r"], 1e-5))
+    # the reference's other two spellings (cplx.py:651-694), against THEIR OWN recorded outputs
+    for algo in ("3m", "cat"):
+        y = getattr(cplx, "linear_" + algo)(cplx.Cplx(leaves["xr"], leaves["xi"]), cplx.Cplx(leaves["wr"], leaves["wi"]),
+                                            cplx.Cplx(leaves["br"], leaves["bi"]))
+        np.testing.assert_allclose(N(y.real), g[k + f"y_{algo}_r"], **_scale_tol(g[k + f"y_{algo}_r"], 1e-5))
+        np.testing.assert_allclose(N(y.imag), g[k + f"y_{algo}_i"], **_scale_tol(g[k + f"y_{algo}_i"], 1e-5))
 
 
 def test_matmul_golden(golden, pkg):
