@@ -43,9 +43,6 @@ constexpr int DUMP = EPI + 8 * EPI_WAVE, SMEM = DUMP + 4096;
 // MOM (batch-norm moments of the output in the epilogue): both planes of a round staged at once -- the second plane's 16
 // rows per wave behind everything else
 constexpr int MOM_X = SMEM, SMEM_MOM = SMEM + 8 * 2048;
-#ifndef CL2_MOM_DBG
-#define CL2_MOM_DBG 0      // ablation (experiments only): 1 = no moment reads / sums, 2 = reads but no sums
-#endif
 static_assert(SMEM_MOM <= 160 * 1024, "LDS");
 constexpr int NST = 16;                                       // global stores per wave in the epilogue
 constexpr uint32_t OOB = 0xF8000000u;
@@ -470,7 +467,6 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     const uint32_t mbase = (uint32_t)((rg << 10) ^ (rg << 7) ^ ((((cp >> 1) ^ (rg << 3) ^ rg) & 15) << 3) ^ ((cp & 1) << 2));
     const bool interior = __builtin_amdgcn_readfirstlane((int)(tc.x0 + TW <= g.Wo && tc.y0 + TH <= g.Ho)) != 0;
     auto moments_of = [&](uint32_t dr, uint32_t di) __attribute__((always_inline)) {
-      if (CL2_MOM_DBG == 2) { asm volatile("" :: "v"(dr), "v"(di)); return; }
       const f2v R = {__uint_as_float(dr << 16), __uint_as_float(dr & 0xffff0000u)};
       const f2v I = {__uint_as_float(di << 16), __uint_as_float(di & 0xffff0000u)};
       m_r += R; m_i += I;
@@ -507,7 +503,7 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
           }
         const bool rowin = interior || __builtin_amdgcn_readfirstlane((int)(y < g.Ho)) != 0;
         uint32_t dr[8], di[8];
-        if (CL2_MOM_DBG != 1 && rowin) {
+        if (rowin) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const uint32_t off = mbase ^ (uint32_t)((k << 7) | (k << 3));
@@ -534,7 +530,7 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (CL2_MOM_DBG != 1 && rowin) {
+        if (rowin) {
           if (interior) {                                        // (scalar branch: most tiles)
 #pragma unroll
             for (int k = 0; k < 8; ++k) moments_of(dr[k], di[k]);

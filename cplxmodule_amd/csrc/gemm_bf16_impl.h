@@ -35,7 +35,8 @@
 // The experiment variants of rounds 2-3 (compile-time ablation bits, the classic per-tile pipeline, alternative MFMA
 // orders) were working COPIES of this header; they are in the history only (git show 1a9fb01:scripts/gemm_experiments/),
 // their results in profiles/r02_gemm_ablation.md / r03_gemm_pair_issue.txt.  Round 4's family (gemm_bf16_w4.hip) keeps
-// its ablation switches in the production file behind W4_DBG / W4_BURST / ... (scripts/r04/w4_build.sh).
+// its ablation switches in the production file behind W4_BURST / W4_LDP / ... (scripts/r04/w4_build.sh; the W4_DBG / W4_PGRID / W4_PDYN ablations and the CPLXAMD_W4P_CPLX
+// selector left the file in round 6: scripts/r06/ablation_switches.patch puts them back).
 #include <stdlib.h>
 
 #include <type_traits>

@@ -46,9 +46,6 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef W4_DBG
-#define W4_DBG 0   // ablation bits (experiments only): 1 no MFMA, 2 no global loads after the prologue, 4 no LDS writes after the prologue, 8 no epilogue stores, 16 hot-source loads (always K tiles 0, 1), 32 complex: only the MFMAs into the real-part accumulators (the instruction mix of pass 1 of a two-pass 3M loop: 32 MFMAs beside the full staging + fragment traffic of a K tile), 64 no barrier in the K loop (wrong results: what the per-K-tile barrier and the waves' skew cost)
-#endif
 // where the two loads of a register pair go, in MFMA slots behind the pair's LDS write (experiments: scripts/r04/w4_build.sh)
 #ifndef W4_LDP
 #define W4_LDP 0
@@ -141,12 +138,10 @@ __device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
   return __builtin_bit_cast(bf16x8, u);
 }
 __device__ __forceinline__ void store16(void* p, uint4 v) {
-  if ((W4_DBG & 8) == 0) *reinterpret_cast<uint4*>(p) = v;
-  else asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
+  *reinterpret_cast<uint4*>(p) = v;
 }
 __device__ __forceinline__ void store16(float* p, const f4& a) {
-  if ((W4_DBG & 8) == 0) st4(p, a);
-  else asm volatile("" ::"v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(p));
+  st4(p, a);
 }
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
@@ -185,9 +180,6 @@ constexpr int ops_after_last_read(bool cplx, bool burst, bool writes) { return !
 #endif
 #ifndef W4P_RELOAD
 #define W4P_RELOAD 1   // PERSIST: re-request the next tile's K tiles 2, 3 behind the epilogue (see the tile loop)
-#endif
-#ifndef W4_PGRID
-#define W4_PGRID 0   // experiment: > 0 = at most that many workgroups, each walking the tile list (lin, lin + grid, ...)
 #endif
 // PERSIST (round 5 experiment, family bit 7; bf16 output, plain epilogue, no bias, (N,N) / (N,T)): ONE workgroup per CU walks
 // the tiles lin0, lin0 + grid, ... and the K-tile ring runs THROUGH the output-tile boundaries -- the loads the one-tile
@@ -297,7 +289,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     if constexpr (PERSIST) {
       base = isa ? rqa[pl] : rqb[pl];          // (set_request(kt) ran for this request group)
     } else {
-      const int64_t kby = (W4_DBG & 16) ? 0 : (int64_t)(kt & ~1) * BK * (isa ? ka : kb);
+      const int64_t kby = (int64_t)(kt & ~1) * BK * (isa ? ka : kb);
       base = (isa ? pa[pl] : pb[pl]) + kby;
     }
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffe, 0x00020000);
@@ -377,11 +369,9 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
   // gemm_bf16_kernel: bit-identical sums.  complex: m = i * 8 + ph * 4 + j * 2 + c;  real: m = i * JB + j
   auto mfma = [&](auto F, auto MM) __attribute__((always_inline)) {
     constexpr int f = decltype(F)::value, m = decltype(MM)::value;
-    if constexpr ((W4_DBG & 1) != 0) return;
     if constexpr (CPLX) {
       constexpr int i = m / 8, ph = (m % 8) / 4, j = (m % 4) / 2, c = m % 2;
       constexpr int d = i < IB - 1 ? i : IB - 1 + f;
-      if constexpr ((W4_DBG & 32) != 0 && c == 1) return;
       if constexpr (ph == 0) {
         if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ar[d], acc_r[i][j], 0, 0, 0);
         else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ai[d], acc_i[i][j], 0, 0, 0);
@@ -437,8 +427,8 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
       if constexpr (!W4_BURST) {
         constexpr int wi = slot_of_write(CPLX, false, NW, m, 0), lp = slot_of_write(CPLX, false, NW, m, W4_LDP),
                       lq = slot_of_write(CPLX, false, NW, m, W4_LDQ);
-        if constexpr (wi >= 0 && (W4_DBG & 4) == 0) write_piece(I_P{}, std::integral_constant<int, h * NW + (wi >= 0 ? wi : 0)>{}, WS);
-        if constexpr (par == 1 && (W4_DBG & 2) == 0) {
+        if constexpr (wi >= 0) write_piece(I_P{}, std::integral_constant<int, h * NW + (wi >= 0 ? wi : 0)>{}, WS);
+        if constexpr (par == 1) {
           if constexpr (lp >= 0) { W4_SB(); load_piece(I0_{}, std::integral_constant<int, h * NW + (lp >= 0 ? lp : 0)>{}, kt_next); }
           if constexpr (lq >= 0) { W4_SB(); load_piece(I1_{}, std::integral_constant<int, h * NW + (lq >= 0 ? lq : 0)>{}, kt_next); }
         }
@@ -448,11 +438,9 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
         constexpr int k = slot_of_write(CPLX, true, NL, m, 0);
         if constexpr (k >= 0) {
           constexpr int q = (par == 0 ? 0 : NW) + (k >= 0 ? k : 0) / 2, reg = (k >= 0 ? k : 0) % 2;
-          if constexpr ((W4_DBG & 4) == 0) {
-            if constexpr (reg == 0) write_piece(I0_{}, std::integral_constant<int, q>{}, WS_P);
-            else write_piece(I1_{}, std::integral_constant<int, q>{}, WS_Q);
-          }
-          if constexpr (reg == 1 && (W4_DBG & 2) == 0) {
+          if constexpr (reg == 0) write_piece(I0_{}, std::integral_constant<int, q>{}, WS_P);
+          else write_piece(I1_{}, std::integral_constant<int, q>{}, WS_Q);
+          if constexpr (reg == 1) {
             W4_SB();
             load_piece(I0_{}, std::integral_constant<int, q>{}, kt_next);
             load_piece(I1_{}, std::integral_constant<int, q>{}, kt_next);
@@ -553,7 +541,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     sub(I0{}, PP, I0{}, CUR{}, I1{}, WR{}, WSP{}, WSQ{}, ktn);
     // every wave: its F1 reads are complete (in-order LDS: all but the operations issued behind the last read)
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ops_after_last_read(CPLX, W4_BURST, !W4_BURST || par == 1)) : "memory");
-    if constexpr ((W4_DBG & 64) == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     W4_SB();
     sub(I1{}, PP, I1{}, NXT{}, I0{}, WR{}, WSP{}, WSQ{}, ktn);
   };
@@ -639,8 +627,7 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
     return __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
   };
   auto stb128 = [](u32x4 v, __amdgpu_buffer_rsrc_t r, uint32_t vo, uint32_t so) __attribute__((always_inline)) {
-    if ((W4_DBG & 8) == 0) __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, 0);
-    else asm volatile("" ::"v"(v), "v"(vo));
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, 0);
   };
   if constexpr (sizeof(TOUT) == 2) {
     // bf16: the wave's tile goes through LDS so that a store instruction writes whole 128-byte lines
@@ -860,40 +847,10 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
   } while (true);
 }
 
-#ifdef W4_PDYN
-__device__ unsigned w4_queue[8];
-#endif
 template <typename TOUT, bool CPLX, bool CONJ, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#if W4_PGRID > 0 && defined(W4_PDYN)
-  // experiment: the tile list as per-XCD ticket queues (a workgroup's first tile is static, the next ones are drawn;
-  // the drawer of an XCD's last ticket puts its counter back to 0 for the next launch)
-  const int total = (g.M / Cfg<CPLX>::BM) * (g.N / Cfg<CPLX>::BN) * (g.splits > 1 ? g.splits : 1);
-  const int xcd = blockIdx.x & 7;
-  const int tiles_x = (total - xcd + 7) >> 3, wgs_x = ((int)gridDim.x - xcd + 7) >> 3;
-  int slot = blockIdx.x >> 3;
-  for (;;) {
-    w4_tile<TOUT, CPLX, CONJ, TA, TB>(g, slot * 8 + xcd, smem);
-    if (threadIdx.x == 0) {
-      const unsigned t = atomicAdd(&w4_queue[xcd], 1u);
-      if ((int)t == tiles_x - 1) __hip_atomic_store(&w4_queue[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *reinterpret_cast<volatile unsigned*>(smem) = t;
-    }
-    __syncthreads();
-    slot = wgs_x + (int)*reinterpret_cast<volatile unsigned*>(smem);
-    __syncthreads();
-    if (slot >= tiles_x) break;
-  }
-#elif W4_PGRID > 0
-  const int total = (g.M / Cfg<CPLX>::BM) * (g.N / Cfg<CPLX>::BN) * (g.splits > 1 ? g.splits : 1);
-  for (int lin = blockIdx.x; lin < total; lin += gridDim.x) {
-    w4_tile<TOUT, CPLX, CONJ, TA, TB>(g, lin, smem);
-    __syncthreads();
-  }
-#else
   w4_tile<TOUT, CPLX, CONJ, TA, TB>(g, (int)blockIdx.x, smem);
-#endif
 }
 
 // PERSIST form (w4_tile<..., true>): one workgroup per CU, bf16 output, plain epilogue
@@ -916,16 +873,15 @@ static int launch(const GemmArgs& g0, hipStream_t st) {
   static const int gm = env_int("CPLXAMD_GEMM_GROUP_M", 4);
   g.group_m = gm > 0 ? gm : 1;
   const int64_t tiles = (int64_t)(g.M / C::BM) * (g.N / C::BN);
-  if constexpr (sizeof(TOUT) == 2 && !TA) {
+  if constexpr (sizeof(TOUT) == 2 && !TA && !CPLX) {      // (complex: not instantiated, see below)
     // round 5 (family bit 7): the ring through the tile boundaries; needs the chip (one workgroup per CU), more than one
     // round of tiles, the plain epilogue and no bias, K tile count even (K % 64 == 0 holds).  Taken where measured faster
     // (profiles/r05_gemm_w4_persistent.txt): the REAL launches -- (N,N) at every K depth this family runs at, (N,T) from
     // K = 4096 -- whose boundary code compiles without a spill.  The complex form is bit-identical too but 1.6-2.9 %
-    // SLOWER than one tile per workgroup (the allocator spills ring state around its epilogue): env CPLXAMD_W4P_CPLX=1
-    // selects it for the A/B only.
-    static const int cplx_too = env_int("CPLXAMD_W4P_CPLX", 0);
+    // SLOWER than one tile per workgroup (the allocator spills ring state around its epilogue) and is not launched
+    // (the A/B switch: scripts/r06/ablation_switches.patch).
     const int ncu = (g.ncu > 0 ? g.ncu : device_cus()) & ~7;
-    const bool measured_faster = CPLX ? cplx_too != 0 : (!TB || g.K >= 4096);
+    const bool measured_faster = !CPLX && (!TB || g.K >= 4096);
     if (((launch_family(g.flags) >> 7) & 1) && measured_faster && launch_owns_chip(g.flags) && tiles > ncu && !g.fga &&
         !g.bias_r && g.splits <= 1) {
       if (g.plan) { *g.plan = 6; return 0; }
@@ -940,8 +896,7 @@ static int launch(const GemmArgs& g0, hipStream_t st) {
   if (g.plan) { *g.plan = 3; return 0; }
   static PerDeviceOnce attr_set;
   if (const int e = set_max_dyn_lds(attr_set, gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB>, C::SMEM)) return e;
-  int64_t grid = tiles * g.splits;
-  if (W4_PGRID > 0 && grid > W4_PGRID) grid = W4_PGRID;
+  const int64_t grid = tiles * g.splits;
   gemm_bf16_w4_kernel<TOUT, CPLX, CONJ, TA, TB><<<dim3((unsigned)grid), C::NT, C::SMEM, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   return 0;

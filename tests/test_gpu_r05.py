@@ -398,21 +398,6 @@ def test_w4_persistent_form_is_bit_identical(K):
         assert torch.equal(r, o) and torch.equal(r, g)
 
 
-def test_w4_persistent_complex_form_in_its_own_process():
-    """The complex persistent kernels are compiled in but not dispatched to (slower than one tile per workgroup:
-    profiles/r05_gemm_w4_persistent.txt); CPLXAMD_W4P_CPLX=1 -- read once per process -- selects them.  They must stay
-    bit-identical: the test above, in a subprocess with the switch on."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, CPLXAMD_W4P_CPLX="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
-                        os.path.join(here, "test_gpu_r05.py") + "::test_w4_persistent_form_is_bit_identical"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
-    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_cfg3_float32_conv_at_full_batch_matches_float64():
     """CplxConv2d(64, 64, 3) on 256 float32 256 x 256 images, channels-last -- the 1e-5 mode at BASELINE configs[2]'s size:
     forward pixels of the last images, the data gradient of the last image and sampled weight-gradient entries against
