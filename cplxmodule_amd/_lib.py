@@ -12,9 +12,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 20
+ABI_VERSION = 21
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
             "cplx_vd_scalefree": 5, "cplx_vd_bogus": 6}
 
@@ -99,6 +99,12 @@ SIGNATURES = {
     "cplxamd_exp": [_P, _P, _L, _I, _P],
     "cplxamd_cast": [_P, _P, _L, _I, _I, _P],
     "cplxamd_split3": [_P, _P, _L, _P, _L, _L, _L, _I, _I, _I, _P],
+    "cplxamd_absmax_ws_bytes": [],
+    "cplxamd_absmax_scale": [_P, _P, _L, _L, _I, _I, _P, _P, _P],
+    "cplxamd_split2h": [_P, _P, _L, _P, _L, _L, _L, _I, _I, _I, _P, _P],
+    "cplxamd_cgemm_sc_fl": [_P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L,
+                            _I, _P],
+    "cplxamd_rgemm_sc_fl": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P],
     "cplxamd_transpose": [_P, _L, _P, _L, _I, _I, _I, _P],
     "cplxamd_colsum_ws_bytes": [_I],
     "cplxamd_colsum": [_P, _L, _P, _I, _I, _I, _P, _P],
@@ -146,7 +152,7 @@ SIGNATURES = {
     "cplxamd_bn_fwd_partials": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _I, _P, _L, _P],
     "cplxamd_bn_bwd_sync": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P],
 }
-_RESTYPES = {"cplxamd_conv2d_cl2_mom_chunks": c_int64, "cplxamd_conv2d_cl2_mom_chunks_fl": c_int64, "cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_lrt_reparam_bwd_cols_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
+_RESTYPES = {"cplxamd_absmax_ws_bytes": c_int64, "cplxamd_conv2d_cl2_mom_chunks": c_int64, "cplxamd_conv2d_cl2_mom_chunks_fl": c_int64, "cplxamd_vd_kl_ws_bytes": c_int64, "cplxamd_lrt_reparam_bwd_cols_ws_bytes": c_int64, "cplxamd_bn_ws_bytes": c_int64,
              "cplxamd_conv2d_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_bf16_wgrad_ws_bytes": c_int64, "cplxamd_colsum_ws_bytes": c_int64, "cplxamd_gemm_ws_bytes": c_int64,
              "cplxamd_cgemm3m_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,

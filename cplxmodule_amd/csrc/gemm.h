@@ -31,6 +31,11 @@ struct GemmArgs {
   // cplxamd_lrt_dx_accum pass (7 plane passes over [B, I]) disappears.  Same arithmetic as the two-kernel path:
   // round(acc) to bf16 first, then fmaf(2 x, ga, that) rounded to bf16.
   const void* fx_r = nullptr; const void* fx_i = nullptr; const void* fga = nullptr; int64_t fld = 0;
+  // operand scales of the half-precision split products (x3.py 'x2' mode, csrc/split.hip): the operands were multiplied by
+  // powers of two sa, sb before they were cut into fp16 pieces; scale_a / scale_b point at DEVICE float[2] = {s, 1 / s}.
+  // The accumulators are multiplied by 1 / (sa sb) right behind the K loop (exact: powers of two), a bias that rides in
+  // the accumulators starts as bias * (sa sb).  nullptr (both): no scaling.
+  const float* scale_a = nullptr; const float* scale_b = nullptr;
   // per-call launch policy (host side only; include/cplxamd.h CPLXAMD_LAUNCH_*, launch.h)
   int flags = 0;
   // dry run (cplxamd_gemm_plan): the launchers write the code of the kernel they WOULD launch here and return; ncu > 0
@@ -39,6 +44,21 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float gemm_beta(const GemmArgs& g) { return (g.accumulate && g.beta) ? *g.beta : 1.0f; }
+// 1 / (sa sb) and sa sb of the scaled split products (1, 1 without scales)
+__device__ __forceinline__ float gemm_alpha(const GemmArgs& g) { return g.scale_a ? g.scale_a[1] * g.scale_b[1] : 1.0f; }
+__device__ __forceinline__ float gemm_alpha_inv(const GemmArgs& g) { return g.scale_a ? g.scale_a[0] * g.scale_b[0] : 1.0f; }
+
+// The 16-bit operand type of the MFMA kernels.  gemm_bf16_impl.h / gemm_bf16_persist.h / gemm_bf16_w4.hip are compiled twice:
+// as they are (bf16 operands) and, from gemm_f16*.hip with CPLXAMD_GEMM_F16 defined, for IEEE half operands -- same staging,
+// same LDS images, same epilogues (a 16-bit pattern is a 16-bit pattern; the conjugate's sign flip is bit 15 in both), only the
+// matrix instruction differs.  The half variants exist for float32 output only (the fp16 split products of x3.py).
+#ifdef CPLXAMD_GEMM_F16
+typedef _Float16 cplxamd_f16x8 __attribute__((ext_vector_type(8)));
+#define CPLXAMD_MFMA16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cplxamd_f16x8, a), __builtin_bit_cast(cplxamd_f16x8, b), c, 0, 0, 0)
+#else
+#define CPLXAMD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 __device__ __forceinline__ float gemm_emul(const GemmArgs& g, float m) { return g.emul_exp ? expf(m) : m; }
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)
@@ -68,5 +88,10 @@ int64_t gemm_bf16_gauss_ws_bytes(int M, int N, int K);
 
 // workspace the bf16 path wants for split-K at this shape (0: no split-K)
 int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx);
+
+// the same two families on IEEE-half operands, float32 output only (gemm_f16.hip, gemm_f16_cplx.hip, gemm_f16_w4.hip)
+template <bool CPLX>
+int launch_gemm_f16(const GemmArgs& g, int out_dtype, hipStream_t st);
+int launch_gemm_f16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bool tb, hipStream_t st, bool& taken);
 
 }  // namespace cplxamd

@@ -168,6 +168,40 @@ int cplxamd_rgemm_fl(const void* a, int64_t a_rs, int64_t a_cs, const void* b, i
   return launch_gemm_generic<false>(g, in_dtype, out_dtype, st);
 }
 
+/* the GEMMs of the half-precision split products (include/cplxamd.h): IEEE-half or bf16 operands, float32 output, the
+ * operands' power-of-two scales undone behind the K loop.  No generic fallback: CPLXAMD_ESHAPE = take the bf16 pieces. */
+int cplxamd_cgemm_sc_fl(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
+                        const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
+                        const float* bias_r, const float* bias_i, const float* emul, void* c_r, void* c_i, int64_t ldc,
+                        int M, int N, int K, int conj_b, int in_dtype, int accumulate, const float* beta,
+                        const float* scale_a, const float* scale_b, void* ws, int64_t ws_bytes, int flags, void* stream) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
+  if (!a_r || !a_i || !b_r || !b_i || !c_r || !c_i) return CPLXAMD_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || ldc < N) return CPLXAMD_EINVAL;
+  if ((bias_r == nullptr) != (bias_i == nullptr) || (scale_a == nullptr) != (scale_b == nullptr)) return CPLXAMD_EINVAL;
+  if (in_dtype != CPLXAMD_F16) return CPLXAMD_EINVAL;
+  GemmArgs g{a_r, a_i, a_rs, a_cs, b_r, b_i, b_rs, b_cs, bias_r, bias_i, emul,
+             c_r, c_i, ldc, M, N, K, conj_b ? 1 : 0, accumulate ? 1 : 0};
+  g.ws = ws; g.ws_bytes = ws_bytes; g.beta = accumulate ? beta : nullptr; g.emul_both = emul ? 1 : 0;
+  g.scale_a = scale_a; g.scale_b = scale_b; g.flags = flags;
+  return launch_gemm_f16<true>(g, CPLXAMD_F32, (hipStream_t)stream);
+}
+
+int cplxamd_rgemm_sc_fl(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs, int64_t b_cs,
+                        const float* bias, const float* emul, int emul_exp, void* c, int64_t ldc, int M, int N, int K,
+                        int in_dtype, int accumulate, const float* beta, const float* scale_a, const float* scale_b,
+                        void* ws, int64_t ws_bytes, int flags, void* stream) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
+  if (!a || !b || !c) return CPLXAMD_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || ldc < N || (scale_a == nullptr) != (scale_b == nullptr)) return CPLXAMD_EINVAL;
+  if (in_dtype != CPLXAMD_F16) return CPLXAMD_EINVAL;
+  GemmArgs g{a, nullptr, a_rs, a_cs, b, nullptr, b_rs, b_cs, bias, nullptr, emul,
+             c, nullptr, ldc, M, N, K, 0, accumulate ? 1 : 0};
+  g.ws = ws; g.ws_bytes = ws_bytes; g.beta = accumulate ? beta : nullptr; g.emul_exp = (emul && emul_exp) ? 1 : 0;
+  g.scale_a = scale_a; g.scale_b = scale_b; g.flags = flags;
+  return launch_gemm_f16<false>(g, CPLXAMD_F32, (hipStream_t)stream);
+}
+
 /* dispatch of a bf16 GEMM call as a pure function (include/cplxamd.h): the launchers run "dry" (GemmArgs::plan) */
 int cplxamd_gemm_plan(int cplx, int M, int N, int K, int ta, int tb, int out_dtype, int epi, int flags, int ncu) {
   if (!launch_flags_ok(flags) || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2) return CPLXAMD_EINVAL;

@@ -206,6 +206,19 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
           }
         }
     }
+#ifdef CPLXAMD_GEMM_F16    // (the half-operand build only: the bf16 kernels' code is untouched)
+    if (g.scale_a) {          // scaled split products (gemm.h): the accumulators are multiplied by 1 / (sa sb) behind the K loop
+      const float inv = gemm_alpha_inv(g);
+#pragma unroll
+      for (int pl = 0; pl < (CPLX ? 2 : 1); ++pl)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_v[pl][j][q].v[e] *= inv;
+    }
+#endif
   }
   auto apply_bias = [&]() __attribute__((always_inline)) {
     if (!bias_in_acc) return;
@@ -336,14 +349,14 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
 #pragma unroll
             for (int j = 0; j < JB; ++j) {
               if (ph == 0) {
-                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
-                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+                acc_r[i][j] = CPLXAMD_MFMA16(br[ks][j], ar[ks][i], acc_r[i][j]);
+                acc_i[i][j] = CPLXAMD_MFMA16(br[ks][j], ai[ks][i], acc_i[i][j]);
               } else if (CONJ) {
-                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+                acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], ai[ks][i], acc_r[i][j]);
+                acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_i[i][j]);
               } else {
-                acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-                acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+                acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_r[i][j]);
+                acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], ar[ks][i], acc_i[i][j]);
               }
               constexpr int PER = (NFRAG + NG - 1) / NG;
               const int g0 = (ph * IB * JB + i * JB + j) * PER;
@@ -365,15 +378,15 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
       for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-          acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+          acc_r[i][j] = CPLXAMD_MFMA16(br[ks][j], ar[ks][i], acc_r[i][j]);
           if (CPLX) {
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+            acc_i[i][j] = CPLXAMD_MFMA16(br[ks][j], ai[ks][i], acc_i[i][j]);
             if (CONJ) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], ai[ks][i], acc_r[i][j]);
+              acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_i[i][j]);
             } else {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_r[i][j]);
+              acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], ar[ks][i], acc_i[i][j]);
             }
           }
           {  // the other half's fragments: a few ds_reads behind every MFMA group instead of one burst of
@@ -422,6 +435,19 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT), 2) void gemm_bf16_kernel(GemmArgs 
     if (t < nt) tile_body(0, 1, 2, t);
     if (t + 1 < nt) tile_body(1, 2, 0, t + 1);
   }
+
+#ifdef CPLXAMD_GEMM_F16
+  if (g.scale_a) {              // scaled split products (gemm.h): exact, the scales are powers of two
+    const float alpha = gemm_alpha(g);
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        acc_r[i][j] *= alpha;
+        if (CPLX) acc_i[i][j] *= alpha;
+      }
+  }
+#endif
 
   // ---- epilogue.  Transposed 32x32 C/D layout: output row = lane & 31, output columns
   // 8 q + 4 (lane >> 5) + {0..3} for register group q: one 8-B (bf16) / 16-B (fp32) store each.
@@ -735,7 +761,7 @@ static int launch_persist(const GemmArgs& g0, hipStream_t st, bool& taken) {
   const GemmArgs& g = g0;
   if (!enabled || !launch_owns_chip(g.flags)) return 0;
   const int ncu = (g.ncu > 0 ? g.ncu : device_cus()) & ~7;
-  if (g.splits > 1 || g.g1 || g.emul || g.accumulate || (g.M % C::BM) || (g.N % C::BN) || g.K / BK < 12) return 0;
+  if (g.splits > 1 || g.g1 || g.emul || g.accumulate || g.scale_a || (g.M % C::BM) || (g.N % C::BN) || g.K / BK < 12) return 0;
   if (g.fga && (!((CPLX ? CONJ : true) && TB && !TA && sizeof(TOUT) == 2) || (g.fld & 7) || !aligned16(g.fga) ||
                 !aligned16(g.fx_r) || (CPLX && !aligned16(g.fx_i)) || g.bias_r)) return 0;   // (the caller runs the two-kernel path)
   // instantiated for the layouts the layers launch with a plain epilogue: forward (N,N), input gradient (N,T)
@@ -820,6 +846,13 @@ template <bool CPLX>
 static int launch_dtype(const GemmArgs& g, int out_dtype, bool ta, bool tb, hipStream_t st) {
   if (out_dtype != CPLXAMD_BF16 && out_dtype != CPLXAMD_F32) return CPLXAMD_EINVAL;
   const bool f32 = out_dtype == CPLXAMD_F32;
+#ifdef CPLXAMD_GEMM_F16            // the half-operand build: float32 output only
+  if (!f32) return CPLXAMD_ESHAPE;
+  if constexpr (CPLX) {
+    if (g.conj_b) return launch_layout<float, true, true>(g, ta, tb, st);
+  }
+  return launch_layout<float, CPLX, false>(g, ta, tb, st);
+#else
   if constexpr (CPLX) {
     if (g.conj_b)
       return f32 ? launch_layout<float, true, true>(g, ta, tb, st)
@@ -827,6 +860,7 @@ static int launch_dtype(const GemmArgs& g, int out_dtype, bool ta, bool tb, hipS
   }
   return f32 ? launch_layout<float, CPLX, false>(g, ta, tb, st)
              : launch_layout<bf16_t, CPLX, false>(g, ta, tb, st);
+#endif
 }
 
 // split-K plan: use it when the tile count leaves CUs idle and K is long
@@ -841,7 +875,7 @@ static int plan_splits(int M, int N, int K, bool cplx) {
   return s < 2 ? 1 : s;
 }
 
-#if GEMM_BF16_TU == 1
+#if GEMM_BF16_TU == 1 && !defined(CPLXAMD_GEMM_F16)
 int64_t gemm_bf16_ws_bytes(int M, int N, int K, bool cplx) {
   const int s = plan_splits(M, N, K, cplx);
   return s > 1 ? (int64_t)s * (cplx ? 2 : 1) * M * N * (int64_t)sizeof(float) : 0;
@@ -930,7 +964,7 @@ int launch_gemm_bf16(const GemmArgs& g, int out_dtype, hipStream_t st) {
   return launch_dtype<CPLX>(g, out_dtype, ta, tb, st);
 }
 
-#if GEMM_BF16_TU == 1
+#if GEMM_BF16_TU == 1 && !defined(CPLXAMD_GEMM_F16)
 // ---- Gauss 3M: t1 = Ar Br, T2 = Ai Bi, t3 = (Ar + Ai)(Br + s Bi) as three real MFMA GEMMs; the
 // combine rides in the third one's epilogue.  25 % fewer MFMAs than 4M, but each real GEMM has half
 // the LDS reuse of the fused 4M loop and the operand sums are rounded to bf16.
@@ -996,7 +1030,9 @@ int launch_gemm_bf16_gauss(const GemmArgs& g, int out_dtype, hipStream_t st) {
   f.g1 = t1; f.g2 = t2; f.gsign = s;
   return launch_gemm_bf16<false>(f, out_dtype, st);
 }
+#endif
 
+#if GEMM_BF16_TU == 1
 template int launch_gemm_bf16<false>(const GemmArgs&, int, hipStream_t);
 #else
 template int launch_gemm_bf16<true>(const GemmArgs&, int, hipStream_t);

@@ -168,14 +168,14 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(Gemm
 #pragma unroll
           for (int j = 0; j < JB; ++j) {
             if (ph == 0) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = CPLXAMD_MFMA16(br[ks][j], ar[ks][i], acc_r[i][j]);
+              acc_i[i][j] = CPLXAMD_MFMA16(br[ks][j], ai[ks][i], acc_i[i][j]);
             } else if (CONJ) {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], ai[ks][i], acc_r[i][j]);
+              acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_i[i][j]);
             } else {
-              acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-              acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+              acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_r[i][j]);
+              acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], ar[ks][i], acc_i[i][j]);
             }
             const int gidx = ph * IB * JB + i * JB + j;
             constexpr int PER = (NFRAG + NG - 1) / NG;
@@ -202,15 +202,15 @@ __global__ __launch_bounds__((Cfg<CPLX>::NT)) void gemm_bf16_persist_kernel(Gemm
     for (int i = 0; i < IB; ++i)
 #pragma unroll
       for (int j = 0; j < JB; ++j) {
-        acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ar[ks][i], acc_r[i][j], 0, 0, 0);
+        acc_r[i][j] = CPLXAMD_MFMA16(br[ks][j], ar[ks][i], acc_r[i][j]);
         if (CPLX) {
-          acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[ks][j], ai[ks][i], acc_i[i][j], 0, 0, 0);
+          acc_i[i][j] = CPLXAMD_MFMA16(br[ks][j], ai[ks][i], acc_i[i][j]);
           if (CONJ) {
-            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ai[ks][i], acc_r[i][j], 0, 0, 0);
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_i[i][j], 0, 0, 0);
+            acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], ai[ks][i], acc_r[i][j]);
+            acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_i[i][j]);
           } else {
-            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], nai[i], acc_r[i][j], 0, 0, 0);
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[ks][j], ar[ks][i], acc_i[i][j], 0, 0, 0);
+            acc_r[i][j] = CPLXAMD_MFMA16(bi[ks][j], nai[i], acc_r[i][j]);
+            acc_i[i][j] = CPLXAMD_MFMA16(bi[ks][j], ar[ks][i], acc_i[i][j]);
           }
         }
         {

@@ -274,6 +274,19 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
 #pragma unroll
         for (int q = 0; q < 4; ++q) bias_v[pl][j][q] = ld4(bias + n0 + wn + j * 32 + 8 * q + 4 * lk);
     }
+#ifdef CPLXAMD_GEMM_F16    // (the half-operand build only: the bf16 kernels' code is untouched)
+    if (g.scale_a) {          // scaled split products: the accumulators are multiplied by 1 / (sa sb) behind the K loop
+      const float inv = gemm_alpha_inv(g);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_v[pl][j][q].v[e] *= inv;
+    }
+#endif
   }
 
   // ---- staging registers: [parity of the K tile][piece] ------------------------------------------------------
@@ -373,19 +386,19 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
       constexpr int i = m / 8, ph = (m % 8) / 4, j = (m % 4) / 2, c = m % 2;
       constexpr int d = i < IB - 1 ? i : IB - 1 + f;
       if constexpr (ph == 0) {
-        if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ar[d], acc_r[i][j], 0, 0, 0);
-        else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ai[d], acc_i[i][j], 0, 0, 0);
+        if constexpr (c == 0) acc_r[i][j] = CPLXAMD_MFMA16(br[f][j], ar[d], acc_r[i][j]);
+        else acc_i[i][j] = CPLXAMD_MFMA16(br[f][j], ai[d], acc_i[i][j]);
       } else if constexpr (CONJ) {
-        if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[f][j], ai[d], acc_r[i][j], 0, 0, 0);
-        else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nbi[j], ar[d], acc_i[i][j], 0, 0, 0);
+        if constexpr (c == 0) acc_r[i][j] = CPLXAMD_MFMA16(bi[f][j], ai[d], acc_r[i][j]);
+        else acc_i[i][j] = CPLXAMD_MFMA16(nbi[j], ar[d], acc_i[i][j]);
       } else {
-        if constexpr (c == 0) acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nbi[j], ai[d], acc_r[i][j], 0, 0, 0);
-        else acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[f][j], ar[d], acc_i[i][j], 0, 0, 0);
+        if constexpr (c == 0) acc_r[i][j] = CPLXAMD_MFMA16(nbi[j], ai[d], acc_r[i][j]);
+        else acc_i[i][j] = CPLXAMD_MFMA16(bi[f][j], ar[d], acc_i[i][j]);
       }
     } else {
       constexpr int i = m / JB, j = m % JB;
       constexpr int d = i < IB - 1 ? i : IB - 1 + f;
-      acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[f][j], ar[d], acc_r[i][j], 0, 0, 0);
+      acc_r[i][j] = CPLXAMD_MFMA16(br[f][j], ar[d], acc_r[i][j]);
     }
   };
 
@@ -597,6 +610,21 @@ __device__ __forceinline__ void w4_tile(const GemmArgs& g, const int lin0, char*
       }
     }
   }
+
+#ifdef CPLXAMD_GEMM_F16
+  if constexpr (!PERSIST) {
+    if (g.scale_a) {            // scaled split products (gemm.h): exact, the scales are powers of two
+      const float alpha = gemm_alpha(g);
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+          acc_r[i][j] *= alpha;
+          if (CPLX) acc_i[i][j] *= alpha;
+        }
+    }
+  }
+#endif
 
   // ---- epilogue (the one-tile kernel's, for IB = 4 and JB / 2 column halves of 64) ------------------------------
   // output planes: C, or -- split-K -- this split's float32 slab pair [split][plane][M][ldc] of the workspace (dense, no
@@ -959,12 +987,18 @@ int launch_gemm_bf16_w4(const GemmArgs& g, bool cplx, int out_dtype, bool ta, bo
   }
   int rc;
   const bool f32 = out_dtype == CPLXAMD_F32;
+#ifdef CPLXAMD_GEMM_F16          // the half-operand build: float32 output only
+  if (!f32) return 0;
+  if (cplx) rc = g.conj_b ? w4::launch_layout<float, true, true>(g, ta, tb, st) : w4::launch_layout<float, true, false>(g, ta, tb, st);
+  else rc = w4::launch_layout<float, false, false>(g, ta, tb, st);
+#else
   if (cplx) {
     if (g.conj_b) rc = f32 ? w4::launch_layout<float, true, true>(g, ta, tb, st) : w4::launch_layout<bf16_t, true, true>(g, ta, tb, st);
     else rc = f32 ? w4::launch_layout<float, true, false>(g, ta, tb, st) : w4::launch_layout<bf16_t, true, false>(g, ta, tb, st);
   } else {
     rc = f32 ? w4::launch_layout<float, false, false>(g, ta, tb, st) : w4::launch_layout<bf16_t, false, false>(g, ta, tb, st);
   }
+#endif
   if (rc == CPLXAMD_ESHAPE) return 0;
   if (rc) return rc;
   taken = true;

@@ -1,0 +1,9 @@
+// Real MFMA GEMM on IEEE-half operands, float32 output: gemm_bf16_impl.h compiled with the half matrix instruction
+// (gemm.h: CPLXAMD_MFMA16) under its own kernel names -- the fp16 split products of x3.py ('x2' mode).
+#define CPLXAMD_GEMM_F16 1
+#define launch_gemm_bf16 launch_gemm_f16
+#define launch_gemm_bf16_w4 launch_gemm_f16_w4
+#define gemm_bf16_kernel gemm_f16_kernel
+#define gemm_bf16_persist_kernel gemm_f16_persist_kernel
+#define GEMM_BF16_TU 1
+#include "gemm_bf16_impl.h"

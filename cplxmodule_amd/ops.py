@@ -206,7 +206,9 @@ _gemm_ws_cache = {}
 
 def _gemm_ws(M, N, K, cplx, a, c):
     """Split-K scratch (asked for by few-tile / long-K GEMMs: wgrad at large batch, small heads)."""
-    need = int(_lib.load().cplxamd_gemm_ws_bytes(M, N, K, int(cplx), dtype_code(a), dtype_code(c)))
+    # (half pieces run the bf16 path's kernels compiled for the half MFMA: same split-K plan)
+    need = int(_lib.load().cplxamd_gemm_ws_bytes(M, N, K, int(cplx), _lib.BF16 if a.dtype == torch.float16 else dtype_code(a),
+                                                 dtype_code(c)))
     if need == 0:
         return None
     key = scratch_key(a.device)
@@ -243,7 +245,7 @@ def _beta(beta):
 
 
 def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False,
-          out_dtype=torch.float32, out=None, accumulate=False, algo=0, beta=None, emul=None):
+          out_dtype=torch.float32, out=None, accumulate=False, algo=0, beta=None, emul=None, scales=None):
     """C[m,n] = sum_k A[m,k] op(B[n,k]) (+ bias[n]) on planar complex operands.
     `a_strides` / `b_strides` are (row, col) element strides into the given planes.
     algo: 0 = 4M (one fused K loop), 1 = Gauss 3M (dense bf16 operands only).
@@ -258,6 +260,14 @@ def cgemm(ar, ai, a_strides, br, bi, b_strides, M, N, K, bias=None, conj_b=False
     b_r, b_i = (None, None) if bias is None else bias
     ws = _gauss_ws(M, N, K, ar.device) if algo == 1 else _gemm_ws(M, N, K, True, ar, cr)
     beta = _beta(beta) if accumulate else None
+    if ar.dtype == torch.float16:
+        # IEEE-half pieces of the float32 split products (x3.py 'x2'): float32 out, `scales` = the operands' device
+        # {s, 1 / s} pairs, undone behind the K loop
+        sa, sb = scales if scales is not None else (None, None)
+        call("cplxamd_cgemm_sc_fl", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi), b_strides[0], b_strides[1],
+             ptr(b_r), ptr(b_i), ptr(emul), ptr(cr), ptr(ci), N, M, N, K, int(conj_b), _lib.F16, int(accumulate), ptr(beta),
+             ptr(sa), ptr(sb), ptr(ws), 0 if ws is None else ws.numel(), launch_flags(), stream_ptr())
+        return cr, ci
     call("cplxamd_cgemm_fl", ptr(ar), ptr(ai), a_strides[0], a_strides[1], ptr(br), ptr(bi),
          b_strides[0], b_strides[1], ptr(b_r), ptr(b_i), ptr(emul), ptr(cr), ptr(ci), N, M, N, K,
          int(conj_b), dtype_code(ar), dtype_code(cr), int(accumulate), ptr(beta), int(algo), ptr(ws),
@@ -277,12 +287,18 @@ def cgemm_batched(ar, ai, a_strides, br, bi, b_strides, batch, M, N, K, conj_b=F
 
 
 def rgemm(a, a_strides, b, b_strides, M, N, K, bias=None, emul=None, out_dtype=torch.float32,
-          out=None, emul_exp=False, accumulate=False, beta=None):
+          out=None, emul_exp=False, accumulate=False, beta=None, scales=None):
     """C = (A B^T + bias) * emul (emul_exp: * exp(emul)); accumulate: C = that + beta * C."""
     require_device(a, b, bias, emul)
     c = torch.empty(M, N, dtype=out_dtype, device=a.device) if out is None else out
     ws = _gemm_ws(M, N, K, False, a, c)
     beta = _beta(beta) if accumulate else None
+    if a.dtype == torch.float16:              # (see cgemm)
+        sa, sb = scales if scales is not None else (None, None)
+        call("cplxamd_rgemm_sc_fl", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1], ptr(bias), ptr(emul),
+             int(emul_exp), ptr(c), N, M, N, K, _lib.F16, int(accumulate), ptr(beta), ptr(sa), ptr(sb), ptr(ws),
+             0 if ws is None else ws.numel(), launch_flags(), stream_ptr())
+        return c
     call("cplxamd_rgemm_fl", ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1],
          ptr(bias), ptr(emul), int(emul_exp), ptr(c), N, M, N, K, dtype_code(a), dtype_code(c),
          int(accumulate), ptr(beta), ptr(ws), 0 if ws is None else ws.numel(), launch_flags(), stream_ptr())
@@ -519,20 +535,35 @@ def _is_bf16(t):
 
 
 class _Pieces:
-    """bf16 pieces (x3.split, A side) of float32 planes, made on first use and shared by the products of one pass that
+    """16-bit pieces (x3.split, A side) of float32 planes, made on first use and shared by the products of one pass that
     read them (the output gradient feeds the weight gradient AND the input gradient).  `abs2`: ONE plane of pieces of
-    xr^2 + xi^2 (xi None: xr^2) -- the |x|^2 operand of the variance products, never materialised in float32."""
+    xr^2 + xi^2 (xi None: xr^2) -- the |x|^2 operand of the variance products, never materialised in float32.
+    `made`: pieces kept from the forward pass."""
 
     def __init__(self, *planes, abs2=False, made=None):
         self.planes, self.abs2, self.v = planes, abs2, made
 
-    def get(self):
-        if self.v is None:
+    def get(self, kind):
+        if self.v is None or self.v[0].kind != kind:
             if self.abs2:
-                self.v = (x3.split(self.planes[0], op=x3.OP_ABS2, t2=self.planes[1] if len(self.planes) > 1 else None),)
+                self.v = (x3.split(self.planes[0], op=x3.OP_ABS2, t2=self.planes[1] if len(self.planes) > 1 else None,
+                                   kind=kind),)
             else:
-                self.v = tuple(x3.split(t) for t in self.planes)
+                self.v = x3.split_planes(self.planes, kind=kind)
         return self.v
+
+    def saved(self):
+        """(piece tensors..., shared scale or None) for ctx.save_for_backward; (None, ..) when nothing was made."""
+        if self.v is None:
+            return (None,) * (len(self.planes) if not self.abs2 else 1) + (None,)
+        return tuple(p.t for p in self.v) + (self.v[0].scale,)
+
+    @staticmethod
+    def restored(kind, tensors, scale):
+        if kind is None or tensors[0] is None:
+            return None
+        n = 3 if kind == "x3" else 2
+        return tuple(x3.Pieces(t, kind, scale, n) for t in tensors)
 
 
 # float32 split products: keep the input's bf16 pieces (6 bytes per element and plane, + 6 for |x|^2) from the forward for
@@ -545,9 +576,10 @@ def _cplx_linear_fwd(x2r, x2i, wr, wi, bias, algo=0, mode=None, xs=None):
     operands on the bf16 pipe where x3.take says so (float32-level results), else the exact float32-MFMA kernel."""
     B, I = x2r.shape
     O = wr.shape[0]
-    if x2r.dtype == torch.float32 and x3.take(B, O, I, x2r, x2i, wr, wi, mode=mode):
-        Xs = (xs or _Pieces(x2r, x2i)).get()
-        Ws = (x3.split(wr, x3.SPLIT_B), x3.split(wi, x3.SPLIT_B))
+    kind = x3.take(B, O, I, x2r, x2i, wr, wi, mode=mode) if x2r.dtype == torch.float32 else None
+    if kind:
+        Xs = (xs or _Pieces(x2r, x2i)).get(kind)
+        Ws = x3.split_planes((wr, wi), x3.SPLIT_B, kind=kind)
         yr, yi = x3.gemm_nn(Xs, Ws, B, O, I, bias=bias)
         return yr, yi, (wr, wi)
     wcr, wci = cast(wr, x2r.dtype), cast(wi, x2r.dtype)
@@ -564,8 +596,9 @@ def _cplx_linear_dx(g2r, g2i, wr, wi, out_dtype, algo=0, mode=None, gs=None):
     if _is_bf16(g2r):
         wr, wi = cast(wr, torch.bfloat16), cast(wi, torch.bfloat16)
     elif out_dtype == torch.float32 and x3.take(B, I, O, g2r, g2i, wr, wi, mode=mode):
-        Gs = (gs or _Pieces(g2r, g2i)).get()
-        Wst = (x3.split(wr, x3.SPLIT_B, stacked=True), x3.split(wi, x3.SPLIT_B, stacked=True))
+        kind = x3.take(B, I, O, mode=mode)
+        Gs = (gs or _Pieces(g2r, g2i)).get(kind)
+        Wst = x3.split_planes((wr, wi), x3.SPLIT_B, stacked=True, kind=kind)
         return x3.gemm_nt(Gs, Wst, B, I, O, conj_b=True)
     return cgemm(g2r, g2i, (O, 1), wr, wi, (1, I), B, I, O, conj_b=True, out_dtype=out_dtype,
                  algo=algo if gauss_ok(B, I, O) and I % 8 == 0 else 0)
@@ -616,9 +649,10 @@ def _cplx_linear_dw(g2r, g2i, x2r, x2i, out=None, algo=0, accumulate=False, beta
     accumulate: out = dW + beta * out (beta a device scalar, None = 1)."""
     B, O = g2r.shape
     I = x2r.shape[1]
-    if g2r.dtype == torch.float32 and x3.take(O, I, B, g2r, g2i, x2r, x2i, mode=mode):
-        return x3.gemm_tt((gs or _Pieces(g2r, g2i)).get(), (xs or _Pieces(x2r, x2i)).get(), O, I, B, conj_b=True, out=out,
-                          accumulate=accumulate, beta=beta, emul=emul)
+    kind = x3.take(O, I, B, g2r, g2i, x2r, x2i, mode=mode) if g2r.dtype == torch.float32 else None
+    if kind:
+        return x3.gemm_tt((gs or _Pieces(g2r, g2i)).get(kind), (xs or _Pieces(x2r, x2i)).get(kind), O, I, B, conj_b=True,
+                          out=out, accumulate=accumulate, beta=beta, emul=emul)
     plain = not accumulate and emul is None
     return cgemm(g2r, g2i, (1, O), x2r, x2i, (1, I), O, I, B, conj_b=True, out=out,
                  accumulate=accumulate, beta=beta, emul=emul,
@@ -629,8 +663,9 @@ def _real_linear_fwd(x2, w, bias, out_dtype=None, mode=None, xs=None):
     """x W^T (+ bias) for float32 or bf16 activations -> (y, the weight as the input gradient wants it)."""
     B, I = x2.shape
     O = w.shape[0]
-    if x2.dtype == torch.float32 and x3.take(B, O, I, x2, w, mode=mode):
-        return x3.gemm_nn((xs or _Pieces(x2)).get(), (x3.split(w, x3.SPLIT_B),), B, O, I, bias=bias), w
+    kind = x3.take(B, O, I, x2, w, mode=mode) if x2.dtype == torch.float32 else None
+    if kind:
+        return x3.gemm_nn((xs or _Pieces(x2)).get(kind), x3.split_planes((w,), x3.SPLIT_B, kind=kind), B, O, I, bias=bias), w
     wm = cast(w, x2.dtype)
     return rgemm(x2, (I, 1), wm, (I, 1), B, O, I, bias=bias, out_dtype=out_dtype or x2.dtype), wm
 
@@ -643,8 +678,9 @@ def _real_linear_dx(g2, w, out_dtype, mode=None, gs=None, w_exp=False):
     if _is_bf16(g2):
         w = cast(w, torch.bfloat16)
     elif out_dtype == torch.float32 and x3.take(B, I, O, g2, w, mode=mode):
-        Wst = x3.split(w, x3.SPLIT_B, op=x3.OP_EXP if w_exp else x3.OP_ID, stacked=True)
-        return x3.gemm_nt((gs or _Pieces(g2)).get(), (Wst,), B, I, O)
+        kind = x3.take(B, I, O, mode=mode)
+        Wst = x3.split(w, x3.SPLIT_B, op=x3.OP_EXP if w_exp else x3.OP_ID, stacked=True, kind=kind)
+        return x3.gemm_nt((gs or _Pieces(g2)).get(kind), (Wst,), B, I, O)
     if w_exp:
         w = exp(w)
     return rgemm(g2, (O, 1), w, (1, I), B, I, O, out_dtype=out_dtype)
@@ -654,10 +690,11 @@ def _real_linear_dw(g2, x2, emul=None, out=None, emul_exp=False, accumulate=Fals
     """G^T X (* emul) -> float32 [O, I].  x2 may be None when `xs` (pieces of it, e.g. of |x|^2) is given and the
     split products take the shape (the caller checked with x3.take)."""
     B, O = g2.shape
-    I = x2.shape[1] if x2 is not None else xs.get()[0].shape[1] // 3
-    if g2.dtype == torch.float32 and (x2 is None or x3.take(O, I, B, g2, x2, mode=mode)):
-        return x3.gemm_tt((gs or _Pieces(g2)).get(), (xs or _Pieces(x2)).get(), O, I, B, out=out, accumulate=accumulate,
-                          beta=beta, emul=emul, emul_exp=emul_exp)
+    I = x2.shape[1] if x2 is not None else xs.planes[0].shape[1]
+    kind = x3.take(O, I, B, g2, x2, mode=mode) if g2.dtype == torch.float32 else None
+    if kind:
+        return x3.gemm_tt((gs or _Pieces(g2)).get(kind), (xs or _Pieces(x2)).get(kind), O, I, B, out=out,
+                          accumulate=accumulate, beta=beta, emul=emul, emul_exp=emul_exp)
     if g2.dtype != x2.dtype:
         g2, x2 = cast(g2, torch.float32), cast(x2, torch.float32)
     return rgemm(g2, (1, O), x2, (1, I), O, I, B, emul=emul, out=out, emul_exp=emul_exp,
@@ -762,7 +799,8 @@ class CplxLinearFn(torch.autograd.Function):
         ctx.mode = x3.get_fp32_mode()        # (the backward runs on an autograd thread: it follows this pass's choice)
         xs = _Pieces(x2r, x2i)
         yr, yi, ctx.wc = _cplx_linear_fwd(x2r, x2i, wmr, wmi, bias, algo, mode=ctx.mode, xs=xs)
-        keep = xs.v if (_X3_SAVE and xs.v is not None and x3.take(O, I, x2r.shape[0], mode=ctx.mode)) else (None, None)
+        ctx.kind = x3.take(O, I, x2r.shape[0], mode=ctx.mode) if xs.v is not None else None     # (the weight gradient's)
+        keep = xs.saved() if (_X3_SAVE and ctx.kind and xs.v[0].kind == ctx.kind) else (None, None, None)
         # (xr, xi as given: the create_graph backward needs graph-connected tensors, and x2r / x2i are views or copies made
         #  here, without history; for a contiguous input they share its storage)
         ctx.save_for_backward(x2r, x2i, wr, wi, mask, *keep, xr, xi)
@@ -772,7 +810,7 @@ class CplxLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gr, gi):
-        x2r, x2i, wr, wi, mask, xsr, xsi, xr0, xi0 = ctx.saved_tensors
+        x2r, x2i, wr, wi, mask, xsr, xsi, xsc, xr0, xi0 = ctx.saved_tensors
         O, I = wr.shape
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
@@ -797,7 +835,7 @@ class CplxLinearFn(torch.autograd.Function):
             return dxr, dxi, dwr, dwi, dbr, dbi, None, None
         g2r, g2i = gr.reshape(-1, O).contiguous(), gi.reshape(-1, O).contiguous()
         gs = _Pieces(g2r, g2i)               # (float32 split products: the pieces of G serve dW and dX)
-        xs = _Pieces(x2r, x2i, made=None if xsr is None else (xsr, xsi))
+        xs = _Pieces(x2r, x2i, made=_Pieces.restored(ctx.kind, (xsr, xsi), xsc))
         # parameter gradients first (into their data-parallel bucket, announced before the dX GEMM)
         if need[2] or need[3]:
             dwr, dwi = grad_buffer(wr), grad_buffer(wi)
@@ -859,7 +897,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
         # float32 layers: the three products of the forward (and the five of the backward) on split bf16 operands where
         # x3.take says so -- float32-level results at the bf16 pipe's rate / 6 instead of the float32 MFMA's
         ctx.mode = mode = x3.get_fp32_mode()
-        use3 = x2r.dtype == torch.float32 and x3.take(B, O, I, x2r, x2i, wrc, wic, ls2c, mode=mode)
+        use3 = x3.take(B, O, I, x2r, x2i, wrc, wic, ls2c, mode=mode) if x2r.dtype == torch.float32 else None
         if _prep_ok(x2r, wrc, wic, ls2c):
             wcr, wci, S, kl, _ = prep_kl(kl_kind, wrc, wic, ls2c, kl_kind is not None, ctx.klg)
         else:
@@ -871,14 +909,16 @@ class CplxLinearLRTFn(torch.autograd.Function):
                 call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wrc)), ptr(_f32(wic)), ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind],
                      1.0, ptr(kl), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(_ws(x2r.device)), O * I, stream_ptr())
         ctx.wc, ctx.S = (wcr, wci), S
-        keep = (None, None, None)
+        keep = (None,) * 5
+        ctx.kind = None
         if use3:
             xs, xa = _Pieces(x2r, x2i), _Pieces(x2r, x2i, abs2=True)
             mur, mui, _ = _cplx_linear_fwd(x2r, x2i, wcr, wci, bias, mode=mode, xs=xs)
-            a = None                                         # |x|^2 exists as bf16 pieces only
-            s2 = x3.gemm_nn(xa.get(), (x3.split(ls2c, x3.SPLIT_B, op=x3.OP_EXP),), B, O, I)
-            if _X3_SAVE and x3.take(O, I, B, mode=mode):     # the weight gradients will read them
-                keep = (*xs.get(), *xa.get())
+            a = None                                         # |x|^2 exists as 16-bit pieces only
+            s2 = x3.gemm_nn(xa.get(use3), (x3.split(ls2c, x3.SPLIT_B, op=x3.OP_EXP, kind=use3),), B, O, I)
+            ctx.kind = x3.take(O, I, B, mode=mode)           # the weight gradients' arithmetic (K = batch)
+            if _X3_SAVE and ctx.kind == use3:                # they will read the same pieces
+                keep = (*xs.saved(), *xa.saved())
         else:
             mur, mui = cgemm(x2r, x2i, (I, 1), wcr, wci, (I, 1), B, O, I, bias=bias, out_dtype=x2r.dtype)
             a = abs2(x2r, x2i)                                   # [B,I], activation dtype
@@ -913,7 +953,7 @@ class CplxLinearLRTFn(torch.autograd.Function):
                     ctx.klg = None           # the hook overwrites the bucket slices with what this pass returns
             ctx.kl_only_ran = True
             return dxr, dxi, dwr, dwi, dbr, dbi, dls2, None, None, None, None, None
-        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi, xsr, xsi, xsa = _saved(ctx)
+        x2r, x2i, wr, wi, ls2, s2, a, eps_r, eps_i, br, bi, xsr, xsi, xsc, xsa, xac = _saved(ctx)
         O, I = wr.shape
         B = x2r.shape[0]
         klg = None
@@ -944,10 +984,10 @@ class CplxLinearLRTFn(torch.autograd.Function):
         # float32 split products: pieces made once per pass, shared by the products that read them
         m3 = ctx.mode
         gs, g2s, xa = _Pieces(g2r, g2i), _Pieces(gs2), None
-        xs = _Pieces(x2r, x2i, made=None if xsr is None else (xsr, xsi))
+        xs = _Pieces(x2r, x2i, made=_Pieces.restored(ctx.kind, (xsr, xsi), xsc))
         if a is None:                                        # the forward ran on pieces of |x|^2
             if x3.take(O, I, B, gs2, mode=m3):
-                xa = _Pieces(x2r, x2i, abs2=True, made=None if xsa is None else (xsa,))
+                xa = _Pieces(x2r, x2i, abs2=True, made=_Pieces.restored(ctx.kind, (xsa,), xac))
             else:
                 a = abs2(x2r, x2i)
         if want_w:
@@ -1006,14 +1046,15 @@ class RealLinearFn(torch.autograd.Function):
         xs = _Pieces(x2)
         y, wm = _real_linear_fwd(x2, wm, _c(b), mode=ctx.mode, xs=xs)
         ctx.wm = wm
-        keep = xs.v[0] if (_X3_SAVE and xs.v is not None and x3.take(O, I, x2.shape[0], mode=ctx.mode)) else None
-        ctx.save_for_backward(x2, w, mask, keep, x)          # (x as given: see CplxLinearFn.forward)
+        ctx.kind = x3.take(O, I, x2.shape[0], mode=ctx.mode) if xs.v is not None else None
+        keep = xs.saved() if (_X3_SAVE and ctx.kind and xs.v[0].kind == ctx.kind) else (None, None)
+        ctx.save_for_backward(x2, w, mask, *keep, x)         # (x as given: see CplxLinearFn.forward)
         ctx.has_bias, ctx.lead = b is not None, x.shape[:-1]
         return y.view(*ctx.lead, O)
 
     @staticmethod
     def backward(ctx, g):
-        x2, w, mask, xsv, x0 = ctx.saved_tensors
+        x2, w, mask, xsv, xsc, x0 = ctx.saved_tensors
         O, I = w.shape
         need = ctx.needs_input_grad
         dx = dw = db = None
@@ -1033,7 +1074,8 @@ class RealLinearFn(torch.autograd.Function):
         gs = _Pieces(g2)
         if need[1]:
             dw = grad_buffer(w)
-            _real_linear_dw(g2, x2, emul=mask, out=dw, mode=ctx.mode, gs=gs, xs=None if xsv is None else _Pieces(x2, made=(xsv,)))
+            _real_linear_dw(g2, x2, emul=mask, out=dw, mode=ctx.mode, gs=gs,
+                            xs=None if xsv is None else _Pieces(x2, made=_Pieces.restored(ctx.kind, (xsv,), xsc)))
             _announce(w)
         if ctx.has_bias and need[2]:
             db = colsum(g2)
@@ -1078,7 +1120,7 @@ class RealLinearLRTFn(torch.autograd.Function):
             ctx.klg = (grad_buffer(ls2), grad_buffer(w))
             ctx.klg_shared = hook_of(ls2) is not None        # (see CplxLinearLRTFn.forward)
         ctx.mode = mode = x3.get_fp32_mode()                 # (see CplxLinearLRTFn.forward)
-        use3 = x2.dtype == torch.float32 and x3.take(B, O, I, x2, wc_, ls2c, mode=mode)
+        use3 = x3.take(B, O, I, x2, wc_, ls2c, mode=mode) if x2.dtype == torch.float32 else None
         if _prep_ok(x2, wc_, ls2c):
             wb, _, S, kl, _ = prep_kl(kl_kind, wc_, None, ls2c, kl_kind is not None,
                                       None if ctx.klg is None else (*ctx.klg, None))
@@ -1089,14 +1131,16 @@ class RealLinearLRTFn(torch.autograd.Function):
                 call("cplxamd_vd_kl_fwd_bwd", ptr(_f32(wc_)), None, ptr(_f32(ls2c)), _lib.KL_KINDS[kl_kind], 1.0,
                      ptr(kl), ptr(ctx.klg[0]), ptr(ctx.klg[1]), None, ptr(_ws(x2.device)), O * I, stream_ptr())
         ctx.wb, ctx.S = wb, S
-        keep = (None, None)
+        keep = (None,) * 4
+        ctx.kind = None
         if use3:
             xs, xa = _Pieces(x2), _Pieces(x2, abs2=True)
             mu, _ = _real_linear_fwd(x2, wb, _c(b), mode=mode, xs=xs)
             a = None
-            s2 = x3.gemm_nn(xa.get(), (x3.split(ls2c, x3.SPLIT_B, op=x3.OP_EXP),), B, O, I)
-            if _X3_SAVE and x3.take(O, I, B, mode=mode):
-                keep = (*xs.get(), *xa.get())
+            s2 = x3.gemm_nn(xa.get(use3), (x3.split(ls2c, x3.SPLIT_B, op=x3.OP_EXP, kind=use3),), B, O, I)
+            ctx.kind = x3.take(O, I, B, mode=mode)
+            if _X3_SAVE and ctx.kind == use3:
+                keep = (*xs.saved(), *xa.saved())
         else:
             mu = rgemm(x2, (I, 1), wb, (I, 1), B, O, I, bias=_c(b), out_dtype=x2.dtype)
             a = abs2(x2)
@@ -1124,7 +1168,7 @@ class RealLinearLRTFn(torch.autograd.Function):
                     ctx.klg = None
             ctx.kl_only_ran = True
             return dx, dw, db, dls2, None, None, None, None
-        x2, w, ls2, s2, a, eps, b, xsv, xsa = _saved(ctx)
+        x2, w, ls2, s2, a, eps, b, xsv, xsc, xsa, xac = _saved(ctx)
         O, I = w.shape
         B = x2.shape[0]
         klg = None
@@ -1144,10 +1188,10 @@ class RealLinearLRTFn(torch.autograd.Function):
             else grad_buffer
         m3 = ctx.mode
         gs, g2s, xa = _Pieces(g2), _Pieces(gs2), None        # (see CplxLinearLRTFn.backward)
-        xs = None if xsv is None else _Pieces(x2, made=(xsv,))
+        xs = None if xsv is None else _Pieces(x2, made=_Pieces.restored(ctx.kind, (xsv,), xsc))
         if a is None:
             if x3.take(O, I, B, gs2, mode=m3):
-                xa = _Pieces(x2, abs2=True, made=None if xsa is None else (xsa,))
+                xa = _Pieces(x2, abs2=True, made=_Pieces.restored(ctx.kind, (xsa,), xac))
             else:
                 a = abs2(x2)
         if need[1]:

@@ -23,10 +23,11 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 20
+#define CPLXAMD_ABI_VERSION 21
 
 /* element types of activations / outputs */
-enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1 };
+enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1,
+       CPLXAMD_F16 = 2 /* IEEE half: operand type of cplxamd_cgemm_sc_fl / cplxamd_rgemm_sc_fl only */ };
 
 /* complex product algorithm of cplxamd_cgemm */
 enum {
@@ -378,9 +379,42 @@ int cplxamd_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dty
  * cols % 8 == 0, ld_src % 4 == 0, ld_dst % 8 == 0, piece_stride % 8 == 0 (CPLXAMD_ESHAPE), 16-byte aligned pointers (CPLXAMD_EALIGN).
  * HBM: 4 (8 with src2) bytes read, 6 (pattern A) / 12 (pattern B) bytes written per element. */
 enum { CPLXAMD_SPLIT_A = 0, CPLXAMD_SPLIT_B = 1 };
-enum { CPLXAMD_SPLIT_ID = 0, CPLXAMD_SPLIT_ABS2 = 1, CPLXAMD_SPLIT_EXP = 2 };
+enum { CPLXAMD_SPLIT_ID = 0, CPLXAMD_SPLIT_ABS2 = 1, CPLXAMD_SPLIT_EXP = 2, CPLXAMD_SPLIT_MAX2 = 3 /* absmax only */ };
 int cplxamd_split3(const float* src, const float* src2, int64_t ld_src, void* dst, int64_t ld_dst, int64_t piece_stride,
                    int64_t rows, int cols, int op, int pattern, void* stream);
+
+/* ---- the same on IEEE-half pieces: three piece products instead of six ("x2" operands) -------------------------------
+ * half has 11 significand bits: x s = h0 + h1 to 2^-22 with h0 = half(x s), h1 = half(x s - h0), and a product needs
+ * h0 w0, h0 w1, h1 w0 (h1 w1 is below 2^-22 |x w|) -- half the matrix work of the bf16 split at 2^-22 instead of 2^-24.
+ * The 5-bit exponent needs care: every operand is multiplied by a power of two s chosen from its largest magnitude
+ * (cplxamd_absmax_scale: max |op(x)| s in [2^14, 2^15); s = 1 for an all-zero or non-finite tensor) before it is cut, and
+ * the GEMM multiplies its accumulators by 1 / (sa sb) behind the K loop (exact).  An element keeps all 22 bits while
+ * |x| >= 2^-17 max |x|; below that its second piece is subnormal and the element's error is <= 2^-39 max |x| absolute --
+ * norm-wise the product is accurate to 2^-22 whatever the dynamic range.
+ *   cplxamd_absmax_scale   scale[0] = s, scale[1] = 1 / s (device floats) for op(src) [rows][cols]; ws >= cplxamd_absmax_ws_bytes();
+ *                          op as cplxamd_split3, or CPLXAMD_SPLIT_MAX2: max(|src|, |src2|) -- the two planes of a complex
+ *                          operand must share one scale (the four real products of the complex GEMM mix them)
+ *   cplxamd_split2h        pieces of op(src) * scale[0] as IEEE half, layouts as cplxamd_split3:
+ *                          CPLXAMD_SPLIT_A (h1, h0)      CPLXAMD_SPLIT_B (w1, w0, w0)
+ *                          launches:  h0 . w1,   [h1|h0] . [w0|w0]
+ *   cplxamd_cgemm_sc_fl / cplxamd_rgemm_sc_fl   cplxamd_cgemm_fl / cplxamd_rgemm_fl for half operands (in_dtype = CPLXAMD_F16),
+ *                          float32 C, with the two operands' scale buffers (both NULL: no scaling).  The MFMA kernel families
+ *                          of the bf16 path compiled for v_mfma_f32_32x32x16_f16; shapes they decline: CPLXAMD_ESHAPE (there
+ *                          is no generic fallback -- run the bf16 pieces). */
+int64_t cplxamd_absmax_ws_bytes(void);
+int cplxamd_absmax_scale(const float* src, const float* src2, int64_t ld_src, int64_t rows, int cols, int op, float* scale,
+                         void* ws, void* stream);
+int cplxamd_split2h(const float* src, const float* src2, int64_t ld_src, void* dst, int64_t ld_dst, int64_t piece_stride,
+                    int64_t rows, int cols, int op, int pattern, const float* scale, void* stream);
+int cplxamd_cgemm_sc_fl(const void* a_r, const void* a_i, int64_t a_rs, int64_t a_cs,
+                        const void* b_r, const void* b_i, int64_t b_rs, int64_t b_cs,
+                        const float* bias_r, const float* bias_i, const float* emul, void* c_r, void* c_i, int64_t ldc,
+                        int M, int N, int K, int conj_b, int in_dtype, int accumulate, const float* beta,
+                        const float* scale_a, const float* scale_b, void* ws, int64_t ws_bytes, int flags, void* stream);
+int cplxamd_rgemm_sc_fl(const void* a, int64_t a_rs, int64_t a_cs, const void* b, int64_t b_rs, int64_t b_cs,
+                        const float* bias, const float* emul, int emul_exp, void* c, int64_t ldc, int M, int N, int K,
+                        int in_dtype, int accumulate, const float* beta, const float* scale_a, const float* scale_b,
+                        void* ws, int64_t ws_bytes, int flags, void* stream);
 /* out[c, r] = in[r, c]  (rows x cols row-major in, ld = leading dims) */
 int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
                       int cols, int dtype, void* stream);

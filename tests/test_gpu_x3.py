@@ -27,19 +27,19 @@ def test_split3_exact_and_layouts(rows, cols):
     x = (rs.randn(rows, cols) * np.exp(rs.uniform(-20, 20, (rows, cols)))).astype(np.float32)
     x[0, 0], x[0, 1] = 0.0, -0.0
     t = torch.from_numpy(x).cuda()
-    a = x3.split(t)                                    # [rows, 3 cols] = [x2 | x1 | x0]
+    a = x3.split(t).t                                  # [rows, 3 cols] = [x2 | x1 | x0]
     p2, p1, p0 = (a[:, j * cols:(j + 1) * cols].float() for j in range(3))
     assert torch.equal(p0, t.bfloat16().float())
     assert torch.equal(p1, (t - p0).bfloat16().float())
     assert torch.equal((p2 + p1) + p0, t)              # exact reconstruction in float32
     assert float((p1.abs() > p0.abs() * 2.0 ** -7).sum()) == 0 and float((p2.abs() > p0.abs() * 2.0 ** -15).sum()) == 0
-    b = x3.split(t, x3.SPLIT_B)                        # [rows, 6 cols] = [x2 | x1 x1 | x0 x0 x0]
+    b = x3.split(t, x3.SPLIT_B).t                      # [rows, 6 cols] = [x2 | x1 x1 | x0 x0 x0]
     for j, want in enumerate((p2, p1, p1, p0, p0, p0)):
         assert torch.equal(b[:, j * cols:(j + 1) * cols].float(), want)
-    s = x3.split(t, x3.SPLIT_B, stacked=True)          # [6, rows, cols]
+    s = x3.split(t, x3.SPLIT_B, stacked=True).t        # [6, rows, cols]
     for j, want in enumerate((p2, p1, p1, p0, p0, p0)):
         assert torch.equal(s[j].float(), want)
-    sa = x3.split(t, stacked=True)
+    sa = x3.split(t, stacked=True).t
     assert torch.equal(sa[2].float(), p0) and torch.equal(sa[0].float(), p2)
 
 
@@ -48,16 +48,16 @@ def test_split3_ops_and_nonfinite():
     rs = np.random.RandomState(3)
     xr = torch.from_numpy(rs.randn(40, 64).astype(np.float32)).cuda()
     xi = torch.from_numpy(rs.randn(40, 64).astype(np.float32)).cuda()
-    a = x3.split(xr, op=x3.OP_ABS2, t2=xi)
+    a = x3.split(xr, op=x3.OP_ABS2, t2=xi).t
     full = (a[:, :64].float() + a[:, 64:128].float()) + a[:, 128:].float()
     assert torch.equal(full, ops.abs2(xr, xi))         # the very arithmetic of the |x|^2 kernel, split exactly
-    a = x3.split(xr, op=x3.OP_ABS2)
+    a = x3.split(xr, op=x3.OP_ABS2).t
     assert torch.equal((a[:, :64].float() + a[:, 64:128].float()) + a[:, 128:].float(), xr * xr)
-    e = x3.split(xr, op=x3.OP_EXP)
+    e = x3.split(xr, op=x3.OP_EXP).t
     assert torch.equal((e[:, :64].float() + e[:, 64:128].float()) + e[:, 128:].float(), ops.exp(xr))
     bad = xr.clone()
     bad[0, 0], bad[0, 1], bad[0, 2], bad[0, 3] = float("inf"), float("-inf"), float("nan"), 3.4e38
-    p = x3.split(bad)
+    p = x3.split(bad).t
     p2, p1, p0 = (p[:, j * 64:(j + 1) * 64].float() for j in range(3))
     assert p0[0, 0] == float("inf") and p0[0, 1] == float("-inf") and torch.isnan(p0[0, 2])
     assert float(p1[0, :3].abs().sum()) == 0 and float(p2[0, :3].abs().sum()) == 0
@@ -65,7 +65,7 @@ def test_split3_ops_and_nonfinite():
     # strided source rows (a column block of a wider matrix) and refusal of shapes the kernel does not take
     wide = torch.from_numpy(rs.randn(16, 128).astype(np.float32)).cuda()
     v = wide[:, 32:96]
-    pv = x3.split(v)
+    pv = x3.split(v).t
     assert torch.equal((pv[:, :64].float() + pv[:, 64:128].float()) + pv[:, 128:].float(), v)
     from cplxmodule_amd._lib import CplxAmdError
     with pytest.raises(CplxAmdError):
@@ -74,7 +74,8 @@ def test_split3_ops_and_nonfinite():
 
 @pytest.mark.parametrize("M,N_,K", [(64, 96, 32), (256, 128, 192), (520, 264, 96), (512, 512, 1024)])
 @pytest.mark.parametrize("cplx", (True, False))
-def test_x3_gemm_forms_vs_float64(M, N_, K, cplx):
+@pytest.mark.parametrize("kind", ("x3", "x2"))
+def test_x3_gemm_forms_vs_float64(M, N_, K, cplx, kind):
     """The three launch sequences (N,N) / (N,T) / (T,T) on split operands against float64 numpy: norm-wise 2e-6, and
     within a small factor of the exact float32-MFMA kernel on the same float32 inputs (both are float32 accumulations; the
     split products run three times the K depth in one accumulator chain)."""
@@ -102,8 +103,8 @@ def test_x3_gemm_forms_vs_float64(M, N_, K, cplx):
 
     # (N,N): C = A B^T + bias
     ref = a64 @ b64.T + (bias[0] + (1j * bias[1] if cplx else 0))
-    got = x3.gemm_nn(tuple(x3.split(t) for t in At), tuple(x3.split(t, x3.SPLIT_B) for t in Bt), M, N_, K,
-                     bias=tuple(bt) if cplx else bt[0])
+    sp = lambda ts, *a, **k: x3.split_planes(tuple(ts), *a, kind=kind, **k)  # noqa: E731
+    got = x3.gemm_nn(sp(At), sp(Bt, x3.SPLIT_B), M, N_, K, bias=tuple(bt) if cplx else bt[0])
     if cplx:
         exact = ops.cgemm(At[0], At[1], (K, 1), Bt[0], Bt[1], (K, 1), M, N_, K, bias=tuple(bt))
     else:
@@ -112,8 +113,7 @@ def test_x3_gemm_forms_vs_float64(M, N_, K, cplx):
     # (N,T): C[m, n] = sum_k A[m, k] conj(Bk[k, n]) with Bk = B^T stored [K, N]
     Bk = [cu(v.T.copy()) for v in B]
     ref = a64 @ (b64.conj() if cplx else b64).T
-    got = x3.gemm_nt(tuple(x3.split(t) for t in At), tuple(x3.split(t, x3.SPLIT_B, stacked=True) for t in Bk), M, N_, K,
-                     conj_b=cplx)
+    got = x3.gemm_nt(sp(At), sp(Bk, x3.SPLIT_B, stacked=True), M, N_, K, conj_b=cplx)
     if cplx:
         exact = ops.cgemm(At[0], At[1], (K, 1), Bk[0], Bk[1], (1, N_), M, N_, K, conj_b=True)
     else:
@@ -125,8 +125,7 @@ def test_x3_gemm_forms_vs_float64(M, N_, K, cplx):
     beta = torch.tensor(0.25, device="cuda")
     ref = a64 @ (b64.conj() if cplx else b64).T + 0.25 * (C0[0] + (1j * C0[1] if cplx else 0))
     out = tuple(cu(v) for v in C0) if cplx else cu(C0[0])
-    got = x3.gemm_tt(tuple(x3.split(t) for t in Ak), tuple(x3.split(t) for t in Bk), M, N_, K, conj_b=cplx, out=out,
-                     accumulate=True, beta=beta)
+    got = x3.gemm_tt(sp(Ak), sp(Bk), M, N_, K, conj_b=cplx, out=out, accumulate=True, beta=beta)
     out2 = tuple(cu(v) for v in C0) if cplx else cu(C0[0])
     if cplx:
         exact = ops.cgemm(Ak[0], Ak[1], (1, M), Bk[0], Bk[1], (1, N_), M, N_, K, conj_b=True, out=out2, accumulate=True,
@@ -139,7 +138,8 @@ def test_x3_gemm_forms_vs_float64(M, N_, K, cplx):
 def test_take_rules():
     from cplxmodule_amd import x3
     t = torch.zeros(8, device="cuda")
-    assert x3.take(64, 64, 32, t, mode="x3") and not x3.take(64, 64, 32, t, mode="exact")
+    assert x3.take(64, 64, 32, t, mode="x3") == "x3" and x3.take(64, 64, 32, t, mode="x2") == "x2"
+    assert not x3.take(64, 64, 32, t, mode="exact")
     assert not x3.take(64, 64, 32, t, mode="auto") and x3.take(1024, 1024, 1024, t, mode="auto")
     assert not x3.take(64, 60, 32, t, mode="x3") and not x3.take(64, 64, 48, t, mode="x3")
     assert not x3.take(64, 64, 32, t.bfloat16(), mode="x3") and not x3.take(1 << 21, 64, 32, t, mode="x3")
@@ -162,7 +162,8 @@ def _count_splits(monkeypatch):
     return n
 
 
-def test_cplx_linear_x3_golden(golden, monkeypatch):
+@pytest.mark.parametrize("mode", ("x3", "x2"))
+def test_cplx_linear_x3_golden(golden, monkeypatch, mode):
     """cplx.linear in x3 mode vs the reference: float32 outputs / autograd gradients at the suite's tolerance, the float64
     ones (same seeds) at 2e-6 norm-wise."""
     from gpu_util import T, N
@@ -170,7 +171,7 @@ def test_cplx_linear_x3_golden(golden, monkeypatch):
     g = golden("x3")
     n = _count_splits(monkeypatch)
     leaves = {m: T(g["f32_lin_" + m]).requires_grad_(True) for m in ("xr", "xi", "wr", "wi", "br", "bi")}
-    with x3.fp32_mode("x3"):
+    with x3.fp32_mode(mode):
         y = cplx.linear(cplx.Cplx(leaves["xr"], leaves["xi"]), cplx.Cplx(leaves["wr"], leaves["wi"]),
                         cplx.Cplx(leaves["br"], leaves["bi"]))
     assert n["split"] == 4                               # x (2 planes) + W (2 planes): the split path ran
@@ -205,7 +206,7 @@ def _cvd_layer(g, k, O, I):
     return layer
 
 
-@pytest.mark.parametrize("mode", ("x3", "exact"))
+@pytest.mark.parametrize("mode", ("x3", "x2", "exact"))
 def test_cplx_linear_vd_x3_golden(golden, monkeypatch, mode):
     """CplxLinearVD (training mode, the reference's noise tape, loss + 1e-2 KL) in x3 mode -- and, for the comparison in
     the parity report, in exact mode -- vs the reference's float32 and float64 numbers."""
@@ -223,7 +224,7 @@ def test_cplx_linear_vd_x3_golden(golden, monkeypatch, mode):
     with x3.fp32_mode(mode):
         y = layer(cplx.Cplx(xr, xi), eps=cplx.Cplx(tape[0], tape[1]))
         kl = sum(rel.penalties(layer))
-    assert (n["split"] > 0) == (mode == "x3")
+    assert (n["split"] > 0) == (mode != "exact")
     np.testing.assert_allclose(float(kl), float(g[k + "kl"]), rtol=1e-5)
     ((y.real * T(g[k + "gr"])).sum() + (y.imag * T(g[k + "gi"])).sum() + 1e-2 * kl).backward()
     got = dict(yr=y.real, yi=y.imag, dxr=xr.grad, dxi=xi.grad, dwr=layer.weight.real.grad, dwi=layer.weight.imag.grad,
@@ -240,7 +241,8 @@ def test_cplx_linear_vd_x3_golden(golden, monkeypatch, mode):
         np.testing.assert_allclose(N(t), t64[m], **_norm_tol(t64[m], 2e-6), err_msg=m + " (float64 oracle)")
 
 
-def test_real_linear_vd_x3_golden(golden, monkeypatch):
+@pytest.mark.parametrize("mode", ("x3", "x2"))
+def test_real_linear_vd_x3_golden(golden, monkeypatch, mode):
     from gpu_util import T, N
     from cplxmodule_amd import x3
     from cplxmodule_amd.nn import relevance as rel
@@ -252,7 +254,7 @@ def test_real_linear_vd_x3_golden(golden, monkeypatch):
     layer.load_state_dict({"weight": T(g[k + "w"]), "bias": T(g[k + "b"]), "log_sigma2": T(g[k + "ls2"])})
     x = T(g[k + "x"]).requires_grad_(True)
     layer.train()
-    with x3.fp32_mode("x3"):
+    with x3.fp32_mode(mode):
         y = layer(x, eps=T(g[k + "eps"]))
         kl = sum(rel.penalties(layer))
     assert n["split"] > 0
@@ -267,12 +269,14 @@ def test_real_linear_vd_x3_golden(golden, monkeypatch):
         np.testing.assert_allclose(N(t), t64[m], **_norm_tol(t64[m], 2e-6), err_msg=m + " (float64 oracle)")
 
 
-def test_lrt_goldens_under_x3(golden):
-    """cfg1's shapes (B = 64, 128 -> 128): the suite's LRT golden tests (complex, clamp boundary, real) with x3 forced."""
+@pytest.mark.parametrize("mode", ("x3", "x2"))
+def test_lrt_goldens_under_x3(golden, mode):
+    """cfg1's shapes (B = 64, 128 -> 128): the suite's LRT golden tests (complex, clamp boundary, real) with the split
+    arithmetic forced."""
     import test_gpu_linear as tl
     import cplxmodule_amd
     from cplxmodule_amd import x3
-    with x3.fp32_mode("x3"):
+    with x3.fp32_mode(mode):
         tl.test_lrt_cplx_linear_layer_golden(golden, cplxmodule_amd)
         tl.test_lrt_clamp_boundary_layer(golden, cplxmodule_amd)
         tl.test_lrt_real_linear_layer_golden(golden, cplxmodule_amd)
@@ -290,7 +294,7 @@ def test_x3_ragged_batch_falls_back_per_product(monkeypatch):
     x = cplx.Cplx(torch.randn(40, 64, device="cuda"), torch.randn(40, 64, device="cuda"))
     eps = cplx.Cplx(torch.randn(40, 96, device="cuda"), torch.randn(40, 96, device="cuda"))
     res = {}
-    for mode in ("exact", "x3"):
+    for mode in ("exact", "x3", "x2"):
         layer.zero_grad()
         xr, xi = x.real.clone().requires_grad_(True), x.imag.clone().requires_grad_(True)
         with x3.fp32_mode(mode):
@@ -298,8 +302,9 @@ def test_x3_ragged_batch_falls_back_per_product(monkeypatch):
         (y.real.square().sum() + y.imag.square().sum()).backward()
         res[mode] = [t.detach().cpu().double().numpy() for t in (y.real, y.imag, xr.grad, xi.grad, layer.weight.real.grad,
                                                                 layer.weight.imag.grad, layer.log_sigma2.grad)]
-    for a, b in zip(res["x3"], res["exact"]):
-        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * float(np.abs(b).max()))
+    for m in ("x3", "x2"):
+        for a, b in zip(res[m], res["exact"]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * float(np.abs(b).max()))
 
 
 def test_x3_masked_layer():
@@ -321,3 +326,58 @@ def test_x3_masked_layer():
     for a, b in zip(res["x3"], res["exact"]):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * float(np.abs(b).max()))
     assert float((torch.from_numpy(res["x3"][2]).cuda().float() * (1 - mask)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("scale_pow", (0, -30, 20))
+def test_split2h_pieces_and_scale(scale_pow):
+    """IEEE-half pieces: scale = the power of two that puts max |x| into [2^14, 2^15); x s = h0 + h1 + r with
+    |r| <= 2^-22 |x s| for every element within 2^17 of the largest, <= 2^-25 (scaled units) below; layouts as the bf16
+    pieces; the planes of a complex operand share one scale."""
+    from cplxmodule_amd import x3
+    rs = np.random.RandomState(11)
+    x = (rs.randn(96, 64) * np.exp(rs.uniform(-12, 0, (96, 64))) * 2.0 ** scale_pow).astype(np.float32)
+    x[0, 0] = 0.0
+    t = torch.from_numpy(x).cuda()
+    sc = x3.scale_of(t)
+    s_, inv = float(sc[0]), float(sc[1])
+    amax = float(np.abs(x).max())
+    assert s_ * inv == 1.0 and 2.0 ** 14 <= amax * s_ < 2.0 ** 15 and np.log2(s_) == round(np.log2(s_))
+    p = x3.split(t, kind="x2")
+    assert p.t.dtype == torch.float16 and p.n == 2 and p.t.shape == (96, 128) and torch.equal(p.scale, sc)
+    h1, h0 = p.t[:, :64].double(), p.t[:, 64:].double()
+    xs = t.double() * s_
+    assert torch.equal(h0.half(), (t * s_).half().to(h0.dtype).half())          # h0 = half(x s)
+    r = (xs - h0 - h1).abs()
+    bound = torch.maximum(xs.abs() * 2.0 ** -22, torch.full_like(xs, 2.0 ** -25))
+    assert bool((r <= bound).all())
+    b = x3.split(t, x3.SPLIT_B, kind="x2", scale=sc)
+    assert b.n == 3 and torch.equal(b.t[:, :64], p.t[:, :64]) and torch.equal(b.t[:, 64:128], p.t[:, 64:])
+    assert torch.equal(b.t[:, 128:], p.t[:, 64:])
+    st = x3.split(t, x3.SPLIT_B, kind="x2", scale=sc, stacked=True)
+    assert torch.equal(st.t[0], p.t[:, :64]) and torch.equal(st.t[2], p.t[:, 64:])
+    # complex pair: one scale from the larger plane; all-zero tensor: scale 1
+    y = torch.from_numpy((rs.randn(96, 64) * 37.0).astype(np.float32)).cuda()
+    pr, pi = x3.split_planes((t, y), kind="x2")
+    assert pr.scale is pi.scale and 2.0 ** 14 <= max(amax, float(y.abs().max())) * float(pr.scale[0]) < 2.0 ** 15
+    z = x3.scale_of(torch.zeros(8, 8, device="cuda"))
+    assert float(z[0]) == 1.0 and float(z[1]) == 1.0
+    a2 = x3.split(t, op=x3.OP_ABS2, t2=y, kind="x2")
+    full = (a2.t[:, :64].double() + a2.t[:, 64:].double()) * float(a2.scale[1])
+    ref = t.double() ** 2 + y.double() ** 2
+    assert float((full - ref).abs().max()) <= 2.0 ** -21 * float(ref.max())
+
+
+def test_x2_dynamic_range_is_normwise_accurate():
+    """Operands spanning 30 binades (gradient-like magnitudes 1e-9 .. 1e-3 against weights of 0.05): the half split with
+    per-operand scales stays at 2^-22 norm-wise -- and the bf16 split at 2^-24 -- against float64."""
+    from cplxmodule_amd import x3
+    rs = np.random.RandomState(5)
+    M, N_, K = 256, 128, 512
+    A = (rs.randn(M, K) * np.exp(rs.uniform(-21, -7, (M, K)))).astype(np.float32)
+    B = (rs.randn(N_, K) * 0.05).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    for kind, tol in (("x2", 1e-6), ("x3", 4e-7)):
+        got = x3.gemm_nn(x3.split_planes((At,), kind=kind), x3.split_planes((Bt,), x3.SPLIT_B, kind=kind), M, N_, K)
+        err = float(np.abs(got.double().cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+        assert err <= tol, (kind, err)
