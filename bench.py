@@ -273,14 +273,10 @@ def conv_point(dev, batch=256, dtype=torch.bfloat16):
         out = {"workload": f"CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, {name}, batch {batch}, fwd+bwd, channels-last",
                "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flop_per_launch": flop}
         if dtype != torch.bfloat16:
-            # the 1e-5 mode: three convolution launches' flop over the whole step, against the float32-MFMA peak and, when
-            # the split-operand products ran, against their bound (bf16 peak / 6)
-            from cplxmodule_amd import get_fp32_mode
-            out["fp32_mode"] = get_fp32_mode()
+            # the 1e-5 mode (float32-MFMA convolution kernels in every fp32 mode: the split products cover the linear
+            # layers only): three convolution launches' flop over the whole step
             out["tflops_whole_step"] = round(3 * flop / dt / 1e12, 1)
             out["frac_of_fp32_mfma_peak_whole_step"] = round(3 * flop / dt / 1e12 / FP32_PEAK_TFLOPS, 4)
-            if out["fp32_mode"] != "exact":
-                out["frac_of_x3_bound_whole_step"] = round(3 * flop / dt / 1e12 / X3_BOUND_TFLOPS, 4)
             return out
         for k in ("fwd", "dgrad", "wgrad"):
             ms = timer.mean_ms(k)
@@ -294,39 +290,44 @@ def conv_point(dev, batch=256, dtype=torch.bfloat16):
         return {"error": str(e)[:200]}
 
 
-X3_BOUND_TFLOPS = BF16_PEAK_TFLOPS / 6.0   # float32 products as six bf16 piece products: what the bf16 pipe allows
+SPLIT_BOUND_TFLOPS = {"x3": BF16_PEAK_TFLOPS / 6.0, "x2": BF16_PEAK_TFLOPS / 3.0}   # piece products per float32 product
+
+
+def _split_kind(mode):
+    from cplxmodule_amd import x3
+    return x3.AUTO_KIND if mode == "auto" else (mode if mode in ("x2", "x3") else None)
 
 
 def fp32_points(dev):
     """The float32 mode -- the one the 1e-5 parity bar is stated in -- at BASELINE's FULL sizes: configs[3] at batch 2^20
-    (about 180 GB of float32 planes and bf16 pieces: only on a GPU with that much free) and configs[2] at batch 256
-    channels-last.  Default arithmetic since round 6: split operands on the bf16 matrix pipe (cplxmodule_amd/x3.py: six
-    bf16 piece products per float32 product, bound 2500 / 6 = 417 TFLOP/s); `*_exact` = the float32-MFMA kernels (157.3
-    TFLOP/s peak) the mode replaced, same process, for the ratio.  Rank 0, N = 1, outside the timed region."""
-    out = {"x3_bound_tflops": round(X3_BOUND_TFLOPS, 1), "fp32_mfma_peak_tflops": FP32_PEAK_TFLOPS}
+    (about 180 GB of float32 planes and 16-bit pieces: only on a GPU with that much free) and configs[2] at batch 256
+    channels-last.  Linear layers since round 6: split operands on the 16-bit matrix pipe (cplxmodule_amd/x3.py) -- default
+    'x2' = two IEEE-half pieces per operand, three piece products per float32 product (bound 2500 / 3 = 833 TFLOP/s, 2^-22
+    norm-wise), `*_x3` = three bf16 pieces, six products (bound 417 TFLOP/s, 2^-24); `*_exact` = the float32-MFMA kernels
+    (157.3 TFLOP/s peak) they replaced, same process, for the ratio.  The convolutions still run the float32-MFMA kernels
+    in every mode.  Rank 0, N = 1, outside the timed region."""
+    out = {"split_bound_tflops": {k: round(v, 1) for k, v in SPLIT_BOUND_TFLOPS.items()}, "fp32_mfma_peak_tflops": FP32_PEAK_TFLOPS}
     try:
         from cplxmodule_amd import fp32_mode
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info(dev)
-        for tag, mode in (("cfg4_lrt_fp32", "auto"), ("cfg4_lrt_fp32_exact", "exact")):
+        for tag, mode in (("cfg4_lrt_fp32", "auto"), ("cfg4_lrt_fp32_x3", "x3"), ("cfg4_lrt_fp32_exact", "exact")):
             if free >= 220 << 30:
                 with fp32_mode(mode):
                     out[tag] = cfg4_point(dev, dtype=torch.float32, steps=2)
             else:
                 out[tag] = {"skipped": f"{free >> 30} GiB free, the float32 step at batch 2^20 wants ~180"}
             torch.cuda.empty_cache()
-        for tag, mode in (("conv_cfg3_fp32", "auto"), ("conv_cfg3_fp32_exact", "exact")):
-            free, _ = torch.cuda.mem_get_info(dev)
-            if free >= 140 << 30:
-                with fp32_mode(mode):
-                    out[tag] = conv_point(dev, dtype=torch.float32)
-            else:
-                out[tag] = {"skipped": f"{free >> 30} GiB free"}
-            torch.cuda.empty_cache()
-        for a in ("cfg4_lrt_fp32", "conv_cfg3_fp32"):
-            p, e = out.get(a, {}), out.get(a + "_exact", {})
-            if "ms_per_step" in p and "ms_per_step" in e:
-                p["speedup_over_fp32_mfma_kernels"] = round(e["ms_per_step"] / p["ms_per_step"], 3)
+        free, _ = torch.cuda.mem_get_info(dev)
+        if free >= 140 << 30:
+            out["conv_cfg3_fp32"] = conv_point(dev, dtype=torch.float32)
+        else:
+            out["conv_cfg3_fp32"] = {"skipped": f"{free >> 30} GiB free"}
+        torch.cuda.empty_cache()
+        p, e = out.get("cfg4_lrt_fp32", {}), out.get("cfg4_lrt_fp32_exact", {})
+        for q in (p, out.get("cfg4_lrt_fp32_x3", {})):
+            if "ms_per_step" in q and "ms_per_step" in e:
+                q["speedup_over_fp32_mfma_kernels"] = round(e["ms_per_step"] / q["ms_per_step"], 3)
     except Exception as e:  # pragma: no cover
         out["error"] = str(e)[:200]
     return out
@@ -513,8 +514,10 @@ def cfg4_point(dev, log2_batch=20, timer=None, dtype=torch.bfloat16, batch=None,
         if not bf:
             from cplxmodule_amd import get_fp32_mode
             out["fp32_mode"] = get_fp32_mode()
-            if out["fp32_mode"] != "exact":      # (a fraction of the float32-MFMA peak above 1 is possible and means nothing)
-                out["frac_of_x3_bound_whole_step"] = round(flop / dt / 1e12 / X3_BOUND_TFLOPS, 4)
+            kind = _split_kind(out["fp32_mode"])
+            if kind:                             # (a fraction of the float32-MFMA peak above 1 is possible and means nothing)
+                out["split_arithmetic"] = kind
+                out["frac_of_split_bound_whole_step"] = round(flop / dt / 1e12 / SPLIT_BOUND_TFLOPS[kind], 4)
         if timer is not None:
             keep, timer.spans, timer.enabled = timer.spans, {}, True
             step()

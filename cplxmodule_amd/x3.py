@@ -38,7 +38,7 @@ _default_mode = os.environ.get("CPLXAMD_FP32", "auto")
 if _default_mode not in _MODES:
     raise ValueError(f"CPLXAMD_FP32 must be one of {_MODES}, got {_default_mode!r}")
 AUTO_MIN_WORK = 1 << 30
-AUTO_KIND = os.environ.get("CPLXAMD_FP32_AUTO", "x3")        # what 'auto' runs above the threshold
+AUTO_KIND = os.environ.get("CPLXAMD_FP32_AUTO", "x2")        # what 'auto' runs above the threshold (x3: 2^-24 at twice the time)
 if AUTO_KIND not in ("x2", "x3"):
     raise ValueError("CPLXAMD_FP32_AUTO must be 'x2' or 'x3'")
 
