@@ -172,7 +172,7 @@ def gemm_traffic():
     bench's three launches at the bench shape, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE;
     scripts/r05/profile_bench.sh): (mean over the three launches, {launch: bytes}).  PMC counters cannot be read from
     inside this process, so this is the committed measurement of the same kernels and shapes, not of this run."""
-    for name in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):
+    for name in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 d = json.load(fh)
