@@ -744,7 +744,7 @@ def _circular_pad(t, padding):
 
 
 def cplx_conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
-                padding_mode="zeros"):
+                padding_mode="zeros", training=True):
     xr, xi = input.real, input.imag
     if padding_mode == "circular":
         xr, xi, padding = _circular_pad(xr, padding), _circular_pad(xi, padding), 0
@@ -761,7 +761,9 @@ def cplx_conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, group
         return Cplx(yr.permute(0, 3, 1, 2), yi.permute(0, 3, 1, 2))
     wkey = weight.real
     yr, yi = CplxConv2dFn.apply(xr, xi, wkey, weight.imag, br, bi, stride, padding,
-                                dilation, groups, _MOMENTS and moments_wanted(wkey, spend=True))
+                                dilation, groups, _MOMENTS and training and moments_wanted(wkey, spend=True))
+    # (training=False -- an evaluation-mode CplxConv2d: no batch-norm layer will read batch statistics, so an armed
+    #  request, permanent ones included, neither runs the +10 % epilogue nor spends a credit: ADVICE r05)
     if _MOMENTS and yr.dtype == torch.bfloat16:
         yr._cplxamd_conv_src = weakref.ref(wkey)       # (a batch-norm layer that consumes yr arms the moments epilogue)
     return Cplx(yr, yi)

@@ -15,7 +15,7 @@
 namespace cplxamd {
 
 extern std::atomic<int> g_default_persistent;   // gemm.hip; 1 at start
-extern std::atomic<int> g_default_family;       // gemm.hip; 0x3f at start (env CPLXAMD_GEMM_W4)
+extern std::atomic<int> g_default_family;       // gemm.hip; 0xbf at start (env CPLXAMD_GEMM_W4)
 
 // may this launch assume the whole chip for its whole duration (persistent forms: one workgroup per CU walking a static
 // tile list)?  CPLXAMD_LAUNCH_SHARED: no -- other kernels (an RCCL all-reduce) hold CUs; one workgroup per tile.

@@ -39,8 +39,11 @@ class CplxConv2d(CplxToCplx):
             init.cplx_uniform_independent_(self.bias, -bound, bound)
 
     def forward(self, input):
-        return cplx.conv2d(input, self.weight, self.bias, self.stride, self.padding,
-                           self.dilation, self.groups, self.padding_mode)
+        from ... import conv
+        # (cplx.conv2d with the layer's training state: an evaluation-mode layer never runs the conv -> batch-norm
+        #  moments epilogue, armed or not)
+        return conv.cplx_conv2d(input, self.weight, self.bias, self.stride, self.padding,
+                                self.dilation, self.groups, self.padding_mode, training=self.training)
 
     def extra_repr(self):
         s = (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "

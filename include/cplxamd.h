@@ -58,8 +58,11 @@ enum {
 
 /* Per-call launch policy (ABI 19): the `flags` argument of the `*_fl` entry points.  The library keeps NO mutable state
  * that a launch depends on (SURVEY 8(b) "Threading": re-entrant, no globals except read-only tuning tables): two threads /
- * streams / models in one process choose their launch forms independently, call by call.  Results do not depend on the
- * flags (every form of a launch produces the same bits; tests/test_gpu_r04.py, test_gpu_gemm_persist.py, test_gpu_r05.py).
+ * streams / models in one process choose their launch forms independently, call by call.  GEMM results do not depend on
+ * the flags (every form of a GEMM launch produces the same bits; tests/test_gpu_r04.py, test_gpu_gemm_persist.py,
+ * test_gpu_r05.py), nor do the convolutions' forward / data-gradient results; the convolution WEIGHT gradients and the
+ * conv -> batch-norm moments are sums of per-workgroup float32 partials whose number follows the flags (SHARED: twice as
+ * many splits), so they agree across flags to float32 summation order, not bit for bit.
  *   CPLXAMD_LAUNCH_SHARED     other kernels hold compute units while this launch runs (an RCCL all-reduce overlapping the
  *                             backward pass): one workgroup per tile instead of the persistent forms, twice as many weight-
  *                             gradient splits -- a launch that expects every CU would wait for the held ones with its last
@@ -67,7 +70,7 @@ enum {
  *   CPLXAMD_LAUNCH_EXCLUSIVE  the chip is this launch's: persistent forms wherever they exist.
  *   neither                   the process default (cplxamd_gemm_set_persistent, deprecated; 1 = exclusive at start).
  *   CPLXAMD_LAUNCH_FAMILY(m)  bf16 GEMM kernel family mask of THIS launch (bit layout of cplxamd_gemm_set_family);
- *                             without it the process default applies (0x3f, env CPLXAMD_GEMM_W4).
+ *                             without it the process default applies (0xbf, env CPLXAMD_GEMM_W4).
  * Both SHARED and EXCLUSIVE, or unknown bits: CPLXAMD_EINVAL.  The flag-less entry points are the `*_fl` ones with
  * flags = 0. */
 enum {

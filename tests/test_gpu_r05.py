@@ -219,8 +219,10 @@ def test_moments_request_expires_when_the_consumer_stops_being_a_batchnorm_and_c
     for k, v in fresh[1].state_dict().items():
         assert torch.equal(v, state[k]), k
     fresh.eval()
+    del seen[:]
     fresh(x)
     assert conv.moments_wanted(fresh[0].weight.real), "a permanent request survives evaluation passes"
+    assert seen == [False], "an evaluation-mode convolution does not run the moments epilogue, armed or not (ADVICE r05)"
     h.remove()
     conv.arm_conv_bn(fresh, on=False)
     assert not conv._MOMENTS_WANTED
@@ -359,7 +361,7 @@ def test_cfg4_float32_forward_at_full_batch_matches_float64_rows():
 
 
 # ---- the ring through the tile boundaries (gemm_bf16_w4.hip: PERSIST, kernel-family bit 7) ----------------
-@pytest.mark.parametrize("K", [384, 448, 512, 4096])      # K tile counts 12, 14, 16: every exit path of the six-tile loop; 128
+@pytest.mark.parametrize("K", [384, 448, 512, 4096])      # K tile counts 12, 14, 16: every exit path of the six-tile loop
 def test_w4_persistent_form_is_bit_identical(K):
     """One workgroup per CU walking its tiles with the K-tile ring continuing into the next output tile (the look-ahead
     loads fetch the next tile's K tiles 0 .. 3; the LDS base registers swap roles at the boundary; the epilogue stages in
@@ -368,7 +370,7 @@ def test_w4_persistent_form_is_bit_identical(K):
     import os
     from cplxmodule_amd import _lib, ops
     L = _lib.load()
-    W4P_CPLX = os.environ.get("CPLXAMD_W4P_CPLX", "0") not in ("", "0")      # (the complex form: A/B only, see the launcher)
+    W4P_CPLX = False                          # (the complex persistent form left the library in round 6)
     B, Nn = 8192, 4096                        # 32 x 32 complex tiles (32 x 16 real): four (two) per workgroup
     E = _lib.LAUNCH_EXCLUSIVE
     assert L.cplxamd_gemm_plan(0, B, Nn, K, 0, 0, _lib.BF16, 0, _lib.LAUNCH_FAMILY(0xff) | E, 0) == 6
@@ -457,3 +459,34 @@ def test_cfg3_float32_conv_at_full_batch_matches_float64():
     assert abs(float(b.real.grad[5]) - ref_b) <= 3e-5 * float(b.real.grad.abs().max())
     del xr, xi, gr, gi
     torch.cuda.empty_cache()
+
+
+# ---- the persistent real kernels where workgroups run OUT of tiles at different times, and at the shortest K ------
+@pytest.mark.parametrize("M,K", [(8192 + 256, 128), (8192 + 256, 192), (8192 + 256, 320), (8192 + 512, 4096), (8192 + 256, 2048)])
+def test_w4_persistent_real_remainder_tiles_and_short_k(M, K):
+    """tiles % CUs != 0 (some workgroups see `has_next == false` one tile earlier than others) and K of 4 / 6 / 10 K tiles
+    (the look-ahead covers the next tile's whole K range at 128): family bit 7 (+ bit 6: regardless of K) against the
+    one-tile family and the 8-wave kernels, bit for bit."""
+    from cplxmodule_amd import _lib, ops
+    L = _lib.load()
+    Nn = 4096
+    E = _lib.LAUNCH_EXCLUSIVE
+    tiles = (M // 256) * (Nn // 256)
+    assert tiles % 256 != 0
+    assert L.cplxamd_gemm_plan(0, M, Nn, K, 0, 0, _lib.BF16, 0, _lib.LAUNCH_FAMILY(0xff) | E, 256) == 6
+    bf = torch.bfloat16
+    a2, S = _bf(M, K, seed=7).abs(), _bf(Nn, K, seed=8).abs()
+    v = _bf(K, Nn, seed=5, scale=0.05)
+
+    def run():
+        return [ops.rgemm(a2, (K, 1), S, (K, 1), M, Nn, K, out_dtype=bf).clone(),
+                ops.rgemm(a2, (K, 1), v, (1, Nn), M, Nn, K, out_dtype=bf).clone()]
+
+    with _lib.launch_policy(_lib.LAUNCH_FAMILY(0) | E):
+        ref = run()
+    with _lib.launch_policy(_lib.LAUNCH_FAMILY(0xff) | E):
+        got = run()
+    with _lib.launch_policy(_lib.LAUNCH_FAMILY(0x7f) | E):
+        one = run()
+    for r, g_, o in zip(ref, got, one):
+        assert torch.equal(r, g_) and torch.equal(r, o)
