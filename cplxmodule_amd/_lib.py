@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 F32, BF16, F16 = 0, 1, 2
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -145,6 +145,11 @@ SIGNATURES = {
     "cplxamd_conv2d_cl2_mom_chunks_fl": [_L] + [_I] * 11,
     "cplxamd_conv2d_cl2_mom_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P, _L, _I, _P],
     "cplxamd_conv2d_cl_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
+    # ABI 22: the channels-last convolutions on IEEE-half pieces (float32 out)
+    "cplxamd_conv2d_cl2h_fl": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L] + [_I] * 7 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_clh_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
+    "cplxamd_conv2d_clh_wgrad": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
+    "cplxamd_conv2d_clh_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
     "cplxamd_conv2d_clr_fl": [_P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _I, _P],
     "cplxamd_conv2d_clr_wgrad_fl": [_P, _P, _P, _I, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
     "cplxamd_bn_moments": [_P, _P, _P, _P, _P, _L, _I, _L, _I, _P, _P, _L, _P],
@@ -158,7 +163,8 @@ _RESTYPES = {"cplxamd_absmax_ws_bytes": c_int64, "cplxamd_conv2d_cl2_mom_chunks"
              "cplxamd_conv2d_nhwc_wgrad_ws_bytes": c_int64,
              "cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes": c_int64,
              "cplxamd_conv2d_cl_pack_bytes": c_int64, "cplxamd_conv2d_cl_ws_bytes": c_int64,
-             "cplxamd_conv2d_cl_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_clr_pack_bytes": c_int64,
+             "cplxamd_conv2d_cl_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_clh_wgrad_ws_bytes": c_int64,
+             "cplxamd_conv2d_clr_pack_bytes": c_int64,
              "cplxamd_conv2d_clr_ws_bytes": c_int64, "cplxamd_conv2d_clr_wgrad_ws_bytes": c_int64}
 
 _lib = None

@@ -623,6 +623,116 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
     return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None, None
 
 
+# ---- float32 layers on IEEE-half pieces (x3.py 'x2'; csrc/conv_cl2_f16.hip, conv_cl_wgrad_f16.hip) ---------------------- #
+# A float32 3 x 3 convolution (stride 1, groups 1, dilation 1, padding <= same, channel counts multiples of 64) runs as
+# three piece products on the half matrix pipe: the channels-last planes, read as [B H W][C] matrices, are cut into
+# [h1|h0] rows (x3.split_planes: one power-of-two scale per operand), forward and data gradient are two launches of the
+# 2-d-patch kernel -- h0 * w1 on the h0 window of the rows, then [h1|h0] * [w0|w0] accumulated into the float32 output --
+# and the weight gradient one launch on ([g1|g0], [x1|x0]) whose four piece blocks give (g0 x1) + (g1 x0) + (g0 x0).
+_X2_CONV_MIN_FLOP = float(1 << 33)
+_X2_BYTES_MAX = 0xF0000000
+
+
+def _x2_conv_kind(geom, *tensors):
+    from . import x3
+    mode = x3.get_fp32_mode()
+    if mode not in ("auto", "x2") or (mode == "auto" and x3.AUTO_KIND != "x2"):
+        return None
+    if any(t is None or t.dtype != torch.float32 or not t.is_cuda for t in tensors):
+        return None
+    B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups = (geom[i] for i in range(14))
+    if not _CL_ENABLED or sh != 1 or sw != 1 or groups != 1 or KH != 3 or KW != 3 or dh != 1 or dw != 1 or ph > 1 or pw > 1:
+        return None
+    if Ci % 64 or Co % 64 or B <= 0 or H + 2 * ph - 2 <= 0 or W + 2 * pw - 2 <= 0:
+        return None
+    if H * W * 2 * max(Ci, Co) * 2 >= _X2_BYTES_MAX:          # one image of pieces must fit a buffer descriptor
+        return None
+    if mode == "auto" and 8.0 * B * H * W * Ci * Co * 9 < _X2_CONV_MIN_FLOP:
+        return None
+    return "x2"
+
+
+def _rows(t):
+    """channels-last [B, C, H, W] -> its storage as a [B H W, C] matrix (a view)."""
+    B, C, H, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def _x2_weight_packs(wr, wi, dgrad):
+    """Packed LDS images of the two launches' weights, and the weights' scale: (pack of w1 -- C channels --, pack of
+    [w0|w0] -- 2 C channels --, scale)."""
+    from . import x3
+    Co, Ci, KH, KW = wr.shape
+    pr, pi = x3.split_planes((wr.reshape(Co, -1), wi.reshape(Co, -1)), kind="x2")          # [Co, 2 Ci 9] = [h1|h0]
+    n = Ci * KH * KW
+    cut = lambda p: (p.t[:, :n].reshape(Co, Ci, KH, KW), p.t[:, n:].reshape(Co, Ci, KH, KW))  # noqa: E731  (w1, w0)
+    (w1r, w0r), (w1i, w0i) = cut(pr), cut(pi)
+    cat = 0 if dgrad else 1                            # the contraction channels: Co for the data gradient, Ci forward
+    small = _cl_pack(w1r.contiguous(), w1i.contiguous(), dgrad)
+    big = _cl_pack(torch.cat([w0r, w0r], cat).contiguous(), torch.cat([w0i, w0i], cat).contiguous(), dgrad)
+    return small, big, pr.scale
+
+
+def _x2_conv(pieces, wr, wi, br, bi, geom, dgrad):
+    """Forward (or data gradient) from the [h1|h0] pieces of the input planes ([B H W, 2 C] half matrices)."""
+    B, Ci, Co, H, W, KH, KW = (geom[i] for i in range(7))
+    C, N = (Co, Ci) if dgrad else (Ci, Co)
+    ph, pw = geom[9], geom[10]
+    Ho, Wo = H + 2 * ph - 2, W + 2 * pw - 2
+    Hin, Win = (Ho, Wo) if dgrad else (H, W)
+    oshape = (B, N, H, W) if dgrad else (B, N, Ho, Wo)
+    pr, pi = pieces
+    dev = pr.t.device
+    yr = torch.empty(oshape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    yi = torch.empty_like(yr)
+    small, big, wscale = _x2_weight_packs(wr, wi, dgrad)
+    ws = _scratch(dev, int(_lib.load().cplxamd_conv2d_cl_ws_bytes(N)))
+    flags = launch_flags()
+    per = Hin * Win * 2 * C * 2                                   # bytes of one image of pieces
+    step = max(1, min(B, (_X2_BYTES_MAX - 1) // per))
+    step = -(-B // (-(-B // step)))                      # equal chunks
+    opix = oshape[2] * oshape[3] * N
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        xr_ = pr.t[b0 * Hin * Win:]
+        xi_ = pi.t[b0 * Hin * Win:]
+        o_r = yr.permute(0, 2, 3, 1).reshape(-1)[b0 * opix:]
+        o_i = yi.permute(0, 2, 3, 1).reshape(-1)[b0 * opix:]
+        # launch 1: h0 (the second half of every row) * w1 (+ bias); launch 2: [h1|h0] * [w0|w0], accumulated
+        h0r, h0i = xr_.reshape(-1)[C:], xi_.reshape(-1)[C:]
+        call("cplxamd_conv2d_cl2h_fl", ptr(h0r), ptr(h0i), 2 * C, ptr(small), ptr(br), ptr(bi), ptr(o_r), ptr(o_i), 0,
+             ptr(pr.scale), ptr(wscale), nb, H, W, C, N, ph, pw, int(dgrad), ptr(ws), ws.numel(), flags, stream_ptr())
+        call("cplxamd_conv2d_cl2h_fl", ptr(xr_), ptr(xi_), 2 * C, ptr(big), None, None, ptr(o_r), ptr(o_i), 1,
+             ptr(pr.scale), ptr(wscale), nb, H, W, 2 * C, N, ph, pw, int(dgrad), ptr(ws), ws.numel(), flags, stream_ptr())
+    return yr, yi
+
+
+def _x2_conv_wgrad(gp, xp, geom, w_shape):
+    """dW from the pieces of the output gradient and of the input: one launch per batch chunk on (2 Co, 2 Ci) channels."""
+    B, Ci, Co, H, W, KH, KW = (geom[i] for i in range(7))
+    ph, pw = geom[9], geom[10]
+    Ho, Wo = H + 2 * ph - 2, W + 2 * pw - 2
+    dev = gp[0].t.device
+    lim = (1 << 32) - 64
+    step = max(1, min(B, (lim // (2 * max(Ci, Co) * 2) - ph * W - 64) // (H * W)))
+    step = -(-B // (-(-B // step)))                      # equal chunks
+    flags = launch_flags()
+    tot_r = tot_i = None
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        ws = _scratch(dev, int(_lib.load().cplxamd_conv2d_clh_wgrad_ws_bytes(nb, H, W, 2 * Ci, 2 * Co)))
+        dwr = torch.empty(2 * Co, 2 * Ci, KH, KW, dtype=torch.float32, device=dev)
+        dwi = torch.empty_like(dwr)
+        g_r, g_i = gp[0].t[b0 * Ho * Wo:], gp[1].t[b0 * Ho * Wo:]
+        x_r, x_i = xp[0].t[b0 * H * W:], xp[1].t[b0 * H * W:]
+        call("cplxamd_conv2d_clh_wgrad_fl", ptr(g_r), ptr(g_i), ptr(x_r), ptr(x_i), None, ptr(dwr), ptr(dwi), nb, H, W, 2 * Ci,
+             2 * Co, KH, KW, 1, 1, ph, pw, ptr(ws), ws.numel(), flags, stream_ptr())
+        tot_r, tot_i = (dwr, dwi) if tot_r is None else (tot_r + dwr, tot_i + dwi)
+    alpha = gp[0].scale[1] * xp[0].scale[1]
+    pick = lambda t: ((t[Co:, :Ci] + t[:Co, Ci:]) + t[Co:, Ci:]) * alpha  # noqa: E731  (g0 x1) + (g1 x0) + (g0 x0)
+    return pick(tot_r).reshape(w_shape).contiguous(), pick(tot_i).reshape(w_shape).contiguous()
+
+
 class CplxConv2dFn(torch.autograd.Function):
     """Zero-padded complex conv (A.1 algebra with cross-correlation)."""
 
@@ -631,6 +741,18 @@ class CplxConv2dFn(torch.autograd.Function):
         require_device(xr, xi, wr, wi, br, bi)
         geom, oshape = _geom(xr.shape, wr.shape, stride, padding, dilation, groups)
         b = (None, None) if br is None else (br.contiguous(), bi.contiguous())
+        ctx.x2 = _x2_conv_kind(geom, xr, xi, wr, wi) is not None
+        if ctx.x2:                       # float32 on IEEE-half pieces, channels-last in and out (see _x2_conv)
+            from . import x3
+            ctx.cl = False
+            ctx.x_planar = xr.is_contiguous() and not xr.is_contiguous(memory_format=torch.channels_last)
+            xr, xi = (t.contiguous(memory_format=torch.channels_last) for t in (xr, xi))
+            xp = x3.split_planes((_rows(xr), _rows(xi)), kind="x2")
+            wr_, wi_ = wr.contiguous(), wi.contiguous()
+            yr, yi = _x2_conv(xp, wr_, wi_, b[0], b[1], geom, dgrad=False)
+            ctx.save_for_backward(xp[0].t, xp[1].t, xp[0].scale, wr_, wi_)   # (the pieces: the float32 input is not needed again)
+            ctx.geom, ctx.has_bias, ctx.wshape, ctx.xshape = geom, br is not None, wr.shape, xr.shape
+            return yr, yi
         # (a layer whose weight gradient cannot run channels-last -- image width not a multiple of 32 -- stays on the
         #  planar path as a whole: converting both operands back for it costs more than the forward saves)
         ctx.cl = xr.dtype == torch.bfloat16 and xi.dtype == torch.bfloat16 and _cl_ok(geom) and (
@@ -655,9 +777,24 @@ class CplxConv2dFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gr, gi):
-        xr, xi, wcr, wci = ctx.saved_tensors
         need = ctx.needs_input_grad
         dxr = dxi = dwr = dwi = dbr = dbi = None
+        if ctx.x2:
+            from . import x3
+            xtr, xti, xsc, wr_, wi_ = ctx.saved_tensors
+            gr, gi = (t.contiguous(memory_format=torch.channels_last) for t in (gr, gi))
+            gp = x3.split_planes((_rows(gr), _rows(gi)), kind="x2")
+            if need[0] or need[1]:
+                dxr, dxi = _x2_conv(gp, wr_, wi_, None, None, ctx.geom, dgrad=True)
+                if ctx.x_planar:
+                    dxr, dxi = dxr.contiguous(), dxi.contiguous()
+            if need[2] or need[3]:
+                xp = (x3.Pieces(xtr, "x2", xsc, 2), x3.Pieces(xti, "x2", xsc, 2))
+                dwr, dwi = _x2_conv_wgrad(gp, xp, ctx.geom, ctx.wshape)
+            if ctx.has_bias and (need[4] or need[5]):
+                dbr, dbi = ops.colsum(_rows(gr)), ops.colsum(_rows(gi))
+            return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None, None
+        xr, xi, wcr, wci = ctx.saved_tensors
         if ctx.cl:
             return _cl_backward(ctx, gr, gi, xr, xi, wcr, wci)
         gr, gi = gr.contiguous(), gi.contiguous()

@@ -11,6 +11,19 @@
     if (e__ != hipSuccess) return (int)e__;             \
   } while (0)
 
+// The 16-bit matrix instruction of a translation unit.  The MFMA GEMM and channels-last convolution sources are compiled
+// twice: as they are (bf16 operands) and, from gemm_f16*.hip / conv_cl*_f16.hip with CPLXAMD_GEMM_F16 / CPLXAMD_CONV_F16
+// defined, for IEEE-half operands -- same staging, same LDS images (a 16-bit pattern is a 16-bit pattern; the conjugate's
+// sign flip is bit 15 in both), only the matrix instruction differs.  The half variants write float32 (the fp16 split
+// products of cplxmodule_amd/x3.py).
+#if defined(CPLXAMD_GEMM_F16) || defined(CPLXAMD_CONV_F16)
+typedef _Float16 cplxamd_f16x8 __attribute__((ext_vector_type(8)));
+#define CPLXAMD_MFMA16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cplxamd_f16x8, a), __builtin_bit_cast(cplxamd_f16x8, b), c, 0, 0, 0)
+#else
+#define CPLXAMD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
 namespace cplxamd {
 
 constexpr int kWave = 64;

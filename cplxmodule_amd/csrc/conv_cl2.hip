@@ -58,6 +58,11 @@ struct Args {
   uint32_t x_bytes, w_bytes;
   int B, Hi, Wi, Ho, Wo, C, Cout, pad_h, pad_w;
   int C16, NS, tiles_x, tiles_y, tiles_n;
+#ifdef CPLXAMD_CONV_F16     // the half-operand build (conv_cl2_f16.hip): float32 output, see epilogue_f32
+  int pitch;                                  // channels between two pixels of x (>= C: a channel window of wider planes)
+  int accumulate;                             // y += result
+  const float* scale_a; const float* scale_b; // device {s, 1 / s} of the two operands (nullptr: no scaling)
+#endif
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -126,7 +131,11 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
 
   const i32x4 rs_xr = make_rsrc(g.x_r, g.x_bytes), rs_xi = make_rsrc(g.x_i, g.x_bytes);
   const i32x4 rs_w = make_rsrc(g.w, g.w_bytes);
+#ifdef CPLXAMD_CONV_F16
+  const uint32_t rowbytes = (uint32_t)g.pitch * 2u;
+#else
   const uint32_t rowbytes = (uint32_t)g.C * 2u;
+#endif
 
   // ---- LDS-DMA lane constants.  Patch: chunk id = q * 512 + tid of the slot image [plane][1280 chunks]; chunk pc of a
   // plane sits at patch pixel pc >> 1 = (row pr, column px), position pc & 1, and holds channel half (pc & 1) ^ ((px >> 3)
@@ -231,11 +240,11 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
         for (int j = 0; j < 2; ++j) {
           if (ph == 1 && j == 0) nai[i] = neg_frag(ai[st][i]);
           if (ph == 0) {
-            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ar[st][i], acc_r[i][j], 0, 0, 0);
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ai[st][i], acc_i[i][j], 0, 0, 0);
+            acc_r[i][j] = CPLXAMD_MFMA16(br[st][j], ar[st][i], acc_r[i][j]);
+            acc_i[i][j] = CPLXAMD_MFMA16(br[st][j], ai[st][i], acc_i[i][j]);
           } else {
-            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[st][j], nai[i], acc_r[i][j], 0, 0, 0);
-            acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[st][j], ar[st][i], acc_i[i][j], 0, 0, 0);
+            acc_r[i][j] = CPLXAMD_MFMA16(bi[st][j], nai[i], acc_r[i][j]);
+            acc_i[i][j] = CPLXAMD_MFMA16(bi[st][j], ar[st][i], acc_i[i][j]);
           }
           const int g8 = ph * 4 + i * 2 + j;
           __builtin_amdgcn_sched_barrier(0);
@@ -251,10 +260,10 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (j == 0) nai[i] = neg_frag(ai[st][i]);
-        acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ar[st][i], acc_r[i][j], 0, 0, 0);
-        acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[st][j], ai[st][i], acc_i[i][j], 0, 0, 0);
-        acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[st][j], nai[i], acc_r[i][j], 0, 0, 0);
-        acc_i[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bi[st][j], ar[st][i], acc_i[i][j], 0, 0, 0);
+        acc_r[i][j] = CPLXAMD_MFMA16(br[st][j], ar[st][i], acc_r[i][j]);
+        acc_i[i][j] = CPLXAMD_MFMA16(br[st][j], ai[st][i], acc_i[i][j]);
+        acc_r[i][j] = CPLXAMD_MFMA16(bi[st][j], nai[i], acc_r[i][j]);
+        acc_i[i][j] = CPLXAMD_MFMA16(bi[st][j], ar[st][i], acc_i[i][j]);
         const int grp = i * 2 + j;
         __builtin_amdgcn_sched_barrier(0);
         if (do_read) {
@@ -446,6 +455,46 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     }
   };
 
+#ifdef CPLXAMD_CONV_F16
+  // ---- float32 epilogue of the half-operand build: straight from the MFMA C layout -- lane (pixel q31 of the tile row,
+  // column group qk) holds, per (tile row i, 32-channel block j, group q), four consecutive channels: one 16-byte store
+  // each (a store instruction covers 32 pixels x 32 bytes; the four q groups of a block complete the 128-byte lines in L2),
+  // times 1 / (sa sb), plus the previous value when accumulating; pixels beyond the image edge are skipped.
+  auto epilogue_f32 = [&]() __attribute__((always_inline)) {
+    const int t = opaque_tid();
+    const int ln = t & 63, w_ = t >> 6, q31 = ln & 31, qk = ln >> 5;
+    const float alpha = g.scale_a ? g.scale_a[1] * g.scale_b[1] : 1.0f;
+    const int64_t ldc = g.Cout;
+    const int x = tc.x0 + q31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = tc.y0 + 2 * w_ + i;
+      if (y < g.Ho && x < g.Wo) {
+        const int64_t base = (((int64_t)tc.b * g.Ho + y) * g.Wo + x) * ldc + tc.nt * BN + 4 * qk;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          float* out = reinterpret_cast<float*>(pl ? g.y_i : g.y_r) + base;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v.v[e] = (pl ? acc_i[i][j][4 * q + e] : acc_r[i][j][4 * q + e]) * alpha;
+              float* dst = out + j * 32 + 8 * q;
+              if (g.accumulate) {
+                const f4 o = ld4(dst);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v.v[e] += o.v[e];
+              }
+              st4(dst, v);
+            }
+        }
+      }
+    }
+  };
+#endif
+
   // ---- MOM epilogue: the same stores, both planes of a round staged at once (the second one in this wave's MOM_X rows),
   // and a second, column-wise read of the staged bf16 rows: lane = (channel pair cp = lane & 31, row group rg = lane >> 5),
   // 8 rows x 2 planes x 4 bytes -- the two row groups take rows of opposite parity in every read, i.e. opposite halves of
@@ -568,6 +617,13 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
         for (int q = 0; q < 4; ++q) {
           f4 b = {{0.f, 0.f, 0.f, 0.f}};
           if (g.bias_r) b = ld4(reinterpret_cast<const float*>(breg + pl * 256 + (j * 32 + 8 * q + 4 * qk) * 4));
+#ifdef CPLXAMD_CONV_F16     // (the accumulators are multiplied by 1 / (sa sb) in the epilogue: the bias starts as bias sa sb)
+          if (g.bias_r && g.scale_a) {
+            const float inv = g.scale_a[0] * g.scale_b[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b.v[e] *= inv;
+          }
+#endif
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -612,9 +668,15 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     body(I1{}, I1{}, I0{}, I0{});
     body(I2{}, I1{}, I1{}, I2{});                          // LAST     (slice C / 16 - 1: patch slot 1)
     bias_dma(has_next ? tn.nt : tc.nt);                    // (older than the stores below)
+#ifdef CPLXAMD_CONV_F16
+    epilogue_f32();
+    if (!has_next) break;
+    wait_vmcnt<0>();                                       // (a lane-dependent number of stores: no counted wait)
+#else
     if constexpr (MOM) epilogue_mom(); else epilogue();
     if (!has_next) break;
     wait_vmcnt<NST>();                                     // everything issued BEFORE the stores has landed
+#endif
     v += nwg;
     tc = tn;
     has_next = v + nwg < ntiles;
@@ -671,6 +733,45 @@ static bool cl2_mom_tiling_ok(int64_t ntiles, int grid, int tiles_n) {
   return (grid % 8) == 0 && ((grid / 8) % tiles_n) == 0;
 }
 
+#ifdef CPLXAMD_CONV_F16
+// The half-operand build: cplxamd_conv2d_cl2 on IEEE-half planes with float32 output (include/cplxamd.h).
+int cplxamd_conv2d_cl2h_fl(const void* x_r, const void* x_i, int pitch, const void* w_packed, const float* bias_r,
+                           const float* bias_i, float* y_r, float* y_i, int accumulate, const float* scale_a,
+                           const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h, int pad_w, int mode, void* ws,
+                           int64_t ws_bytes, int flags, void* stream) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
+  if (!x_r || !x_i || !w_packed || !y_r || !y_i || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || pad_h < 0 || pad_w < 0 ||
+      (bias_r == nullptr) != (bias_i == nullptr) || (mode != 0 && mode != 1) || (scale_a == nullptr) != (scale_b == nullptr))
+    return CPLXAMD_EINVAL;
+  const int Hs = H + 2 * pad_h - 2, Ws = W + 2 * pad_w - 2;           // the smaller image
+  if (C % 32 || N % 64 || pitch < C || pitch % 8 || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W) return CPLXAMD_ESHAPE;
+  if (B == 0) return 0;
+  cl2::Args g{};
+  g.Hi = mode ? Hs : H; g.Wi = mode ? Ws : W; g.Ho = mode ? H : Hs; g.Wo = mode ? W : Ws;
+  if (B * g.Hi * g.Wi * pitch * 2 >= (int64_t)0xF0000000 || B >= 65536) return CPLXAMD_ESHAPE;
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!a16(x_r) || !a16(x_i) || !a16(w_packed) || !a16(y_r) || !a16(y_i) || !a16(ws) || (bias_r && (!a16(bias_r) || !a16(bias_i))))
+    return CPLXAMD_EALIGN;
+  if (!ws || ws_bytes < cplxamd_conv2d_cl_ws_bytes(N)) return CPLXAMD_EINVAL;
+  g.x_r = x_r; g.x_i = x_i; g.w = w_packed; g.bias_r = bias_r; g.bias_i = bias_i; g.y_r = y_r; g.y_i = y_i; g.dump = ws;
+  g.B = (int)B;
+  g.pad_h = mode ? 2 - pad_h : pad_h; g.pad_w = mode ? 2 - pad_w : pad_w;
+  g.x_bytes = (uint32_t)(B * g.Hi * g.Wi * pitch * 2 - (pitch - C) * 2);     // (the window ends C channels into the last pixel)
+  g.w_bytes = (uint32_t)cplxamd_conv2d_cl_pack_bytes(N, C, 3, 3);
+  g.C = C; g.Cout = N; g.C16 = C / 16; g.NS = 3 * g.C16;
+  g.pitch = pitch; g.accumulate = accumulate ? 1 : 0; g.scale_a = scale_a; g.scale_b = scale_b;
+  g.tiles_x = (g.Wo + cl2::TW - 1) / cl2::TW; g.tiles_y = (g.Ho + cl2::TH - 1) / cl2::TH; g.tiles_n = N / 64;
+  const int64_t ntiles = B * g.tiles_x * g.tiles_y * g.tiles_n;
+  if (ntiles > 0x7fffffff) return CPLXAMD_ESHAPE;
+  const int ncu = cl2_cus();
+  const int grid = (ntiles < ncu || !launch_owns_chip(flags)) ? (int)ntiles : ncu;
+  static PerDeviceOnce attr_set;
+  if (const int e = set_max_dyn_lds(attr_set, cl2::conv_cl2_kernel<false>, cl2::SMEM)) return e;
+  cl2::conv_cl2_kernel<false><<<dim3((unsigned)grid), cl2::NT, cl2::SMEM, (hipStream_t)stream>>>(g);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+#else
 static int launch_cl2(const void* x_r, const void* x_i, const void* w_packed, const float* bias_r, const float* bias_i,
                       const void* fx_r, const void* fx_i, const void* fga, void* y_r, void* y_i, int64_t B, int H, int W, int C,
                       int N, int KH, int KW, int dil_h, int dil_w, int pad_h, int pad_w, int mode, void* ws, int64_t ws_bytes,
@@ -813,5 +914,7 @@ int cplxamd_conv2d_cl2_lrt_dx_fl(const void* g_r, const void* g_i, const void* w
   return launch_cl2(g_r, g_i, w_packed, nullptr, nullptr, x_r, x_i, ga, dx_r, dx_i, B, H, W, C, N, 3, 3, 1, 1, pad_h, pad_w, 1,
                     ws, ws_bytes, flags, stream);
 }
+
+#endif   // CPLXAMD_CONV_F16
 
 }  // extern "C"

@@ -218,10 +218,10 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   bf16x8 xr[2], xi[2], gr[2], gi[2], hr, hi;
   auto mfma_block = [&](int n, bf16x8 ar, bf16x8 ai, bf16x8 pr, bf16x8 pi, bf16x8 npr) __attribute__((always_inline)) {
     // G conj(X): re = gr xr + gi xi, im = gi xr - gr xi; X first: accumulator rows = co, 4 consecutive ci per group
-    acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, pr, acc_r[n], 0, 0, 0);
-    acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, pi, acc_i[n], 0, 0, 0);
-    acc_r[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, pi, acc_r[n], 0, 0, 0);
-    acc_i[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, npr, acc_i[n], 0, 0, 0);
+    acc_r[n] = CPLXAMD_MFMA16(ar, pr, acc_r[n]);
+    acc_i[n] = CPLXAMD_MFMA16(ar, pi, acc_i[n]);
+    acc_r[n] = CPLXAMD_MFMA16(ai, pi, acc_r[n]);
+    acc_i[n] = CPLXAMD_MFMA16(ai, npr, acc_i[n]);
   };
   auto stage = [&](uint32_t cur_off, uint32_t nxt_off, uint32_t next_cur_off) __attribute__((always_inline)) {
     const char* st = smem + cur_off;

@@ -48,17 +48,7 @@ __device__ __forceinline__ float gemm_beta(const GemmArgs& g) { return (g.accumu
 __device__ __forceinline__ float gemm_alpha(const GemmArgs& g) { return g.scale_a ? g.scale_a[1] * g.scale_b[1] : 1.0f; }
 __device__ __forceinline__ float gemm_alpha_inv(const GemmArgs& g) { return g.scale_a ? g.scale_a[0] * g.scale_b[0] : 1.0f; }
 
-// The 16-bit operand type of the MFMA kernels.  gemm_bf16_impl.h / gemm_bf16_persist.h / gemm_bf16_w4.hip are compiled twice:
-// as they are (bf16 operands) and, from gemm_f16*.hip with CPLXAMD_GEMM_F16 defined, for IEEE half operands -- same staging,
-// same LDS images, same epilogues (a 16-bit pattern is a 16-bit pattern; the conjugate's sign flip is bit 15 in both), only the
-// matrix instruction differs.  The half variants exist for float32 output only (the fp16 split products of x3.py).
-#ifdef CPLXAMD_GEMM_F16
-typedef _Float16 cplxamd_f16x8 __attribute__((ext_vector_type(8)));
-#define CPLXAMD_MFMA16(a, b, c) \
-  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cplxamd_f16x8, a), __builtin_bit_cast(cplxamd_f16x8, b), c, 0, 0, 0)
-#else
-#define CPLXAMD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
+// (CPLXAMD_MFMA16, the 16-bit matrix instruction of this translation unit: common.h)
 __device__ __forceinline__ float gemm_emul(const GemmArgs& g, float m) { return g.emul_exp ? expf(m) : m; }
 
 // any strides / shapes, exact-f32 MFMA (gemm_generic.hip)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 21
+#define CPLXAMD_ABI_VERSION 22
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1,
@@ -418,6 +418,31 @@ int cplxamd_rgemm_sc_fl(const void* a, int64_t a_rs, int64_t a_cs, const void* b
                         const float* bias, const float* emul, int emul_exp, void* c, int64_t ldc, int M, int N, int K,
                         int in_dtype, int accumulate, const float* beta, const float* scale_a, const float* scale_b,
                         void* ws, int64_t ws_bytes, int flags, void* stream);
+
+/* The channels-last 3 x 3 convolutions on IEEE-half pieces (ABI 22; csrc/conv_cl2_f16.hip, conv_cl_wgrad_f16.hip: the bf16
+ * kernels' sources compiled for the half matrix instruction): cplx.conv2d (cplxmodule/cplx.py:717-838) and its autograd in
+ * float32-level accuracy for float32 layers -- the pieces are the [h1|h0] rows of cplxamd_split2h over the channels-last
+ * planes read as [B H W][C] matrices, the weights' pieces are packed by cplxamd_conv2d_cl_pack (16-bit agnostic).
+ *   cplxamd_conv2d_cl2h_fl   cplxamd_conv2d_cl2_fl with x: half planes [B][H][W][pitch] of which the C channels behind the
+ *                            given pointers are convolved (pitch >= C: a channel window, e.g. the h0 half of [h1|h0]),
+ *                            y: FLOAT32 [B][Ho][Wo][N], accumulate != 0: y += result, the result times 1 / (sa sb) from the
+ *                            operands' scale buffers (both NULL: none), bias added once (pass it to the first launch).
+ *                            forward y = h0 * w1 (+ b), then += [h1|h0] * [w0|w0]; the data gradient likewise (mode 1).
+ *                            B H W pitch 2 < 0xF0000000 bytes per plane (CPLXAMD_ESHAPE: chunk the batch).
+ *   cplxamd_conv2d_clh_wgrad(_fl / _ws_bytes)   cplxamd_conv2d_cl_wgrad on half planes: with G = [g1|g0] (2 Co channels) and
+ *                            X = [x1|x0] (2 Ci) one launch gives the four piece blocks [2 Co][2 Ci][3][3]; the weight gradient is
+ *                            (g0 x1) + (g1 x0) + (g0 x0) times 1 / (sg sx). */
+int cplxamd_conv2d_cl2h_fl(const void* x_r, const void* x_i, int pitch, const void* w_packed, const float* bias_r,
+                           const float* bias_i, float* y_r, float* y_i, int accumulate, const float* scale_a,
+                           const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h, int pad_w, int mode, void* ws,
+                           int64_t ws_bytes, int flags, void* stream);
+int64_t cplxamd_conv2d_clh_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co);
+int cplxamd_conv2d_clh_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
+                             float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
+                             int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, void* stream);
+int cplxamd_conv2d_clh_wgrad_fl(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
+                                float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
+                                int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream);
 /* out[c, r] = in[r, c]  (rows x cols row-major in, ld = leading dims) */
 int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
                       int cols, int dtype, void* stream);

@@ -381,3 +381,70 @@ def test_x2_dynamic_range_is_normwise_accurate():
         got = x3.gemm_nn(x3.split_planes((At,), kind=kind), x3.split_planes((Bt,), x3.SPLIT_B, kind=kind), M, N_, K)
         err = float(np.abs(got.double().cpu().numpy() - ref).max()) / float(np.abs(ref).max())
         assert err <= tol, (kind, err)
+
+
+# ---- float32 3 x 3 convolutions on IEEE-half pieces (conv.py: _x2_conv*, csrc/conv_cl2_f16.hip, conv_cl_wgrad_f16.hip) -------
+@pytest.mark.parametrize("pad,H,W,bias", [(1, 20, 40, True), (0, 35, 33, False), (1, 16, 32, True)])
+def test_x2_conv_vs_float64_and_exact(pad, H, W, bias):
+    """CplxConv2d(64, 128, 3) float32, channels-last and planar inputs: forward, input gradient, weight and bias gradients
+    in 'x2' mode and in exact mode against the float64 oracle (cplx.py:717-838 restated) at 4e-6 norm-wise (K = 9 x 128
+    float32 accumulations: the exact kernel itself reaches 2.2e-6 here)."""
+    from cplxmodule_amd import Cplx, conv, nn, x3
+    rs = np.random.RandomState(H + W + pad)
+    B, Ci, Co = 3, 64, 128
+    layer = nn.CplxConv2d(Ci, Co, 3, padding=pad, bias=bias).cuda()
+    xr, xi = (rs.randn(B, Ci, H, W).astype(np.float32) for _ in range(2))
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    gr, gi = (rs.randn(B, Co, Ho, Wo).astype(np.float32) for _ in range(2))
+    f = np.float64
+    wr, wi = (layer.weight.real.detach().cpu().numpy().astype(f), layer.weight.imag.detach().cpu().numpy().astype(f))
+    br = bi = None
+    if bias:
+        br, bi = layer.bias.real.detach().cpu().numpy().astype(f), layer.bias.imag.detach().cpu().numpy().astype(f)
+    yr64, yi64 = orc.cplx_conv2d(xr.astype(f), xi.astype(f), wr, wi, br, bi, padding=pad)
+    bw = orc.cplx_conv2d_bwd(gr.astype(f), gi.astype(f), xr.astype(f), xi.astype(f), wr, wi, padding=pad)
+    res = {}
+    for mode, cl in (("exact", True), ("x2", True), ("x2", False)):
+        layer.zero_grad()
+        mk = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+        txr, txi = mk(xr), mk(xi)
+        if cl:
+            txr, txi = (t.contiguous(memory_format=torch.channels_last) for t in (txr, txi))
+        txr.requires_grad_(True); txi.requires_grad_(True)
+        with x3.fp32_mode(mode):
+            assert (conv._x2_conv_kind(conv._geom(txr.shape, layer.weight.real.shape, 1, pad, 1, 1)[0], txr, txi,
+                                       layer.weight.real, layer.weight.imag) == "x2") == (mode == "x2")
+            y = layer(Cplx(txr, txi))
+        torch.autograd.backward((y.real, y.imag), (mk(gr), mk(gi)))
+        got = dict(yr=y.real, yi=y.imag, dxr=txr.grad, dxi=txi.grad, dwr=layer.weight.real.grad, dwi=layer.weight.imag.grad)
+        if bias:
+            got.update(dbr=layer.bias.real.grad, dbi=layer.bias.imag.grad)
+        res[(mode, cl)] = {k: v.detach().double().cpu().numpy() for k, v in got.items()}
+    ref = dict(yr=yr64, yi=yi64, dxr=bw["dxr"], dxi=bw["dxi"], dwr=bw["dwr"], dwi=bw["dwi"])
+    if bias:
+        ref.update(dbr=gr.astype(f).sum((0, 2, 3)), dbi=gi.astype(f).sum((0, 2, 3)))
+    for key, got in res.items():
+        for k, r in ref.items():
+            np.testing.assert_allclose(got[k], r, rtol=0, atol=4e-6 * float(np.abs(r).max()), err_msg=f"{key} {k}")
+    assert res[("x2", True)]["yr"].shape == (B, Co, Ho, Wo)
+
+
+def test_x2_conv_batch_chunks(monkeypatch):
+    """The 4-GB buffer-descriptor limit chunks the batch: force chunks of two images and compare with one launch set."""
+    from cplxmodule_amd import Cplx, conv, nn, x3
+    torch.manual_seed(8)
+    layer = nn.CplxConv2d(64, 64, 3, padding=1).cuda()
+    x = Cplx(*(torch.randn(5, 64, 24, 32, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+               for _ in range(2)))
+    out = {}
+    for tag, lim in (("one", conv._X2_BYTES_MAX), ("chunks", 2 * 24 * 32 * 128 * 2 + 1)):
+        monkeypatch.setattr(conv, "_X2_BYTES_MAX", lim)
+        layer.zero_grad(); x.real.grad = x.imag.grad = None
+        with x3.fp32_mode("x2"):
+            y = layer(x)
+        torch.autograd.backward((y.real, y.imag), (y.real.detach(), y.imag.detach()))
+        out[tag] = [t.detach().clone() for t in (y.real, y.imag, x.real.grad, x.imag.grad, layer.weight.real.grad)]
+    for a, b in zip(out["one"][:4], out["chunks"][:4]):
+        assert torch.equal(a, b)                              # forward / data gradient: per-image results, same bits
+    a, b = out["one"][4], out["chunks"][4]
+    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())      # weight gradient: a sum over chunks
