@@ -273,10 +273,15 @@ def conv_point(dev, batch=256, dtype=torch.bfloat16):
         out = {"workload": f"CplxConv2d(64,64,3)@256x256 + CplxBatchNorm2d, {name}, batch {batch}, fwd+bwd, channels-last",
                "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flop_per_launch": flop}
         if dtype != torch.bfloat16:
-            # the 1e-5 mode (float32-MFMA convolution kernels in every fp32 mode: the split products cover the linear
-            # layers only): three convolution launches' flop over the whole step
+            # the 1e-5 mode: three convolutions' flop over the whole step (batch-norm passes included), against the
+            # float32-MFMA peak and -- when the half split products ran (conv.py: _x2_conv*) -- against their bound
+            from cplxmodule_amd import get_fp32_mode
+            out["fp32_mode"] = get_fp32_mode()
             out["tflops_whole_step"] = round(3 * flop / dt / 1e12, 1)
             out["frac_of_fp32_mfma_peak_whole_step"] = round(3 * flop / dt / 1e12 / FP32_PEAK_TFLOPS, 4)
+            if _split_kind(out["fp32_mode"]) == "x2":
+                out["split_arithmetic"] = "x2"
+                out["frac_of_split_bound_whole_step"] = round(3 * flop / dt / 1e12 / SPLIT_BOUND_TFLOPS["x2"], 4)
             return out
         for k in ("fwd", "dgrad", "wgrad"):
             ms = timer.mean_ms(k)
@@ -304,8 +309,8 @@ def fp32_points(dev):
     channels-last.  Linear layers since round 6: split operands on the 16-bit matrix pipe (cplxmodule_amd/x3.py) -- default
     'x2' = two IEEE-half pieces per operand, three piece products per float32 product (bound 2500 / 3 = 833 TFLOP/s, 2^-22
     norm-wise), `*_x3` = three bf16 pieces, six products (bound 417 TFLOP/s, 2^-24); `*_exact` = the float32-MFMA kernels
-    (157.3 TFLOP/s peak) they replaced, same process, for the ratio.  The convolutions still run the float32-MFMA kernels
-    in every mode.  Rank 0, N = 1, outside the timed region."""
+    (157.3 TFLOP/s peak) they replaced, same process, for the ratio.  The 3 x 3 convolutions take the half pieces too
+    (`x2` only; `conv_cfg3_fp32` vs `_exact`).  Rank 0, N = 1, outside the timed region."""
     out = {"split_bound_tflops": {k: round(v, 1) for k, v in SPLIT_BOUND_TFLOPS.items()}, "fp32_mfma_peak_tflops": FP32_PEAK_TFLOPS}
     try:
         from cplxmodule_amd import fp32_mode
@@ -318,16 +323,20 @@ def fp32_points(dev):
             else:
                 out[tag] = {"skipped": f"{free >> 30} GiB free, the float32 step at batch 2^20 wants ~180"}
             torch.cuda.empty_cache()
-        free, _ = torch.cuda.mem_get_info(dev)
-        if free >= 140 << 30:
-            out["conv_cfg3_fp32"] = conv_point(dev, dtype=torch.float32)
-        else:
-            out["conv_cfg3_fp32"] = {"skipped": f"{free >> 30} GiB free"}
-        torch.cuda.empty_cache()
-        p, e = out.get("cfg4_lrt_fp32", {}), out.get("cfg4_lrt_fp32_exact", {})
-        for q in (p, out.get("cfg4_lrt_fp32_x3", {})):
-            if "ms_per_step" in q and "ms_per_step" in e:
-                q["speedup_over_fp32_mfma_kernels"] = round(e["ms_per_step"] / q["ms_per_step"], 3)
+        for tag, mode in (("conv_cfg3_fp32", "auto"), ("conv_cfg3_fp32_exact", "exact")):
+            free, _ = torch.cuda.mem_get_info(dev)
+            if free >= 140 << 30:
+                with fp32_mode(mode):
+                    out[tag] = conv_point(dev, dtype=torch.float32)
+            else:
+                out[tag] = {"skipped": f"{free >> 30} GiB free"}
+            torch.cuda.empty_cache()
+        for a, variants in (("cfg4_lrt_fp32", ("", "_x3")), ("conv_cfg3_fp32", ("",))):
+            e = out.get(a + "_exact", {})
+            for v in variants:
+                q = out.get(a + v, {})
+                if "ms_per_step" in q and "ms_per_step" in e:
+                    q["speedup_over_fp32_mfma_kernels"] = round(e["ms_per_step"] / q["ms_per_step"], 3)
     except Exception as e:  # pragma: no cover
         out["error"] = str(e)[:200]
     return out
