@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 F32, BF16, F16 = 0, 1, 2
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -145,6 +145,10 @@ SIGNATURES = {
     "cplxamd_conv2d_cl2_mom_chunks_fl": [_L] + [_I] * 11,
     "cplxamd_conv2d_cl2_mom_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P, _L, _I, _P],
     "cplxamd_conv2d_cl_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
+    # ABI 23: float64 contractions (parity mode)
+    "cplxamd_gemm_f64": [_P, _P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P],
+    "cplxamd_conv2d_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "cplxamd_expi_f64": [_P, _P, _L, _P],
     # ABI 22: the channels-last convolutions on IEEE-half pieces (float32 out)
     "cplxamd_conv2d_cl2h_fl": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L] + [_I] * 7 + [_P, _L, _I, _P],
     "cplxamd_conv2d_clh_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
@@ -343,7 +347,8 @@ def dtype_code(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise CplxAmdError(f"unsupported dtype {t.dtype}: the kernels take float32 and bfloat16")
+    raise CplxAmdError(f"unsupported dtype {t.dtype}: this kernel takes float32 and bfloat16 (float64 is offered for the "
+                       "linear / convolution / batch-norm / relevance layers only: cplxmodule_amd/f64.py)")
 
 
 def require_device(*tensors):

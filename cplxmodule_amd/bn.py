@@ -152,3 +152,6 @@ class CplxBatchNormFn(torch.autograd.Function):
             ops.attach_colsum(dxr, sums[0])
             ops.attach_colsum(dxi, sums[1])
         return dxr, dxi, dw, db, None, None, None, None, None, None, None
+
+
+CplxBatchNormFn = ops.Route(CplxBatchNormFn, "cplx_batch_norm")      # float64: f64.py (the reference's algorithm in torch ops)

@@ -1243,3 +1243,10 @@ def cplx_conv_transpose1d(input, weight, bias=None, stride=1, padding=0, output_
     y = cplx_conv_transpose2d(_up(input), w2, bias, (1, _one(stride)), (0, _one(padding)),
                               (0, _one(output_padding)), groups, (1, _one(dilation)))
     return _down(y)
+
+
+# float64: a parity mode on its own kernels (f64.py; ops.Route dispatches on the dtype of the first tensor argument)
+CplxConv2dFn = ops.Route(CplxConv2dFn, "cplx_conv2d")
+RealConv2dFn = ops.Route(RealConv2dFn, "real_conv2d")
+CplxConv2dLRTFn = ops.Route(CplxConv2dLRTFn, "cplx_conv2d_lrt")
+RealConv2dLRTFn = ops.Route(RealConv2dLRTFn, "real_conv2d_lrt")

@@ -577,3 +577,8 @@ def max_pool3d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode
     """[B, C, D, H, W] (cplxmodule/cplx.py:1193-1200): separable, 2-d pool then 1-d pool over depth."""
     from .conv3d import cplx_max_pool3d
     return cplx_max_pool3d(input, kernel_size, stride, padding, dilation, ceil_mode)
+
+
+# float64: a parity mode on its own kernels (f64.py)
+_BatchedMatmulFn = ops.Route(_BatchedMatmulFn, "matmul_batched")
+_MatmulFn = ops.Route(_MatmulFn, "matmul2d")

@@ -1809,3 +1809,50 @@ class CplxMaxPool2dFn(torch.autograd.Function):
         call("cplxamd_cplx_maxpool2d_bwd" + ctx.sfx, ptr(gr), ptr(gi), ptr(idx), ptr(dzr), ptr(dzi), ctx.pool,
              dtype_code(gr), stream_ptr())
         return dzr, dzi, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ #
+#  float64: a parity mode on its own kernels (cplxmodule_amd/f64.py, csrc/f64.hip)           #
+# ------------------------------------------------------------------------------------------ #
+class Route:
+    """`.apply` of an autograd Function that hands float64 arguments (the dtype of its first tensor argument) to the
+    float64 implementation in f64.py and everything else to the Function.  Every float32 / bf16 call pays one dtype test."""
+
+    def __init__(self, fn, f64_name):
+        self.fn, self.f64_name = fn, f64_name
+        self.__name__, self.__doc__ = fn.__name__, fn.__doc__
+
+    def apply(self, *args):
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if a.dtype == torch.float64:
+                    from . import f64
+                    return getattr(f64, self.f64_name)(*args)
+                break
+        return self.fn.apply(*args)
+
+    def __getattr__(self, name):            # (class attributes / static helpers of the Function)
+        return getattr(self.fn, name)
+
+
+CplxLinearFn = Route(CplxLinearFn, "cplx_linear")
+RealLinearFn = Route(RealLinearFn, "real_linear")
+CplxLinearLRTFn = Route(CplxLinearLRTFn, "cplx_linear_lrt")
+RealLinearLRTFn = Route(RealLinearLRTFn, "real_linear_lrt")
+LogAlphaFn = Route(LogAlphaFn, "log_alpha")
+PenaltyFn = Route(PenaltyFn, "penalty")
+PenaltySumFn = Route(PenaltySumFn, "penalty_sum")
+AbsFn = Route(AbsFn, "cplx_abs")
+ExpiFn = Route(ExpiFn, "expi")
+MaskMulFn = Route(MaskMulFn, "mask_mul")
+_relevance_mask32 = relevance_mask
+
+
+def relevance_mask(wr, wi, ls2, threshold, count=False):  # noqa: F811
+    if ls2.dtype == torch.float64:
+        from . import f64
+        return f64.relevance_mask(wr, wi, ls2, threshold, count)
+    return _relevance_mask32(wr, wi, ls2, threshold, count)
+
+
+relevance_mask.__doc__ = _relevance_mask32.__doc__

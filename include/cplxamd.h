@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 22
+#define CPLXAMD_ABI_VERSION 23
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1,
@@ -806,6 +806,27 @@ int cplxamd_bilinear_reduce_fwd(const void* ur, const void* ui, const void* tr, 
 int cplxamd_bilinear_reduce_bwd(const void* ur, const void* ui, const void* tr, const void* ti,
                                 const void* gr, const void* gi, void* dx1r, void* dx1i, void* dtr,
                                 void* dti, int64_t B, int O, int I1, int conj_u, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * float64 (ABI 23; csrc/f64.hip): the contractions of the reference's `.double()` models and the exponential integral,
+ * as a PARITY mode -- plain v_fma_f64 kernels, nothing tuned.  The float64 layers of the host package
+ * (cplxmodule_amd/f64.py) spell their elementwise algebra with torch ops under autograd, as the reference does, and call
+ * these for what torch would hand to a vendor library (or to scipy on the host).
+ *   cplxamd_gemm_f64     C[z][m][n] = sum_k A[z][m][k] op(B[z][n][k]) (+ bias[n]); element strides (row, column, batch) per
+ *                        operand, planar complex (a_i / b_i / c_i all non-NULL) or real (all NULL); conj_b: conj(B).
+ *                        cplx.py:634-648, :167-174 and their autograd (dX = G conj(W), dW = G^T conj(X)).
+ *   cplxamd_conv2d_f64   mode 0: y = x (*) w + bias (p = x, q = w); mode 1: dx = data gradient (p = g, q = w); mode 2:
+ *                        dw = weight gradient (p = g, q = x); NCHW planes, complex or real, any stride / padding / dilation /
+ *                        groups; geom = {B, Ci, Co, H, W, KH, KW, sh, sw, ph, pw, dh, dw, groups}.  cplx.py:717-838.
+ *   cplxamd_expi_f64     y = Ei(x), both signs, ~1e-15 relative to scipy.special.expi.  nn/relevance/complex/vd.py:15-44.
+ * ---------------------------------------------------------------------------------- */
+int cplxamd_gemm_f64(const double* a_r, const double* a_i, int64_t a_rs, int64_t a_cs, int64_t a_bs,
+                     const double* b_r, const double* b_i, int64_t b_rs, int64_t b_cs, int64_t b_bs,
+                     const double* bias_r, const double* bias_i, double* c_r, double* c_i, int64_t ldc, int64_t c_bs,
+                     int batch, int M, int N, int K, int conj_b, void* stream);
+int cplxamd_conv2d_f64(const double* p_r, const double* p_i, const double* q_r, const double* q_i, const double* bias_r,
+                       const double* bias_i, double* out_r, double* out_i, const int* geom, int mode, void* stream);
+int cplxamd_expi_f64(const double* x, double* y, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

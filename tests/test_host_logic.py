@@ -176,3 +176,27 @@ def test_x3_take_rules_host():
         assert x3.get_fp32_mode() == "exact"
     finally:
         x3.set_fp32_mode(prev)
+
+
+def test_float64_routes_resolve_and_refuse_cpu_tensors():
+    """Every ops.Route names a function of f64.py taking the Function's own positional arguments (forward minus ctx);
+    float64 tensors on the CPU reach the library's device check and raise -- no torch fallback behind the route."""
+    import inspect
+    import torch
+    from cplxmodule_amd import bn, conv, cplx, f64, ops
+    from cplxmodule_amd._lib import CplxAmdError
+    routes = [v for m in (ops, conv, bn, cplx) for v in vars(m).values() if isinstance(v, ops.Route)]
+    assert len({id(r) for r in routes}) >= 17
+    for r in routes:
+        target = getattr(f64, r.f64_name)
+        want = list(inspect.signature(r.fn.forward).parameters)[1:]
+        got = inspect.signature(target).parameters
+        n_pos = sum(p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) for p in got.values())
+        var = any(p.kind == p.VAR_POSITIONAL for p in got.values())
+        assert var or n_pos == len(want), (r.f64_name, want, list(got))
+    x = torch.randn(4, 6, dtype=torch.float64)
+    w = torch.randn(3, 6, dtype=torch.float64)
+    with pytest.raises(CplxAmdError):
+        cplx.linear(cplx.Cplx(x, x), cplx.Cplx(w, w))
+    with pytest.raises(CplxAmdError):
+        ops.ExpiFn.apply(x)
