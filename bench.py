@@ -248,6 +248,8 @@ def conv_point(dev, batch=256, dtype=torch.bfloat16):
         timer = KernelTimer()
         timer.wrap(cv, "cl_conv", lambda *a, **k: "dgrad" if k.get("dgrad") else "fwd")
         timer.wrap(cv, "cl_wgrad", lambda *a, **k: "wgrad")
+        # (round 6: the weight-gradient launch that is also the batch-norm layer's backward apply: conv.cl_wgrad_bn)
+        timer.wrap(cv, "cl_wgrad_bn", lambda *a, **k: "wgrad")
         torch.manual_seed(0)
         layer, bn = nn.CplxConv2d(64, 64, 3).to(dev), nn.CplxBatchNorm2d(64).to(dev)
         mk = lambda: (torch.randn(batch, 64, 256, 256, device=dev).to(dtype)  # noqa: E731
@@ -290,6 +292,9 @@ def conv_point(dev, batch=256, dtype=torch.bfloat16):
         # the forward launch also forms the batch-norm layer's statistics in its epilogue (one pass over y less in the layer;
         # its fraction is still the convolution's flop over the whole launch): CPLXAMD_CONV_BN_MOMENTS=0 for the A/B
         out["bn_moments_in_conv_epilogue"] = bool(cv._MOMENTS and cv._MOMENTS_WANTED)
+        # ... and the weight-gradient launch also forms, stores and sums the batch-norm layer's input gradient (the layer's
+        # backward apply pass is not launched; `wgrad_ms` includes that work): CPLXAMD_BN_FOLD=0 for the A/B
+        out["bn_backward_apply_in_wgrad"] = bool(cv._BN_FOLD)
         return out
     except Exception as e:  # pragma: no cover
         return {"error": str(e)[:200]}

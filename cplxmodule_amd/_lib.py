@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPLXAMD_LIB") or os.path.join(_HERE, "libcplxamd.so")   # env: A/B builds
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 F32, BF16, F16 = 0, 1, 2
 KL_KINDS = {"real_vd": 0, "real_ard": 1, "cplx_vd": 2, "cplx_ard": 3, "cplx_vd_approx": 4,
@@ -145,6 +145,9 @@ SIGNATURES = {
     "cplxamd_conv2d_cl2_mom_chunks_fl": [_L] + [_I] * 11,
     "cplxamd_conv2d_cl2_mom_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P, _L, _I, _P],
     "cplxamd_conv2d_cl_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
+    # ABI 24: batch-norm backward without its apply pass + the weight gradient that forms dX while staging it
+    "cplxamd_bn_bwd_coef": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P, _L, _P],
+    "cplxamd_conv2d_cl_wgrad_bn_fl": [_P] * 11 + [_L] + [_I] * 10 + [_P, _L, _I, _P],
     # ABI 23: float64 contractions (parity mode)
     "cplxamd_gemm_f64": [_P, _P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P],
     "cplxamd_conv2d_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
@@ -168,6 +171,7 @@ _RESTYPES = {"cplxamd_absmax_ws_bytes": c_int64, "cplxamd_conv2d_cl2_mom_chunks"
              "cplxamd_conv2d_nhwc_wgrad_f32_ws_bytes": c_int64,
              "cplxamd_conv2d_cl_pack_bytes": c_int64, "cplxamd_conv2d_cl_ws_bytes": c_int64,
              "cplxamd_conv2d_cl_wgrad_ws_bytes": c_int64, "cplxamd_conv2d_clh_wgrad_ws_bytes": c_int64,
+
              "cplxamd_conv2d_clr_pack_bytes": c_int64,
              "cplxamd_conv2d_clr_ws_bytes": c_int64, "cplxamd_conv2d_clr_wgrad_ws_bytes": c_int64}
 

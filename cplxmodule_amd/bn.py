@@ -80,6 +80,11 @@ class CplxBatchNormFn(torch.autograd.Function):
         # but was not asked to, ask for the next step (conv.want_moments) -- in evaluation mode take the request back
         hint = ops.moments_hint(xr, xi) if training else None
         src = getattr(xr, "_cplxamd_conv_src", None)
+        # the backward can hand its apply pass to the weight gradient of the convolution that produced x (conv.bn_fold_node)
+        ctx.fold = None
+        if src is not None and xr.requires_grad:
+            from . import conv
+            ctx.fold = conv.bn_fold_node(xr, xi)
         xr, xi, (B, F, S), ctx.cl = _prep(xr, xi)
         yr, yi = torch.empty_like(xr), torch.empty_like(xi)      # (preserve_format: channels-last stays channels-last)
         saved = torch.empty(8, F, dtype=torch.float32, device=xr.device)
@@ -124,7 +129,6 @@ class CplxBatchNormFn(torch.autograd.Function):
         else:
             gr, gi = _al16(gr.contiguous()), _al16(gi.contiguous())
             B, F, S = _geom(xr)
-        dxr, dxi = torch.empty_like(xr), torch.empty_like(xi)
         dw = db = None
         if ctx.affine:
             dw = torch.empty(2, 2, F, dtype=torch.float32, device=xr.device)
@@ -135,6 +139,21 @@ class CplxBatchNormFn(torch.autograd.Function):
         sums = None
         if ctx.cl and _lib.load().cplxamd_bn_rows_path(B, F, S):
             sums = torch.empty(2, F, dtype=torch.float32, device=xr.device)
+        if ctx.fold is not None and ctx.group is None and sums is not None and gr.dtype == xr.dtype == torch.bfloat16:
+            # the apply pass happens inside the weight-gradient launch of the convolution that produced x: sums + finalize
+            # here, then that launch writes dX (the same values), its column sums and dW, which travels on dX
+            from . import conv
+            coef = torch.empty(F, 12, dtype=torch.float32, device=xr.device)
+            call("cplxamd_bn_bwd_coef", ptr(gr), ptr(gi), ptr(xr), ptr(xi), B, F, S, ptr(w), ptr(saved), ptr(dw), ptr(db),
+                 int(ctx.training), dtype_code(xr), ptr(coef), ptr(sums), ptr(ws), ws.numel(), stream_ptr())
+            out = conv.cl_wgrad_bn(gr, gi, xr, xi, coef, ctx.fold)
+            if out is not None:
+                dxr, dxi, dwh = out
+                ops.attach_colsum(dxr, sums[0])
+                ops.attach_colsum(dxi, sums[1])
+                ops.attach_wgrad(dxr, dxi, dwh)
+                return dxr, dxi, dw, db, None, None, None, None, None, None, None
+        dxr, dxi = torch.empty_like(xr), torch.empty_like(xi)
         if ctx.group is not None:
             local = torch.empty(F * 6, dtype=torch.float64, device=xr.device)
             call("cplxamd_bn_moments", ptr(xr), ptr(xi), ptr(gr), ptr(gi), ptr(saved), B, F, S, dtype_code(xr),

@@ -201,6 +201,43 @@ def cl_wgrad(gr, gi, xr, xi, geom, w_shape, emul=None):
     return dwr, dwi
 
 
+# The batch-norm backward folded into the weight gradient (csrc/conv_cl_wgrad.hip FOLD; A/B: CPLXAMD_BN_FOLD=0).
+_BN_FOLD = os.environ.get("CPLXAMD_BN_FOLD", "1") != "0"
+
+
+def bn_fold_node(xr, xi):
+    """Called by the batch-norm forward with its input planes: the autograd node of the channels-last 3 x 3 convolution
+    that produced exactly these two tensors (and whose weight gradient the folded kernel can form), or None."""
+    node = xr.grad_fn
+    if (not _BN_FOLD or node is None or node is not xi.grad_fn or not isinstance(node, CplxConv2dFn.fn._backward_cls)
+            or xr.output_nr != 0 or xi.output_nr != 1 or not getattr(node, "cl", False)):
+        return None
+    if xr.dtype != torch.bfloat16 or not _cl_wgrad_ok(node.geom) or node.wshape[0] % 64:
+        return None
+    return node
+
+
+def cl_wgrad_bn(gr, gi, zr, zi, coef, node):
+    """-> (dy_r, dy_i, (dW_r, dW_i, node)) or None: the input gradient of the batch-norm layer (coef: cplxamd_bn_bwd_coef)
+    formed inside the weight-gradient launch of the convolution `node` that produced z."""
+    if not (node.needs_input_grad[2] or node.needs_input_grad[3]):
+        return None
+    xr, xi = node.saved_tensors[:2]
+    geom = node.geom
+    B, Ci, Co, H, W = (geom[i] for i in range(5))
+    if tuple(zr.shape) != tuple(gr.shape) or zr.shape[1] != Co:
+        return None
+    ws = _scratch(gr.device, int(_lib.load().cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, Ci, Co)))
+    dyr, dyi = torch.empty_like(zr), torch.empty_like(zi)
+    dwr = torch.empty(node.wshape, dtype=torch.float32, device=gr.device)
+    dwi = torch.empty_like(dwr)
+    if not try_call("cplxamd_conv2d_cl_wgrad_bn_fl", ptr(gr), ptr(gi), ptr(zr), ptr(zi), ptr(coef), ptr(xr), ptr(xi), ptr(dyr),
+                    ptr(dyi), ptr(dwr), ptr(dwi), B, H, W, Ci, Co, geom[5], geom[6], geom[11], geom[12], geom[9], geom[10],
+                    ptr(ws), ws.numel(), launch_flags(), stream_ptr()):
+        return None
+    return dyr, dyi, (dwr, dwi, node)
+
+
 def to_channels_last(t):
     """[B, C, H, W] -> the same logical tensor stored [B, H, W, C] (torch.channels_last); no copy if it already is."""
     if t.is_contiguous(memory_format=torch.channels_last):
@@ -602,6 +639,7 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
     geom = ctx.geom
     dxr = dxi = dwr = dwi = dbr = dbi = None
     hint_r, hint_i = ops.colsum_hint(gr), ops.colsum_hint(gi)
+    dw_hint = ops.wgrad_hint(gr, gi, ctx)      # (bn.py: the batch-norm backward formed gr / gi inside this layer's wgrad kernel)
     gr, gi = to_channels_last(gr), to_channels_last(gi)
     if need[0] or need[1]:
         if _cl_ok(geom, dgrad=True):
@@ -611,7 +649,9 @@ def _cl_backward(ctx, gr, gi, xr, xi, wcr, wci):
         else:
             dxr, dxi = conv_dgrad(from_channels_last(gr), from_channels_last(gi), wcr, wci, geom, ctx.xshape)
     if need[2] or need[3]:
-        if _cl_wgrad_ok(geom):
+        if dw_hint is not None:
+            dwr, dwi = dw_hint
+        elif _cl_wgrad_ok(geom):
             dwr, dwi = cl_wgrad(gr, gi, xr, xi, geom, ctx.wshape)
         else:
             dwr, dwi = conv_wgrad(from_channels_last(gr), from_channels_last(gi), from_channels_last(xr),

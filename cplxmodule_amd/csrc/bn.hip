@@ -16,7 +16,56 @@ constexpr int kBnT = 256;
 constexpr int kBnMaxChunks = 512;
 constexpr int kSaved = 8;    // per-feature saved stats: mu, mv, p, q, w, vuu, vuv, vvv
 constexpr int kFwdCoef = 8;  // mu, mv, a00, a01, a10, a11, b0, b1
-constexpr int kBwdCoef = 12; // mu, mv, e00, e01, e10, e11, cuu, cuv, cvv, ku, kv, pad
+constexpr int kBwdCoef = kBnBwdCoef; // mu, mv, e00, e01, e10, e11, cuu, cuv, cvv, ku, kv, pad
+
+// The channels-last row kernels stream planes of gigabytes, every byte touched once per pass: nontemporal accesses
+// (bit 0: stores, bit 1: loads), as in kl.hip.
+#ifndef BN_NT
+#define BN_NT 3
+#endif
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f8 ld8s(const bf16_t* p) {
+#if BN_NT & 2
+  const u32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+  f8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r.h[e >> 1].v[(e & 1) * 2] = __uint_as_float(t[e] << 16);
+    r.h[e >> 1].v[(e & 1) * 2 + 1] = __uint_as_float(t[e] & 0xffff0000u);
+  }
+  return r;
+#else
+  return ld8(p);
+#endif
+}
+__device__ __forceinline__ f8 ld8s(const float* p) {
+#if BN_NT & 2
+  const f32x4_nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+  const f32x4_nt b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p + 4));
+  return f8{{f4{{a[0], a[1], a[2], a[3]}}, f4{{b[0], b[1], b[2], b[3]}}}};
+#else
+  return ld8(p);
+#endif
+}
+__device__ __forceinline__ void st8s(bf16_t* p, const f8& a) {
+#if BN_NT & 1
+  u32x4_nt w;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] = pack_bf16(a.h[e >> 1].v[(e & 1) * 2], a.h[e >> 1].v[(e & 1) * 2 + 1]);
+  __builtin_nontemporal_store(w, reinterpret_cast<u32x4_nt*>(p));
+#else
+  st8(p, a);
+#endif
+}
+__device__ __forceinline__ void st8s(float* p, const f8& a) {
+#if BN_NT & 1
+  __builtin_nontemporal_store(f32x4_nt{a.h[0].v[0], a.h[0].v[1], a.h[0].v[2], a.h[0].v[3]}, reinterpret_cast<f32x4_nt*>(p));
+  __builtin_nontemporal_store(f32x4_nt{a.h[1].v[0], a.h[1].v[1], a.h[1].v[2], a.h[1].v[3]}, reinterpret_cast<f32x4_nt*>(p + 4));
+#else
+  st8(p, a);
+#endif
+}
 
 struct BnGeom {
   int64_t B, S;
@@ -219,9 +268,9 @@ __global__ __launch_bounds__(kBnT) void bn_reduce_rows(const T* xr, const T* xi,
       const int64_t o0 = r * F + cg * 8;
       const bool two = r + step < R;
       const int64_t o1 = two ? o0 + step * F : o0;
-      const f8 u0 = ld8(xr + o0), v0 = ld8(xi + o0), u1 = ld8(xr + o1), v1 = ld8(xi + o1);
+      const f8 u0 = ld8s(xr + o0), v0 = ld8s(xi + o0), u1 = ld8s(xr + o1), v1 = ld8s(xi + o1);
       f8 p0 = u0, q0 = v0, p1 = u1, q1 = v1;
-      if (BWD) { p0 = ld8(gr + o0); q0 = ld8(gi + o0); p1 = ld8(gr + o1); q1 = ld8(gi + o1); }
+      if (BWD) { p0 = ld8s(gr + o0); q0 = ld8s(gi + o0); p1 = ld8s(gr + o1); q1 = ld8s(gi + o1); }
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         accum<NS, BWD>(a[c], u0.h[c >> 2].v[c & 3], v0.h[c >> 2].v[c & 3], p0.h[c >> 2].v[c & 3], q0.h[c >> 2].v[c & 3], mu[c], mv[c]);
@@ -268,9 +317,9 @@ __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, 
   const int64_t step = (int64_t)gridDim.x * RL;
   for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < R; r += step) {
     const int64_t o = r * F + cg * 8;
-    const f8 u = ld8(xr + o), v = ld8(xi + o);
+    const f8 u = ld8s(xr + o), v = ld8s(xi + o);
     f8 p = u, q = v, ou, ov;
-    if (BWD) { p = ld8(gr + o); q = ld8(gi + o); }
+    if (BWD) { p = ld8s(gr + o); q = ld8s(gi + o); }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float cu = u.h[c >> 2].v[c & 3] - k[c][0], cv = v.h[c >> 2].v[c & 3] - k[c][1];
@@ -283,8 +332,8 @@ __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, 
         ov.h[c >> 2].v[c & 3] = k[c][4] * pp + k[c][5] * qq + k[c][8] * cv + k[c][7] * cu - k[c][10];
       }
     }
-    st8(yr + o, ou);
-    st8(yi + o, ov);
+    st8s(yr + o, ou);
+    st8s(yi + o, ov);
     if (SUMS) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -352,6 +401,8 @@ struct BnSync {
   int moments_chunks = 1;                // rows of moments_in ([row][F][NS]): 1 = totals
   const double* local_in = nullptr;
   const double* count_dev = nullptr;
+  float* coef_out = nullptr;             // backward: leave the apply coefficients here and do NOT apply (cplxamd_bn_bwd_coef)
+  float* dx_sums_out = nullptr;          // ... and the per-feature sums of dX, [2][F], from the sums of the pass
 };
 
 template <int NS>
@@ -419,7 +470,7 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize(const double* partial, int
 __global__ __launch_bounds__(64) void bn_bwd_finalize(const double* partial, int chunks, int F, double count,
                                 const float* weight, const float* saved, int training,
                                 float* dweight, float* dbias, float* coef, const double* local,
-                                const double* count_dev) {
+                                const double* count_dev, float* dx_sums = nullptr) {
   const int f = blockIdx.x;
   if (count_dev) count = *count_dev;
   double s[6] = {0, 0, 0, 0, 0, 0};
@@ -472,6 +523,11 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize(const double* partial, int
   }
   c[6] = (float)cuu; c[7] = (float)cuv; c[8] = (float)cvv; c[9] = (float)ku; c[10] = (float)kv;
   c[11] = 0.f;
+  if (dx_sums) {
+    // sum over rows of dX = E sum(g) + C sum(x - mu) - count k; sum(x - mu) = 0 against the batch mean, C = 0 otherwise
+    dx_sums[f] = (float)((p * w00 + q * w01) * Sgu + (p * w10 + q * w11) * Sgv - count * ku);
+    dx_sums[F + f] = (float)((q * w00 + w * w01) * Sgu + (q * w10 + w * w11) * Sgv - count * kv);
+  }
 }
 
 // apply, S > 1: grid (ceil(S/(4*256)) , B*F)
@@ -570,7 +626,7 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
                   hipStream_t st, float* dx_sums = nullptr, BnSync sync = BnSync()) {
   const BnGeom g = bn_geom(B, F, S);
   double* partial = (double*)ws;
-  float* coef = (float*)((char*)ws + bn_coef_off(F));
+  float* coef = sync.coef_out ? sync.coef_out : (float*)((char*)ws + bn_coef_off(F));
   const bool rows = bn_rows_ok(B, F, S);
   int chunks = g.chunks;
   if (rows) {
@@ -612,8 +668,9 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
                                         running_var, training, momentum, eps, saved, coef, sync.count_dev, sync.tracked_inc);
   else
     bn_bwd_finalize<<<F, 64, 0, st>>>(totals, tchunks, F, count, weight, saved, training,
-                                        dweight, dbias, coef, sync.local_in, sync.count_dev);
+                                        dweight, dbias, coef, sync.local_in, sync.count_dev, sync.dx_sums_out);
   CPLXAMD_CHECK_LAUNCH();
+  if (BWD && sync.coef_out) return 0;                  // the consumer of the coefficients applies them (conv_cl_wgrad.hip FOLD)
   if (rows) {
     const int RL = kBnT / (F / 8);
     const int grid = stream_grid((B + RL - 1) / RL * kBnT, kBnT);
@@ -726,6 +783,27 @@ int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const vo
     return bn_run<bf16_t, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr,
                                 nullptr, const_cast<float*>(saved), dweight, dbias, training, 0.f,
                                 0.f, ws, st, dx_sums);
+  return CPLXAMD_EINVAL;
+}
+
+// The first half of cplxamd_bn_bwd: sums + finalize (dweight, dbias as there) and the per-channel coefficients of the
+// input gradient, dX = E g + C (x - mu) - k, left in coef[F][12] (float32: mu mv | e00 e01 e10 e11 | cuu cuv cvv | ku kv |
+// pad) for a consumer that applies them itself -- cplxamd_conv2d_cl_wgrad_bn_fl forms dX while it stages it.
+int cplxamd_bn_bwd_coef(const void* gr, const void* gi, const void* xr, const void* xi, int64_t B, int F, int64_t S,
+                        const float* weight, const float* saved, float* dweight, float* dbias, int training, int dtype,
+                        float* coef, float* dx_sums, void* ws, int64_t ws_bytes, void* stream) {
+  if (!gr || !gi || !xr || !xi || !saved || !coef || !ws || B <= 0 || F <= 0 || S <= 0) return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  BnSync sync;
+  sync.coef_out = coef;
+  sync.dx_sums_out = dx_sums;
+  if (dtype == CPLXAMD_F32)
+    return bn_run<float, true>(xr, xi, gr, gi, nullptr, nullptr, B, F, S, weight, nullptr, nullptr, nullptr,
+                               const_cast<float*>(saved), dweight, dbias, training, 0.f, 0.f, ws, st, nullptr, sync);
+  if (dtype == CPLXAMD_BF16)
+    return bn_run<bf16_t, true>(xr, xi, gr, gi, nullptr, nullptr, B, F, S, weight, nullptr, nullptr, nullptr,
+                                const_cast<float*>(saved), dweight, dbias, training, 0.f, 0.f, ws, st, nullptr, sync);
   return CPLXAMD_EINVAL;
 }
 

@@ -41,6 +41,10 @@ constexpr int kPhiloxRounds = CPLXAMD_PHILOX_ROUNDS;
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 
+// floats per channel of the batch-norm backward coefficients (bn.hip bn_bwd_finalize; read by conv_cl_wgrad.hip's FOLD kernel):
+// mu, mv, e00, e01, e10, e11, cuu, cuv, cvv, ku, kv, pad
+constexpr int kBnBwdCoef = 12;
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }

@@ -30,6 +30,9 @@
 #include "common.h"
 #include "launch.h"   // per-call launch policy (CPLXAMD_LAUNCH_SHARED: the chip is shared with collectives)
 
+#ifndef CLW_NT
+#define CLW_NT 3       // FOLD: nontemporal G stores (bit 0) / raw tile loads (bit 1)
+#endif
 namespace cplxamd {
 namespace clw {
 
@@ -38,6 +41,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KR = 32, NT = 512, TC = 64;
 constexpr int G_BYTES = 2 * KR * 128;              // [plane][32 pixels][64 co]
@@ -47,6 +51,10 @@ constexpr int STAGE = G_BYTES + X_BYTES;           // 40 KiB
 constexpr int L = 5;                               // LDS-DMA pieces per wave and stage
 constexpr int NBLK = 40;                           // slab blocks per tile: 2 x 18 + the 4 second halves
 constexpr uint32_t OOB = 0xFFFFFFF0u;
+// FOLD (the batch-norm backward apply folded into the G staging, see the kernel): two raw tiles
+// [g_r | g_i | z_r | z_i][32 pixels][128 B] behind the ring
+constexpr int RAW = 3 * STAGE, RAW_BYTES = 4 * KR * 128, SMEM_FOLD = RAW + 2 * RAW_BYTES;
+static_assert(SMEM_FOLD <= 160 * 1024, "LDS");
 
 struct Args {
   const void* g_r; const void* g_i;                // [P][Co] bf16
@@ -58,12 +66,32 @@ struct Args {
   int Ho, Wo;                                        // the output image (<= H x W, top-left aligned on the grid)
   int strips;                                        // stages per image row: ceil(W / 32)
   int nstages, per_split, splits, tiles_ci;
+  // FOLD: G = A g + B (z - mu) - k per output channel (bn.hip's backward apply) is formed on the way into the LDS
+  const void* z_r; const void* z_i;                // [P][Co] bf16: the batch-norm layer's input = the convolution's output
+  const float* coef;                               // [Co][kBnBwdCoef] (bn_bwd_finalize)
+  void* dy_r; void* dy_i;                          // [P][Co] bf16 out: G as the MFMAs see it (the data gradient reads it next)
 };
 
 __device__ __forceinline__ void buf_lds16(i32x4 rsrc, uint32_t voff, uint32_t lds_off_uniform) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_off_uniform);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :
+               : "v"(voff), "s"(rsrc), "s"(m0v)
+               : "memory");
+#endif
+}
+
+// the same for data that is read once (FOLD: the raw g / z tiles): nontemporal, so that it does not push the x rows -- each
+// fetched by three kernel rows -- out of the L2
+__device__ __forceinline__ void buf_lds16_nt(i32x4 rsrc, uint32_t voff, uint32_t lds_off_uniform) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_off_uniform);
+#if CLW_NT & 2
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen nt lds"
+#else
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+#endif
                :
                : "v"(voff), "s"(rsrc), "s"(m0v)
                : "memory");
@@ -107,6 +135,23 @@ __device__ __forceinline__ bf16x8 neg(bf16x8 v) {
 }
 
 // grid: x = split, y = co tile * tiles_ci + ci tile
+//
+// FOLD: G is not in memory yet -- it is the input gradient of the batch-norm layer that consumed this convolution's output
+// z, G = E g + C (z - mu) - k per output channel (the 2 x 2 real matrices and constants bn_bwd_finalize leaves in `coef`;
+// bn_apply_rows<BWD>'s arithmetic with the means multiplied out: G = E g + C z + c, c = -k - C mu, 9 coefficients per
+// channel in registers).  The G tile of a stage is then not LDS-DMA'd: the raw g and z tiles (4 planes x 32 pixels x 64
+// channels, two LDS-DMA pieces per wave) land in one of two raw buffers a full stage ahead; during stage t every lane
+// turns (2 pixels) x (2 channels) of stage t + 1's raw tiles into G -- 8 LDS dword reads, ~30 packed VALU operations that
+// run in the shadow of the other wave's MFMAs, bf16 rounding -- and writes them into the G image of stage t + 1's slot,
+// where the MFMAs find it as before; the per-lane column sums of G (the convolution's bias gradient) are kept on the way.
+// G also goes to memory (dy_r / dy_i: the data gradient reads it after this launch): during stage t every lane reads 16
+// bytes of the finished G image of stage t back -- the lane mapping of the LDS-DMA piece it replaces, inverted -- and
+// stores them: one store instruction per wave and stage (stores straight from the forming lanes, 4 bytes each, cost 0.5 ms
+// of the launch at cfg3).  The batch-norm layer's apply pass -- 4 planes read, 2 written, 2.4-2.6 ms at cfg3 -- is not
+// launched.  VMEM order per wave and stage: raw g, raw z | store | pieces 1, 2, 3, 4; the stage-end wait leaves the 5
+// youngest in flight (the raw tiles were issued first and must have landed: every wave reads every wave's lanes of them
+// behind the barrier).
+template <bool FOLD>
 __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -140,6 +185,8 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   const uint32_t rb_g = (uint32_t)g.Co * 2u, rb_x = (uint32_t)g.Ci * 2u;
   uint32_t vo[L], vflag[L];                          // lane offset inside the stage window; bit0 always out of range,
   {                                                  // bit1 top rows, bit2 bottom rows, bit3 set for every lane
+    // (FOLD: the raw g / z tiles are fetched with this very mapping -- they sit in the LDS swizzled like the G image the
+    //  lanes form from them, one offset serves both -- and the store of the finished tile reads G back with it)
     const int c = (int)(wid_u & 3) * 64 + lane, k = c >> 3, ch = (c & 7) ^ (((k >> 1) & 1) << 2);
     vo[0] = (uint32_t)k * rb_g + (uint32_t)(co0 + ch * 8) * 2u;
     vflag[0] = (uint32_t)k;                          // (piece 0: the pixel of this lane inside the stage)
@@ -210,22 +257,162 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
     if (d_w0 >= g.W) { d_q0 -= (uint32_t)(d_w0 - g.W); d_w0 = 0; if (++d_h == g.H) { d_h = 0; ++d_b; } }
   };
 
+  // ---- FOLD: lane (channel pair cp, pixel slot ps) forms G for pixels ps and ps + 16 of the stage at the pointer e_* ----
+  const int cp = lane & 31, ps = (lane >> 5) + 2 * (int)wid_u;
+  const bool writer = tci == 0;                      // (one ci tile stores G and its sums)
+  f32x2 kc[9];                                       // e00 e01 e10 e11 | cuu cuv cvv | c_r c_i, each for this lane's two channels
+  uint32_t f_img = 0;                                // this lane's dword inside a raw plane and inside a G image plane
+  uint32_t vo_b = 0;                                 // x pieces: lane offset of window row lane >> 3 (FOLD: one for all)
+  i32x4 rs_z = rs_g, rs_dy = rs_g;
+  // e: the stage whose G is being formed (one ahead of the MFMAs); p: the one before it, whose finished G is being stored
+  int e_t = 0, e_w0 = d_w0, e_h = d_h, e_lim = 0, p_lim = 0;
+  uint32_t e_row = 0, p_goff = 0;                    // G byte offset of the first pixel of e's image row
+  auto e_set = [&]() __attribute__((always_inline)) {
+    e_lim = (e_t < nt && e_h < g.Ho) ? g.Wo - e_w0 : 0;
+  };
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float* kp = g.coef + (int64_t)(co0 + 2 * cp + c) * kBnBwdCoef;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) kc[j][c] = kp[2 + j];
+      kc[7][c] = -kp[9] - kp[6] * kp[0] - kp[7] * kp[1];
+      kc[8][c] = -kp[10] - kp[7] * kp[0] - kp[8] * kp[1];
+    }
+    f_img = (uint32_t)(img_off(ps, cp >> 2) + (cp & 3) * 4);     // (pixel ps + 16 swizzles alike: + 16 rows)
+    {
+      const int rl = lane >> 3, ch = (lane & 7) ^ (((rl >> 1) & 1) << 2);     // (rows r = 8 sub + rl swizzle like rl)
+      vo_b = (uint32_t)rl * rb_x + (uint32_t)(ci0 + ch * 8) * 2u;
+    }
+    rs_z = make_rsrc(wid_u < 4 ? g.z_r : g.z_i, g.g_bytes);
+    rs_dy = make_rsrc(wid_u < 4 ? g.dy_r : g.dy_i, g.g_bytes);
+    e_row = (((uint32_t)d_b * (uint32_t)g.Ho + (uint32_t)d_h) * (uint32_t)g.Wo) * rb_g;
+    e_set();
+  }
+  auto issue_raw = [&](uint32_t raw_lds) __attribute__((always_inline)) {
+    const bool live = d_t < nt;
+    const uint32_t goff = (((uint32_t)d_b * (uint32_t)g.Ho + (uint32_t)d_h) * (uint32_t)g.Wo + (uint32_t)d_w0) * rb_g;
+    const int lim = (live && d_h < g.Ho) ? g.Wo - d_w0 : 0;
+    const uint32_t v = (int)vflag[0] < lim ? vo[0] + goff : OOB;
+    buf_lds16_nt(rs_g, v, raw_lds + dst[0]);
+    buf_lds16_nt(rs_z, v, raw_lds + (uint32_t)(2 * KR * 128) + dst[0]);
+  };
+  // the x pieces as issue_piece does them, on ONE lane offset (vo_b) and the lane's window row recomputed per use:
+  // the row and flag words of the four pieces are registers this variant does not have
+  int sub8_of[L];
+#pragma unroll
+  for (int j = 1; j < L; ++j) {
+    const int u = ((j - 1) & 1) * 8 + (int)wid_u, kh_ = u / 5;
+    sub8_of[j] = u >= 15 ? -1 : (u - kh_ * 5) * 8;
+  }
+  auto issue_piece_f = [&](int j, uint32_t slot_off) __attribute__((always_inline)) {
+    const bool live = d_t < nt;
+    const int kh = kh_of[j], sub8 = sub8_of[j];
+    const int hh = d_h + kh * g.dil_h - g.pad_h;
+    const int nval = g.W - d_w0 < KR ? g.W - d_w0 : KR;
+    int hi = KR + 2 * g.dil_w;
+    if (d_w0 + KR >= g.W && nval + g.pad_w < hi) hi = nval + g.pad_w;
+    const int lo = d_w0 == 0 ? g.pad_w : 0;
+    const bool none = hh < 0 || hh >= g.H || !live || sub8 < 0;
+    const uint32_t soff = (d_q0 - (uint32_t)g.pad_w + (uint32_t)((kh * g.dil_h - g.pad_h) * g.W) + (uint32_t)sub8) * rb_x;
+    uint32_t l = (uint32_t)lane;
+    asm volatile("" : "+v"(l));                      // (keeps lane >> 3 out of a loop-invariant register)
+    const uint32_t span = none ? 0u : (uint32_t)(hi - lo);
+    const uint32_t v = ((l >> 3) + (uint32_t)(sub8 - lo)) < span ? vo_b + soff : OOB;
+    buf_lds16(j < 3 ? rs_xr : rs_xi, v, slot_off + dst[j]);
+  };
+  auto e_advance = [&]() __attribute__((always_inline)) {
+    p_goff = e_row + (uint32_t)e_w0 * rb_g; p_lim = e_lim;
+    ++e_t; e_w0 += KR;
+    if (e_w0 >= g.W) {
+      e_w0 = 0;
+      e_row += (uint32_t)g.Wo * rb_g;
+      if (++e_h == g.H) { e_h = 0; e_row -= (uint32_t)(g.H - g.Ho) * (uint32_t)g.Wo * rb_g; }
+    }
+    e_set();
+  };
+  auto unpk = [](uint32_t d) __attribute__((always_inline)) { return f32x2{__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)}; };
+  // One (pixel, channel pair) item in pieces the stage spreads between MFMAs (a wave that does all of it in one go leaves
+  // the matrix pipe idle for the length of an LDS round trip plus ~30 dependent operations, and so does its twin on the
+  // SIMD, which reaches the same place at the same time): x_read issues the four LDS reads a block ahead, x_chunk(0..3)
+  // are <= 8 packed operations each, one behind every MFMA of a block, x_write puts the two dwords into the G image.
+  uint32_t ra = 0, rb = 0, rc = 0, rd = 0, x_dr = 0, x_di = 0;
+  f32x2 x_ou = {0.f, 0.f}, x_ov = {0.f, 0.f};
+  i32x4 gtile = {0, 0, 0, 0};
+  auto x_read = [&](int it, const char* raw) __attribute__((always_inline)) {
+    const char* rp = raw + f_img + it * 2048;
+    ra = *reinterpret_cast<const uint32_t*>(rp); rb = *reinterpret_cast<const uint32_t*>(rp + KR * 128);
+    rc = *reinterpret_cast<const uint32_t*>(rp + 2 * KR * 128); rd = *reinterpret_cast<const uint32_t*>(rp + 3 * KR * 128);
+  };
+  auto x_chunk = [&](int i, int it) __attribute__((always_inline)) {
+    if (i == 0) {
+      const f32x2 P = unpk(ra), Q = unpk(rb);
+      x_ou = kc[0] * P + kc[7]; x_ov = kc[2] * P + kc[8];
+      x_ou = kc[1] * Q + x_ou; x_ov = kc[3] * Q + x_ov;
+    } else if (i == 1) {
+      const f32x2 U = unpk(rc), V = unpk(rd);
+      x_ou = kc[4] * U + x_ou; x_ov = kc[5] * U + x_ov;
+      x_ou = kc[5] * V + x_ou; x_ov = kc[6] * V + x_ov;
+    } else if (i == 2) {
+      const float okf = ps + 16 * it < e_lim ? 1.f : 0.f;    // (pixels without a G: the raw rows read as zeros, G must too)
+      x_ou *= okf; x_ov *= okf;
+      x_dr = pack_bf16(x_ou[0], x_ou[1]); x_di = pack_bf16(x_ov[0], x_ov[1]);
+    }
+  };
+  auto x_write = [&](int it, char* img) __attribute__((always_inline)) {
+    *reinterpret_cast<uint32_t*>(img + f_img + it * 2048) = x_dr;
+    *reinterpret_cast<uint32_t*>(img + KR * 128 + f_img + it * 2048) = x_di;
+  };
+  auto xform = [&](int it, const char* raw, char* img) __attribute__((always_inline)) {    // (prologue: all of it at once)
+    x_read(it, raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x_chunk(i, it);
+    x_write(it, img);
+  };
+  // the finished G image of the stage the MFMAs are in -> dy (the lane mapping of LDS-DMA piece 0, backwards): read ahead
+  // of a block, stored behind it
+  auto tile_read = [&](const char* slot) __attribute__((always_inline)) {
+    gtile = *reinterpret_cast<const i32x4*>(slot + dst[0] + lane * 16);
+  };
+  auto tile_store = [&]() __attribute__((always_inline)) {
+    const uint32_t vs = ((int)vflag[0] < p_lim && writer) ? vo[0] + p_goff : OOB;
+#if defined(__HIP_DEVICE_COMPILE__)
+#if CLW_NT & 1
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt" : : "v"(gtile), "v"(vs), "s"(rs_dy) : "memory");
+#else
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(gtile), "v"(vs), "s"(rs_dy) : "memory");
+#endif
+#endif
+  };
+
   // ---- one stage: 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity) ---------------
   // One stage = 2 sub-steps of 16 pixels x (4 blocks + the shared block on this wave's parity).  Fragments are read one
   // block ahead of the MFMAs.  The barrier sits in front of the LAST block of the stage, when every read of this slot
   // has been issued and completed: the first fragments of the next stage are then read under that block's MFMAs
   // instead of right behind a barrier at which all eight waves (both of every SIMD) would wait for the LDS together.
   bf16x8 xr[2], xi[2], gr[2], gi[2], hr, hi;
-  auto mfma_block = [&](int n, bf16x8 ar, bf16x8 ai, bf16x8 pr, bf16x8 pi, bf16x8 npr) __attribute__((always_inline)) {
+  // fill >= 0 (FOLD): x_chunk(0..3) of item `fill` behind the four MFMAs
+  auto mfma_block = [&](int n, bf16x8 ar, bf16x8 ai, bf16x8 pr, bf16x8 pi, bf16x8 npr, int fill = -1) __attribute__((always_inline)) {
     // G conj(X): re = gr xr + gi xi, im = gi xr - gr xi; X first: accumulator rows = co, 4 consecutive ci per group
-    acc_r[n] = CPLXAMD_MFMA16(ar, pr, acc_r[n]);
-    acc_i[n] = CPLXAMD_MFMA16(ar, pi, acc_i[n]);
-    acc_r[n] = CPLXAMD_MFMA16(ai, pi, acc_r[n]);
-    acc_i[n] = CPLXAMD_MFMA16(ai, npr, acc_i[n]);
+    auto f = [&](int i) __attribute__((always_inline)) {
+      if (FOLD && fill >= 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        x_chunk(i, fill);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    acc_r[n] = CPLXAMD_MFMA16(ar, pr, acc_r[n]); f(0);
+    acc_i[n] = CPLXAMD_MFMA16(ar, pi, acc_i[n]); f(1);
+    acc_r[n] = CPLXAMD_MFMA16(ai, pi, acc_r[n]); f(2);
+    acc_i[n] = CPLXAMD_MFMA16(ai, npr, acc_i[n]); f(3);
   };
-  auto stage = [&](uint32_t cur_off, uint32_t nxt_off, uint32_t next_cur_off) __attribute__((always_inline)) {
+  auto stage = [&](uint32_t cur_off, uint32_t nxt_off, uint32_t next_cur_off, uint32_t rawsel) __attribute__((always_inline)) {
     const char* st = smem + cur_off;
     const char* sn = smem + next_cur_off;
+    // FOLD: raw tiles of stage t + 2 -> buffer rawsel, G of stage t + 1 from buffer rawsel ^ 1 -> its slot
+    const uint32_t raw_dma = smem_off + (uint32_t)RAW + rawsel * (uint32_t)RAW_BYTES;
+    const char* raw_src = smem + RAW + (rawsel ^ 1u) * RAW_BYTES;
+    char* g_img = smem + next_cur_off;
     // ---- sub-step 0 (entry: gr[0], gi[0], xr[0], xi[0] hold block 0 of this stage)
     {
       const bf16x8 ngr = neg(gr[0]);
@@ -239,11 +426,28 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
           xr[cur ^ 1] = frag_at(st, xa[0], 1); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[0], 1);
           if (hpar == 0) { hr = frag_at(st, xa[4], 0); hi = frag_at(st + XW_BYTES, xa[4], 0); }
         }
-        mfma_block(n, xr[cur], xi[cur], gr[0], gi[0], ngr);
-        const int piece = n == 0 ? 0 : (n == 2 ? 1 : (n == 3 ? 2 : -1));
-        if (piece >= 0) {
+        if (FOLD && n != 2) {                           // LDS reads a block ahead of their use
           __builtin_amdgcn_sched_barrier(0);
-          issue_piece(piece, nxt_off);
+          if (n == 0) tile_read(st);
+          else x_read(n == 1 ? 0 : 1, raw_src);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_block(n, xr[cur], xi[cur], gr[0], gi[0], ngr, n == 2 ? 0 : -1);
+        const int piece = n == 0 ? 0 : (n == 2 ? 1 : (n == 3 ? 2 : -1));
+        if (FOLD && n == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_raw(raw_dma);
+          tile_store();
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (piece > 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (FOLD && n == 2) x_write(0, g_img);
+          if (FOLD) issue_piece_f(piece, nxt_off);
+          else issue_piece(piece, nxt_off);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (piece == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(0, nxt_off);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -257,16 +461,20 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
         const int cur = n & 1;
         xr[cur ^ 1] = frag_at(st, xa[n + 1], 1); xi[cur ^ 1] = frag_at(st + XW_BYTES, xa[n + 1], 1);
         if (n == 2 && hpar == 1) { hr = frag_at(st, xa[4], 1); hi = frag_at(st + XW_BYTES, xa[4], 1); }
-        mfma_block(n, xr[cur], xi[cur], gr[1], gi[1], ngr);
+        mfma_block(n, xr[cur], xi[cur], gr[1], gi[1], ngr, n == 0 ? 1 : -1);
         const int piece = n == 0 ? 3 : (n == 2 ? 4 : -1);
         if (piece >= 0) {
           __builtin_amdgcn_sched_barrier(0);
-          issue_piece(piece, nxt_off);
+          if (FOLD && n == 0) x_write(1, g_img);
+          if (FOLD) issue_piece_f(piece, nxt_off);
+          else issue_piece(piece, nxt_off);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // every read of this slot has completed
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");       // the next stage has landed (this wave's pieces)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // every read of this slot has completed (FOLD: and G written)
+      // the next stage has landed (this wave's pieces); FOLD: and the raw tiles issued at the head of this one
+      if (FOLD) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
       __builtin_amdgcn_s_barrier();
       gr[0] = frag_at(sn, ga, 0); gi[0] = frag_at(sn + KR * 128, ga, 0);
       xr[0] = frag_at(sn, xa[0], 0); xi[0] = frag_at(sn + XW_BYTES, xa[0], 0);
@@ -278,18 +486,32 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   if (nt > 0) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if (FOLD) issue_raw(smem_off + (uint32_t)(RAW + s * RAW_BYTES));
 #pragma unroll
-      for (int j = 0; j < L; ++j) issue_piece(j, smem_off + (uint32_t)(s * STAGE));
+      for (int j = FOLD ? 1 : 0; j < L; ++j) {
+        if (FOLD) issue_piece_f(j, smem_off + (uint32_t)(s * STAGE));
+        else issue_piece(j, smem_off + (uint32_t)(s * STAGE));
+      }
       advance();
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");         // stage 0 landed; stage 1 may be in flight
+    if (FOLD) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // both raw tiles (and both stages) landed
+      __builtin_amdgcn_s_barrier();
+      xform(0, smem + RAW, smem);                                    // G of stage 0 -> slot 0
+      xform(1, smem + RAW, smem);
+      e_advance();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");       // stage 0 landed; stage 1 may be in flight
+    }
     __builtin_amdgcn_s_barrier();
     gr[0] = frag_at(smem, ga, 0); gi[0] = frag_at(smem + KR * 128, ga, 0);
     xr[0] = frag_at(smem, xa[0], 0); xi[0] = frag_at(smem + XW_BYTES, xa[0], 0);
     uint32_t cur = 0, nx1 = STAGE, nx2 = 2u * STAGE;
     for (int t = 0; t < nt; ++t) {
-      stage(cur, smem_off + nx2, nx1);
+      stage(cur, smem_off + nx2, nx1, (uint32_t)(t & 1));
       advance();
+      if (FOLD) e_advance();
       const uint32_t c = cur; cur = nx1; nx1 = nx2; nx2 = c;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the zero re-loads land before the LDS is released
@@ -432,13 +654,57 @@ int cplxamd_conv2d_cl_wgrad_fl(const void* g_r, const void* g_i, const void* x_r
   g.splits = clw::plan(g.nstages, tiles, g.per_split, !launch_owns_chip(flags));
   constexpr int smem = 3 * clw::STAGE;
   static PerDeviceOnce attr_set;
-  if (const int e = set_max_dyn_lds(attr_set, clw::conv_cl_wgrad_kernel, smem)) return e;
-  clw::conv_cl_wgrad_kernel<<<dim3((unsigned)g.splits, (unsigned)tiles), clw::NT, smem, st>>>(g);
+  if (const int e = set_max_dyn_lds(attr_set, clw::conv_cl_wgrad_kernel<false>, smem)) return e;
+  clw::conv_cl_wgrad_kernel<false><<<dim3((unsigned)g.splits, (unsigned)tiles), clw::NT, smem, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
   clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, Co, Ci,
                                                                                    emul, dw_r, dw_i);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
+
+#ifndef CPLXAMD_CONV_F16
+// ---- the weight gradient that also IS the batch-norm layer's backward apply (kernel comment: FOLD) ---------------------
+// g: the gradient that reached the batch-norm layer, z: that layer's input (this convolution's output), both [B][Ho][Wo][Co]
+// bf16 channels-last planes; coef: [Co][12] float32 from cplxamd_bn_bwd_coef.  Writes dy = the layer's input gradient (bf16
+// planes like g: what cplxamd_bn_bwd would have written, to the last bit or one bf16 rounding step) and dW = the weight
+// gradient of dy against x.  ws as cplxamd_conv2d_cl_wgrad (cplxamd_conv2d_cl_wgrad_ws_bytes).
+
+int cplxamd_conv2d_cl_wgrad_bn_fl(const void* g_r, const void* g_i, const void* z_r, const void* z_i, const float* coef,
+                                  const void* x_r, const void* x_i, void* dy_r, void* dy_i, float* dw_r,
+                                  float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w,
+                                  int pad_h, int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream) {
+  if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
+  if (!g_r || !g_i || !z_r || !z_i || !coef || !x_r || !x_i || !dy_r || !dy_i || !dw_r || !dw_i || B <= 0 || H <= 0 ||
+      W <= 0 || Ci <= 0 || Co <= 0)
+    return CPLXAMD_EINVAL;
+  if (!clw_shape_ok(B, H, W, Ci, Co, KH, KW, dil_h, dil_w, pad_h, pad_w)) return CPLXAMD_ESHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!a16(g_r) || !a16(g_i) || !a16(z_r) || !a16(z_i) || !a16(x_r) || !a16(x_i) || !a16(dy_r) || !a16(dy_i) || !a16(ws))
+    return CPLXAMD_EALIGN;
+  if (!ws || ws_bytes < cplxamd_conv2d_cl_wgrad_ws_bytes(B, H, W, Ci, Co)) return CPLXAMD_EINVAL;
+  clw::Args g{};
+  g.g_r = g_r; g.g_i = g_i; g.x_r = x_r; g.x_i = x_i; g.ws = (float*)ws; g.P = B * H * W;
+  g.z_r = z_r; g.z_i = z_i; g.coef = coef; g.dy_r = dy_r; g.dy_i = dy_i;
+  g.Ho = H + 2 * pad_h - 2 * dil_h; g.Wo = W + 2 * pad_w - 2 * dil_w;
+  g.g_bytes = (uint32_t)(B * g.Ho * g.Wo * Co * 2); g.x_bytes = (uint32_t)(g.P * Ci * 2);
+  g.H = H; g.W = W; g.Co = Co; g.Ci = Ci; g.dil_h = dil_h; g.dil_w = dil_w; g.pad_h = pad_h; g.pad_w = pad_w;
+  g.strips = (W + clw::KR - 1) / clw::KR;
+  g.nstages = (int)(B * H * g.strips);
+  g.tiles_ci = Ci / 64;
+  const int tiles = (Co / 64) * g.tiles_ci;
+  g.splits = clw::plan(g.nstages, tiles, g.per_split, !launch_owns_chip(flags));
+  constexpr int smem = clw::SMEM_FOLD;
+  static PerDeviceOnce attr_set;
+  if (const int e = set_max_dyn_lds(attr_set, clw::conv_cl_wgrad_kernel<true>, smem)) return e;
+  clw::conv_cl_wgrad_kernel<true><<<dim3((unsigned)g.splits, (unsigned)tiles), clw::NT, smem, st>>>(g);
+  CPLXAMD_CHECK_LAUNCH();
+  clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, Co, Ci,
+                                                                                   nullptr, dw_r, dw_i);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+#endif
 
 }  // extern "C"

@@ -131,6 +131,22 @@ def colsum_hint(t):
     return None
 
 
+def attach_wgrad(tr, ti, dw):
+    """Remember on the two planes of a convolution's output gradient that `dw` = (dW_r, dW_i) is the weight gradient of
+    exactly these planes against the input of the convolution whose autograd node is `node` (bn.py: the batch-norm
+    backward that formed the planes inside the weight-gradient kernel).  Validated on use like attach_colsum."""
+    tr._cplxamd_wgrad = (dw, tr.data_ptr(), tr._version, ti.data_ptr(), ti._version, tuple(tr.shape))
+
+
+def wgrad_hint(tr, ti, node):
+    """(dW_r, dW_i) attach_wgrad left for exactly this pair of planes and this convolution node, or None."""
+    h = getattr(tr, "_cplxamd_wgrad", None)
+    if (h is not None and h[1] == tr.data_ptr() and h[2] == tr._version and h[3] == ti.data_ptr() and h[4] == ti._version
+            and h[5] == tuple(tr.shape) == tuple(ti.shape) and h[0][2] is node):
+        return h[0][0], h[0][1]
+    return None
+
+
 def attach_moments(tr, ti, partials, chunks):
     """Remember on the two planes of a convolution output that `partials` ([chunks][C][5] float64) holds the batch-norm
     forward moments of exactly these tensors (conv.cl_conv, csrc/conv_cl2.hip MOM epilogue): the batch-norm layer that

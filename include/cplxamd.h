@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CPLXAMD_ABI_VERSION 23
+#define CPLXAMD_ABI_VERSION 24
 
 /* element types of activations / outputs */
 enum { CPLXAMD_F32 = 0, CPLXAMD_BF16 = 1,
@@ -710,6 +710,31 @@ int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const vo
                         void* dxi, int64_t B, int F, int64_t S, const float* weight,
                         const float* saved, float* dweight, float* dbias, int training, int dtype,
                         float* dx_sums, void* ws, int64_t ws_bytes, void* stream);
+
+/* ABI 24: the backward of a batch-norm layer that directly follows a channels-last 3 x 3 convolution, WITHOUT its apply
+ * pass (nn/modules/batchnorm.py:189-278 under autograd followed by the autograd of cplx.py:717-838).  The layer's input
+ * gradient is dX = E g + C (x - mu) - k with per-channel 2 x 2 real matrices E, C and constants k:
+ *   cplxamd_bn_bwd_coef            sums + finalize of cplxamd_bn_bwd (dweight, dbias as there) and coef[F][12] float32 =
+ *                                  (mu mv | e00 e01 e10 e11 | cuu cuv cvv | ku kv | pad); no dX is written.  dx_sums (may be
+ *                                  NULL): float32 [2][F], the per-feature sums of dX over all rows -- the bias gradient of the
+ *                                  layer that produced x -- from the sums this pass has anyway: E sum(g) - count k (the C term
+ *                                  sums to zero against the batch mean and C = 0 in evaluation mode; in training mode the
+ *                                  whole expression is zero up to rounding, which is what the reference's float32 sum of dX
+ *                                  gives too);
+ *   cplxamd_conv2d_cl_wgrad_bn_fl  the convolution's weight gradient, which forms dX tile by tile on the way into its
+ *                                  LDS stages (bn_apply's arithmetic with the means multiplied out: the same bf16 values
+ *                                  up to one rounding step in a few elements), multiplies it against x, and also stores it
+ *                                  (dy_r / dy_i: the data gradient reads it next).  g, z (= the batch-norm layer's input =
+ *                                  the convolution's output), dy: [B][Ho][Wo][Co] bf16 channels-last planes; x:
+ *                                  [B][H][W][Ci]; shapes and ws as cplxamd_conv2d_cl_wgrad.
+ * Against cplxamd_bn_bwd_sums + cplxamd_conv2d_cl_wgrad_fl: one pass over 6 planes less (4 read, 2 written). */
+int cplxamd_bn_bwd_coef(const void* gr, const void* gi, const void* xr, const void* xi, int64_t B, int F, int64_t S,
+                        const float* weight, const float* saved, float* dweight, float* dbias, int training, int dtype,
+                        float* coef, float* dx_sums, void* ws, int64_t ws_bytes, void* stream);
+int cplxamd_conv2d_cl_wgrad_bn_fl(const void* g_r, const void* g_i, const void* z_r, const void* z_i, const float* coef,
+                                  const void* x_r, const void* x_i, void* dy_r, void* dy_i, float* dw_r, float* dw_i,
+                                  int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
+                                  int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream);
 
 /* Batch statistics shared between data-parallel ranks ("optional SyncBN"; the reference normalises
  * with the statistics of the local batch only, nn/modules/batchnorm.py:70-99).  A pass is split around ONE

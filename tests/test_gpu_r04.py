@@ -302,10 +302,15 @@ def test_conv_batchnorm_pair_uses_the_epilogue_moments():
         np.testing.assert_allclose(N(fused[2][k].float()), N(plain[2][k].float()), rtol=2e-5, atol=2e-6, err_msg=k)
     for k in plain[3]:
         r = N(plain[3][k])
-        # (the bias of a convolution in front of a batch-norm layer has a zero gradient in exact arithmetic: what both runs
-        #  report is the sum of the bf16 rounding of dX over 17 280 pixels, which a handful of flipped last bits moves)
-        tol = 5e-2 if k.startswith("0.bias") else 2e-3
-        np.testing.assert_allclose(N(fused[3][k]), r, rtol=0, atol=tol * np.abs(r).max(), err_msg=k)
+        if k.startswith("0.bias"):
+            # the bias of a convolution in front of a batch-norm layer has a zero gradient in exact arithmetic.  The plain
+            # run reports the sum of the bf16 rounding of dX over 17 280 pixels (the layer's own apply pass sums what it
+            # stores); the armed pair takes the round-6 path in which the apply runs inside the weight-gradient launch and
+            # the sum comes from the reduce pass analytically, E sum(g) - N k = 0 up to float64 rounding
+            # (tests/test_gpu_bn_fold.py): nothing to compare but the size of the noise
+            assert np.abs(N(fused[3][k])).max() <= 1.5 * max(np.abs(r).max(), 1e-6), k
+            continue
+        np.testing.assert_allclose(N(fused[3][k]), r, rtol=0, atol=2e-3 * np.abs(r).max(), err_msg=k)
     # evaluation mode takes the request back
     net.eval()
     net(x)
