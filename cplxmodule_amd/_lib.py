@@ -154,6 +154,7 @@ SIGNATURES = {
     "cplxamd_expi_f64": [_P, _P, _L, _P],
     # ABI 22: the channels-last convolutions on IEEE-half pieces (float32 out)
     "cplxamd_conv2d_cl2h_fl": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L] + [_I] * 7 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_cl2h_wrap_fl": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _L] + [_I] * 7 + [_P, _L, _I, _P],
     "cplxamd_conv2d_clh_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
     "cplxamd_conv2d_clh_wgrad": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
     "cplxamd_conv2d_clh_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],

@@ -82,7 +82,7 @@ class CplxBatchNormFn(torch.autograd.Function):
         src = getattr(xr, "_cplxamd_conv_src", None)
         # the backward can hand its apply pass to the weight gradient of the convolution that produced x (conv.bn_fold_node)
         ctx.fold = None
-        if src is not None and xr.requires_grad:
+        if xr.requires_grad and xr.grad_fn is not None:
             from . import conv
             ctx.fold = conv.bn_fold_node(xr, xi)
         xr, xi, (B, F, S), ctx.cl = _prep(xr, xi)

@@ -698,9 +698,13 @@ def _rows(t):
     return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
 
 
+_X2_ONE_LAUNCH = os.environ.get("CPLXAMD_X2_ONE", "1") != "0"    # (A/B: 0 = the two launches of the first x2 form)
+
+
 def _x2_weight_packs(wr, wi, dgrad):
-    """Packed LDS images of the two launches' weights, and the weights' scale: (pack of w1 -- C channels --, pack of
-    [w0|w0] -- 2 C channels --, scale)."""
+    """Packed LDS images of the weights, and the weights' scale.  One launch (the contraction window wraps around the
+    [h1|h0] pixel as [h0|h1|h0]): (None, pack of [w1|w0|w0] -- 3 C channels --, scale); two launches: (pack of w1 -- C
+    channels --, pack of [w0|w0] -- 2 C channels --, scale)."""
     from . import x3
     Co, Ci, KH, KW = wr.shape
     pr, pi = x3.split_planes((wr.reshape(Co, -1), wi.reshape(Co, -1)), kind="x2")          # [Co, 2 Ci 9] = [h1|h0]
@@ -708,6 +712,9 @@ def _x2_weight_packs(wr, wi, dgrad):
     cut = lambda p: (p.t[:, :n].reshape(Co, Ci, KH, KW), p.t[:, n:].reshape(Co, Ci, KH, KW))  # noqa: E731  (w1, w0)
     (w1r, w0r), (w1i, w0i) = cut(pr), cut(pi)
     cat = 0 if dgrad else 1                            # the contraction channels: Co for the data gradient, Ci forward
+    if _X2_ONE_LAUNCH:
+        return None, _cl_pack(torch.cat([w1r, w0r, w0r], cat).contiguous(), torch.cat([w1i, w0i, w0i], cat).contiguous(),
+                              dgrad), pr.scale
     small = _cl_pack(w1r.contiguous(), w1i.contiguous(), dgrad)
     big = _cl_pack(torch.cat([w0r, w0r], cat).contiguous(), torch.cat([w0i, w0i], cat).contiguous(), dgrad)
     return small, big, pr.scale
@@ -738,6 +745,11 @@ def _x2_conv(pieces, wr, wi, br, bi, geom, dgrad):
         xi_ = pi.t[b0 * Hin * Win:]
         o_r = yr.permute(0, 2, 3, 1).reshape(-1)[b0 * opix:]
         o_i = yi.permute(0, 2, 3, 1).reshape(-1)[b0 * opix:]
+        if small is None:
+            # one launch: the window [h0|h1|h0] (starts C channels into the [h1|h0] pixel, wraps) * [w1|w0|w0] (+ bias)
+            call("cplxamd_conv2d_cl2h_wrap_fl", ptr(xr_), ptr(xi_), 2 * C, C, ptr(big), ptr(br), ptr(bi), ptr(o_r), ptr(o_i), 0,
+                 ptr(pr.scale), ptr(wscale), nb, H, W, 3 * C, N, ph, pw, int(dgrad), ptr(ws), ws.numel(), flags, stream_ptr())
+            continue
         # launch 1: h0 (the second half of every row) * w1 (+ bias); launch 2: [h1|h0] * [w0|w0], accumulated
         h0r, h0i = xr_.reshape(-1)[C:], xi_.reshape(-1)[C:]
         call("cplxamd_conv2d_cl2h_fl", ptr(h0r), ptr(h0i), 2 * C, ptr(small), ptr(br), ptr(bi), ptr(o_r), ptr(o_i), 0,
@@ -822,6 +834,7 @@ class CplxConv2dFn(torch.autograd.Function):
         if ctx.x2:
             from . import x3
             xtr, xti, xsc, wr_, wi_ = ctx.saved_tensors
+            hint_r, hint_i = ops.colsum_hint(gr), ops.colsum_hint(gi)      # (a batch-norm backward's column sums of gr / gi)
             gr, gi = (t.contiguous(memory_format=torch.channels_last) for t in (gr, gi))
             gp = x3.split_planes((_rows(gr), _rows(gi)), kind="x2")
             if need[0] or need[1]:
@@ -832,7 +845,8 @@ class CplxConv2dFn(torch.autograd.Function):
                 xp = (x3.Pieces(xtr, "x2", xsc, 2), x3.Pieces(xti, "x2", xsc, 2))
                 dwr, dwi = _x2_conv_wgrad(gp, xp, ctx.geom, ctx.wshape)
             if ctx.has_bias and (need[4] or need[5]):
-                dbr, dbi = ops.colsum(_rows(gr)), ops.colsum(_rows(gi))
+                dbr = hint_r if hint_r is not None else ops.colsum(_rows(gr))
+                dbi = hint_i if hint_i is not None else ops.colsum(_rows(gi))
             return dxr, dxi, dwr, dwi, dbr, dbi, None, None, None, None, None
         xr, xi, wcr, wci = ctx.saved_tensors
         if ctx.cl:

@@ -60,6 +60,7 @@ struct Args {
   int C16, NS, tiles_x, tiles_y, tiles_n;
 #ifdef CPLXAMD_CONV_F16     // the half-operand build (conv_cl2_f16.hip): float32 output, see epilogue_f32
   int pitch;                                  // channels between two pixels of x (>= C: a channel window of wider planes)
+  int cs0, p16;                               // 16-channel slice s of the contraction is slice (cs0 + s) mod p16 of a pixel
   int accumulate;                             // y += result
   const float* scale_a; const float* scale_b; // device {s, 1 / s} of the two operands (nullptr: no scaling)
 #endif
@@ -197,6 +198,10 @@ __global__ __launch_bounds__(NT) void conv_cl2_kernel(Args g) {
     int cc = c_cs + delta;
     const bool nx = cc >= g.C16;
     cc -= nx ? g.C16 : 0;
+#ifdef CPLXAMD_CONV_F16     // (a window that wraps around the pixel: [h0 | h1 | h0] of rows stored [h1 | h0])
+    cc += g.cs0;
+    cc -= cc >= g.p16 ? g.p16 : 0;
+#endif
     const uint32_t voff = (nx ? voa_n[q] : voa_c[q]) + (uint32_t)cc * 32u;
     const uint32_t dst = smem_off + (uint32_t)(aslot * A_SLOT + q * 8192) + wave_lds;
     if ((uint32_t)(q * 8) + wid_u < 20u) buf_lds16(rs_xr, voff, 0u, dst);
@@ -735,16 +740,42 @@ static bool cl2_mom_tiling_ok(int64_t ntiles, int grid, int tiles_n) {
 
 #ifdef CPLXAMD_CONV_F16
 // The half-operand build: cplxamd_conv2d_cl2 on IEEE-half planes with float32 output (include/cplxamd.h).
+static int launch_cl2h(const void* x_r, const void* x_i, int pitch, int c_start, const void* w_packed, const float* bias_r,
+                       const float* bias_i, float* y_r, float* y_i, int accumulate, const float* scale_a,
+                       const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h, int pad_w, int mode, void* ws,
+                       int64_t ws_bytes, int flags, void* stream);
+
 int cplxamd_conv2d_cl2h_fl(const void* x_r, const void* x_i, int pitch, const void* w_packed, const float* bias_r,
                            const float* bias_i, float* y_r, float* y_i, int accumulate, const float* scale_a,
                            const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h, int pad_w, int mode, void* ws,
                            int64_t ws_bytes, int flags, void* stream) {
+  return launch_cl2h(x_r, x_i, pitch, -1, w_packed, bias_r, bias_i, y_r, y_i, accumulate, scale_a, scale_b, B, H, W, C, N, pad_h,
+                     pad_w, mode, ws, ws_bytes, flags, stream);
+}
+
+// The same with a contraction window that WRAPS around the pixel: channel j of the contraction is channel
+// (c_start + j) mod pitch of the pixel, C <= 2 pitch - c_start.  With rows stored [h1 | h0] (pitch = 2 c), c_start = c and
+// C = 3 c read [h0 | h1 | h0]: against weights packed [w1 | w0 | w0] that is all three piece products of a float32
+// convolution in ONE launch (one float32 epilogue, no accumulate pass).
+int cplxamd_conv2d_cl2h_wrap_fl(const void* x_r, const void* x_i, int pitch, int c_start, const void* w_packed,
+                                const float* bias_r, const float* bias_i, float* y_r, float* y_i, int accumulate,
+                                const float* scale_a, const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h,
+                                int pad_w, int mode, void* ws, int64_t ws_bytes, int flags, void* stream) {
+  if (c_start < 0 || c_start >= pitch || c_start % 16 || pitch % 16 || C + c_start > 2 * pitch) return CPLXAMD_ESHAPE;
+  return launch_cl2h(x_r, x_i, pitch, c_start, w_packed, bias_r, bias_i, y_r, y_i, accumulate, scale_a, scale_b, B, H, W, C, N,
+                     pad_h, pad_w, mode, ws, ws_bytes, flags, stream);
+}
+
+static int launch_cl2h(const void* x_r, const void* x_i, int pitch, int c_start, const void* w_packed, const float* bias_r,
+                       const float* bias_i, float* y_r, float* y_i, int accumulate, const float* scale_a,
+                       const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h, int pad_w, int mode, void* ws,
+                       int64_t ws_bytes, int flags, void* stream) {
   if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
   if (!x_r || !x_i || !w_packed || !y_r || !y_i || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || pad_h < 0 || pad_w < 0 ||
       (bias_r == nullptr) != (bias_i == nullptr) || (mode != 0 && mode != 1) || (scale_a == nullptr) != (scale_b == nullptr))
     return CPLXAMD_EINVAL;
   const int Hs = H + 2 * pad_h - 2, Ws = W + 2 * pad_w - 2;           // the smaller image
-  if (C % 32 || N % 64 || pitch < C || pitch % 8 || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W) return CPLXAMD_ESHAPE;
+  if (C % 32 || N % 64 || (c_start < 0 && pitch < C) || pitch % 8 || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W) return CPLXAMD_ESHAPE;
   if (B == 0) return 0;
   cl2::Args g{};
   g.Hi = mode ? Hs : H; g.Wi = mode ? Ws : W; g.Ho = mode ? H : Hs; g.Wo = mode ? W : Ws;
@@ -756,7 +787,9 @@ int cplxamd_conv2d_cl2h_fl(const void* x_r, const void* x_i, int pitch, const vo
   g.x_r = x_r; g.x_i = x_i; g.w = w_packed; g.bias_r = bias_r; g.bias_i = bias_i; g.y_r = y_r; g.y_i = y_i; g.dump = ws;
   g.B = (int)B;
   g.pad_h = mode ? 2 - pad_h : pad_h; g.pad_w = mode ? 2 - pad_w : pad_w;
-  g.x_bytes = (uint32_t)(B * g.Hi * g.Wi * pitch * 2 - (pitch - C) * 2);     // (the window ends C channels into the last pixel)
+  g.x_bytes = c_start >= 0 ? (uint32_t)(B * g.Hi * g.Wi * pitch * 2)          // (a wrapping window stays inside its pixel)
+                           : (uint32_t)(B * g.Hi * g.Wi * pitch * 2 - (pitch - C) * 2);     // (the window ends C channels into the last pixel)
+  g.cs0 = c_start >= 0 ? c_start / 16 : 0; g.p16 = c_start >= 0 ? pitch / 16 : 0x7fffffff;
   g.w_bytes = (uint32_t)cplxamd_conv2d_cl_pack_bytes(N, C, 3, 3);
   g.C = C; g.Cout = N; g.C16 = C / 16; g.NS = 3 * g.C16;
   g.pitch = pitch; g.accumulate = accumulate ? 1 : 0; g.scale_a = scale_a; g.scale_b = scale_b;

@@ -436,6 +436,14 @@ int cplxamd_conv2d_cl2h_fl(const void* x_r, const void* x_i, int pitch, const vo
                            const float* bias_i, float* y_r, float* y_i, int accumulate, const float* scale_a,
                            const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h, int pad_w, int mode, void* ws,
                            int64_t ws_bytes, int flags, void* stream);
+/* ABI 24: the same with a contraction window that WRAPS around the pixel -- channel j of the contraction is channel
+ * (c_start + j) mod pitch of the pixel (c_start, pitch multiples of 16; C + c_start <= 2 pitch).  Rows stored [h1 | h0]
+ * (pitch = 2 c) read with c_start = c, C = 3 c give [h0 | h1 | h0]; against weights packed [w1 | w0 | w0] that is all three
+ * piece products of a float32 convolution in ONE launch (one float32 epilogue instead of two, no accumulate pass). */
+int cplxamd_conv2d_cl2h_wrap_fl(const void* x_r, const void* x_i, int pitch, int c_start, const void* w_packed,
+                                const float* bias_r, const float* bias_i, float* y_r, float* y_i, int accumulate,
+                                const float* scale_a, const float* scale_b, int64_t B, int H, int W, int C, int N, int pad_h,
+                                int pad_w, int mode, void* ws, int64_t ws_bytes, int flags, void* stream);
 int64_t cplxamd_conv2d_clh_wgrad_ws_bytes(int64_t B, int H, int W, int Ci, int Co);
 int cplxamd_conv2d_clh_wgrad(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                              float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
