@@ -158,6 +158,7 @@ SIGNATURES = {
     "cplxamd_conv2d_clh_wgrad_ws_bytes": [_L, _I, _I, _I, _I],
     "cplxamd_conv2d_clh_wgrad": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P],
     "cplxamd_conv2d_clh_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
+    "cplxamd_conv2d_clh_wgrad_skip_fl": [_P, _P, _P, _P, _P, _P, _L] + [_I] * 12 + [_P, _L, _I, _P],
     "cplxamd_conv2d_clr_fl": [_P, _P, _P, _P, _L] + [_I] * 11 + [_P, _L, _I, _P],
     "cplxamd_conv2d_clr_wgrad_fl": [_P, _P, _P, _I, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
     "cplxamd_bn_moments": [_P, _P, _P, _P, _P, _L, _I, _L, _I, _P, _P, _L, _P],

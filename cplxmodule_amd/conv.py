@@ -777,8 +777,11 @@ def _x2_conv_wgrad(gp, xp, geom, w_shape):
         dwi = torch.empty_like(dwr)
         g_r, g_i = gp[0].t[b0 * Ho * Wo:], gp[1].t[b0 * Ho * Wo:]
         x_r, x_i = xp[0].t[b0 * H * W:], xp[1].t[b0 * H * W:]
-        call("cplxamd_conv2d_clh_wgrad_fl", ptr(g_r), ptr(g_i), ptr(x_r), ptr(x_i), None, ptr(dwr), ptr(dwi), nb, H, W, 2 * Ci,
-             2 * Co, KH, KW, 1, 1, ph, pw, ptr(ws), ws.numel(), flags, stream_ptr())
+        # (the block g1 x1 -- rows < Co, columns < Ci -- is none of the three piece products: not computed, not read below)
+        call("cplxamd_conv2d_clh_wgrad_skip_fl", ptr(g_r), ptr(g_i), ptr(x_r), ptr(x_i), ptr(dwr), ptr(dwi), nb, H, W, 2 * Ci,
+             2 * Co, KH, KW, 1, 1, ph, pw, Co, Ci, ptr(ws), ws.numel(), flags, stream_ptr())
+        dwr[:Co, :Ci] = 0
+        dwi[:Co, :Ci] = 0
         tot_r, tot_i = (dwr, dwi) if tot_r is None else (tot_r + dwr, tot_i + dwi)
     alpha = gp[0].scale[1] * xp[0].scale[1]
     pick = lambda t: ((t[Co:, :Ci] + t[:Co, Ci:]) + t[Co:, Ci:]) * alpha  # noqa: E731  (g0 x1) + (g1 x0) + (g0 x0)

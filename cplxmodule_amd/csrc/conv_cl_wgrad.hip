@@ -66,6 +66,7 @@ struct Args {
   int Ho, Wo;                                        // the output image (<= H x W, top-left aligned on the grid)
   int strips;                                        // stages per image row: ceil(W / 32)
   int nstages, per_split, splits, tiles_ci;
+  int sk_co, sk_ci;                                  // tiles (co tile < sk_co, ci tile < sk_ci) are not computed (grid y is compact)
   // FOLD: G = A g + B (z - mu) - k per output channel (bn.hip's backward apply) is formed on the way into the LDS
   const void* z_r; const void* z_i;                // [P][Co] bf16: the batch-norm layer's input = the convolution's output
   const float* coef;                               // [Co][kBnBwdCoef] (bn_bwd_finalize)
@@ -134,7 +135,14 @@ __device__ __forceinline__ bf16x8 neg(bf16x8 v) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
-// grid: x = split, y = co tile * tiles_ci + ci tile
+// compact tile index -> (co tile, ci tile) when the rectangle (co tile < sk_co, ci tile < sk_ci) is left out
+__device__ __forceinline__ void tile_of(int v, int tiles_ci, int sk_co, int sk_ci, int& tco, int& tci) {
+  const int head = sk_co * (tiles_ci - sk_ci);
+  if (v < head) { tco = v / (tiles_ci - sk_ci); tci = sk_ci + v - tco * (tiles_ci - sk_ci); }
+  else { v -= head; tco = v / tiles_ci; tci = v - tco * tiles_ci; tco += sk_co; }
+}
+
+// grid: x = split, y = the tiles, co tile major (tile_of)
 //
 // FOLD: G is not in memory yet -- it is the input gradient of the batch-norm layer that consumed this convolution's output
 // z, G = E g + C (z - mu) - k per output channel (the 2 x 2 real matrices and constants bn_bwd_finalize leaves in `coef`;
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lk = lane >> 5, l15 = lane & 15, lg = (lane >> 4) & 1;
   const int split = blockIdx.x;
-  const int tco = blockIdx.y / g.tiles_ci, tci = blockIdx.y - tco * g.tiles_ci;
+  int tco, tci;
+  tile_of((int)blockIdx.y, g.tiles_ci, g.sk_co, g.sk_ci, tco, tci);
   const int co0 = tco * TC, ci0 = tci * TC;
   const uint32_t wid_u = (uint32_t)__builtin_amdgcn_readfirstlane(wid);
 
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(NT) void conv_cl_wgrad_kernel(Args g) {
 // emul if given.  64 consecutive SLAB elements x 4 split lanes per block (consecutive threads read consecutive
 // addresses of a split; lane s sums splits s, s + 4, ... in a fixed order, then the four are added in order): the
 // 4-byte writes into dW are scattered but few.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int splits, int tiles, int tiles_ci, int Co,
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int splits, int tiles, int tiles_ci, int sk_co, int sk_ci, int Co,
                                                            int Ci, const float* emul, float* dw_r, float* dw_i) {
   __shared__ float red[4][64];
   const int tile = blockIdx.y;
@@ -571,7 +580,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
   __syncthreads();
   if (ty != 0) return;
   const float acc = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-  const int co = (tile / tiles_ci) * TC + coh * 32 + col, ci = (tile % tiles_ci) * TC + cih * 32 + cil;
+  int tco, tci;
+  tile_of(tile, tiles_ci, sk_co, sk_ci, tco, tci);
+  const int co = tco * TC + coh * 32 + col, ci = tci * TC + cih * 32 + cil;
   const int64_t i = ((int64_t)co * Ci + ci) * 9 + tap;
   float* dw = pl ? dw_i : dw_r;
   dw[i] = emul ? acc * emul[i] : acc;
@@ -626,9 +637,35 @@ int cplxamd_conv2d_cl_wgrad(const void* g_r, const void* g_i, const void* x_r, c
                                     ws_bytes, CPLXAMD_LAUNCH_DEFAULT, stream);
 }
 
+static int launch_clw(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul, float* dw_r,
+                      float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
+                      int pad_w, int skip_co, int skip_ci, void* ws, int64_t ws_bytes, int flags, void* stream);
+
 int cplxamd_conv2d_cl_wgrad_fl(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                                float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
                                int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream) {
+  return launch_clw(g_r, g_i, x_r, x_i, emul, dw_r, dw_i, B, H, W, Ci, Co, KH, KW, dil_h, dil_w, pad_h, pad_w, 0, 0, ws, ws_bytes,
+                    flags, stream);
+}
+
+#ifdef CPLXAMD_CONV_F16
+// The same without the block dW[0:skip_co, 0:skip_ci] (multiples of 64; those entries of dw are left untouched): with
+// G = [g1|g0] and X = [x1|x0] and skip = (Co, Ci) the product g1 x1 -- 2^-22 of the result, not part of the three piece
+// products -- is not computed: 3 of 4 tiles.
+int cplxamd_conv2d_clh_wgrad_skip_fl(const void* g_r, const void* g_i, const void* x_r, const void* x_i, float* dw_r, float* dw_i,
+                                     int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
+                                     int pad_w, int skip_co, int skip_ci, void* ws, int64_t ws_bytes, int flags, void* stream) {
+  if (skip_co < 0 || skip_ci < 0 || skip_co % 64 || skip_ci % 64 || skip_co > Co || skip_ci > Ci ||
+      (skip_co == Co && skip_ci == Ci) || (skip_co == 0) != (skip_ci == 0))
+    return CPLXAMD_EINVAL;
+  return launch_clw(g_r, g_i, x_r, x_i, nullptr, dw_r, dw_i, B, H, W, Ci, Co, KH, KW, dil_h, dil_w, pad_h, pad_w, skip_co,
+                    skip_ci, ws, ws_bytes, flags, stream);
+}
+#endif
+
+static int launch_clw(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul, float* dw_r,
+                      float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
+                      int pad_w, int skip_co, int skip_ci, void* ws, int64_t ws_bytes, int flags, void* stream) {
   if (!launch_flags_ok(flags)) return CPLXAMD_EINVAL;
   if (!g_r || !g_i || !x_r || !x_i || !dw_r || !dw_i || B < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return CPLXAMD_EINVAL;
   if (!clw_shape_ok(B, H, W, Ci, Co, KH, KW, dil_h, dil_w, pad_h, pad_w)) return CPLXAMD_ESHAPE;
@@ -650,15 +687,19 @@ int cplxamd_conv2d_cl_wgrad_fl(const void* g_r, const void* g_i, const void* x_r
   g.strips = (W + clw::KR - 1) / clw::KR;
   g.nstages = (int)(B * H * g.strips);
   g.tiles_ci = Ci / 64;
-  const int tiles = (Co / 64) * g.tiles_ci;
+  g.sk_co = skip_co / 64; g.sk_ci = skip_ci / 64;
+  const int tiles = (Co / 64) * g.tiles_ci - g.sk_co * g.sk_ci;
+  // (fewer tiles, more splits each: never more slabs than the workspace of the full tile count holds -- plan() rounds the
+  //  split count down to whole workgroups per tile)
   g.splits = clw::plan(g.nstages, tiles, g.per_split, !launch_owns_chip(flags));
+  if ((int64_t)g.splits * tiles * clw::NBLK * 2048 * 4 > ws_bytes) return CPLXAMD_EWS;
   constexpr int smem = 3 * clw::STAGE;
   static PerDeviceOnce attr_set;
   if (const int e = set_max_dyn_lds(attr_set, clw::conv_cl_wgrad_kernel<false>, smem)) return e;
   clw::conv_cl_wgrad_kernel<false><<<dim3((unsigned)g.splits, (unsigned)tiles), clw::NT, smem, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
-  clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, Co, Ci,
-                                                                                   emul, dw_r, dw_i);
+  clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, g.sk_co,
+                                                                                   g.sk_ci, Co, Ci, emul, dw_r, dw_i);
   CPLXAMD_CHECK_LAUNCH();
   return 0;
 }
@@ -700,7 +741,7 @@ int cplxamd_conv2d_cl_wgrad_bn_fl(const void* g_r, const void* g_i, const void* 
   if (const int e = set_max_dyn_lds(attr_set, clw::conv_cl_wgrad_kernel<true>, smem)) return e;
   clw::conv_cl_wgrad_kernel<true><<<dim3((unsigned)g.splits, (unsigned)tiles), clw::NT, smem, st>>>(g);
   CPLXAMD_CHECK_LAUNCH();
-  clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, Co, Ci,
+  clw::wgrad_reduce_kernel<<<dim3(36 * 2048 / 64, (unsigned)tiles), 256, 0, st>>>(g.ws, g.splits, tiles, g.tiles_ci, 0, 0, Co, Ci,
                                                                                    nullptr, dw_r, dw_i);
   CPLXAMD_CHECK_LAUNCH();
   return 0;

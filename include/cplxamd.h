@@ -451,6 +451,12 @@ int cplxamd_conv2d_clh_wgrad(const void* g_r, const void* g_i, const void* x_r, 
 int cplxamd_conv2d_clh_wgrad_fl(const void* g_r, const void* g_i, const void* x_r, const void* x_i, const float* emul,
                                 float* dw_r, float* dw_i, int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h,
                                 int dil_w, int pad_h, int pad_w, void* ws, int64_t ws_bytes, int flags, void* stream);
+/* ABI 24: the same without the block dW[0:skip_co, 0:skip_ci] (multiples of 64, both zero or both positive; those entries of
+ * dw are left untouched): with G = [g1|g0], X = [x1|x0] and skip = (Co, Ci) the product g1 x1 -- 2^-22 of the result, not
+ * one of the three piece products -- is not computed (3 of 4 tiles). */
+int cplxamd_conv2d_clh_wgrad_skip_fl(const void* g_r, const void* g_i, const void* x_r, const void* x_i, float* dw_r, float* dw_i,
+                                     int64_t B, int H, int W, int Ci, int Co, int KH, int KW, int dil_h, int dil_w, int pad_h,
+                                     int pad_w, int skip_co, int skip_ci, void* ws, int64_t ws_bytes, int flags, void* stream);
 /* out[c, r] = in[r, c]  (rows x cols row-major in, ld = leading dims) */
 int cplxamd_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
                       int cols, int dtype, void* stream);
