@@ -18,8 +18,8 @@ constexpr int kSaved = 8;    // per-feature saved stats: mu, mv, p, q, w, vuu, v
 constexpr int kFwdCoef = 8;  // mu, mv, a00, a01, a10, a11, b0, b1
 constexpr int kBwdCoef = kBnBwdCoef; // mu, mv, e00, e01, e10, e11, cuu, cuv, cvv, ku, kv, pad
 
-// The channels-last row kernels stream planes of gigabytes, every byte touched once per pass: nontemporal accesses
-// (bit 0: stores, bit 1: loads), as in kl.hip.
+// The channels-last row kernels stream planes of gigabytes, every byte touched once per pass: nontemporal accesses for
+// the bf16 planes (bit 0: stores, bit 1: loads), as in kl.hip: forward -4 %, backward -4 % same box.
 #ifndef BN_NT
 #define BN_NT 3
 #endif
@@ -39,15 +39,8 @@ __device__ __forceinline__ f8 ld8s(const bf16_t* p) {
   return ld8(p);
 #endif
 }
-__device__ __forceinline__ f8 ld8s(const float* p) {
-#if BN_NT & 2
-  const f32x4_nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
-  const f32x4_nt b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p + 4));
-  return f8{{f4{{a[0], a[1], a[2], a[3]}}, f4{{b[0], b[1], b[2], b[3]}}}};
-#else
-  return ld8(p);
-#endif
-}
+// (float32 planes: plain accesses -- nontemporal ones cost the backward 25 % on the same box, scripts/r06/bn_nt_ab.py)
+__device__ __forceinline__ f8 ld8s(const float* p) { return ld8(p); }
 __device__ __forceinline__ void st8s(bf16_t* p, const f8& a) {
 #if BN_NT & 1
   u32x4_nt w;
@@ -58,14 +51,7 @@ __device__ __forceinline__ void st8s(bf16_t* p, const f8& a) {
   st8(p, a);
 #endif
 }
-__device__ __forceinline__ void st8s(float* p, const f8& a) {
-#if BN_NT & 1
-  __builtin_nontemporal_store(f32x4_nt{a.h[0].v[0], a.h[0].v[1], a.h[0].v[2], a.h[0].v[3]}, reinterpret_cast<f32x4_nt*>(p));
-  __builtin_nontemporal_store(f32x4_nt{a.h[1].v[0], a.h[1].v[1], a.h[1].v[2], a.h[1].v[3]}, reinterpret_cast<f32x4_nt*>(p + 4));
-#else
-  st8(p, a);
-#endif
-}
+__device__ __forceinline__ void st8s(float* p, const f8& a) { st8(p, a); }
 
 struct BnGeom {
   int64_t B, S;

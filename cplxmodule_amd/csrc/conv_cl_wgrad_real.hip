@@ -35,6 +35,7 @@ struct Args {
   int Ho, Wo;                                        // the output image (<= H x W, top-left aligned on the grid)
   int strips;                                        // stages per image row: ceil(W / 32)
   int nstages, per_split, splits, tiles_ci;
+  int walk;                                          // stage order: 0 = along image rows, 1 = down image columns (conv_cl_wgrad.hip)
 };
 
 __device__ __forceinline__ void buf_lds16(i32x4 rsrc, uint32_t voff, uint32_t lds_off_uniform) {
@@ -152,7 +153,13 @@ __global__ __launch_bounds__(NT) void conv_clr_wgrad_kernel(Args g) {
   // pixels have no G: out of range, zeros)
   uint32_t d_q0;                                     // first pixel of the stage at the pointer
   int d_w0, d_h, d_b;
-  {
+  if (g.walk) {                                      // t = (b strips + strip) H + h
+    const uint32_t col = (uint32_t)t0 / (uint32_t)g.H;
+    d_h = (int)((uint32_t)t0 - col * (uint32_t)g.H);
+    d_b = (int)(col / (uint32_t)g.strips);
+    d_w0 = (int)(col - (uint32_t)d_b * (uint32_t)g.strips) * KR;
+    d_q0 = ((uint32_t)d_b * (uint32_t)g.H + (uint32_t)d_h) * (uint32_t)g.W + (uint32_t)d_w0;
+  } else {                                           // t = (b H + h) strips + strip
     const uint32_t row = (uint32_t)t0 / (uint32_t)g.strips;
     d_w0 = (int)((uint32_t)t0 - row * (uint32_t)g.strips) * KR;
     d_b = (int)(row / (uint32_t)g.H);
@@ -181,7 +188,16 @@ __global__ __launch_bounds__(NT) void conv_clr_wgrad_kernel(Args g) {
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {
-    ++d_t; d_q0 += KR; d_w0 += KR;
+    ++d_t;
+    if (g.walk) {
+      ++d_h; d_q0 += (uint32_t)g.W;
+      if (d_h == g.H) {
+        d_h = 0; d_w0 += KR; d_q0 += (uint32_t)KR - (uint32_t)g.H * (uint32_t)g.W;
+        if (d_w0 >= g.W) { d_w0 = 0; ++d_b; d_q0 = (uint32_t)d_b * (uint32_t)g.H * (uint32_t)g.W; }
+      }
+      return;
+    }
+    d_q0 += KR; d_w0 += KR;
     if (d_w0 >= g.W) { d_q0 -= (uint32_t)(d_w0 - g.W); d_w0 = 0; if (++d_h == g.H) { d_h = 0; ++d_b; } }
   };
 
@@ -392,6 +408,10 @@ int cplxamd_conv2d_clr_wgrad_fl(const void* g_, const void* x, const float* emul
   g.tiles_ci = Ci / 64;
   const int tiles = (Co / 64) * g.tiles_ci;
   g.splits = clwr::plan(g.nstages, tiles, g.per_split, !launch_owns_chip(flags));
+  {
+    static const int w = [] { const char* e = getenv("CPLXAMD_CLW_WALK"); return e ? (atoi(e) != 0) : 1; }();
+    g.walk = w;
+  }
   constexpr int smem = 3 * clwr::STAGE;
   static PerDeviceOnce attr_set;
   if (const int e = set_max_dyn_lds(attr_set, clwr::conv_clr_wgrad_kernel, smem)) return e;

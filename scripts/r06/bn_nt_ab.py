@@ -12,7 +12,8 @@ if os.environ.get("CPLXAMD_LIB"):
     _lib.LIB_PATH = os.environ["CPLXAMD_LIB"]
 dev = "cuda"
 bn = nn.CplxBatchNorm2d(64).to(dev)
-mk = lambda: (torch.randn(256, 64, 254, 254, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)  # noqa: E731
+DT = torch.float32 if os.environ.get("DT") == "f32" else torch.bfloat16
+mk = lambda: (torch.randn(256, 64, 254, 254, device=dev).to(DT).contiguous(memory_format=torch.channels_last)  # noqa: E731
               .requires_grad_(True))
 x = Cplx(mk(), mk())
 g = (mk().detach(), mk().detach())
