@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 dev = "cuda"
 
 
-def _pair(B, Ci, Co, H, W, pad, seed=0):
+def _pair(B, Ci, Co, H, W, pad, seed=0, dilation=1):
     from cplxmodule_amd import Cplx, nn
     torch.manual_seed(seed)
-    layer, bn = nn.CplxConv2d(Ci, Co, 3, padding=pad).to(dev), nn.CplxBatchNorm2d(Co).to(dev)
+    layer, bn = nn.CplxConv2d(Ci, Co, 3, padding=pad, dilation=dilation).to(dev), nn.CplxBatchNorm2d(Co).to(dev)
     with torch.no_grad():
         bn.weight.add_(0.3 * torch.randn_like(bn.weight)); bn.bias.add_(0.3 * torch.randn_like(bn.bias))
     mk = lambda: (torch.randn(B, Ci, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)  # noqa: E731
@@ -171,3 +171,31 @@ def test_no_hand_over_when_the_convolution_output_has_another_consumer(force_cl)
     for u, v in zip(res[False], res[True]):
         assert float((u.float() - v.float()).abs().max()) <= 8e-3 * float(u.float().abs().max())
     del Cplx
+
+
+def test_fold_with_dilation_and_with_a_frozen_weight(force_cl):
+    """Dilation 2 (the row kernel's geometry: the weight-gradient windows are 36 rows wide) takes the folded launch too; a
+    convolution whose weight does not ask for a gradient has no weight-gradient launch to fold into and keeps the layer's
+    own apply pass."""
+    cv = force_cl
+    res = {}
+    for fold in (False, True):
+        cv._BN_FOLD = fold
+        layer, bn, x = _pair(2, 64, 64, 48, 64, 2, seed=7, dilation=2)
+        torch.manual_seed(8)
+        g = tuple(torch.randn(2, 64, 48, 64, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(2))
+        res[fold] = _grads(layer, bn, x, g)
+    for i, (u, v) in enumerate(zip(res[False][:4], res[True][:4])):
+        assert float((u.float() - v.float()).abs().max()) <= (8e-3 if i < 2 else 3e-4) * float(u.float().abs().max()), i
+    cv._BN_FOLD = True
+    calls = []
+    real = cv.cl_wgrad_bn
+    cv.cl_wgrad_bn = lambda *a, **k: (calls.append(real(*a, **k)), calls[-1])[1]
+    try:
+        layer, bn, x = _pair(2, 64, 64, 64, 64, 1, seed=9)
+        layer.weight.real.requires_grad_(False); layer.weight.imag.requires_grad_(False)
+        y = bn(layer(x))
+        torch.autograd.backward((y.real, y.imag), (torch.ones_like(y.real), torch.ones_like(y.imag)))
+    finally:
+        cv.cl_wgrad_bn = real
+    assert calls == [None] and x.real.grad is not None and layer.weight.real.grad is None
