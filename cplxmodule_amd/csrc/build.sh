@@ -10,7 +10,9 @@ pids=()
 for f in *.hip; do
   o=build/${f%.hip}.o
   stale=0
-  for h in "$f" *.h ../../include/cplxamd.h; do
+  # (the half-operand translation units are wrappers that #include a .hip source: that source is a dependency too)
+  inc=$(sed -n 's/^#include "\(.*\.hip\)".*/\1/p' "$f")
+  for h in "$f" $inc *.h ../../include/cplxamd.h; do
     if [ ! -f "$o" ] || [ "$h" -nt "$o" ]; then stale=1; fi
   done
   if [ $stale = 1 ]; then
