@@ -146,6 +146,8 @@ SIGNATURES = {
     "cplxamd_conv2d_cl2_mom_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _P, _L, _I, _P],
     "cplxamd_conv2d_cl_wgrad_fl": [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P, _L, _I, _P],
     # ABI 24: batch-norm backward without its apply pass + the weight gradient that forms dX while staging it
+    "cplxamd_bn_bwd_sums_amax": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P, _L, _P],
+    "cplxamd_absmax_scale_partials": [_P, _I, _P, _P],
     "cplxamd_bn_bwd_coef": [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P, _L, _P],
     "cplxamd_conv2d_cl_wgrad_bn_fl": [_P] * 11 + [_L] + [_I] * 10 + [_P, _L, _I, _P],
     # ABI 23: float64 contractions (parity mode)

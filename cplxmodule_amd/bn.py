@@ -82,9 +82,11 @@ class CplxBatchNormFn(torch.autograd.Function):
         src = getattr(xr, "_cplxamd_conv_src", None)
         # the backward can hand its apply pass to the weight gradient of the convolution that produced x (conv.bn_fold_node)
         ctx.fold = None
+        ctx.amax = False       # x came out of a float32 convolution on half pieces: its backward wants max |dX| (see backward)
         if xr.requires_grad and xr.grad_fn is not None:
             from . import conv
             ctx.fold = conv.bn_fold_node(xr, xi)
+            ctx.amax = xr.grad_fn is xi.grad_fn and bool(getattr(xr.grad_fn, "x2", False))
         xr, xi, (B, F, S), ctx.cl = _prep(xr, xi)
         yr, yi = torch.empty_like(xr), torch.empty_like(xi)      # (preserve_format: channels-last stays channels-last)
         saved = torch.empty(8, F, dtype=torch.float32, device=xr.device)
@@ -163,6 +165,16 @@ class CplxBatchNormFn(torch.autograd.Function):
             call("cplxamd_bn_bwd_sync", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S, ptr(w),
                  ptr(saved), ptr(dw), ptr(db), dtype_code(xr), ptr(sums), ptr(total), ptr(local), ptr(ctx.count),
                  ptr(ws), ws.numel(), stream_ptr())
+        elif sums is not None and ctx.amax and xr.dtype == torch.float32:
+            # float32 planes in front of a float32 convolution: that layer's backward cuts dX into half pieces and needs
+            # max |dX| first -- the apply pass, which has every value in registers, leaves it (ops.attach_scale)
+            amax = torch.zeros(2048, dtype=torch.float32, device=xr.device)
+            scale = torch.empty(2, dtype=torch.float32, device=xr.device)
+            call("cplxamd_bn_bwd_sums_amax", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S, ptr(w),
+                 ptr(saved), ptr(dw), ptr(db), int(ctx.training), dtype_code(xr), ptr(sums), ptr(amax), ptr(ws), ws.numel(),
+                 stream_ptr())
+            call("cplxamd_absmax_scale_partials", ptr(amax), 2048, ptr(scale), stream_ptr())
+            ops.attach_scale(dxr, dxi, scale)
         else:
             call("cplxamd_bn_bwd_sums", ptr(gr), ptr(gi), ptr(xr), ptr(xi), ptr(dxr), ptr(dxi), B, F, S,
                  ptr(w), ptr(saved), ptr(dw), ptr(db), int(ctx.training), dtype_code(xr), ptr(sums), ptr(ws),

@@ -838,8 +838,9 @@ class CplxConv2dFn(torch.autograd.Function):
             from . import x3
             xtr, xti, xsc, wr_, wi_ = ctx.saved_tensors
             hint_r, hint_i = ops.colsum_hint(gr), ops.colsum_hint(gi)      # (a batch-norm backward's column sums of gr / gi)
+            gscale = ops.scale_hint(gr, gi)                                # (... and the scale of their largest magnitude)
             gr, gi = (t.contiguous(memory_format=torch.channels_last) for t in (gr, gi))
-            gp = x3.split_planes((_rows(gr), _rows(gi)), kind="x2")
+            gp = x3.split_planes((_rows(gr), _rows(gi)), kind="x2", scale=gscale)
             if need[0] or need[1]:
                 dxr, dxi = _x2_conv(gp, wr_, wi_, None, None, ctx.geom, dgrad=True)
                 if ctx.x_planar:

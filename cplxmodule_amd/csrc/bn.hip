@@ -13,6 +13,7 @@
 namespace cplxamd {
 
 constexpr int kBnT = 256;
+constexpr int kBnAmaxSlots = 2048;   // per-block maxima of the row-kernel backward (cplxamd_bn_bwd_sums_amax): its grid never exceeds this
 constexpr int kBnMaxChunks = 512;
 constexpr int kSaved = 8;    // per-feature saved stats: mu, mv, p, q, w, vuu, vuv, vvv
 constexpr int kFwdCoef = 8;  // mu, mv, a00, a01, a10, a11, b0, b1
@@ -288,11 +289,13 @@ __global__ __launch_bounds__(kBnT) void bn_reduce_rows(const T* xr, const T* xi,
 // pass already holds every dX value in registers.
 template <typename T, bool BWD, bool SUMS>
 __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, const T* gr, const T* gi, T* yr, T* yi,
-                                                      const float* coef, int64_t R, int F, float* sums_partial) {
+                                                      const float* coef, int64_t R, int F, float* sums_partial,
+                                                      float* amax_partial = nullptr) {
   __shared__ float sred[SUMS ? kBnT * 16 : 1];
   const int CG = F >> 3, RL = kBnT / CG;
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
   float su[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;                    // SUMS + amax_partial: max |.| over both output planes as stored (this block's rows)
   if (rl < RL) {
   constexpr int NC = BWD ? kBwdCoef : kFwdCoef;
   float k[8][BWD ? 11 : 8];
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, 
         float a = ou.h[c >> 2].v[c & 3], b = ov.h[c >> 2].v[c & 3];
         if (sizeof(T) == 2) { a = bf16_to_f32(f32_to_bf16(a)); b = bf16_to_f32(f32_to_bf16(b)); }
         su[c] += a; sv[c] += b;
+        amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
       }
     }
   }
@@ -343,6 +347,18 @@ __global__ __launch_bounds__(kBnT) void bn_apply_rows(const T* xr, const T* xi, 
       float t = 0.f;
       for (int l = 0; l < RL; ++l) t += sred[l * 2 * F + f];
       sums_partial[(int64_t)blockIdx.x * 2 * F + f] = t;
+    }
+    if (amax_partial) {                // (a producer-side absmax: the consumer that cuts these planes into half pieces
+      __syncthreads();                 //  -- x3.py 'x2' -- needs max |.| of both and would otherwise read them once more)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = amax;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float m = sred[0];
+        for (int w = 1; w < kBnT / 64; ++w) m = fmaxf(m, sred[w]);
+        amax_partial[blockIdx.x] = m;
+      }
     }
   }
 }
@@ -389,6 +405,7 @@ struct BnSync {
   const double* count_dev = nullptr;
   float* coef_out = nullptr;             // backward: leave the apply coefficients here and do NOT apply (cplxamd_bn_bwd_coef)
   float* dx_sums_out = nullptr;          // ... and the per-feature sums of dX, [2][F], from the sums of the pass
+  float* amax_partial = nullptr;         // backward rows path with dx_sums: per-block max |dX| (kBnAmaxSlots floats, zeroed by the caller)
 };
 
 template <int NS>
@@ -663,7 +680,7 @@ static int bn_run(const void* xr, const void* xi, const void* gr, const void* gi
     if (BWD && dx_sums) {
       float* sp = (float*)((char*)ws + bn_sums_off(F));
       bn_apply_rows<T, BWD, true><<<grid, kBnT, 0, st>>>((const T*)xr, (const T*)xi, (const T*)gr, (const T*)gi, (T*)yr,
-                                                        (T*)yi, coef, B, F, sp);
+                                                        (T*)yi, coef, B, F, sp, grid <= kBnAmaxSlots ? sync.amax_partial : nullptr);
       CPLXAMD_CHECK_LAUNCH();
       bn_sums_final<<<(2 * F + 15) / 16, 1024, 0, st>>>(sp, grid, 2 * F, dx_sums);
     } else {
@@ -769,6 +786,28 @@ int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const vo
     return bn_run<bf16_t, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr,
                                 nullptr, const_cast<float*>(saved), dweight, dbias, training, 0.f,
                                 0.f, ws, st, dx_sums);
+  return CPLXAMD_EINVAL;
+}
+
+// cplxamd_bn_bwd_sums that also leaves the per-block maxima of |dX| (both planes, as stored) in amax_partial[2048] (float32,
+// ZEROED by the caller): cplxamd_absmax_scale_partials turns them into the power-of-two scale a consumer cutting dX into
+// half pieces needs -- a pass over both planes less.  Row-kernel path only (as dx_sums).
+int cplxamd_bn_bwd_sums_amax(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr, void* dxi, int64_t B,
+                             int F, int64_t S, const float* weight, const float* saved, float* dweight, float* dbias,
+                             int training, int dtype, float* dx_sums, float* amax_partial, void* ws, int64_t ws_bytes,
+                             void* stream) {
+  if (!dx_sums || !amax_partial || !bn_rows_ok(B, F, S)) return CPLXAMD_ESHAPE;
+  if (!gr || !gi || !xr || !xi || !dxr || !dxi || !saved || !ws || B <= 0 || F <= 0 || S <= 0) return CPLXAMD_EINVAL;
+  if (ws_bytes < bn_ws_bytes(F)) return CPLXAMD_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  BnSync sync;
+  sync.amax_partial = amax_partial;
+  if (dtype == CPLXAMD_F32)
+    return bn_run<float, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr, nullptr,
+                               const_cast<float*>(saved), dweight, dbias, training, 0.f, 0.f, ws, st, dx_sums, sync);
+  if (dtype == CPLXAMD_BF16)
+    return bn_run<bf16_t, true>(xr, xi, gr, gi, dxr, dxi, B, F, S, weight, nullptr, nullptr, nullptr,
+                                const_cast<float*>(saved), dweight, dbias, training, 0.f, 0.f, ws, st, dx_sums, sync);
   return CPLXAMD_EINVAL;
 }
 

@@ -245,6 +245,14 @@ extern "C" int cplxamd_absmax_scale(const float* src, const float* src2, int64_t
   return 0;
 }
 
+// The second stage alone: n per-block maxima formed by a producer (cplxamd_bn_bwd_sums_amax) -> scale = {s, 1 / s}.
+extern "C" int cplxamd_absmax_scale_partials(const float* partial, int n, float* scale, void* stream) {
+  if (!partial || !scale || n < 0) return CPLXAMD_EINVAL;
+  absmax_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partial, n, scale);
+  CPLXAMD_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int cplxamd_split2h(const float* src, const float* src2, int64_t ld_src, void* dst, int64_t ld_dst,
                                int64_t piece_stride, int64_t rows, int cols, int op, int pattern, const float* scale,
                                void* stream) {

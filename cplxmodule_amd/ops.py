@@ -131,6 +131,23 @@ def colsum_hint(t):
     return None
 
 
+def attach_scale(tr, ti, scale):
+    """Remember on the two float32 planes of a complex tensor that `scale` (device float32[2] = {s, 1 / s}, x3.scale_of's
+    format) is the power-of-two scale of max |.| over both: the producer (the batch-norm backward's apply pass) had every
+    value in registers; the consumer that cuts the planes into half pieces (x3 'x2') skips its absmax pass.  Validated on
+    use like attach_colsum."""
+    tr._cplxamd_scale = (scale, tr.data_ptr(), tr._version, ti.data_ptr(), ti._version, tuple(tr.shape))
+
+
+def scale_hint(tr, ti):
+    """The scale attach_scale left for exactly this pair of planes (same storage, unmodified since), or None."""
+    h = getattr(tr, "_cplxamd_scale", None)
+    if (h is not None and h[1] == tr.data_ptr() and h[2] == tr._version and h[3] == ti.data_ptr() and h[4] == ti._version
+            and h[5] == tuple(tr.shape) == tuple(ti.shape)):
+        return h[0]
+    return None
+
+
 def attach_wgrad(tr, ti, dw):
     """Remember on the two planes of a convolution's output gradient that `dw` = (dW_r, dW_i) is the weight gradient of
     exactly these planes against the input of the convolution whose autograd node is `node` (bn.py: the batch-norm

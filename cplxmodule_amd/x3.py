@@ -163,10 +163,10 @@ def split(t, pattern=SPLIT_A, op=OP_ID, t2=None, stacked=False, kind="x3", scale
     return Pieces(out, kind, scale, npc)
 
 
-def split_planes(planes, pattern=SPLIT_A, stacked=False, kind="x3"):
-    """Pieces of the plane(s) of one operand -- one real plane or the (re, im) pair of a complex one, which shares a scale."""
-    scale = None
-    if kind == "x2":
+def split_planes(planes, pattern=SPLIT_A, stacked=False, kind="x3", scale=None):
+    """Pieces of the plane(s) of one operand -- one real plane or the (re, im) pair of a complex one, which shares a scale
+    (`scale`: one a producer already formed for exactly these planes, ops.scale_hint)."""
+    if kind == "x2" and scale is None:
         scale = scale_of(planes[0]) if len(planes) == 1 else scale_of(planes[0], planes[1], OP_MAX2)
     return tuple(split(p, pattern, stacked=stacked, kind=kind, scale=scale) for p in planes)
 

@@ -725,6 +725,16 @@ int cplxamd_bn_bwd_sums(const void* gr, const void* gi, const void* xr, const vo
                         const float* saved, float* dweight, float* dbias, int training, int dtype,
                         float* dx_sums, void* ws, int64_t ws_bytes, void* stream);
 
+/* ABI 24: cplxamd_bn_bwd_sums that also leaves per-block maxima of |dX| (both planes, as stored) in amax_partial[2048]
+ * (float32, ZEROED by the caller; row-kernel path only): cplxamd_absmax_scale_partials(amax_partial, 2048, scale) then gives
+ * the {s, 1 / s} that cplxamd_absmax_scale would have computed from dX -- the consumer that cuts dX into half pieces (a
+ * float32 convolution's backward on 'x2' pieces) reads the planes once less. */
+int cplxamd_bn_bwd_sums_amax(const void* gr, const void* gi, const void* xr, const void* xi, void* dxr, void* dxi, int64_t B,
+                             int F, int64_t S, const float* weight, const float* saved, float* dweight, float* dbias,
+                             int training, int dtype, float* dx_sums, float* amax_partial, void* ws, int64_t ws_bytes,
+                             void* stream);
+int cplxamd_absmax_scale_partials(const float* partial, int n, float* scale, void* stream);
+
 /* ABI 24: the backward of a batch-norm layer that directly follows a channels-last 3 x 3 convolution, WITHOUT its apply
  * pass (nn/modules/batchnorm.py:189-278 under autograd followed by the autograd of cplx.py:717-838).  The layer's input
  * gradient is dX = E g + C (x - mu) - k with per-channel 2 x 2 real matrices E, C and constants k:

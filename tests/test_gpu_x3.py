@@ -448,3 +448,41 @@ def test_x2_conv_batch_chunks(monkeypatch):
         assert torch.equal(a, b)                              # forward / data gradient: per-image results, same bits
     a, b = out["one"][4], out["chunks"][4]
     assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())      # weight gradient: a sum over chunks
+
+
+def test_x2_conv_backward_takes_the_scale_from_the_batchnorm_backward():
+    """float32 conv (half pieces) -> batch-norm: the layer's backward apply leaves the power-of-two scale of max |dX| on the
+    planes it writes (cplxamd_bn_bwd_sums_amax + cplxamd_absmax_scale_partials); it equals the scale the absmax pass computes
+    from the planes, the convolution's backward uses it, and the gradients are the same bits as without the hint."""
+    from cplxmodule_amd import Cplx, fp32_mode, nn, ops, x3
+    dev = "cuda"
+    res, seen = {}, []
+    real_hint = ops.scale_hint
+    for use in (True, False):
+        ops.scale_hint = (lambda a, b: (seen.append(real_hint(a, b)), seen[-1])[1]) if use else (lambda a, b: None)
+        try:
+            torch.manual_seed(0)
+            layer, bn = nn.CplxConv2d(64, 64, 3, padding=1).to(dev), nn.CplxBatchNorm2d(64).to(dev)
+            mk = lambda: (torch.randn(4, 64, 48, 64, device=dev).contiguous(memory_format=torch.channels_last)  # noqa: E731
+                          .requires_grad_(True))
+            x = Cplx(mk(), mk())
+            with fp32_mode("x2"):
+                y = bn(layer(x))
+                g = (torch.randn_like(y.real), torch.randn_like(y.imag))
+                torch.autograd.backward((y.real, y.imag), g)
+            res[use] = [x.real.grad, x.imag.grad, layer.weight.real.grad, layer.weight.imag.grad]
+        finally:
+            ops.scale_hint = real_hint
+    assert len(seen) == 1 and seen[0] is not None
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    # the hinted scale against the absmax pass on an arbitrary pair of planes
+    from cplxmodule_amd._lib import call, ptr, stream_ptr
+    p = torch.randn(5000, 64, device=dev) * 37.0
+    q = torch.randn(5000, 64, device=dev)
+    ref = x3.scale_of(p, q, x3.OP_MAX2)
+    part = torch.zeros(2048, device=dev)
+    part[:7] = torch.stack([t.abs().max() for t in (p[:900], q, p[900:], q[:3], p[:1], q[:1], p[4000:])])
+    out = torch.empty(2, device=dev)
+    call("cplxamd_absmax_scale_partials", ptr(part), 2048, ptr(out), stream_ptr())
+    assert torch.equal(ref, out)
