@@ -261,3 +261,35 @@ def test_f64_second_derivatives_and_unsupported_layers():
     with pytest.raises(CplxAmdError):
         cplx.linear(x, Cplx(torch.randn(3, 6, device="cuda"), torch.randn(3, 6, device="cuda")))     # mixed precision
     del nn
+
+
+def test_f64_conv_random_geometries_against_aten():
+    """Thirty random (stride, padding, dilation, groups, kernel, channels) draws: the float64 convolution kernel (forward, data
+    gradient, weight gradient) against aten's float64 convolution of the same operands -- a checker only."""
+    from cplxmodule_amd import Cplx, cplx
+    F_ = torch.nn.functional
+    rs = np.random.RandomState(5)
+    for it in range(30):
+        groups = int(rs.choice([1, 1, 2, 3]))
+        Ci, Co = groups * int(rs.randint(1, 5)), groups * int(rs.randint(1, 5))
+        kh, kw = int(rs.randint(1, 4)), int(rs.randint(1, 4))
+        st = (int(rs.randint(1, 3)), int(rs.randint(1, 3)))
+        dl = (int(rs.randint(1, 3)), int(rs.randint(1, 3)))
+        pd = (int(rs.randint(0, 3)), int(rs.randint(0, 3)))
+        B, H, W = int(rs.randint(1, 4)), int(rs.randint(6, 14)), int(rs.randint(6, 14))
+        if (H + 2 * pd[0] - dl[0] * (kh - 1) - 1) < 0 or (W + 2 * pd[1] - dl[1] * (kw - 1) - 1) < 0:
+            continue
+        mk = lambda *s: torch.from_numpy(rs.randn(*s)).cuda().requires_grad_(True)  # noqa: E731
+        xr, xi, wr, wi, br, bi = mk(B, Ci, H, W), mk(B, Ci, H, W), mk(Co, Ci // groups, kh, kw), mk(Co, Ci // groups, kh, kw), mk(Co), mk(Co)
+        kw_ = dict(stride=st, padding=pd, dilation=dl, groups=groups)
+        y = cplx.conv2d(Cplx(xr, xi), Cplx(wr, wi), Cplx(br, bi), **kw_)
+        c = lambda a, b: F_.conv2d(a, b, None, **kw_)  # noqa: E731
+        ref_r = c(xr, wr) - c(xi, wi) + br.view(1, -1, 1, 1)
+        ref_i = c(xr, wi) + c(xi, wr) + bi.view(1, -1, 1, 1)
+        assert y.real.dtype == torch.float64 and y.real.shape == ref_r.shape, (it, y.real.shape, ref_r.shape)
+        gr, gi = torch.from_numpy(rs.randn(*ref_r.shape)).cuda(), torch.from_numpy(rs.randn(*ref_r.shape)).cuda()
+        leaves = [xr, xi, wr, wi, br, bi]
+        got = torch.autograd.grad((y.real * gr).sum() + (y.imag * gi).sum(), leaves)
+        ref = torch.autograd.grad((ref_r * gr).sum() + (ref_i * gi).sum(), leaves)
+        for a, b in [(y.real, ref_r), (y.imag, ref_i)] + list(zip(got, ref)):
+            np.testing.assert_allclose(N(a), N(b), rtol=1e-10, atol=1e-11 * float(b.detach().abs().max()), err_msg=str((it, kw_, kh, kw)))
